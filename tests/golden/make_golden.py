@@ -1,0 +1,292 @@
+"""Generate the golden fixtures under tests/golden/ from the REAL reference (build container only).
+
+    python tests/golden/make_golden.py [--cases small,config1,...]
+
+For every case the reference model (ref_harness.build_reference_model, config of record, CPU fp32) is loaded with
+oneshotdet_amd.synth weights by state_dict key, run on oneshotdet_amd.synth inputs, and its hot-path intermediates are
+captured with forward hooks.  The oracle restatement (oracle/hotpath_ref.py) is run on the same data and MUST agree
+(assertions below) before anything is written.  Fixtures hold data only: inputs are regenerated from the hash, so
+each .npz stores reference outputs (or compact checksums of them).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
+
+import golden_utils as gu            # noqa: E402
+import ref_harness as rh             # noqa: E402
+from oneshotdet_amd import spec, synth  # noqa: E402
+from oracle import hotpath_ref as orc   # noqa: E402
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def load_synth_weights(model, seed=0):
+    shapes = spec.hot_path_shapes()
+    ref_sd = model.state_dict()
+    hot = {k: v for k, v in ref_sd.items() if k.split(".")[0] in ("backbone", "supp_backbone", "rpn")}
+    assert list(hot.keys()) == list(shapes.keys()), "spec.hot_path_shapes() key list/order differs from reference"
+    for k, v in hot.items():
+        assert tuple(v.shape) == tuple(shapes[k]), (k, v.shape, shapes[k])
+    np_sd = synth.make_state_dict(shapes, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in np_sd.items()}, strict=False)
+    return np_sd
+
+
+def run_reference(model, images, queries, batch):
+    """Hooks on backbone / supp_backbone / supp_pooling / rpn.head capture the hot-path intermediates."""
+    cap = {}
+    def grab(key, what="out"):
+        def hook(m, i, o):
+            cap[key] = o if what == "out" else i[0]
+        return hook
+    hooks = [
+        model.backbone.register_forward_hook(grab("features")),
+        model.supp_backbone.register_forward_hook(grab("query_features")),
+        model.supp_pooling.register_forward_hook(grab("pooled_raw")),
+        model.rpn.head.register_forward_hook(grab("head_in", "in")),
+        model.rpn.head.register_forward_hook(grab("head_out")),
+        model.rpn.box_selector_test.register_forward_hook(grab("proposals")),
+    ]
+    model.eval()
+    t0 = time.time()
+    with torch.no_grad():
+        try:
+            model(images, queries, None, device=torch.device("cpu"), target_ids=[1] * batch)
+        except AssertionError:
+            # The reference's SECOND stage (out of scope) asserts equal proposal counts per image
+            # (modeling/poolers.py:80) and so cannot run batch > 1 when NMS leaves < 2000 boxes; the hot path
+            # (everything up to rpn.box_selector_test) has already been captured by the hooks at that point.
+            if "proposals" not in cap:
+                raise
+    cap["seconds"] = time.time() - t0
+    for h in hooks:
+        h.remove()
+    return cap
+
+
+def gen_case(model, np_sd, name):
+    B, H, W, S, qh, qw = gu.CASES[name]
+    img_np, q_np = gu.case_inputs(name)
+    images, queries = torch.from_numpy(img_np), torch.from_numpy(q_np)
+    cap = run_reference(model, images, queries, B)
+    sd = orc.to_torch_state_dict(np_sd)
+    with torch.no_grad():
+        o = orc.hot_path_forward(images, queries, sd, shots=S)
+    out = {}
+    # ---- oracle vs reference (pins the restatement) ----
+    maxerr = {}
+    for lvl in range(5):
+        for key, ref_t in (("features", cap["features"][lvl]), ("query_features", cap["query_features"][lvl]),
+                           ("combined", cap["head_in"][lvl])):
+            d = (o[key][lvl] - ref_t).abs().max().item()
+            scale = ref_t.abs().max().item()
+            maxerr[key] = max(maxerr.get(key, 0.0), d / max(scale, 1e-6))
+        pooled_ref = model.batch_pooling(cap["pooled_raw"][lvl], B)
+        d = (o["pooled"][lvl] - pooled_ref).abs().max().item()
+        maxerr["pooled"] = max(maxerr.get("pooled", 0.0), d / max(pooled_ref.abs().max().item(), 1e-6))
+        out["pooled.%d" % lvl] = t2n(pooled_ref).reshape(B, -1)
+    ref_head = gu.flatten_head(*[[t2n(t) for t in lst] for lst in cap["head_out"]])
+    orc_head = gu.flatten_head(*[[t2n(t) for t in o[k]] for k in ("logits", "bbox_reg", "centerness")])
+    maxerr["head"] = float(np.abs(ref_head - orc_head).max())
+    print(name, "oracle-vs-reference rel/abs err:", {k: "%.2e" % v for k, v in maxerr.items()},
+          "ref fwd %.2fs" % cap["seconds"])
+    assert maxerr["features"] < 1e-4 and maxerr["combined"] < 1e-4 and maxerr["pooled"] < 1e-5, maxerr
+    assert maxerr["head"] < 2e-4, maxerr
+    out["head"] = ref_head
+    for lvl in range(5):
+        out.update(gu.checksum(t2n(cap["features"][lvl]), "features.%d" % lvl))
+        out.update(gu.checksum(t2n(cap["query_features"][lvl]), "query_features.%d" % lvl))
+        out.update(gu.checksum(t2n(cap["head_in"][lvl]), "combined.%d" % lvl))
+    # ---- proposals (R10/R11): reference output + oracle check ----
+    image_sizes = [(H, W)] * B
+    orc_props = orc.fcos_postprocess(*cap["head_out"], image_sizes)
+    for i, bl in enumerate(cap["proposals"]):
+        rb, rs = t2n(bl.bbox), t2n(bl.get_field("scores"))
+        ob, os_ = t2n(orc_props[i][0]), t2n(orc_props[i][1])
+        frac = gu.match_boxes(rb, rs, ob, os_)
+        print("  image %d: reference %d proposals, oracle %d, overlap %.4f" % (i, len(rb), len(ob), frac))
+        assert len(rb) == len(ob) and frac >= 0.999, (len(rb), len(ob), frac)
+        order = np.argsort(-rs, kind="stable")
+        out["proposals.%d.boxes" % i] = rb[order]
+        out["proposals.%d.scores" % i] = rs[order]
+    out["ref_seconds"] = np.float64(cap["seconds"])
+    np.savez_compressed(os.path.join(HERE, "case_%s.npz" % name), **out)
+
+
+def gen_train_case(model, np_sd, name="small"):
+    """R12 + gradients.  The reference's loss_evaluator (fcos/loss.py:213) is called directly on head outputs; parameter
+    gradients come from the reference modules with the pooled query vector DETACHED (ROIAlign has no CPU backward in the
+    reference: csrc/ROIAlign.h:44).  The oracle must reproduce both; the oracle's full gradient (query branch attached,
+    ROIAlign backward restated from csrc/cuda/ROIAlign_cuda.cu:178-254) is stored beside them as 'oracle-only'."""
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    B, H, W, S, qh, qw = gu.CASES[name]
+    img_np, q_np = gu.case_inputs(name)
+    images, queries = torch.from_numpy(img_np), torch.from_numpy(q_np)
+    gts = synth.make_gt_boxes(B, H, W, seed=3, max_boxes=3)
+    targets = []
+    for g in gts:
+        bl = BoxList(torch.from_numpy(g), (W, H), mode="xyxy")
+        bl.add_field("labels", torch.ones(len(g), dtype=torch.int64))
+        targets.append(bl)
+    model.train()
+    model.zero_grad()
+    feats = model.backbone(images)
+    qfeats = model.supp_backbone(queries)
+    rois_boxes = [BoxList([[0, 0, qh, qw]], image_size=(qh, qw), mode="xyxy") for _ in range(B * S)]
+    with torch.no_grad():
+        pooled = [model.batch_pooling(p, B) for p in model.supp_pooling([f.detach() for f in qfeats], rois_boxes)]
+    combined = [f * p.expand(-1, -1, f.shape[2], f.shape[3]) for f, p in zip(feats, pooled)]
+    box_cls, box_reg, ctr = model.rpn.head(combined)
+    locations = model.rpn.compute_locations(combined)
+    lc, lr, lctr = model.rpn.loss_evaluator(locations, box_cls, box_reg, ctr, model.rpn.clean_targets(targets))
+    (lc + lr + lctr).backward()
+    ref_grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.eval()
+
+    def oracle_run(detach_pooled, focal):
+        sd = orc.to_torch_state_dict(np_sd)
+        for k in sd:
+            if not spec.is_frozen(k):
+                sd[k].requires_grad_(True)
+        f = orc.backbone(images, sd, "backbone.")
+        qf = orc.backbone(queries, sd, "supp_backbone.")
+        pl = orc.query_pool(qf, [(qh, qw)] * (B * S), B)
+        if detach_pooled:
+            pl = [p.detach() for p in pl]
+        comb = orc.correlate(f, pl)
+        lg, br, ct = orc.fcos_head(comb, sd)
+        c, r, t, info = orc.fcos_loss(lg, br, ct, gts, focal=focal)
+        (c + r + t).backward()
+        return (c, r, t), {k: v.grad for k, v in sd.items() if v.grad is not None}, info
+
+    (oc, orr, octr), og, info = oracle_run(True, "cpu")
+    print("train: reference losses", lc.item(), lr.item(), lctr.item(), "| oracle", oc.item(), orr.item(), octr.item(),
+          "num_pos", info["num_pos"])
+    for a, b in ((lc, oc), (lr, orr), (lctr, octr)):
+        assert abs(a.item() - b.item()) <= 1e-5 * max(1.0, abs(a.item())), (a.item(), b.item())
+    worst = 0.0
+    for k, g in ref_grads.items():
+        assert k in og, k
+        e = (og[k] - g).abs().max().item() / max(g.abs().max().item(), 1e-8)
+        worst = max(worst, e)
+    print("train: worst relative grad error oracle-vs-reference (pooled detached): %.2e over %d tensors"
+          % (worst, len(ref_grads)))
+    assert worst < 2e-3, worst
+    out = {"losses_ref_cpu_formula": np.array([lc.item(), lr.item(), lctr.item()], dtype=np.float64),
+           "num_pos": np.int64(info["num_pos"]),
+           "labels": t2n(info["labels"]).astype(np.int8), "reg_targets": t2n(info["reg_targets"])}
+    (fc, fr, ft), fg, _ = oracle_run(False, "cuda")
+    out["losses_cuda_formula"] = np.array([fc.item(), fr.item(), ft.item()], dtype=np.float64)
+    names = ["backbone.body.layer2.0.conv1.weight", "backbone.body.layer4.2.conv3.weight",
+             "backbone.fpn.fpn_inner2.weight", "backbone.fpn.fpn_layer4.bias", "backbone.fpn.top_blocks.p7.weight",
+             "supp_backbone.body.layer3.1.conv2.weight", "supp_backbone.fpn.fpn_layer2.weight",
+             "rpn.head.cls_tower.0.weight", "rpn.head.cls_tower.1.weight", "rpn.head.bbox_tower.9.bias",
+             "rpn.head.bbox_tower.10.bias", "rpn.head.cls_logits.weight", "rpn.head.bbox_pred.weight",
+             "rpn.head.centerness.bias", "rpn.head.scales.0.scale", "rpn.head.scales.4.scale"]
+    for k in names:
+        for tag, gd in (("refgrad_detached", ref_grads), ("fullgrad_oracle", fg)):
+            if k not in gd:      # query-branch params get no gradient when the pooled vector is detached
+                continue
+            g = t2n(gd[k]).reshape(-1)
+            idx = gu.sample_indices(g.size, "grad." + k)[:256]
+            out["%s.%s.samples" % (tag, k)] = g[idx]
+            out["%s.%s.absmax" % (tag, k)] = np.float32(np.abs(g).max())
+            out["%s.%s.sum" % (tag, k)] = np.float64(g.astype(np.float64).sum())
+    out["gt_boxes"] = np.concatenate([np.concatenate([np.full((len(g), 1), i, np.float32), g], 1)
+                                      for i, g in enumerate(gts)], 0)
+    np.savez_compressed(os.path.join(HERE, "train_%s.npz" % name), **out)
+
+
+def gen_nms_kat():
+    """The reference's own known-answer vectors: /root/reference/tests/test_nms.py:11-217 executed against the
+    reference's nms with a recorder, so the fixture holds (boxes, scores, thresh, expected keep) as data."""
+    import importlib.util
+    import unittest
+    spec_ = importlib.util.spec_from_file_location("ref_test_nms", os.path.join(rh.REFERENCE_ROOT, "tests", "test_nms.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    real = mod.box_nms
+    rec = []
+
+    def recorder(boxes, scores, thresh):
+        keep = real(boxes, scores, thresh)
+        rec.append((t2n(boxes).copy(), t2n(scores).copy(), float(thresh), np.sort(t2n(keep))))
+        return keep
+    mod.box_nms = recorder
+    res = unittest.TextTestRunner(verbosity=0).run(unittest.defaultTestLoader.loadTestsFromModule(mod))
+    assert res.wasSuccessful()
+    out = {"n": np.int64(len(rec))}
+    for i, (b, s, t, k) in enumerate(rec):
+        out["boxes.%d" % i], out["scores.%d" % i], out["thresh.%d" % i], out["keep.%d" % i] = b, s, np.float32(t), k
+        ok = orc.nms(b, s, t)
+        assert np.array_equal(ok, k), (i, ok, k)
+    print("nms KAT: %d reference vectors recorded, oracle agrees on all" % len(rec))
+    np.savez_compressed(os.path.join(HERE, "nms_kat.npz"), **out)
+
+
+def gen_roialign():
+    """Random + edge ROIAlign cases through the reference's _C.roi_align_forward (csrc/cpu/ROIAlign_cpu.cpp:221)."""
+    C = rh.load_reference()._C
+    rng = np.random.RandomState(5)
+    out = {}
+    cases = [(2, 8, 16, 16, 0.125, 1, 1, 2), (3, 4, 7, 5, 0.0625, 1, 1, 2), (1, 6, 1, 1, 0.0078125, 1, 1, 2),
+             (2, 5, 13, 9, 0.25, 7, 7, 2), (1, 3, 10, 12, 0.5, 3, 2, 0), (2, 4, 4, 2, 0.03125, 1, 1, 2)]
+    for ci, (B, Cc, H, W, scale, ph, pw, sr) in enumerate(cases):
+        x = torch.from_numpy(rng.randn(B, Cc, H, W).astype(np.float32))
+        R = 5
+        rois = np.zeros((R, 5), np.float32)
+        rois[:, 0] = rng.randint(0, B, R)
+        rois[:, 1:3] = rng.uniform(-8, W / scale * 0.6, (R, 2))
+        rois[:, 3:5] = rois[:, 1:3] + rng.uniform(0, W / scale, (R, 2))
+        rois[0, 1:] = (0, 0, H / scale * 1.7, W / scale * 0.4)      # whole-image style box with swapped extents
+        y = C.roi_align_forward(x, torch.from_numpy(rois), scale, ph, pw, sr)
+        oy = orc.roi_align(x, torch.from_numpy(rois), scale, ph, pw, sr)
+        err = (y - oy).abs().max().item()
+        assert err <= 1e-6, (ci, err)
+        out["x.%d" % ci], out["rois.%d" % ci], out["y.%d" % ci] = t2n(x), rois, t2n(y)
+        out["args.%d" % ci] = np.array([scale, ph, pw, sr], np.float64)
+    out["n"] = np.int64(len(cases))
+    print("roi_align: %d reference cases recorded, oracle agrees (<=1e-6)" % len(cases))
+    np.savez_compressed(os.path.join(HERE, "roialign.npz"), **out)
+
+
+def gen_keys(model):
+    import json
+    sd = model.state_dict()
+    hot = {k: list(v.shape) for k, v in sd.items() if k.split(".")[0] in ("backbone", "supp_backbone", "rpn")}
+    frozen = sorted(n for n, p in model.named_parameters() if not p.requires_grad and n in hot)
+    json.dump({"shapes": hot, "frozen_params": frozen, "num_all_keys": len(sd)},
+              open(os.path.join(HERE, "state_dict_keys.json"), "w"), indent=0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", default="small,nonsquare,shots5,tall,config1")
+    ap.add_argument("--skip-train", action="store_true")
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    model, cfg = rh.build_reference_model()
+    np_sd = load_synth_weights(model)
+    gen_keys(model)
+    gen_nms_kat()
+    gen_roialign()
+    for name in [c for c in args.cases.split(",") if c]:
+        gen_case(model, np_sd, name)
+    if not args.skip_train:
+        gen_train_case(model, np_sd, "small")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,216 @@
+"""Import the real reference (RyanXLi/OneshotDet, /root/reference) on CPU, in THIS container only.
+
+Test infrastructure for *generating* golden fixtures (tests/golden/make_golden.py) and for validating the
+oracle restatement (oracle/hotpath_ref.py).  Never imported by the product, never needed on the GPU box:
+`/root/reference` does not exist there and nothing under tests marked gpu touches this file.
+
+The reference cannot be imported as shipped in this image: four oracle-only shims are needed.
+  1. `maskrcnn_benchmark._C`: the reference's csrc/cpu sources are compiled with torch.utils.cpp_extension from a
+     SCRATCH COPY under /tmp (never inside this repo).  Two lines need `x.type()` -> `x.scalar_type()` for torch 2.10
+     (csrc/cpu/nms_cpu.cpp:71, csrc/cpu/ROIAlign_cpu.cpp:242); the sed below applies exactly that to the scratch copy.
+  2. `yacs.config.CfgNode`: tiny attribute-dict stand-in (the reference only uses attribute access, merge_from_file,
+     merge_from_list, freeze/defrost/clone).
+  3. `cv2`, `pycocotools(.mask)`: empty stub modules (imported at module scope by code that is never executed here).
+  4. `torch._six`: removed from torch; `PY3 = True`.
+"""
+import os
+import re
+import shutil
+import sys
+import types
+
+REFERENCE_ROOT = "/root/reference"
+SCRATCH = "/tmp/osd_ref_scratch"
+CONFIG_OF_RECORD = "configs/fcos/2019_10_25_vanilla_siamse_backbone.yaml"
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "maskrcnn_benchmark"))
+
+
+class _CfgNode(dict):
+    """Minimal yacs.config.CfgNode stand-in (shim 2)."""
+
+    def __init__(self, init=None):
+        super().__init__()
+        self.__dict__["_frozen"] = False
+        if init:
+            for k, v in init.items():
+                self[k] = _CfgNode(v) if isinstance(v, dict) and not isinstance(v, _CfgNode) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        if self.__dict__.get("_frozen"):
+            raise AttributeError("frozen cfg")
+        self[k] = v
+
+    def freeze(self):
+        self.__dict__["_frozen"] = True
+        for v in self.values():
+            if isinstance(v, _CfgNode):
+                v.freeze()
+
+    def defrost(self):
+        self.__dict__["_frozen"] = False
+        for v in self.values():
+            if isinstance(v, _CfgNode):
+                v.defrost()
+
+    def clone(self):
+        import copy
+        return copy.deepcopy(self)
+
+    def __deepcopy__(self, memo):
+        import copy
+        n = _CfgNode()
+        for k, v in self.items():
+            n[k] = copy.deepcopy(v, memo)
+        return n
+
+    @staticmethod
+    def _coerce(new, old):
+        if isinstance(old, tuple) and isinstance(new, list):
+            return tuple(new)
+        if isinstance(old, list) and isinstance(new, tuple):
+            return list(new)
+        if isinstance(old, float) and isinstance(new, int):
+            return float(new)
+        return new
+
+    def _merge(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict):
+                if k not in self:
+                    self[k] = _CfgNode()
+                self[k]._merge(v)
+            else:
+                if isinstance(v, str):  # yacs literal_evals yaml strings such as "(0.125, 0.0625)"
+                    import ast
+                    try:
+                        v = ast.literal_eval(v)
+                    except Exception:
+                        pass
+                self[k] = self._coerce(v, self.get(k)) if k in self else v
+
+    def merge_from_file(self, path):
+        import yaml
+        with open(path) as f:
+            self._merge(yaml.safe_load(f) or {})
+
+    def merge_from_list(self, lst):
+        assert len(lst) % 2 == 0
+        for key, val in zip(lst[0::2], lst[1::2]):
+            node = self
+            parts = key.split(".")
+            for p in parts[:-1]:
+                node = node[p]
+            if isinstance(val, str):
+                import ast
+                try:
+                    val = ast.literal_eval(val)
+                except Exception:
+                    pass
+            node[parts[-1]] = self._coerce(val, node.get(parts[-1]))
+
+
+def _install_shims():
+    if "yacs" not in sys.modules:
+        yacs = types.ModuleType("yacs")
+        yacs_config = types.ModuleType("yacs.config")
+        yacs_config.CfgNode = _CfgNode
+        yacs.config = yacs_config
+        sys.modules["yacs"] = yacs
+        sys.modules["yacs.config"] = yacs_config
+    for name in ("cv2", "pycocotools", "pycocotools.mask", "pycocotools.coco", "pycocotools.cocoeval"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["pycocotools"].mask = sys.modules["pycocotools.mask"]
+    if "torch._six" not in sys.modules:
+        import torch
+        six = types.ModuleType("torch._six")
+        six.PY3 = True
+        six.string_classes = (str,)
+        sys.modules["torch._six"] = six
+        torch._six = six
+    try:
+        import torchvision  # noqa: F401
+    except Exception:
+        tv = types.ModuleType("torchvision")
+        for sub in ("transforms", "datasets", "models", "ops"):
+            m = types.ModuleType("torchvision." + sub)
+            setattr(tv, sub, m)
+            sys.modules["torchvision." + sub] = m
+        tvf = types.ModuleType("torchvision.transforms.functional")
+        sys.modules["torchvision.transforms.functional"] = tvf
+        tv.transforms.functional = tvf
+        tvc = types.ModuleType("torchvision.datasets.coco")
+
+        class _CocoDetection(object):
+            pass
+        tvc.CocoDetection = _CocoDetection
+        tv.datasets.coco = tvc
+        tv.datasets.CocoDetection = _CocoDetection
+        sys.modules["torchvision.datasets.coco"] = tvc
+        sys.modules["torchvision"] = tv
+
+
+def _build_C():
+    """Shim 1: compile the reference's CPU extension from a scratch copy (needs 2 one-token patches)."""
+    from torch.utils.cpp_extension import load
+    src = os.path.join(SCRATCH, "maskrcnn_benchmark", "csrc")
+    for rel, pat in (("cpu/nms_cpu.cpp", r"AT_DISPATCH_FLOATING_TYPES\(dets\.type\(\)"),
+                     ("cpu/ROIAlign_cpu.cpp", r"AT_DISPATCH_FLOATING_TYPES\(input\.type\(\)")):
+        p = os.path.join(src, rel)
+        s = open(p).read()
+        s2 = re.sub(pat, lambda m: m.group(0).replace(".type()", ".scalar_type()"), s)
+        if s2 != s:
+            open(p, "w").write(s2)
+    sources = [os.path.join(src, "vision.cpp"), os.path.join(src, "cpu", "nms_cpu.cpp"),
+               os.path.join(src, "cpu", "ROIAlign_cpu.cpp")]
+    os.makedirs(os.path.join(SCRATCH, "build"), exist_ok=True)
+    return load(name="osd_ref_C", sources=sources, extra_include_paths=[src],
+                build_directory=os.path.join(SCRATCH, "build"), verbose=False,
+                extra_cflags=["-O2", "-w"])
+
+
+_loaded = {}
+
+
+def load_reference():
+    """Returns the imported `maskrcnn_benchmark` package (CPU), building the scratch copy on first use."""
+    if "pkg" in _loaded:
+        return _loaded["pkg"]
+    if not reference_available():
+        raise RuntimeError("reference not present at %s (it only exists in the build container)" % REFERENCE_ROOT)
+    if not os.path.isdir(os.path.join(SCRATCH, "maskrcnn_benchmark")):
+        os.makedirs(SCRATCH, exist_ok=True)
+        shutil.copytree(os.path.join(REFERENCE_ROOT, "maskrcnn_benchmark"),
+                        os.path.join(SCRATCH, "maskrcnn_benchmark"))
+    _install_shims()
+    C = _build_C()
+    sys.modules["maskrcnn_benchmark._C"] = C
+    if SCRATCH not in sys.path:
+        sys.path.insert(0, SCRATCH)
+    import maskrcnn_benchmark
+    maskrcnn_benchmark._C = C
+    _loaded["pkg"] = maskrcnn_benchmark
+    return maskrcnn_benchmark
+
+
+def build_reference_model(extra_opts=()):
+    """build_detection_model(cfg) with the config of record on CPU (SURVEY.md §8c 'What runs')."""
+    load_reference()
+    from maskrcnn_benchmark.config import cfg as global_cfg
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    cfg = global_cfg.clone()
+    cfg.defrost()
+    cfg.merge_from_file(os.path.join(REFERENCE_ROOT, CONFIG_OF_RECORD))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.WEIGHT", ""] + list(extra_opts))
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    return model, cfg

@@ -1,0 +1,87 @@
+"""Helpers shared by tests/golden/make_golden.py (fixture writer) and the parity tests (fixture readers)."""
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+N_SAMPLES = 4096
+
+
+def sample_indices(numel, tag):
+    """Deterministic pseudo-random flat indices (with replacement) into a tensor of `numel` elements."""
+    from oneshotdet_amd.synth import uniform01
+    u = uniform01("sample." + tag, N_SAMPLES, seed=7).astype(np.float64)
+    return np.minimum((u * numel).astype(np.int64), numel - 1)
+
+
+def checksum(arr, tag):
+    """Compact summary of a [B, C, H, W] float tensor: per-channel mean / absmax + hashed sample points."""
+    a = np.asarray(arr, dtype=np.float32)
+    flat = a.reshape(-1)
+    return {
+        tag + ".shape": np.asarray(a.shape, dtype=np.int64),
+        tag + ".mean": a.astype(np.float64).mean(axis=(0, 2, 3)).astype(np.float32),
+        tag + ".absmax": np.abs(a).max(axis=(0, 2, 3)),
+        tag + ".samples": flat[sample_indices(flat.size, tag)],
+    }
+
+
+def check_against(arr, fixture, tag, atol_rel=1e-3, rtol=1e-3):
+    """Assert `arr` matches the checksum stored under `tag` (features: atol = atol_rel * absmax, rtol)."""
+    a = np.asarray(arr, dtype=np.float32)
+    assert tuple(fixture[tag + ".shape"]) == a.shape, (tag, a.shape, fixture[tag + ".shape"])
+    absmax = float(fixture[tag + ".absmax"].max())
+    atol = atol_rel * absmax
+    flat = a.reshape(-1)
+    got = flat[sample_indices(flat.size, tag)]
+    np.testing.assert_allclose(got, fixture[tag + ".samples"], rtol=rtol, atol=atol, err_msg=tag + " samples")
+    np.testing.assert_allclose(a.astype(np.float64).mean(axis=(0, 2, 3)), fixture[tag + ".mean"], rtol=rtol,
+                               atol=atol, err_msg=tag + " mean")
+    np.testing.assert_allclose(np.abs(a).max(axis=(0, 2, 3)), fixture[tag + ".absmax"], rtol=rtol, atol=atol,
+                               err_msg=tag + " absmax")
+
+
+def flatten_head(logits, bbox_reg, centerness):
+    """list of [B,C,H,W] per level -> [B, sum(HW), 6] (logit, l, t, r, b, ctr) in level-major, row-major order."""
+    outs = []
+    for lg, br, ct in zip(logits, bbox_reg, centerness):
+        lg, br, ct = (np.asarray(t, dtype=np.float32) for t in (lg, br, ct))
+        B = lg.shape[0]
+        outs.append(np.concatenate([lg.reshape(B, 1, -1), br.reshape(B, 4, -1), ct.reshape(B, 1, -1)], axis=1)
+                    .transpose(0, 2, 1))
+    return np.concatenate(outs, axis=1)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, name))
+
+
+def match_boxes(boxes_a, scores_a, boxes_b, scores_b, tol=1e-2):
+    """Fraction of (box, score) rows of A that have a counterpart in B (order-free; scores sorted then matched)."""
+    if len(boxes_a) == 0:
+        return 1.0 if len(boxes_b) == 0 else 0.0
+    ra = np.concatenate([boxes_a, scores_a[:, None] * 1000.0], axis=1)
+    rb = np.concatenate([boxes_b, scores_b[:, None] * 1000.0], axis=1)
+    hits = 0
+    from scipy.spatial import cKDTree
+    tree = cKDTree(rb)
+    d, _ = tree.query(ra, k=1)
+    hits = int((d <= tol * 5).sum())
+    return hits / float(len(ra))
+
+
+# name -> (batch, H, W, shots, query_h, query_w)
+CASES = {
+    "small": (1, 128, 160, 1, 63, 63),          # full tensors
+    "config1": (1, 800, 1024, 1, 127, 127),     # BASELINE.json configs[0]
+    "nonsquare": (2, 96, 160, 1, 96, 160),      # pins the (h, w)-as-(x2, y2) query-box quirk
+    "shots5": (2, 128, 128, 5, 127, 127),       # S=5 mean-pooled queries (configs[4])
+    "tall": (1, 160, 96, 1, 64, 96),
+}
+
+
+def case_inputs(name, seed=0):
+    """(images [B,3,H,W], queries [B*S,3,h,w]) float32 numpy for a named case."""
+    from oneshotdet_amd import synth
+    B, H, W, S, qh, qw = CASES[name]
+    return (synth.make_images("target." + name, B, H, W, seed), synth.make_images("query." + name, B * S, qh, qw, seed))

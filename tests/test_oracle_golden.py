@@ -1,0 +1,121 @@
+"""CPU: the oracle restatement (oracle/hotpath_ref.py) against the golden fixtures generated from the REAL reference
+(tests/golden/make_golden.py), and against the reference's own known-answer NMS vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+from oneshotdet_amd import spec, synth
+from oracle import hotpath_ref as orc
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return orc.to_torch_state_dict(synth.make_state_dict(spec.hot_path_shapes()))
+
+
+def test_state_dict_keys_match_reference():
+    ref = json.load(open(os.path.join(gu.GOLDEN_DIR, "state_dict_keys.json")))
+    mine = spec.hot_path_shapes()
+    assert list(mine.keys()) == list(ref["shapes"].keys())
+    for k, s in mine.items():
+        assert list(s) == ref["shapes"][k], k
+    frozen_params = sorted(k for k in mine if spec.is_frozen(k) and not any(
+        k.endswith(b) for b in ("running_mean", "running_var")) and ".bn" not in k and "downsample.1" not in k)
+    assert frozen_params == ref["frozen_params"]
+
+
+def test_nms_known_answers():
+    """reference tests/test_nms.py:11-217 vectors (recorded through the reference's own nms)."""
+    f = gu.load("nms_kat.npz")
+    assert int(f["n"]) == 6
+    for i in range(int(f["n"])):
+        keep = orc.nms(f["boxes.%d" % i], f["scores.%d" % i], float(f["thresh.%d" % i]))
+        np.testing.assert_array_equal(keep, f["keep.%d" % i])
+
+
+def test_nms_edge_cases():
+    assert orc.nms(np.zeros((0, 4), np.float32), np.zeros((0,), np.float32), 0.5).shape == (0,)
+    b = np.array([[0, 0, 9, 9], [0, 0, 9, 9], [20, 20, 30, 30]], np.float32)
+    s = np.array([0.5, 0.9, 0.1], np.float32)
+    np.testing.assert_array_equal(orc.nms(b, s, 1.0), [1, 2])          # IoU == 1.0 >= 1.0 suppresses (CPU rule)
+    np.testing.assert_array_equal(orc.nms(b, s, 1.0, cuda_semantics=True), [0, 1, 2])   # '>' rule keeps it
+
+
+def test_roi_align_reference_vectors():
+    f = gu.load("roialign.npz")
+    for i in range(int(f["n"])):
+        scale, ph, pw, sr = f["args.%d" % i]
+        y = orc.roi_align(torch.from_numpy(f["x.%d" % i]), torch.from_numpy(f["rois.%d" % i]), float(scale),
+                          int(ph), int(pw), int(sr))
+        np.testing.assert_allclose(y.numpy(), f["y.%d" % i], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["small", "nonsquare", "shots5", "tall", "config1"])
+def test_hot_path_forward_matches_reference(name, sd):
+    B, H, W, S, qh, qw = gu.CASES[name]
+    img, q = gu.case_inputs(name)
+    f = gu.load("case_%s.npz" % name)
+    with torch.no_grad():
+        o = orc.hot_path_forward(torch.from_numpy(img), torch.from_numpy(q), sd, shots=S)
+    head = gu.flatten_head(*[[t.numpy() for t in o[k]] for k in ("logits", "bbox_reg", "centerness")])
+    # oneDNN thread-count / blocking noise only: same algorithm, same machine class
+    np.testing.assert_allclose(head, f["head"], rtol=1e-4, atol=1e-4)
+    for lvl in range(5):
+        np.testing.assert_allclose(o["pooled"][lvl].reshape(B, -1).numpy(), f["pooled.%d" % lvl], rtol=1e-5,
+                                   atol=1e-5)
+        gu.check_against(o["features"][lvl].numpy(), f, "features.%d" % lvl, 1e-5, 1e-4)
+        gu.check_against(o["combined"][lvl].numpy(), f, "combined.%d" % lvl, 1e-5, 1e-4)
+        gu.check_against(o["query_features"][lvl].numpy(), f, "query_features.%d" % lvl, 1e-5, 1e-4)
+    if name != "config1":   # proposals from the oracle's own head outputs
+        props = orc.fcos_postprocess(o["logits"], o["bbox_reg"], o["centerness"], [(H, W)] * B)
+        for i in range(B):
+            rb, rs = f["proposals.%d.boxes" % i], f["proposals.%d.scores" % i]
+            assert abs(len(props[i][0]) - len(rb)) <= max(1, len(rb) // 500)
+            assert gu.match_boxes(rb, rs, props[i][0].numpy(), props[i][1].numpy()) >= 0.995
+
+
+def test_postprocess_config1_from_golden_head():
+    """R10/R11 at the real size (17064 locations -> 10264 candidates -> NMS -> 2000), from the stored head."""
+    f = gu.load("case_config1.npz")
+    head = torch.from_numpy(f["head"])
+    hw = spec.level_sizes(800, 1024)
+    logits, reg, ctr, off = [], [], [], 0
+    for (h, w) in hw:
+        blk = head[:, off:off + h * w].permute(0, 2, 1).reshape(1, 6, h, w)
+        logits.append(blk[:, 0:1]), reg.append(blk[:, 1:5]), ctr.append(blk[:, 5:6])
+        off += h * w
+    (boxes, scores), = orc.fcos_postprocess(logits, reg, ctr, [(800, 1024)])
+    rb, rs = f["proposals.0.boxes"], f["proposals.0.scores"]
+    assert len(boxes) == len(rb) == 2000
+    assert gu.match_boxes(rb, rs, boxes.numpy(), scores.numpy()) >= 0.999
+
+
+def test_loss_and_gradients_match_reference(sd):
+    f = gu.load("train_small.npz")
+    B, H, W, S, qh, qw = gu.CASES["small"]
+    img, q = gu.case_inputs("small")
+    gts = synth.make_gt_boxes(B, H, W, seed=3, max_boxes=3)
+    np.testing.assert_array_equal(np.concatenate(gts, 0), f["gt_boxes"][:, 1:])
+    sd2 = {k: v.clone().requires_grad_(not spec.is_frozen(k)) for k, v in sd.items()}
+    o = orc.hot_path_forward(torch.from_numpy(img), torch.from_numpy(q), sd2, shots=S)
+    c, r, t, info = orc.fcos_loss(o["logits"], o["bbox_reg"], o["centerness"], gts, focal="cuda")
+    np.testing.assert_allclose([c.item(), r.item(), t.item()], f["losses_cuda_formula"], rtol=1e-5)
+    # CUDA formula vs the CPU formula the reference evaluates here: differ only by the 1e-6 epsilon
+    np.testing.assert_allclose(f["losses_cuda_formula"], f["losses_ref_cpu_formula"], rtol=2e-4)
+    assert info["num_pos"] == int(f["num_pos"])
+    np.testing.assert_array_equal(info["labels"].numpy().astype(np.int8), f["labels"])
+    (c + r + t).backward()
+    checked = 0
+    for key in f.files:
+        if key.startswith("fullgrad_oracle.") and key.endswith(".samples"):
+            k = key[len("fullgrad_oracle."):-len(".samples")]
+            g = sd2[k].grad.numpy().reshape(-1)
+            idx = gu.sample_indices(g.size, "grad." + k)[:256]
+            scale = float(f["fullgrad_oracle.%s.absmax" % k])
+            np.testing.assert_allclose(g[idx], f[key], rtol=1e-3, atol=1e-4 * scale, err_msg=k)
+            checked += 1
+    assert checked >= 16
