@@ -1,0 +1,165 @@
+/*
+ * oneshotdet_hip.h — C-ABI of liboneshotdet_hip.so: the MI355X (gfx950) kernels of the siamese-FCOS hot path.
+ *
+ * This is the drop-in boundary.  The reference's native plugin is the pybind11 module
+ * `maskrcnn_benchmark._C` (csrc/vision.cpp:7-15) plus the stock ATen ops its Python modules call; every entry
+ * point below names the reference interface it replaces (paths relative to /root/reference/maskrcnn_benchmark/).
+ *
+ * Conventions (all entry points):
+ *   - plain C types only: raw DEVICE pointers, ints, floats, an opaque stream handle (hipStream_t passed as void*);
+ *   - the CALLER allocates every output and workspace; the library never allocates, frees or synchronises;
+ *   - every call is asynchronous on `stream`; no host synchronisation anywhere (NMS returns a device-side count);
+ *   - return value 0 = OK; negative = error (OSD_ERR_*); osd_last_error_string() describes the last failure of the
+ *     calling thread;
+ *   - activations are NHWC ("channels last"), element type selected by `dtype`: OSD_F32 or OSD_BF16
+ *     (accumulation is always fp32); weights are packed by osd_pack_* into K-contiguous [Cout][R][S][Cin] rows.
+ */
+#ifndef ONESHOTDET_HIP_H
+#define ONESHOTDET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSD_F32 0
+#define OSD_BF16 1
+
+#define OSD_OK 0
+#define OSD_ERR_INVALID_ARG (-1)
+#define OSD_ERR_UNSUPPORTED (-2)
+#define OSD_ERR_LAUNCH (-3)
+#define OSD_ERR_WORKSPACE (-4)
+
+/* epilogue activation */
+#define OSD_ACT_NONE 0
+#define OSD_ACT_RELU 1
+#define OSD_ACT_EXP_SCALE 2 /* y = exp(act_scale * x): FCOSHead bbox_reg, modeling/rpn/fcos/fcos.py:95-97 */
+
+/* residual operand of the conv epilogue */
+#define OSD_RES_NONE 0
+#define OSD_RES_SAME 1   /* y += res[n,ho,wo,c]            Bottleneck `out += identity`, modeling/backbone/resnet.py:312 */
+#define OSD_RES_UP2X 2   /* y += res[n,ho/2,wo/2,c]        FPN top-down nearest 2x + add, modeling/backbone/fpn.py:59-64 */
+
+const char* osd_last_error_string(void);
+int osd_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Convolution (implicit GEMM on MFMA).  Replaces layers.Conv2d / nn.Conv2d (ATen conv2d) + FrozenBatchNorm2d
+ * (layers/batch_norm.py:19-24, folded into weight/bias by osd_pack_conv_weight) + relu_ + residual add as used by
+ * modeling/backbone/resnet.py:295-315,332-337, modeling/backbone/fpn.py:51-75,95-99 and modeling/rpn/fcos/fcos.py:89-97.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct osd_conv_desc {
+  int32_t dtype;          /* OSD_F32 | OSD_BF16: element type of x, w, res, y */
+  int32_t n, h, w;        /* input batch and spatial size (as stored) */
+  int32_t cin;            /* K elements per filter tap (multiple of 16 (f32) / 32 (bf16)) */
+  int32_t in_stride_n, in_stride_h, in_stride_w; /* input strides in ELEMENTS (in_stride_w = cin for dense NHWC) */
+  int32_t ho, wo, cout;   /* output spatial size and channels (cout multiple of 4) */
+  int32_t r, s;           /* filter taps */
+  int32_t stride_h, stride_w, pad_h, pad_w;
+  int32_t w_rows;         /* rows in the packed weight matrix (>= cout, zero padded) */
+  int32_t out_stride;     /* elements between consecutive output pixels (>= cout) */
+  int32_t res_mode;       /* OSD_RES_* */
+  int32_t res_h, res_w, res_stride; /* residual spatial size and pixel stride in elements */
+  int32_t act;            /* OSD_ACT_* */
+  float act_scale;
+  int32_t relu_in;        /* 1: apply ReLU to x while staging (P7 = conv(relu(P6)), fpn.py:98) */
+  int32_t gn_in;          /* 1: x' = relu(x * gn_a[n,c] + gn_b[n,c]) while staging (GroupNorm+ReLU of the previous tower conv,
+                             fcos.py:37-38 fused into the consumer); gn_a/gn_b are [n][cin] fp32 from osd_groupnorm_finalize */
+} osd_conv_desc;
+
+int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void* w, const float* bias, const void* res,
+                   const float* gn_a, const float* gn_b, void* y, void* stream);
+
+/* OIHW fp32 conv weight (+ optional per-Cout scale = FrozenBN weight*rsqrt(var), layers/batch_norm.py:20) ->
+ * packed [w_rows][r][s][cin_pad] rows of `dtype`, zero padded. */
+int osd_pack_conv_weight(const float* w_oihw, const float* scale, void* dst, int cout, int cin, int r, int s,
+                         int w_rows, int cin_pad, int dtype, void* stream);
+/* 7x7 stem weight [64][3][7][7] (BaseStem conv1, resnet.py:323-325) -> [w_rows][7][32] with (s, c) at s*4+c. */
+int osd_pack_stem_weight(const float* w_oihw, const float* scale, void* dst, int cout, int w_rows, int dtype,
+                         void* stream);
+/* NCHW fp32 image batch -> zero-padded NHWC4 [n][hp][wp][4] of `dtype` with the image at (pad_t, pad_l). Replaces the
+ * implicit zero padding of the stem conv (padding=3) and the layout change. */
+int osd_pack_image(const float* src_nchw, void* dst, int n, int h, int w, int hp, int wp, int pad_t, int pad_l,
+                   int dtype, void* stream);
+/* NHWC `dtype` [n][h][w][c] (pixel stride `stride`, first channel c0, c channels) -> NCHW fp32 (the reference's
+ * layout contract) */
+int osd_nhwc_to_nchw_f32(const void* src, float* dst, int n, int h, int w, int c, int stride, int c0, int dtype,
+                         void* stream);
+/* NCHW fp32 -> dense NHWC `dtype` */
+int osd_nchw_f32_to_nhwc(const float* src, void* dst, int n, int c, int h, int w, int dtype, void* stream);
+
+/* F.max_pool2d(kernel 3, stride 2, pad 1) of the stem, modeling/backbone/resnet.py:336.  NHWC. */
+int osd_maxpool3x3s2_fwd(const void* x, void* y, int n, int h, int w, int c, int ho, int wo, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * GroupNorm(32, C) + ReLU of the FCOS towers (nn.GroupNorm, modeling/rpn/fcos/fcos.py:37-38,46-47).
+ * stats: per (image, group) partial sum and sum of squares over an [n][hw][c] tensor ->
+ * ws[n][OSD_GN_SPLITS][groups][2] fp32 (deterministic two-stage reduction, no atomics); finalize: a[n][c] = gamma*rstd, b[n][c] = beta - mean*gamma*rstd; apply: y = relu(x*a + b).
+ * ---------------------------------------------------------------------------------------------------------------- */
+#define OSD_GN_SPLITS 64
+int osd_groupnorm_stats(const void* x, float* ws, int n, int hw, int c, int groups, int dtype, void* stream);
+int osd_groupnorm_finalize(const float* ws, const float* gamma, const float* beta, float* a, float* b, int n, int hw,
+                           int c, int groups, float eps, void* stream);
+int osd_groupnorm_relu_apply(const void* x, const float* a, const float* b, void* y, int n, int hw, int c, int dtype,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * ROIAlign forward.  Replaces _C.roi_align_forward (csrc/ROIAlign.h:11-25; csrc/cuda/ROIAlign_cuda.cu:65-122,257-290).
+ * x: NHWC [b][h][w][c]; rois: [r][5] fp32 (batch_idx, x1, y1, x2, y2); y: [r][ph][pw][c] fp32.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int osd_roialign_fwd(const void* x, const float* rois, float* y, int b, int h, int w, int c, int num_rois,
+                     float spatial_scale, int ph, int pw, int sampling_ratio, int dtype, void* stream);
+/* batch_pooling: mean over the `shots` queries of each target image (generalized_rcnn.py:100-104).
+ * x [b*shots][c] fp32 -> y [b][c] fp32 */
+int osd_shot_mean(const float* x, float* y, int b, int shots, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Query<->target correlation: y[n,h,w,c] = x[n,h,w,c] * q[n,c] (depthwise cross-correlation with a 1x1 query kernel),
+ * generalized_rcnn.py:307-311.  x, y NHWC `dtype`; q [n][c] fp32.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int osd_correlate_fwd(const void* x, const float* q, void* y, int n, int hw, int c, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Proposal pipeline (FCOSPostProcessor, modeling/rpn/fcos/inference.py:46-137,251-323) and NMS (_C.nms,
+ * csrc/nms.h:10-28, csrc/cuda/nms.cu:23-131), batched over images, no host sync.
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* score = sigmoid(cls)*sigmoid(ctr), decode + clip for one FPN level.  cls_ctr: [n][hw][cc_stride] (logit at +0,
+ * centerness at +1), reg: [n][hw][reg_stride] (l,t,r,b).  Writes scores[n][total_locs] and boxes[n][total_locs][4]
+ * at location offset `loc_offset` (fp32).  inference.py:53-79,104-117; locations fcos.py:220-234. */
+int osd_fcos_score_decode(const void* cls_ctr, const void* reg, float* scores, float* boxes, int n, int h, int w,
+                          int cc_stride, int reg_stride, int stride, int loc_offset, int total_locs, float img_h,
+                          float img_w, int dtype, void* stream);
+/* Per-level top-k of inference.py:97-102 (exact, by rank): within keys[img][lo .. lo+cnt) keep the `topn` largest
+ * (ties: lower index first), write key -1 for the rest.  keys_in/keys_out: [n][total] fp32 (may alias). */
+int osd_level_topk(const float* keys_in, float* keys_out, int n, int total, int lo, int cnt, int topn, void* stream);
+/* Sort the live (key >= 0) candidates of each image by (key descending, index ascending) and gather their boxes:
+ * boxes_sorted [n][max_count][4], scores_sorted [n][max_count], idx_sorted [n][max_count] (original index),
+ * counts [n] (live candidates, written by the call).  Replaces scores.sort(descending) + index_select of
+ * csrc/cuda/nms.cu:73-75. */
+int osd_rank_sort_gather(const float* keys, const float* boxes, int n, int total, int max_count, float* boxes_sorted,
+                         float* scores_sorted, int32_t* idx_sorted, int32_t* counts, void* stream);
+/* Greedy NMS over boxes ALREADY SORTED by descending score, per image, stopping after max_keep survivors
+ * (= boxlist_nms + the post-NMS top-n of inference.py:316-321).  mask_ws: osd_nms_workspace_bytes(n, max_count)
+ * bytes.  out_boxes [n][max_keep][4], out_scores [n][max_keep], out_pos [n][max_keep] (position in the sorted
+ * list), out_count [n].  Suppression rule: IoU > thresh when cuda_semantics != 0 (csrc/cuda/nms.cu:60) else
+ * IoU >= thresh (csrc/cpu/nms_cpu.cpp:60); "+1" areas as in both. */
+int osd_nms_sorted(const float* boxes_sorted, const float* scores_sorted, const int32_t* counts, int n, int max_count,
+                   float thresh, int cuda_semantics, int max_keep, uint64_t* mask_ws, float* out_boxes,
+                   float* out_scores, int32_t* out_pos, int32_t* out_count, void* stream);
+int64_t osd_nms_workspace_bytes(int n, int max_count);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Sigmoid focal loss.  Replaces _C.sigmoid_focalloss_forward/backward (csrc/SigmoidFocalLoss.h;
+ * csrc/cuda/SigmoidFocalLoss_cuda.cu:21-58,62-101).  logits [m][classes] fp32, targets [m] int32.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int osd_sigmoid_focal_fwd(const float* logits, const int32_t* targets, float* losses, int m, int classes, float gamma,
+                          float alpha, void* stream);
+int osd_sigmoid_focal_bwd(const float* logits, const int32_t* targets, const float* d_losses, float* d_logits, int m,
+                          int classes, float gamma, float alpha, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ONESHOTDET_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of liboneshotdet_hip.so (C-ABI declared in include/oneshotdet_hip.h).
+
+There is NO fallback: if the library is missing or fails to load, every op raises.  (The oracle under oracle/ is test
+infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liboneshotdet_hip.so")
+
+OSD_F32, OSD_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_EXP_SCALE = 0, 1, 2
+RES_NONE, RES_SAME, RES_UP2X = 0, 1, 2
+GN_SPLITS = 64
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "n", "h", "w", "cin", "in_stride_n", "in_stride_h", "in_stride_w", "ho", "wo", "cout", "r", "s",
+        "stride_h", "stride_w", "pad_h", "pad_w", "w_rows", "out_stride", "res_mode", "res_h", "res_w", "res_stride",
+        "act")] + [("act_scale", C.c_float), ("relu_in", C.c_int32), ("gn_in", C.c_int32)]
+
+
+_p, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> (restype, argtypes); must list every symbol declared in include/oneshotdet_hip.h
+SIGNATURES = {
+    "osd_last_error_string": (C.c_char_p, []),
+    "osd_abi_version": (_i, []),
+    "osd_conv2d_fwd": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
+    "osd_pack_conv_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "osd_pack_stem_weight": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "osd_pack_image": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "osd_nhwc_to_nchw_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "osd_nchw_f32_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "osd_maxpool3x3s2_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "osd_groupnorm_stats": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "osd_groupnorm_finalize": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "osd_groupnorm_relu_apply": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "osd_roialign_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _p]),
+    "osd_shot_mean": (_i, [_p, _p, _i, _i, _i, _p]),
+    "osd_correlate_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "osd_fcos_score_decode": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "osd_level_topk": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "osd_rank_sort_gather": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "osd_nms_sorted": (_i, [_p, _p, _p, _i, _i, _f, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "osd_nms_workspace_bytes": (_i64, [_i, _i]),
+    "osd_sigmoid_focal_fwd": (_i, [_p, _p, _p, _i, _i, _f, _f, _p]),
+    "osd_sigmoid_focal_bwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _f, _p]),
+}
+
+_lib = None
+
+
+class OsdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  torch must be imported first so that libamdhip64.so.7 resolves to the HIP runtime
+    PyTorch already loaded (one runtime per process: streams and device pointers are shared with torch)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OsdError("liboneshotdet_hip.so not built (%s missing): run `python -m oneshotdet_amd.build` or "
+                       "__graft_entry__.build(); there is no CPU/eager fallback" % LIB_PATH)
+    import torch  # noqa: F401  (loads libamdhip64 first)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().osd_last_error_string()
+        raise OsdError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

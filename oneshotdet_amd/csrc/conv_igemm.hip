@@ -1,0 +1,361 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4) on MFMA — the K1/K2/K6 kernel family of SURVEY.md §2.1.
+//
+// GEMM view (per launch):  Y[m][co] = sum_k X[m @ tap(k)][ci(k)] * Wp[co][k],   m = (n, ho, wo),  k = (r, s, ci)
+//   * activations are NHWC, so for one filter tap the Cin run of a pixel is contiguous: a K-slice of one stage is a
+//     64- or 128-byte contiguous run per output pixel (im2col on the fly, never materialised);
+//   * weights are pre-packed [Cout][R][S][Cin] (K contiguous) with FrozenBN folded in (osd_pack_conv_weight);
+//   * MFMA operands are swapped: the WEIGHT tile is the MFMA "A" operand (rows = output channels) and the PIXEL
+//     tile the "B" operand (columns = pixels).  A lane's 4 accumulator registers are then 4 consecutive output
+//     channels of ONE pixel, i.e. one 16-byte (fp32) / 8-byte (bf16) NHWC store, and the epilogue (bias, residual /
+//     nearest-2x top-down add, ReLU / exp) is applied in registers;
+//   * both tiles live in LDS as [row][K bytes] rows of KB = 64 or 128 bytes with a 16-byte-chunk XOR swizzle that
+//     makes every ds_read_b128 fragment read and every ds_write_b128 staging write bank-conflict free
+//     (checked exhaustively against the gfx950 lane-group/bank rules);
+//   * fp32 uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains) with the k index permuted inside each 16-wide k block
+//     so one 16-byte LDS read feeds 4 MFMAs; bf16 uses v_mfma_f32_16x16x32_bf16 (8 k per lane = one 16-byte read);
+//   * global -> register -> LDS staging, issued one K-stage ahead of the MFMAs (two LDS buffers, one barrier per
+//     stage); zero padding and the M tail are handled by predicating the 16-byte loads;
+//   * 1-D grid remapped so consecutive tiles (sharing the same pixel rows / halo) land on the same XCD's L2.
+#include "osd_common.h"
+
+namespace {
+
+struct ConvKParams {
+  const void* x;
+  const void* w;
+  const float* bias;
+  const void* res;
+  void* y;
+  int H, W, Cin, sN, sH, sW;
+  int Ho, Wo, Cout, HoWo;
+  int R, S, sh, sw, ph, pw;
+  int w_rows, Ktot, out_stride;
+  int res_mode, res_h, res_w, res_stride;
+  int act;
+  float act_scale;
+  int relu_in;
+  int M, tilesM, tilesN, KT;
+};
+
+template <int KB> __device__ __forceinline__ int swz(int row, int chunk) {
+  if constexpr (KB == 64) {
+    return row * 64 + ((chunk ^ ((-(row >> 2)) & 3)) << 4);
+  } else {
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+  }
+}
+
+__device__ __forceinline__ uint4 relu_chunk(uint4 v, float) {
+  float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = fmaxf(f[i], 0.f);
+  return v;
+}
+__device__ __forceinline__ uint4 relu_chunk(uint4 v, __bf16) {
+  unsigned* u = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] &= ~(((u[i] >> 15) & 0x00010001u) * 0xFFFFu);
+  return v;
+}
+
+template <typename T, int BM, int BN, int KB, int WM, int WN>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(ConvKParams p) {
+  constexpr int CH = KB / 16;                 // 16-byte chunks per tile row
+  constexpr int EPC = 16 / (int)sizeof(T);    // elements per chunk
+  constexpr int BKE = KB / (int)sizeof(T);    // K elements per stage
+  constexpr int RPP = 256 / CH;               // tile rows staged per pass of the 256 threads
+  constexpr int PA = (BM + RPP - 1) / RPP;
+  constexpr int PB = (BN + RPP - 1) / RPP;
+  constexpr int TM = BM / WM / 16;            // 16-pixel MFMA tiles per wave
+  constexpr int TN = BN / WN / 16;            // 16-channel MFMA tiles per wave
+  constexpr int STAGE = (BM + BN) * KB;
+  static_assert(WM * WN == 4, "4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // XCD-aware bijective remap: blocks b and b+8 share an XCD, give each XCD a contiguous run of tiles.
+  int t;
+  {
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = t % p.tilesN, tile_m = t / p.tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+
+  // ---- per-thread staging coordinates (fixed across K stages) ----
+  const int srow = tid / CH;       // row within a pass
+  const int schunk = tid % CH;     // 16-byte chunk within the row
+  const T* a_ptr[PA];
+  int a_hi0[PA], a_wi0[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = i * RPP + srow;
+    const int m = m0 + row;
+    if (row < BM && m < p.M) {
+      const int n_img = m / p.HoWo;
+      const int rem = m - n_img * p.HoWo;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      a_ptr[i] = xg + (size_t)n_img * p.sN + schunk * EPC;
+      a_hi0[i] = ho * p.sh - p.ph;
+      a_wi0[i] = wo * p.sw - p.pw;
+    } else {
+      a_ptr[i] = xg;
+      a_hi0[i] = -0x40000000;
+      a_wi0[i] = 0;
+    }
+  }
+  const T* b_ptr[PB];
+  bool b_ok[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int row = i * RPP + srow;
+    b_ok[i] = (row < BN) && (n0 + row < p.w_rows);
+    b_ptr[i] = wg + (size_t)(b_ok[i] ? (n0 + row) : 0) * p.Ktot + schunk * EPC;
+  }
+
+  uint4 a_reg[PA], b_reg[PB];
+  int kr = 0, ks = 0, kc = 0;  // filter row, filter col, channel offset of the NEXT stage to load
+
+  auto load_stage = [&](int kt) {
+    const int hoff = kr, woff = ks, c0 = kc;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int hi = a_hi0[i] + hoff, wi = a_wi0[i] + woff;
+      const bool ok = ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) v = *reinterpret_cast<const uint4*>(a_ptr[i] + (hi * p.sH + wi * p.sW + c0));
+      a_reg[i] = v;
+    }
+    const int koff = kt * BKE;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b_ok[i]) v = *reinterpret_cast<const uint4*>(b_ptr[i] + koff);
+      b_reg[i] = v;
+    }
+    kc += BKE;
+    if (kc >= p.Cin) {
+      kc = 0;
+      if (++ks >= p.S) { ks = 0; ++kr; }
+    }
+  };
+
+  auto store_stage = [&](int buf) {
+    char* xs = smem + buf * STAGE;
+    char* ws = xs + BM * KB;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int row = i * RPP + srow;
+      if (row < BM) {
+        uint4 v = a_reg[i];
+        if (p.relu_in) v = relu_chunk(v, T());
+        *reinterpret_cast<uint4*>(xs + swz<KB>(row, schunk)) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int row = i * RPP + srow;
+      if (row < BN) *reinterpret_cast<uint4*>(ws + swz<KB>(row, schunk)) = b_reg[i];
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;   // row of the 16-row fragment this lane reads
+  const int fkq = lane >> 4;    // 16-byte k chunk (0..3) within a 64-byte k block
+
+  auto compute_stage = [&](int buf) {
+    const char* xs = smem + buf * STAGE;
+    const char* ws = xs + BM * KB;
+#pragma unroll
+    for (int kb = 0; kb < KB / 64; ++kb) {
+      uint4 wf[TN], xf[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        wf[i] = *reinterpret_cast<const uint4*>(ws + swz<KB>((wn * TN + i) * 16 + frow, kb * 4 + fkq));
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        xf[j] = *reinterpret_cast<const uint4*>(xs + swz<KB>((wm * TM + j) * 16 + frow, kb * 4 + fkq));
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&wf[i]),
+                                                                *reinterpret_cast<const bf16x8*>(&xf[j]), acc[i][j],
+                                                                0, 0, 0);
+          } else {
+            const float* a = reinterpret_cast<const float*>(&wf[i]);
+            const float* b = reinterpret_cast<const float*>(&xf[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
+  // ---- main loop: stage kt+1 is fetched from HBM/L2 while stage kt is multiplied ----
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int kt = 0; kt < p.KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < p.KT) load_stage(kt + 1);
+    compute_stage(cur);
+    if (kt + 1 < p.KT) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias (+ residual) (+ activation), 4 consecutive channels of one pixel per lane and tile ----
+  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+  const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + (wm * TM + j) * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    size_t res_off = 0;
+    if (p.res_mode == OSD_RES_SAME) {
+      res_off = (size_t)m * p.res_stride;
+    } else if (p.res_mode == OSD_RES_UP2X) {
+      const int n_img = m / p.HoWo;
+      const int rem = m - n_img * p.HoWo;
+      const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
+      res_off = ((size_t)(n_img * p.res_h + (ho >> 1)) * p.res_w + (wo >> 1)) * p.res_stride;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int c = n0 + (wn * TN + i) * 16 + (lane >> 4) * 4;
+      if (c >= p.Cout) continue;
+      const float4 bv = *reinterpret_cast<const float4*>(p.bias + c);
+      float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+      if (p.res_mode != OSD_RES_NONE) {
+        if constexpr (sizeof(T) == 2) {
+          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rg + res_off + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+        } else {
+          const float4 rv = *reinterpret_cast<const float4*>(rg + res_off + c);
+          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        }
+      }
+      if (p.act == OSD_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == OSD_ACT_EXP_SCALE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = expf(v[e] * p.act_scale);
+      }
+      T* dst = yg + (size_t)m * p.out_stride + c;
+      if constexpr (sizeof(T) == 2) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+        *reinterpret_cast<bf16x4*>(dst) = o;
+      } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int KB, int WM, int WN>
+int launch_conv(const ConvKParams& pin, hipStream_t stream) {
+  ConvKParams p = pin;
+  p.tilesM = cdiv(p.M, BM);
+  p.tilesN = cdiv(p.Cout, BN);
+  constexpr int BKE = KB / (int)sizeof(T);
+  if (p.Cin % BKE != 0) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: cin %d not a multiple of %d", p.Cin, BKE);
+  p.KT = p.Ktot / BKE;
+  constexpr int lds = 2 * (BM + BN) * KB;
+  auto kern = conv_igemm_kernel<T, BM, BN, KB, WM, WN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  const long long nblocks = (long long)p.tilesM * p.tilesN;
+  if (nblocks <= 0 || nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad grid");
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds, stream, p);
+  return osd_check_launch("conv_igemm");
+}
+
+// tile ids: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x16
+template <typename T, int KB>
+int dispatch_tile(int tile, const ConvKParams& p, hipStream_t s) {
+  switch (tile) {
+    case 0: return launch_conv<T, 128, 128, KB, 2, 2>(p, s);
+    case 1: return launch_conv<T, 128, 64, KB, 4, 1>(p, s);
+    case 2: return launch_conv<T, 64, 64, KB, 2, 2>(p, s);
+    case 3: return launch_conv<T, 256, 16, KB, 4, 1>(p, s);
+  }
+  return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad tile id %d", tile);
+}
+
+int choose_tile(int M, int cout) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("OSD_CONV_TILE");
+    forced = e ? atoi(e) : -1;
+  }
+  if (forced >= 0) return forced;
+  if (cout <= 16) return 3;
+  const long long t128 = (long long)cdiv(M, 128) * cdiv(cout, 128);
+  if (cout % 128 == 0 && t128 >= 512) return 0;
+  const long long t12864 = (long long)cdiv(M, 128) * cdiv(cout, 64);
+  if (t12864 >= 512) return 1;
+  return 2;
+}
+
+}  // namespace
+
+extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void* w, const float* bias,
+                              const void* res, const float* gn_a, const float* gn_b, void* y, void* stream) {
+  if (!d || !x || !w || !bias || !y) return osd_fail(OSD_ERR_INVALID_ARG, "conv: null argument");
+  if (d->gn_in) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: gn_in fusion not available in this build");
+  (void)gn_a; (void)gn_b;
+  if (d->cout % 4 != 0 || d->out_stride % 4 != 0)
+    return osd_fail(OSD_ERR_INVALID_ARG, "conv: cout/out_stride must be multiples of 4 (got %d/%d)", d->cout,
+                    d->out_stride);
+  if (d->res_mode != OSD_RES_NONE && (!res || d->res_stride % 4 != 0))
+    return osd_fail(OSD_ERR_INVALID_ARG, "conv: residual requested without a valid residual tensor");
+  if (d->w_rows < d->cout) return osd_fail(OSD_ERR_INVALID_ARG, "conv: w_rows < cout");
+  const int epc = d->dtype == OSD_BF16 ? 8 : 4;
+  if (d->in_stride_w % epc || d->in_stride_h % epc || d->in_stride_n % epc)
+    return osd_fail(OSD_ERR_INVALID_ARG, "conv: input strides must keep 16-byte alignment");
+  ConvKParams p;
+  p.x = x; p.w = w; p.bias = bias; p.res = res; p.y = y;
+  p.H = d->h; p.W = d->w; p.Cin = d->cin; p.sN = d->in_stride_n; p.sH = d->in_stride_h; p.sW = d->in_stride_w;
+  p.Ho = d->ho; p.Wo = d->wo; p.Cout = d->cout; p.HoWo = d->ho * d->wo;
+  p.R = d->r; p.S = d->s; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
+  p.w_rows = d->w_rows; p.Ktot = d->r * d->s * d->cin; p.out_stride = d->out_stride;
+  p.res_mode = d->res_mode; p.res_h = d->res_h; p.res_w = d->res_w; p.res_stride = d->res_stride;
+  p.act = d->act; p.act_scale = d->act_scale; p.relu_in = d->relu_in;
+  const long long M = (long long)d->n * d->ho * d->wo;
+  if (M <= 0 || M > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad M");
+  p.M = (int)M; p.tilesM = p.tilesN = p.KT = 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int tile = choose_tile(p.M, p.Cout);
+  if (d->dtype == OSD_F32) {
+    return dispatch_tile<float, 64>(tile, p, s);
+  } else if (d->dtype == OSD_BF16) {
+    if (d->cin % 64 == 0) return dispatch_tile<__bf16, 128>(tile, p, s);
+    return dispatch_tile<__bf16, 64>(tile, p, s);
+  }
+  return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad dtype %d", d->dtype);
+}

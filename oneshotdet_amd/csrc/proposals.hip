@@ -1,0 +1,267 @@
+// Proposal pipeline on device, batched over images, no host synchronisation (K9 / K7 of SURVEY.md §2.1):
+//   score+decode+clip  ->  per-level top-k (exact, by rank)  ->  global descending order (exact, by rank)
+//   ->  64x64-tile IoU bitmask (upper triangle)  ->  single-workgroup greedy scan with early exit at max_keep.
+// Ordering is by (score descending, original index ascending): deterministic where the reference's topk/sort leave
+// ties unspecified.  Rank sorting is O(n^2) compares but n <= 17064 per image (2.9e8 compares, ~0.1 ms) and it is
+// exact, branch-free and needs no scratch memory or multi-pass radix machinery.
+#include "osd_common.h"
+
+namespace {
+
+// ---- score = sigmoid(cls) * sigmoid(ctr); box = location -/+ distances, clipped  (fcos/inference.py:53-117) ----
+template <typename T>
+__global__ void fcos_score_decode_kernel(const T* __restrict__ cls_ctr, const T* __restrict__ reg, float* __restrict__ scores,
+                                         float* __restrict__ boxes, int h, int w, int cc_stride, int reg_stride, int stride,
+                                         int loc_offset, int total_locs, float img_h, float img_w) {
+  const int img = blockIdx.y;
+  const int hw = h * w;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+    const size_t pix = (size_t)img * hw + i;
+    const float lg = to_f32(cls_ctr[pix * cc_stride + 0]);
+    const float ct = to_f32(cls_ctr[pix * cc_stride + 1]);
+    const float p = 1.f / (1.f + expf(-lg));
+    const float pc = 1.f / (1.f + expf(-ct));
+    // candidate test `sigmoid(cls) > pre_nms_thresh (= 0)` of inference.py:72: a sigmoid that underflows to 0 is dropped
+    const float score = p > 0.f ? p * pc : -1.f;
+    const int y = i / w, x = i - y * w;
+    const float lx = (float)(x * stride + stride / 2), ly = (float)(y * stride + stride / 2);   // fcos.py:220-234
+    const float l = to_f32(reg[pix * reg_stride + 0]), t = to_f32(reg[pix * reg_stride + 1]);
+    const float r = to_f32(reg[pix * reg_stride + 2]), b = to_f32(reg[pix * reg_stride + 3]);
+    const float x1 = fminf(fmaxf(lx - l, 0.f), img_w - 1.f), y1 = fminf(fmaxf(ly - t, 0.f), img_h - 1.f);
+    const float x2 = fminf(fmaxf(lx + r, 0.f), img_w - 1.f), y2 = fminf(fmaxf(ly + b, 0.f), img_h - 1.f);
+    const size_t o = (size_t)img * total_locs + loc_offset + i;
+    scores[o] = score;
+    *reinterpret_cast<float4*>(boxes + o * 4) = make_float4(x1, y1, x2, y2);
+  }
+}
+
+// key order: a before b  <=>  ka > kb || (ka == kb && ia < ib)
+__device__ __forceinline__ int before(float kj, int j, float ki, int i) { return (kj > ki) || (kj == ki && j < i); }
+
+// ---- per-level top-k: keys of one level [lo, lo+cnt) ; elements whose rank within the level >= topn get key -1 ----
+__global__ void __launch_bounds__(256) level_topk_kernel(const float* __restrict__ keys_in, float* __restrict__ keys_out,
+                                                         int total, int lo, int cnt, int topn) {
+  __shared__ float tile[1024];
+  const int img = blockIdx.y;
+  const float* k = keys_in + (size_t)img * total + lo;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float ki = i < cnt ? k[i] : 0.f;
+  int rank = 0;
+  for (int j0 = 0; j0 < cnt; j0 += 1024) {
+    const int m = min(1024, cnt - j0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < m; t += blockDim.x) tile[t] = k[j0 + t];
+    __syncthreads();
+    for (int t = 0; t < m; ++t) rank += before(tile[t], j0 + t, ki, i);
+  }
+  if (i < cnt) keys_out[(size_t)img * total + lo + i] = (rank < topn && ki >= 0.f) ? ki : -1.f;
+}
+
+// ---- global rank sort + gather: position of element i = #elements before it; dropped elements (key < 0) skipped ----
+__global__ void __launch_bounds__(256) rank_sort_gather_kernel(const float* __restrict__ keys, const float* __restrict__ boxes,
+                                                               int total, int max_count, float* __restrict__ boxes_sorted,
+                                                               float* __restrict__ scores_sorted, int* __restrict__ idx_sorted,
+                                                               int* __restrict__ counts) {
+  __shared__ float tile[1024];
+  const int img = blockIdx.y;
+  const float* k = keys + (size_t)img * total;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float ki = i < total ? k[i] : -1.f;
+  int rank = 0;
+  for (int j0 = 0; j0 < total; j0 += 1024) {
+    const int m = min(1024, total - j0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < m; t += blockDim.x) tile[t] = k[j0 + t];
+    __syncthreads();
+    for (int t = 0; t < m; ++t) rank += before(tile[t], j0 + t, ki, i);
+  }
+  const bool live = (i < total) && (ki >= 0.f) && (rank < max_count);
+  if (live) {
+    const size_t o = (size_t)img * max_count + rank;
+    *reinterpret_cast<float4*>(boxes_sorted + o * 4) =
+        *reinterpret_cast<const float4*>(boxes + ((size_t)img * total + i) * 4);
+    scores_sorted[o] = ki;
+    idx_sorted[o] = i;
+  }
+  const unsigned long long b = __ballot(live);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(counts + img, __popcll(b));
+}
+
+// ---- IoU bitmask, "+1" areas (csrc/cuda/nms.cu:13-21).  One wavefront = one 64-box row block x one column block ----
+__device__ __forceinline__ float iou_plus1(const float4 a, const float4 b) {
+  const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
+  const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+  const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
+  const float inter = width * height;
+  const float sa = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
+  const float sb = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+  return inter / (sa + sb - inter);
+}
+
+__global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
+                                                      int max_count, int col_blocks, float thresh, int gt_rule,
+                                                      unsigned long long* __restrict__ mask) {
+  const int img = blockIdx.z, row_b = blockIdx.y, col_b = blockIdx.x;
+  if (col_b < row_b) return;                     // lower triangle is never read by the scan
+  const int n = counts[img];
+  if (row_b * 64 >= n || col_b * 64 >= n) return;
+  __shared__ float4 cb[64];
+  const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)img * max_count;
+  const int lane = threadIdx.x;
+  const int col_size = min(64, n - col_b * 64);
+  if (lane < col_size) cb[lane] = bx[col_b * 64 + lane];
+  __syncthreads();
+  const int i = row_b * 64 + lane;
+  if (i < n) {
+    const float4 me = bx[i];
+    unsigned long long bits = 0;
+    const int start = (row_b == col_b) ? lane + 1 : 0;
+    for (int j = start; j < col_size; ++j) {
+      const float v = iou_plus1(me, cb[j]);
+      const bool hit = gt_rule ? (v > thresh) : (v >= thresh);
+      if (hit) bits |= 1ULL << j;
+    }
+    mask[((size_t)img * max_count + i) * col_blocks + col_b] = bits;
+  }
+}
+
+// ---- greedy scan: one workgroup per image walks the 64-box blocks in score order ----
+__global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                       const int* __restrict__ counts, int max_count, int col_blocks,
+                                                       int max_keep, const unsigned long long* __restrict__ mask,
+                                                       float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                       int* __restrict__ out_pos, int* __restrict__ out_count) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* remv = reinterpret_cast<unsigned long long*>(smem);   // [col_blocks]
+  __shared__ unsigned long long s_keep;
+  __shared__ int s_kept[2];   // double-buffered so the next block's writer cannot race this block's readers
+  const int img = blockIdx.x;
+  const int n = counts[img];
+  const int nblk = (n + 63) / 64;
+  const unsigned long long* mk = mask + (size_t)img * max_count * col_blocks;
+  for (int c = threadIdx.x; c < col_blocks; c += blockDim.x) remv[c] = 0ULL;
+  if (threadIdx.x == 0) s_kept[0] = 0;
+  __syncthreads();
+  int blk = 0;
+  for (; blk < nblk; ++blk) {
+    const int kept_before = s_kept[blk & 1];
+    if (kept_before >= max_keep) break;
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      const int i = blk * 64 + lane;
+      const unsigned long long diag = (i < n) ? mk[(size_t)i * col_blocks + blk] : 0ULL;
+      const int valid = min(64, n - blk * 64);
+      unsigned long long alive = ~remv[blk];
+      if (valid < 64) alive &= (1ULL << valid) - 1ULL;
+      for (int l = 0; l < 64; ++l) {
+        const unsigned long long d = __shfl(diag, l);
+        if ((alive >> l) & 1ULL) alive &= ~d;
+      }
+      // cap at max_keep: keep only the first (max_keep - kept_before) survivors
+      int room = max_keep - kept_before;
+      unsigned long long keep = alive;
+      if (__popcll(keep) > room) {
+        unsigned long long trimmed = 0ULL;
+        for (int l = 0; l < 64 && room > 0; ++l)
+          if ((keep >> l) & 1ULL) { trimmed |= 1ULL << l; --room; }
+        keep = trimmed;
+      }
+      if ((keep >> lane) & 1ULL) {
+        const int o = kept_before + __popcll(keep & ((1ULL << lane) - 1ULL));
+        const size_t src = (size_t)img * max_count + i, dst = (size_t)img * max_keep + o;
+        *reinterpret_cast<float4*>(out_boxes + dst * 4) = *reinterpret_cast<const float4*>(boxes + src * 4);
+        out_scores[dst] = scores[src];
+        out_pos[dst] = i;
+      }
+      if (lane == 0) {
+        s_keep = keep;
+        s_kept[(blk + 1) & 1] = kept_before + __popcll(keep);
+      }
+    }
+    __syncthreads();
+    const unsigned long long keep = s_keep;
+    for (int c = blk + 1 + threadIdx.x; c < nblk; c += blockDim.x) {
+      unsigned long long acc = 0ULL, bits = keep;
+      while (bits) {
+        const int l = __ffsll((long long)bits) - 1;
+        bits &= bits - 1ULL;
+        acc |= mk[(size_t)(blk * 64 + l) * col_blocks + c];
+      }
+      remv[c] |= acc;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_count[img] = s_kept[blk & 1];
+}
+
+}  // namespace
+
+#define OSD_STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int osd_fcos_score_decode(const void* cls_ctr, const void* reg, float* scores, float* boxes, int n, int h,
+                                     int w, int cc_stride, int reg_stride, int stride, int loc_offset, int total_locs,
+                                     float img_h, float img_w, int dtype, void* stream) {
+  if (!cls_ctr || !reg || !scores || !boxes) return osd_fail(OSD_ERR_INVALID_ARG, "score_decode: null argument");
+  if (n == 0 || h * w == 0) return OSD_OK;
+  dim3 grid(cdiv(h * w, 256), n);
+  if (dtype == OSD_F32)
+    hipLaunchKernelGGL(fcos_score_decode_kernel<float>, grid, dim3(256), 0, OSD_STREAM(stream), (const float*)cls_ctr,
+                       (const float*)reg, scores, boxes, h, w, cc_stride, reg_stride, stride, loc_offset, total_locs, img_h,
+                       img_w);
+  else if (dtype == OSD_BF16)
+    hipLaunchKernelGGL(fcos_score_decode_kernel<__bf16>, grid, dim3(256), 0, OSD_STREAM(stream), (const __bf16*)cls_ctr,
+                       (const __bf16*)reg, scores, boxes, h, w, cc_stride, reg_stride, stride, loc_offset, total_locs, img_h,
+                       img_w);
+  else
+    return osd_fail(OSD_ERR_INVALID_ARG, "score_decode: bad dtype");
+  return osd_check_launch("fcos_score_decode");
+}
+
+extern "C" int osd_level_topk(const float* keys_in, float* keys_out, int n, int total, int lo, int cnt, int topn,
+                              void* stream) {
+  if (!keys_in || !keys_out || lo < 0 || lo + cnt > total) return osd_fail(OSD_ERR_INVALID_ARG, "level_topk: bad args");
+  if (n == 0 || cnt == 0) return OSD_OK;
+  hipLaunchKernelGGL(level_topk_kernel, dim3(cdiv(cnt, 256), n), dim3(256), 0, OSD_STREAM(stream), keys_in, keys_out, total,
+                     lo, cnt, topn);
+  return osd_check_launch("level_topk");
+}
+
+extern "C" int osd_rank_sort_gather(const float* keys, const float* boxes, int n, int total, int max_count,
+                                    float* boxes_sorted, float* scores_sorted, int32_t* idx_sorted, int32_t* counts,
+                                    void* stream) {
+  if (!keys || !boxes || !boxes_sorted || !scores_sorted || !idx_sorted || !counts)
+    return osd_fail(OSD_ERR_INVALID_ARG, "rank_sort_gather: null argument");
+  if (n == 0) return OSD_OK;
+  hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * n, OSD_STREAM(stream));
+  if (e != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "rank_sort_gather: memset: %s", hipGetErrorString(e));
+  if (total == 0) return OSD_OK;
+  hipLaunchKernelGGL(rank_sort_gather_kernel, dim3(cdiv(total, 256), n), dim3(256), 0, OSD_STREAM(stream), keys, boxes,
+                     total, max_count, boxes_sorted, scores_sorted, idx_sorted, counts);
+  return osd_check_launch("rank_sort_gather");
+}
+
+extern "C" int64_t osd_nms_workspace_bytes(int n, int max_count) {
+  return (int64_t)n * max_count * cdiv(max_count, 64) * 8;
+}
+
+extern "C" int osd_nms_sorted(const float* boxes_sorted, const float* scores_sorted, const int32_t* counts, int n,
+                              int max_count, float thresh, int cuda_semantics, int max_keep, uint64_t* mask_ws,
+                              float* out_boxes, float* out_scores, int32_t* out_pos, int32_t* out_count, void* stream) {
+  if (!boxes_sorted || !scores_sorted || !counts || !mask_ws || !out_boxes || !out_scores || !out_pos || !out_count)
+    return osd_fail(OSD_ERR_INVALID_ARG, "nms_sorted: null argument");
+  if (n == 0) return OSD_OK;
+  if (max_count == 0) {
+    hipError_t e = hipMemsetAsync(out_count, 0, sizeof(int32_t) * n, OSD_STREAM(stream));
+    return e == hipSuccess ? OSD_OK : osd_fail(OSD_ERR_LAUNCH, "nms_sorted: memset failed");
+  }
+  const int col_blocks = cdiv(max_count, 64);
+  if ((size_t)col_blocks * 8 > 60000) return osd_fail(OSD_ERR_UNSUPPORTED, "nms_sorted: max_count %d too large", max_count);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks, n), dim3(64), 0, OSD_STREAM(stream), boxes_sorted, counts,
+                     max_count, col_blocks, thresh, cuda_semantics, reinterpret_cast<unsigned long long*>(mask_ws));
+  int rc = osd_check_launch("nms_mask");
+  if (rc) return rc;
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8, OSD_STREAM(stream), boxes_sorted, scores_sorted,
+                     counts, max_count, col_blocks, max_keep, reinterpret_cast<const unsigned long long*>(mask_ws), out_boxes,
+                     out_scores, out_pos, out_count);
+  return osd_check_launch("nms_scan");
+}

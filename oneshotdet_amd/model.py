@@ -1,0 +1,206 @@
+"""Host side of the siamese-FCOS hot path on MI355X: weight packing and kernel sequencing.
+
+Mirrors, function for function, the reference call stack of SURVEY.md §3.1:
+  GeneralizedRCNN.forward (modeling/detector/generalized_rcnn.py:226-312)
+    backbone / supp_backbone  = Sequential(ResNet body, FPN)   (modeling/backbone/backbone.py:51-72)
+    supp_pooling + batch_pooling + correlation                   (generalized_rcnn.py:297-311)
+    rpn = FCOSModule: FCOSHead + FCOSPostProcessor               (modeling/rpn/fcos/fcos.py, inference.py)
+All tensors between kernels are NHWC; state_dict names and OIHW shapes are the reference's (oneshotdet_amd/spec.py).
+"""
+import torch
+
+from . import ops, spec
+from .ops import ACT_EXP_SCALE, ACT_NONE, ACT_RELU, RES_SAME, RES_UP2X
+
+
+def _bn(sd, p):
+    return (sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"])
+
+
+class BackboneWeights(object):
+    """Packed weights of one ResNet-50-FPN (resnet.py:80-145, fpn.py:28-41,82-94)."""
+
+    def __init__(self, sd, prefix, dtype):
+        b = prefix + "body."
+        self.stem = ops.pack_conv(sd[b + "stem.conv1.weight"], bn=_bn(sd, b + "stem.bn1"), dtype=dtype, stem=True)
+        self.blocks = []
+        for si, nblocks in enumerate(spec.STAGE_BLOCKS):
+            for bi in range(nblocks):
+                p = "%slayer%d.%d." % (b, si + 1, bi)
+                blk = {"stride": 2 if (bi == 0 and si > 0) else 1, "ds": None}
+                if (p + "downsample.0.weight") in sd:
+                    blk["ds"] = ops.pack_conv(sd[p + "downsample.0.weight"], bn=_bn(sd, p + "downsample.1"), dtype=dtype)
+                for i in (1, 2, 3):
+                    blk["c%d" % i] = ops.pack_conv(sd["%sconv%d.weight" % (p, i)], bn=_bn(sd, "%sbn%d" % (p, i)),
+                                                   dtype=dtype)
+                blk["last_of_stage"] = bi == nblocks - 1
+                self.blocks.append(blk)
+        f = prefix + "fpn."
+        self.fpn = {}
+        for name in ("fpn_inner2", "fpn_inner3", "fpn_inner4", "fpn_layer2", "fpn_layer3", "fpn_layer4",
+                     "top_blocks.p6", "top_blocks.p7"):
+            self.fpn[name] = ops.pack_conv(sd[f + name + ".weight"], bias=sd[f + name + ".bias"], dtype=dtype)
+
+
+class HeadWeights(object):
+    """Packed FCOSHead (fcos.py:27-81).  cls_logits and centerness both read the cls tower (fcos.py:91-92), so they
+    are fused into one 2-output conv (stored as 4 channels: logit, centerness, 0, 0)."""
+
+    def __init__(self, sd, dtype, prefix="rpn.head."):
+        self.towers = {}
+        for tower in ("cls_tower", "bbox_tower"):
+            layers = []
+            for i in range(spec.NUM_CONVS):
+                conv = ops.pack_conv(sd["%s%s.%d.weight" % (prefix, tower, 3 * i)],
+                                     bias=sd["%s%s.%d.bias" % (prefix, tower, 3 * i)], dtype=dtype)
+                layers.append((conv, sd["%s%s.%d.weight" % (prefix, tower, 3 * i + 1)].float().contiguous(),
+                               sd["%s%s.%d.bias" % (prefix, tower, 3 * i + 1)].float().contiguous()))
+            self.towers[tower] = layers
+        w = torch.cat([sd[prefix + "cls_logits.weight"], sd[prefix + "centerness.weight"]], 0)
+        b = torch.cat([sd[prefix + "cls_logits.bias"], sd[prefix + "centerness.bias"]], 0)
+        self.pred_cls_ctr = ops.pack_conv(w, bias=b, dtype=dtype)
+        self.pred_box = ops.pack_conv(sd[prefix + "bbox_pred.weight"], bias=sd[prefix + "bbox_pred.bias"], dtype=dtype)
+        # Scale modules (layers/scale.py): the scalar is folded into the exp epilogue; one host read at pack time
+        self.scales = [float(sd["%sscales.%d.scale" % (prefix, i)].item()) for i in range(5)]
+
+
+def run_backbone(wts, images, dtype, return_body=False):
+    """images NCHW fp32 -> [P3, P4, P5, P6, P7] NHWC.  resnet.py:138-145,295-315,332-337; fpn.py:43-75,95-99."""
+    n, _, h, w = images.shape
+    ho, wo = ops.conv_out(h, 7, 2, 3), ops.conv_out(w, 7, 2, 3)
+    hp, wp = 2 * (ho - 1) + 7, 2 * (wo - 1) + 8
+    hp, wp = max(hp, h + 3), max(wp, w + 3)
+    wp += wp & 1
+    x = ops.pack_image(images, dtype, hp, wp)
+    x = ops.conv2d(x, wts.stem, act=ACT_RELU, out_hw=(ho, wo))
+    x = ops.maxpool3x3s2(x)
+    feats = []
+    for blk in wts.blocks:
+        s = blk["stride"]
+        identity = x if blk["ds"] is None else ops.conv2d(x, blk["ds"], stride=s)
+        out = ops.conv2d(x, blk["c1"], stride=s, act=ACT_RELU)
+        out = ops.conv2d(out, blk["c2"], pad=1, act=ACT_RELU)
+        x = ops.conv2d(out, blk["c3"], act=ACT_RELU, res=identity, res_mode=RES_SAME)
+        if blk["last_of_stage"]:
+            feats.append(x)
+    c3, c4, c5 = feats[1], feats[2], feats[3]
+    f = wts.fpn
+    inner4 = ops.conv2d(c5, f["fpn_inner4"])
+    p5 = ops.conv2d(inner4, f["fpn_layer4"], pad=1)
+    inner3 = ops.conv2d(c4, f["fpn_inner3"], res=inner4, res_mode=RES_UP2X)
+    p4 = ops.conv2d(inner3, f["fpn_layer3"], pad=1)
+    inner2 = ops.conv2d(c3, f["fpn_inner2"], res=inner3, res_mode=RES_UP2X)
+    p3 = ops.conv2d(inner2, f["fpn_layer2"], pad=1)
+    p6 = ops.conv2d(p5, f["top_blocks.p6"], stride=2, pad=1)
+    p7 = ops.conv2d(p6, f["top_blocks.p7"], stride=2, pad=1, relu_in=True)
+    out = [p3, p4, p5, p6, p7]
+    return (out, feats) if return_body else out
+
+
+def run_query_pool(qfeats, q_sizes, batch):
+    """SuppAlignLayer (generalized_rcnn.py:20-52) + batch_pooling (:100-104) -> 5 x [B, C] fp32.
+    Quirk kept: the whole-image box is [0, 0, h, w] consumed as (x1, y1, x2, y2) (generalized_rcnn.py:257)."""
+    dev = qfeats[0].device
+    rois = torch.tensor([[float(i), 0.0, 0.0, float(h), float(w)] for i, (h, w) in enumerate(q_sizes)],
+                        dtype=torch.float32, device=dev)
+    pooled = []
+    for feat, scale in zip(qfeats, spec.POOLER_SCALES):
+        v = ops.roi_align(feat, rois, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
+        pooled.append(ops.shot_mean(v.view(v.shape[0], -1), batch))
+    return pooled
+
+
+def run_correlate(feats, pooled):
+    """generalized_rcnn.py:307-311."""
+    return [ops.correlate(f, q) for f, q in zip(feats, pooled)]
+
+
+def run_head(hw, feats):
+    """FCOSHead.forward (fcos.py:83-99).  Per level returns (cls_ctr [N,H,W,4] = (logit, centerness, 0, 0),
+    reg [N,H,W,4] = exp(scale_l * bbox_pred))."""
+    outs = []
+    for lvl, f in enumerate(feats):
+        t = f
+        for conv, gamma, beta in hw.towers["cls_tower"]:
+            t = ops.conv2d(t, conv, pad=1)
+            t = ops.groupnorm_relu(t, gamma, beta, spec.GN_GROUPS, spec.GN_EPS, out=t)
+        cls_ctr = ops.conv2d(t, hw.pred_cls_ctr, pad=1)
+        t = f
+        for conv, gamma, beta in hw.towers["bbox_tower"]:
+            t = ops.conv2d(t, conv, pad=1)
+            t = ops.groupnorm_relu(t, gamma, beta, spec.GN_GROUPS, spec.GN_EPS, out=t)
+        reg = ops.conv2d(t, hw.pred_box, pad=1, act=ACT_EXP_SCALE, act_scale=hw.scales[lvl])
+        outs.append((cls_ctr, reg))
+    return outs
+
+
+def run_proposals(head_out, img_h, img_w, pre_nms_top_n, post_nms_top_n, nms_thresh, cuda_nms=True, workspace=None):
+    """FCOSPostProcessor.forward (fcos/inference.py:251-323) for a batch whose images all have size (img_h, img_w)
+    (the 4-D tensor path of to_image_list, structures/image_list.py:44-50).  Everything stays on the device; returns
+    boxes [N, post, 4], scores [N, post] (descending), counts [N] int32."""
+    n = head_out[0][0].shape[0]
+    dev = head_out[0][0].device
+    sizes = [(c.shape[1], c.shape[2]) for c, _ in head_out]
+    total = sum(h * w for h, w in sizes)
+    scores = torch.empty((n, total), device=dev, dtype=torch.float32)
+    boxes = torch.empty((n, total, 4), device=dev, dtype=torch.float32)
+    off = 0
+    offs = []
+    for (cls_ctr, reg), stride in zip(head_out, spec.FPN_STRIDES):
+        ops.fcos_score_decode(cls_ctr, reg, scores, boxes, stride, off, img_h, img_w)
+        offs.append(off)
+        off += cls_ctr.shape[1] * cls_ctr.shape[2]
+    max_count = 0
+    for (h, w), lo in zip(sizes, offs):
+        if h * w > pre_nms_top_n:
+            ops.level_topk(scores, lo, h * w, pre_nms_top_n)
+        max_count += min(h * w, pre_nms_top_n)
+    bs, ss, idx, cnt = ops.rank_sort_gather(scores, boxes, max_count)
+    ob, os_, op, oc = ops.nms_sorted(bs, ss, cnt, nms_thresh, post_nms_top_n, cuda_semantics=cuda_nms,
+                                     workspace=workspace)
+    return ob, os_, oc
+
+
+class HotPathEngine(object):
+    """Packed weights + forward of the hot path.  state_dict: reference-named fp32 tensors (any device; moved to
+    `device`).  dtype: torch.float32 (exact-fp32 MFMA) or torch.bfloat16 (bf16 MFMA, fp32 accumulate)."""
+
+    def __init__(self, state_dict, dtype=torch.float32, device="cuda"):
+        if not torch.cuda.is_available():
+            raise ops._lib.OsdError("HotPathEngine needs an MI355X: no GPU visible and there is no CPU fallback")
+        ops._lib.load()
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.sd = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state_dict.items()}
+        missing = [k for k in spec.hot_path_shapes() if k not in self.sd]
+        if missing:
+            raise KeyError("state_dict is missing hot-path keys, e.g. %s" % missing[:3])
+        self.repack()
+
+    def repack(self):
+        self.backbone = BackboneWeights(self.sd, "backbone.", self.dtype)
+        self.supp_backbone = BackboneWeights(self.sd, "supp_backbone.", self.dtype)
+        self.head = HeadWeights(self.sd, self.dtype)
+
+    def forward_features(self, images, queries):
+        batch = images.shape[0]
+        feats = run_backbone(self.backbone, images, self.dtype)
+        qfeats = run_backbone(self.supp_backbone, queries, self.dtype)
+        q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0]
+        pooled = run_query_pool(qfeats, q_sizes, batch)
+        combined = run_correlate(feats, pooled)
+        return feats, qfeats, pooled, combined
+
+    def forward(self, images, queries):
+        """images [B,3,H,W], queries [B*S,3,h,w] NCHW fp32 on the device -> dict of NHWC intermediates."""
+        feats, qfeats, pooled, combined = self.forward_features(images, queries)
+        head = run_head(self.head, combined)
+        return dict(features=feats, query_features=qfeats, pooled=pooled, combined=combined, head=head)
+
+    def detect(self, images, queries, training=False, cuda_nms=True):
+        out = self.forward(images, queries)
+        h, w = images.shape[-2:]
+        pre = spec.PRE_NMS_TOP_N_TRAIN if training else spec.PRE_NMS_TOP_N_TEST
+        post = spec.POST_NMS_TOP_N_TRAIN if training else spec.POST_NMS_TOP_N_TEST
+        out["proposals"] = run_proposals(out["head"], h, w, pre, post, spec.NMS_THRESH, cuda_nms)
+        return out

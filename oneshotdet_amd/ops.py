@@ -1,0 +1,262 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/oneshotdet_hip.h).  torch supplies device memory and the stream;
+all arithmetic happens in liboneshotdet_hip.so.  Activations are NHWC tensors [N, H, W, C] (float32 or bfloat16)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_EXP_SCALE, ACT_NONE, ACT_RELU, GN_SPLITS, OSD_BF16, OSD_F32, RES_NONE, RES_SAME, RES_UP2X,
+                   ConvDesc)
+
+__all__ = ["ACT_NONE", "ACT_RELU", "ACT_EXP_SCALE", "RES_NONE", "RES_SAME", "RES_UP2X"]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return OSD_F32
+    if t.dtype == torch.bfloat16:
+        return OSD_BF16
+    raise TypeError("unsupported activation dtype %s" % t.dtype)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.OsdError("oneshotdet_amd ops need device tensors (no CPU path): got %s" % t.device)
+
+
+def conv_out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+class PackedConv(object):
+    """Weights of one conv in kernel layout: [w_rows][R][S][cin_k] rows (K contiguous), fp32 bias (BN folded)."""
+    __slots__ = ("w", "bias", "cout", "cout_store", "w_rows", "cin_k", "r", "s", "stem")
+
+    def __init__(self, w, bias, cout, cout_store, w_rows, cin_k, r, s, stem=False):
+        self.w, self.bias, self.cout, self.cout_store = w, bias, cout, cout_store
+        self.w_rows, self.cin_k, self.r, self.s, self.stem = w_rows, cin_k, r, s, stem
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def pack_conv(weight, bias=None, bn=None, dtype=torch.float32, stem=False):
+    """weight: OIHW fp32 device tensor.  bn = (weight, bias, running_mean, running_var) of a FrozenBatchNorm2d
+    (layers/batch_norm.py:19-24, NO eps) folded as w' = w * scale, b' = bn_bias - mean * scale."""
+    _chk_dev(weight)
+    cout, cin, r, s = weight.shape
+    weight = weight.contiguous().float()
+    scale = None
+    if bn is not None:
+        g, b, mean, var = (t.float() for t in bn)
+        scale = (g * var.rsqrt()).contiguous()
+        fbias = b - mean * scale
+    else:
+        fbias = bias.float() if bias is not None else torch.zeros(cout, device=weight.device)
+    cout_store = _round_up(cout, 4)
+    w_rows = _round_up(cout, 16)
+    bias_p = torch.zeros(_round_up(cout_store, 16), device=weight.device, dtype=torch.float32)
+    bias_p[:cout] = fbias
+    if stem:
+        assert (cin, r, s) == (3, 7, 7)
+        wp = torch.empty((w_rows, 7, 32), device=weight.device, dtype=dtype)
+        _lib.call("osd_pack_stem_weight", _ptr(weight), _ptr(scale), _ptr(wp), cout, w_rows, _dt(wp), _stream())
+        return PackedConv(wp, bias_p, cout, cout_store, w_rows, 32, 7, 1, stem=True)
+    mult = 64 if dtype == torch.bfloat16 else 16
+    cin_pad = _round_up(cin, mult)
+    wp = torch.empty((w_rows, r, s, cin_pad), device=weight.device, dtype=dtype)
+    _lib.call("osd_pack_conv_weight", _ptr(weight), _ptr(scale), _ptr(wp), cout, cin, r, s, w_rows, cin_pad, _dt(wp),
+              _stream())
+    return PackedConv(wp, bias_p, cout, cout_store, w_rows, cin_pad, r, s)
+
+
+def pack_image(images, dtype, hp, wp, pad_t=3, pad_l=3):
+    """NCHW fp32 [N,3,H,W] -> zero padded NHWC4 [N,hp,wp,4] (the stem conv's padding=3 materialised)."""
+    _chk_dev(images)
+    n, c, h, w = images.shape
+    assert c == 3 and images.dtype == torch.float32
+    out = torch.empty((n, hp, wp, 4), device=images.device, dtype=dtype)
+    _lib.call("osd_pack_image", _ptr(images.contiguous()), _ptr(out), n, h, w, hp, wp, pad_t, pad_l, _dt(out), _stream())
+    return out
+
+
+def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, relu_in=False, act_scale=1.0, out=None,
+           out_hw=None):
+    """x NHWC [N,H,W,C] -> [N,Ho,Wo,cout_store].  For the stem, x is the padded NHWC4 image from pack_image and
+    out_hw gives (Ho, Wo)."""
+    _chk_dev(x, res, out)
+    n, h, w, c = x.shape
+    d = ConvDesc()
+    d.dtype = _dt(x)
+    d.n, d.h, d.w = n, h, w
+    if pc.stem:
+        ho, wo = out_hw
+        d.cin, d.r, d.s = 32, 7, 1
+        d.in_stride_n, d.in_stride_h, d.in_stride_w = h * w * 4, w * 4, 4
+        d.stride_h, d.stride_w, d.pad_h, d.pad_w = 2, 2, 0, 0
+        # the 32-element K run of a tap starts at pixel (2*ho + r, 2*wo) and spans 8 padded pixels
+        d.h, d.w = h, w - 7
+        assert 2 * (wo - 1) + 8 <= w and 2 * (ho - 1) + 7 <= h, "stem input not padded enough"
+    else:
+        assert c == pc.cin_k, "input channels %d != packed K per tap %d" % (c, pc.cin_k)
+        ho, wo = conv_out(h, pc.r, stride, pad), conv_out(w, pc.s, stride, pad)
+        d.cin, d.r, d.s = c, pc.r, pc.s
+        d.in_stride_n, d.in_stride_h, d.in_stride_w = h * w * c, w * c, c
+        d.stride_h = d.stride_w = stride
+        d.pad_h = d.pad_w = pad
+    d.ho, d.wo, d.cout, d.w_rows = ho, wo, pc.cout_store, pc.w_rows
+    if out is None:
+        out = torch.empty((n, ho, wo, pc.cout_store), device=x.device, dtype=x.dtype)
+    d.out_stride = out.shape[-1]
+    d.res_mode = res_mode
+    if res_mode != RES_NONE:
+        d.res_h, d.res_w, d.res_stride = res.shape[1], res.shape[2], res.shape[3]
+        if res_mode == RES_UP2X:
+            assert res.shape[1] * 2 == ho and res.shape[2] * 2 == wo, "top-down map must be exactly half size"
+    d.act, d.act_scale, d.relu_in, d.gn_in = act, float(act_scale), int(relu_in), 0
+    _lib.call("osd_conv2d_fwd", C.byref(d), _ptr(x), _ptr(pc.w), _ptr(pc.bias), _ptr(res), None, None, _ptr(out),
+              _stream())
+    return out
+
+
+def maxpool3x3s2(x):
+    _chk_dev(x)
+    n, h, w, c = x.shape
+    ho, wo = conv_out(h, 3, 2, 1), conv_out(w, 3, 2, 1)
+    y = torch.empty((n, ho, wo, c), device=x.device, dtype=x.dtype)
+    _lib.call("osd_maxpool3x3s2_fwd", _ptr(x), _ptr(y), n, h, w, c, ho, wo, _dt(x), _stream())
+    return y
+
+
+def groupnorm_relu(x, gamma, beta, groups=32, eps=1e-5, out=None):
+    """relu(GroupNorm(groups, C)(x)) on NHWC x; in place when out is x."""
+    _chk_dev(x, gamma, beta)
+    n, h, w, c = x.shape
+    ws = torch.empty((n, GN_SPLITS, groups, 2), device=x.device, dtype=torch.float32)
+    ab = torch.empty((2, n, c), device=x.device, dtype=torch.float32)
+    st = _stream()
+    _lib.call("osd_groupnorm_stats", _ptr(x), _ptr(ws), n, h * w, c, groups, _dt(x), st)
+    _lib.call("osd_groupnorm_finalize", _ptr(ws), _ptr(gamma), _ptr(beta), _ptr(ab[0]), _ptr(ab[1]), n, h * w, c, groups,
+              float(eps), st)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("osd_groupnorm_relu_apply", _ptr(x), _ptr(ab[0]), _ptr(ab[1]), _ptr(out), n, h * w, c, _dt(x), st)
+    return out
+
+
+def roi_align(x, rois, spatial_scale, ph, pw, sampling_ratio):
+    """x NHWC, rois [R,5] fp32 (batch_idx, x1, y1, x2, y2) -> [R, ph, pw, C] fp32."""
+    _chk_dev(x, rois)
+    n, h, w, c = x.shape
+    r = rois.shape[0]
+    y = torch.empty((r, ph, pw, c), device=x.device, dtype=torch.float32)
+    _lib.call("osd_roialign_fwd", _ptr(x), _ptr(rois.contiguous().float()), _ptr(y), n, h, w, c, r, float(spatial_scale),
+              ph, pw, sampling_ratio, _dt(x), _stream())
+    return y
+
+
+def shot_mean(x, batch):
+    """[B*S, C] fp32 -> [B, C] fp32 (batch_pooling)."""
+    _chk_dev(x)
+    d, c = x.shape
+    assert d % batch == 0
+    y = torch.empty((batch, c), device=x.device, dtype=torch.float32)
+    _lib.call("osd_shot_mean", _ptr(x.contiguous()), _ptr(y), batch, d // batch, c, _stream())
+    return y
+
+
+def correlate(x, q, out=None):
+    """x NHWC [N,H,W,C] * q [N,C] fp32 (broadcast over H, W)."""
+    _chk_dev(x, q)
+    n, h, w, c = x.shape
+    assert q.shape == (n, c) and q.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("osd_correlate_fwd", _ptr(x), _ptr(q.contiguous()), _ptr(out), n, h * w, c, _dt(x), _stream())
+    return out
+
+
+def nhwc_to_nchw_f32(x, c0=0, c=None):
+    _chk_dev(x)
+    n, h, w, stride = x.shape
+    c = stride - c0 if c is None else c
+    y = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    _lib.call("osd_nhwc_to_nchw_f32", _ptr(x), _ptr(y), n, h, w, c, stride, c0, _dt(x), _stream())
+    return y
+
+
+def nchw_f32_to_nhwc(x, dtype):
+    _chk_dev(x)
+    n, c, h, w = x.shape
+    y = torch.empty((n, h, w, c), device=x.device, dtype=dtype)
+    _lib.call("osd_nchw_f32_to_nhwc", _ptr(x.contiguous().float()), _ptr(y), n, c, h, w, _dt(y), _stream())
+    return y
+
+
+def fcos_score_decode(cls_ctr, reg, scores, boxes, stride, loc_offset, img_h, img_w):
+    _chk_dev(cls_ctr, reg, scores, boxes)
+    n, h, w, ccs = cls_ctr.shape
+    _lib.call("osd_fcos_score_decode", _ptr(cls_ctr), _ptr(reg), _ptr(scores), _ptr(boxes), n, h, w, ccs, reg.shape[-1],
+              stride, loc_offset, scores.shape[1], float(img_h), float(img_w), _dt(cls_ctr), _stream())
+
+
+def level_topk(keys, lo, cnt, topn):
+    n, total = keys.shape
+    _lib.call("osd_level_topk", _ptr(keys), _ptr(keys), n, total, lo, cnt, topn, _stream())
+
+
+def rank_sort_gather(keys, boxes, max_count):
+    """keys [N,T] fp32 (dropped = -1), boxes [N,T,4] -> boxes_sorted [N,max_count,4], scores_sorted, idx_sorted, counts"""
+    _chk_dev(keys, boxes)
+    n, total = keys.shape
+    dev = keys.device
+    bs = torch.empty((n, max_count, 4), device=dev, dtype=torch.float32)
+    ss = torch.empty((n, max_count), device=dev, dtype=torch.float32)
+    idx = torch.empty((n, max_count), device=dev, dtype=torch.int32)
+    cnt = torch.empty((n,), device=dev, dtype=torch.int32)
+    _lib.call("osd_rank_sort_gather", _ptr(keys), _ptr(boxes), n, total, max_count, _ptr(bs), _ptr(ss), _ptr(idx),
+              _ptr(cnt), _stream())
+    return bs, ss, idx, cnt
+
+
+def nms_sorted(boxes_sorted, scores_sorted, counts, thresh, max_keep, cuda_semantics=False, workspace=None):
+    _chk_dev(boxes_sorted, scores_sorted, counts)
+    n, max_count, _ = boxes_sorted.shape
+    dev = boxes_sorted.device
+    need = _lib.load().osd_nms_workspace_bytes(n, max_count)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((max(need, 8) // 8,), device=dev, dtype=torch.int64)
+    ob = torch.zeros((n, max_keep, 4), device=dev, dtype=torch.float32)
+    os_ = torch.zeros((n, max_keep), device=dev, dtype=torch.float32)
+    op = torch.zeros((n, max_keep), device=dev, dtype=torch.int32)
+    oc = torch.empty((n,), device=dev, dtype=torch.int32)
+    _lib.call("osd_nms_sorted", _ptr(boxes_sorted), _ptr(scores_sorted), _ptr(counts), n, max_count, float(thresh),
+              int(cuda_semantics), max_keep, _ptr(workspace), _ptr(ob), _ptr(os_), _ptr(op), _ptr(oc), _stream())
+    return ob, os_, op, oc
+
+
+def sigmoid_focal_loss_fwd(logits, targets, gamma, alpha):
+    _chk_dev(logits, targets)
+    m, classes = logits.shape
+    losses = torch.empty_like(logits)
+    _lib.call("osd_sigmoid_focal_fwd", _ptr(logits.contiguous()), _ptr(targets.contiguous()), _ptr(losses), m, classes,
+              float(gamma), float(alpha), _stream())
+    return losses
+
+
+def sigmoid_focal_loss_bwd(logits, targets, d_losses, gamma, alpha):
+    m, classes = logits.shape
+    d_logits = torch.empty_like(logits)
+    _lib.call("osd_sigmoid_focal_bwd", _ptr(logits.contiguous()), _ptr(targets.contiguous()),
+              _ptr(d_losses.contiguous()), _ptr(d_logits), m, classes, float(gamma), float(alpha), _stream())
+    return d_logits
