@@ -1,0 +1,197 @@
+"""bench.py — throughput of the siamese-FCOS hot path on MI355X (contract: see the task's bench section / DESIGN.md §5).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|f32] [--batch 8] [--no-cpu-baseline]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+              bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic (target, query) pairs already resident in HBM:
+two ResNet-50-FPN backbones, query pooling, correlation, FCOS towers + predictions, score/decode/top-k/NMS proposals.
+Weak scaling: every rank processes its own batch (forward needs no collective); value = images of all ranks / max time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+METRIC = "images/sec/GPU fwd+bwd, 800x1024 target + 127x127 query, bs=8; 1->8 GPU scaling"
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (f32-in MFMA = vector rate)
+
+
+class ConvTimer(object):
+    """HIP-event timing of every conv_igemm launch on the stream it is launched on (torch's current stream is the
+    stream handed to the C-ABI).  Algorithmic FLOPs = 2 * M * Cout * Cin * R * S with the REAL (unpadded) channels."""
+
+    def __init__(self):
+        self.records = []
+        self.flops = 0.0
+        self.launches = 0
+
+    def install(self, ops):
+        self._orig = ops.conv2d
+        timer = self
+
+        def timed_conv2d(x, pc, *a, **kw):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = timer._orig(x, pc, *a, **kw)
+            e.record()
+            m = y.shape[0] * y.shape[1] * y.shape[2]
+            k_real = 147 if pc.stem else pc.r * pc.s * getattr(pc, "cin_real", pc.cin_k)
+            timer.records.append((s, e))
+            timer.flops += 2.0 * m * pc.cout * k_real
+            timer.launches += 1
+            return y
+        ops.conv2d = timed_conv2d
+
+    def uninstall(self, ops):
+        ops.conv2d = self._orig
+
+    def reset(self):
+        self.records, self.flops, self.launches = [], 0.0, 0
+
+    def total_ms(self):
+        return sum(s.elapsed_time(e) for s, e in self.records)
+
+
+def cpu_baseline(dtype_name, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores on a bounded sample of
+    the same workload: single 800x1024 + 127x127 pairs, forward incl. proposals."""
+    import golden_utils as gu
+    from oneshotdet_amd import spec, synth
+    from oracle import hotpath_ref as orc
+    sd = orc.to_torch_state_dict(synth.make_state_dict(spec.hot_path_shapes()))
+    img, q = gu.case_inputs("config1")
+    img, q = torch.from_numpy(img), torch.from_numpy(q)
+    cores = torch.get_num_threads()
+
+    def one():
+        with torch.no_grad():
+            o = orc.hot_path_forward(img, q, sd)
+            orc.fcos_postprocess(o["logits"], o["bbox_reg"], o["centerness"], [(800, 1024)])
+    one()                      # warm-up (oneDNN primitive creation)
+    t0 = time.time()
+    n = 0
+    while True:
+        one()
+        n += 1
+        if time.time() - t0 > seconds_budget * 0.6 or n >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": round(n / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d x (1x800x1024 target + 1x127x127 query) forward incl. proposals, oracle/hotpath_ref.py "
+                      "(torch CPU fp32, %d threads)" % (n, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default=os.environ.get("OSD_BENCH_DTYPE", "f32"), choices=["f32", "bf16"])
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-conv-timing", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from oneshotdet_amd import model, ops, spec, synth
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    eng = model.HotPathEngine(synth.make_state_dict(spec.hot_path_shapes()), dtype=dtype)
+    B = args.batch
+    images = torch.from_numpy(synth.make_images("bench.target", B, 800, 1024, seed=1000 + rank)).cuda()
+    queries = torch.from_numpy(synth.make_images("bench.query", B, 127, 127, seed=1000 + rank)).cuda()
+
+    use_graph = not args.no_graph
+    if use_graph:
+        # production path: the whole forward captured once into a hipGraph (multi-stream branches), then replayed
+        runner = model.GraphedDetect(eng, images, queries)
+
+        def step():
+            return runner()
+    else:
+        def step():
+            return eng.detect(images, queries)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # Roofline of the dominant kernel family (conv_igemm): HIP events around every conv launch, on the stream the
+    # kernel is launched on, over `steps` further steps of the SAME workload in this process, run eagerly on one
+    # stream (kernels inside a replayed hipGraph cannot be bracketed individually, and concurrent branches would
+    # inflate each other's durations).
+    roofline = None
+    if not args.no_conv_timing:
+        timer = ConvTimer()
+        timer.install(ops)
+        torch.cuda.synchronize()
+        for _ in range(args.steps):
+            eng.detect(images, queries, concurrent=False)
+        torch.cuda.synchronize()
+        conv_ms = timer.total_ms()
+        tflops = timer.flops / (conv_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                    "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "kernel": "conv_igemm_kernel (all instantiations)",
+                    "avg_launch_us": round(conv_ms * 1e3 / max(timer.launches, 1), 2),
+                    "launches_per_step": timer.launches // max(args.steps, 1),
+                    "gflop_per_step": round(timer.flops / max(args.steps, 1) / 1e9, 1),
+                    "conv_ms_per_step": round(conv_ms / max(args.steps, 1), 3),
+                    "measured": "HIP events per launch, %d eager single-stream steps after the timed region" % args.steps}
+        timer.uninstall(ops)
+
+    if rank == 0:
+        line = {
+            "metric": METRIC, "value": round(B * world * args.steps / elapsed, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1] shape, FORWARD ONLY (backward not built yet): bs=%d/GPU, "
+                                   "800x1024 target + 127x127 query, two R-50-FPN backbones + query pooling + "
+                                   "correlation + FCOS head + proposals (top-k, NMS 0.8, top-2000), %s MFMA convs"
+                                   % (B, args.dtype),
+                       "global_batch": B * world, "parallelism": "dp%d (no collective in forward)" % world,
+                       "launch": "hipGraph replay, 4 streams" if use_graph else "eager, 4 streams"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.dtype)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

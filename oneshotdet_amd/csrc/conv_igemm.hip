@@ -336,7 +336,11 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
     return osd_fail(OSD_ERR_INVALID_ARG, "conv: residual requested without a valid residual tensor");
   if (d->w_rows < d->cout) return osd_fail(OSD_ERR_INVALID_ARG, "conv: w_rows < cout");
   const int epc = d->dtype == OSD_BF16 ? 8 : 4;
-  if (d->in_stride_w % epc || d->in_stride_h % epc || d->in_stride_n % epc)
+  // every staged 16-byte chunk must be 16-byte aligned: dense NHWC (pixel stride multiple of a chunk) or the stem's
+  // packed NHWC4 form where only even pixels are ever addressed (s == 1, no padding, stride_w * pixel stride aligned)
+  const bool w_ok = (d->in_stride_w % epc == 0) ||
+                    (d->s == 1 && d->pad_w == 0 && (d->stride_w * d->in_stride_w) % epc == 0);
+  if (!w_ok || d->in_stride_h % epc || d->in_stride_n % epc || d->cin % epc)
     return osd_fail(OSD_ERR_INVALID_ARG, "conv: input strides must keep 16-byte alignment");
   ConvKParams p;
   p.x = x; p.w = w; p.bias = bias; p.res = res; p.y = y;

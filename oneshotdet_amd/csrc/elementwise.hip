@@ -477,8 +477,8 @@ extern "C" int osd_groupnorm_relu_apply(const void* x, const float* a, const flo
 extern "C" int osd_roialign_fwd(const void* x, const float* rois, float* y, int b, int h, int w, int c, int num_rois,
                                 float spatial_scale, int ph, int pw, int sampling_ratio, int dtype, void* stream) {
   (void)b;
-  if (!x || !rois || !y) return osd_fail(OSD_ERR_INVALID_ARG, "roialign: null argument");
   if (num_rois == 0) return OSD_OK;
+  if (!x || !rois || !y) return osd_fail(OSD_ERR_INVALID_ARG, "roialign: null argument");
   const int g = grid_for((long long)num_rois * ph * pw * c, 256);
   OSD_DISPATCH_DTYPE(dtype,
       hipLaunchKernelGGL(roialign_fwd_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const float*)x, rois, y, h, w, c, num_rois, spatial_scale, ph, pw, sampling_ratio),
@@ -494,8 +494,9 @@ extern "C" int osd_shot_mean(const float* x, float* y, int b, int shots, int c, 
 
 extern "C" int osd_correlate_fwd(const void* x, const float* q, void* y, int n, int hw, int c, int dtype, void* stream) {
   const int e = dtype == OSD_BF16 ? 8 : 4;
-  if (!x || !q || !y || c % e != 0 || c > 8192) return osd_fail(OSD_ERR_INVALID_ARG, "correlate: bad args");
+  if (c % e != 0 || c > 8192) return osd_fail(OSD_ERR_INVALID_ARG, "correlate: bad channel count %d", c);
   if (n == 0 || hw == 0) return OSD_OK;
+  if (!x || !q || !y) return osd_fail(OSD_ERR_INVALID_ARG, "correlate: null argument");
   const long long chunks = (long long)hw * (c / e);
   // >= 8 chunks (128 B) per thread where the image is large enough; blocks x images >> 256 CUs at the P3 size
   int bx = (int)((chunks + 256LL * 8 - 1) / (256LL * 8));

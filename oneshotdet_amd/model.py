@@ -97,12 +97,23 @@ def run_backbone(wts, images, dtype, return_body=False):
     return (out, feats) if return_body else out
 
 
+_ROI_CACHE = {}
+
+
+def whole_image_rois(q_sizes, device):
+    """[i, 0, 0, h, w] per query — the reference's quirk: the box is built from image_sizes = (h, w) but consumed as
+    (x1, y1, x2, y2) (generalized_rcnn.py:257).  Cached per device so no host->device copy happens in steady state
+    (and none inside a hipGraph capture)."""
+    key = (tuple(q_sizes), str(device))
+    if key not in _ROI_CACHE:
+        _ROI_CACHE[key] = torch.tensor([[float(i), 0.0, 0.0, float(h), float(w)] for i, (h, w) in enumerate(q_sizes)],
+                                       dtype=torch.float32, device=device)
+    return _ROI_CACHE[key]
+
+
 def run_query_pool(qfeats, q_sizes, batch):
-    """SuppAlignLayer (generalized_rcnn.py:20-52) + batch_pooling (:100-104) -> 5 x [B, C] fp32.
-    Quirk kept: the whole-image box is [0, 0, h, w] consumed as (x1, y1, x2, y2) (generalized_rcnn.py:257)."""
-    dev = qfeats[0].device
-    rois = torch.tensor([[float(i), 0.0, 0.0, float(h), float(w)] for i, (h, w) in enumerate(q_sizes)],
-                        dtype=torch.float32, device=dev)
+    """SuppAlignLayer (generalized_rcnn.py:20-52) + batch_pooling (:100-104) -> 5 x [B, C] fp32."""
+    rois = whole_image_rois(q_sizes, qfeats[0].device)
     pooled = []
     for feat, scale in zip(qfeats, spec.POOLER_SCALES):
         v = ops.roi_align(feat, rois, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
@@ -115,23 +126,42 @@ def run_correlate(feats, pooled):
     return [ops.correlate(f, q) for f, q in zip(feats, pooled)]
 
 
-def run_head(hw, feats):
+def run_head_tower(hw, f, lvl, tower):
+    """One tower + its prediction conv for one level (fcos.py:89-97)."""
+    t = f
+    for conv, gamma, beta in hw.towers[tower]:
+        t = ops.conv2d(t, conv, pad=1)
+        t = ops.groupnorm_relu(t, gamma, beta, spec.GN_GROUPS, spec.GN_EPS, out=t)
+    if tower == "cls_tower":
+        return ops.conv2d(t, hw.pred_cls_ctr, pad=1)
+    return ops.conv2d(t, hw.pred_box, pad=1, act=ACT_EXP_SCALE, act_scale=hw.scales[lvl])
+
+
+def run_head(hw, feats, streams=None):
     """FCOSHead.forward (fcos.py:83-99).  Per level returns (cls_ctr [N,H,W,4] = (logit, centerness, 0, 0),
-    reg [N,H,W,4] = exp(scale_l * bbox_pred))."""
-    outs = []
-    for lvl, f in enumerate(feats):
-        t = f
-        for conv, gamma, beta in hw.towers["cls_tower"]:
-            t = ops.conv2d(t, conv, pad=1)
-            t = ops.groupnorm_relu(t, gamma, beta, spec.GN_GROUPS, spec.GN_EPS, out=t)
-        cls_ctr = ops.conv2d(t, hw.pred_cls_ctr, pad=1)
-        t = f
-        for conv, gamma, beta in hw.towers["bbox_tower"]:
-            t = ops.conv2d(t, conv, pad=1)
-            t = ops.groupnorm_relu(t, gamma, beta, spec.GN_GROUPS, spec.GN_EPS, out=t)
-        reg = ops.conv2d(t, hw.pred_box, pad=1, act=ACT_EXP_SCALE, act_scale=hw.scales[lvl])
-        outs.append((cls_ctr, reg))
-    return outs
+    reg [N,H,W,4] = exp(scale_l * bbox_pred)).  The two towers and the five levels are independent: with `streams`
+    (3 side streams) P3/cls runs on the current stream, P3/bbox, P4-P7/cls and P4-P7/bbox on the side streams, so the
+    small levels' launch-latency-bound kernels fill the CUs the P3 GEMMs leave idle."""
+    n = len(feats)
+    if not streams:
+        return [(run_head_tower(hw, f, l, "cls_tower"), run_head_tower(hw, f, l, "bbox_tower"))
+                for l, f in enumerate(feats)]
+    main = torch.cuda.current_stream()
+    cls_out, box_out = [None] * n, [None] * n
+    for st in streams[:3]:
+        st.wait_stream(main)
+    with torch.cuda.stream(streams[0]):
+        box_out[0] = run_head_tower(hw, feats[0], 0, "bbox_tower")
+    with torch.cuda.stream(streams[1]):
+        for l in range(1, n):
+            cls_out[l] = run_head_tower(hw, feats[l], l, "cls_tower")
+    with torch.cuda.stream(streams[2]):
+        for l in range(1, n):
+            box_out[l] = run_head_tower(hw, feats[l], l, "bbox_tower")
+    cls_out[0] = run_head_tower(hw, feats[0], 0, "cls_tower")
+    for st in streams[:3]:
+        main.wait_stream(st)
+    return list(zip(cls_out, box_out))
 
 
 def run_proposals(head_out, img_h, img_w, pre_nms_top_n, post_nms_top_n, nms_thresh, cuda_nms=True, workspace=None):
@@ -182,25 +212,69 @@ class HotPathEngine(object):
         self.supp_backbone = BackboneWeights(self.sd, "supp_backbone.", self.dtype)
         self.head = HeadWeights(self.sd, self.dtype)
 
-    def forward_features(self, images, queries):
+    def side_streams(self):
+        if getattr(self, "_streams", None) is None:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        return self._streams
+
+    def forward_features(self, images, queries, concurrent=True):
+        """Target backbone on the current stream; the (independent, tiny) query backbone + pooling on a side stream."""
         batch = images.shape[0]
-        feats = run_backbone(self.backbone, images, self.dtype)
-        qfeats = run_backbone(self.supp_backbone, queries, self.dtype)
         q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0]
-        pooled = run_query_pool(qfeats, q_sizes, batch)
+        if concurrent:
+            main, side = torch.cuda.current_stream(), self.side_streams()[0]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                qfeats = run_backbone(self.supp_backbone, queries, self.dtype)
+                pooled = run_query_pool(qfeats, q_sizes, batch)
+            feats = run_backbone(self.backbone, images, self.dtype)
+            main.wait_stream(side)
+        else:
+            feats = run_backbone(self.backbone, images, self.dtype)
+            qfeats = run_backbone(self.supp_backbone, queries, self.dtype)
+            pooled = run_query_pool(qfeats, q_sizes, batch)
         combined = run_correlate(feats, pooled)
         return feats, qfeats, pooled, combined
 
-    def forward(self, images, queries):
+    def forward(self, images, queries, concurrent=True):
         """images [B,3,H,W], queries [B*S,3,h,w] NCHW fp32 on the device -> dict of NHWC intermediates."""
-        feats, qfeats, pooled, combined = self.forward_features(images, queries)
-        head = run_head(self.head, combined)
+        feats, qfeats, pooled, combined = self.forward_features(images, queries, concurrent)
+        head = run_head(self.head, combined, self.side_streams() if concurrent else None)
         return dict(features=feats, query_features=qfeats, pooled=pooled, combined=combined, head=head)
 
-    def detect(self, images, queries, training=False, cuda_nms=True):
-        out = self.forward(images, queries)
+    def detect(self, images, queries, training=False, cuda_nms=True, concurrent=True):
+        out = self.forward(images, queries, concurrent)
         h, w = images.shape[-2:]
         pre = spec.PRE_NMS_TOP_N_TRAIN if training else spec.PRE_NMS_TOP_N_TEST
         post = spec.POST_NMS_TOP_N_TRAIN if training else spec.POST_NMS_TOP_N_TEST
         out["proposals"] = run_proposals(out["head"], h, w, pre, post, spec.NMS_THRESH, cuda_nms)
         return out
+
+
+class GraphedDetect(object):
+    """The whole hot-path forward captured once into a hipGraph (static shapes, static HBM buffers) and replayed:
+    ~250 kernel launches per step cost one graph launch on the host, and the multi-stream fork/join of
+    HotPathEngine.forward becomes parallel branches of the graph."""
+
+    def __init__(self, engine, images, queries, warmup=2, **kw):
+        self.engine = engine
+        self.images = images.clone()
+        self.queries = queries.clone()
+        side = torch.cuda.Stream(device=engine.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                engine.detect(self.images, self.queries, **kw)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = engine.detect(self.images, self.queries, **kw)
+
+    def __call__(self, images=None, queries=None):
+        if images is not None:
+            self.images.copy_(images, non_blocking=True)
+        if queries is not None:
+            self.queries.copy_(queries, non_blocking=True)
+        self.graph.replay()
+        return self.out

@@ -39,11 +39,12 @@ def conv_out(n, k, s, p):
 
 class PackedConv(object):
     """Weights of one conv in kernel layout: [w_rows][R][S][cin_k] rows (K contiguous), fp32 bias (BN folded)."""
-    __slots__ = ("w", "bias", "cout", "cout_store", "w_rows", "cin_k", "r", "s", "stem")
+    __slots__ = ("w", "bias", "cout", "cout_store", "w_rows", "cin_k", "cin_real", "r", "s", "stem")
 
-    def __init__(self, w, bias, cout, cout_store, w_rows, cin_k, r, s, stem=False):
+    def __init__(self, w, bias, cout, cout_store, w_rows, cin_k, r, s, stem=False, cin_real=None):
         self.w, self.bias, self.cout, self.cout_store = w, bias, cout, cout_store
         self.w_rows, self.cin_k, self.r, self.s, self.stem = w_rows, cin_k, r, s, stem
+        self.cin_real = cin_k if cin_real is None else cin_real
 
 
 def _round_up(x, m):
@@ -71,13 +72,13 @@ def pack_conv(weight, bias=None, bn=None, dtype=torch.float32, stem=False):
         assert (cin, r, s) == (3, 7, 7)
         wp = torch.empty((w_rows, 7, 32), device=weight.device, dtype=dtype)
         _lib.call("osd_pack_stem_weight", _ptr(weight), _ptr(scale), _ptr(wp), cout, w_rows, _dt(wp), _stream())
-        return PackedConv(wp, bias_p, cout, cout_store, w_rows, 32, 7, 1, stem=True)
+        return PackedConv(wp, bias_p, cout, cout_store, w_rows, 32, 7, 1, stem=True, cin_real=3)
     mult = 64 if dtype == torch.bfloat16 else 16
     cin_pad = _round_up(cin, mult)
     wp = torch.empty((w_rows, r, s, cin_pad), device=weight.device, dtype=dtype)
     _lib.call("osd_pack_conv_weight", _ptr(weight), _ptr(scale), _ptr(wp), cout, cin, r, s, w_rows, cin_pad, _dt(wp),
               _stream())
-    return PackedConv(wp, bias_p, cout, cout_store, w_rows, cin_pad, r, s)
+    return PackedConv(wp, bias_p, cout, cout_store, w_rows, cin_pad, r, s, cin_real=cin)
 
 
 def pack_image(images, dtype, hp, wp, pad_t=3, pad_l=3):

@@ -1,0 +1,194 @@
+"""GPU (-m gpu): every HIP kernel through the C-ABI against the oracle / a plain PyTorch fp32 CPU reference of the
+same op, on small seeded inputs incl. the edge cases (ragged M tails, odd sizes, empty inputs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_utils as gu
+from oracle import hotpath_ref as orc
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+# fp32 path: exact-fp32 MFMA, only summation order differs from oneDNN.  bf16: 8-bit mantissa inputs, fp32 accumulate.
+TOL = {"f32": dict(rtol=2e-5, atol=2e-5), "bf16": dict(rtol=3e-2, atol=3e-2)}
+
+
+def ops():
+    from oneshotdet_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def to_nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+
+
+def from_nhwc(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+CONV_CASES = [
+    # n, cin, h, w, cout, k, stride, pad
+    (2, 64, 13, 17, 64, 1, 1, 0),
+    (1, 128, 16, 12, 256, 1, 2, 0),
+    (2, 64, 9, 11, 128, 3, 1, 1),
+    (1, 256, 14, 10, 256, 3, 2, 1),
+    (3, 64, 7, 5, 4, 3, 1, 1),          # skinny-N prediction conv
+    (1, 512, 25, 32, 512, 3, 1, 1),     # deep K, 64x64 tiles
+    (2, 256, 40, 48, 256, 3, 1, 1),     # 128x64 / 128x128 tiles with a ragged M tail
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_bias_matches_torch(case, dt):
+    n, cin, h, w, cout, k, s, p = case
+    x, wt, b = rnd(n, cin, h, w, seed=1), rnd(cout, cin, k, k, seed=2) / np.sqrt(cin * k * k), rnd(cout, seed=3)
+    if dt == "bf16":
+        x, wt = x.bfloat16().float(), wt.bfloat16().float()
+    ref = F.conv2d(x, wt, b, stride=s, padding=p)
+    pc = ops().pack_conv(wt.cuda(), bias=b.cuda(), dtype=DT[dt])
+    y = ops().conv2d(to_nhwc(x, DT[dt]), pc, stride=s, pad=p)
+    assert y.shape[-1] == (cout + 3) // 4 * 4
+    torch.testing.assert_close(from_nhwc(y)[:, :cout], ref, **TOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv2d_frozenbn_residual_relu(dt):
+    """Bottleneck tail: relu(bn3(conv3(x)) + identity) with the no-eps FrozenBN folded (batch_norm.py:19-24)."""
+    n, cin, h, w, cout = 2, 64, 12, 20, 256
+    x, wt, idn = rnd(n, cin, h, w, seed=1), rnd(cout, cin, 1, 1, seed=2) / 8, rnd(n, cout, h, w, seed=3)
+    bn = [rnd(cout, seed=4).abs() + 0.5, rnd(cout, seed=5), rnd(cout, seed=6), rnd(cout, seed=7).abs() + 0.5]
+    if dt == "bf16":
+        x, idn = x.bfloat16().float(), idn.bfloat16().float()
+    sd = {"bn.weight": bn[0], "bn.bias": bn[1], "bn.running_mean": bn[2], "bn.running_var": bn[3]}
+    ref = F.relu(orc.frozen_bn(F.conv2d(x, wt), sd, "bn") + idn)
+    pc = ops().pack_conv(wt.cuda(), bn=[t.cuda() for t in bn], dtype=DT[dt])
+    y = ops().conv2d(to_nhwc(x, DT[dt]), pc, act=ops().ACT_RELU, res=to_nhwc(idn, DT[dt]), res_mode=ops().RES_SAME)
+    torch.testing.assert_close(from_nhwc(y), ref, **TOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv2d_fpn_lateral_upsample_add(dt):
+    """inner = conv1x1(C) + nearest_up2x(top)  (fpn.py:59-64)."""
+    n, cin, h, w, cout = 2, 128, 10, 14, 256
+    x, wt, b, top = rnd(n, cin, h, w, seed=1), rnd(cout, cin, 1, 1, seed=2) / 11, rnd(cout, seed=3), rnd(n, cout, h // 2, w // 2, seed=4)
+    if dt == "bf16":
+        x, wt, top = x.bfloat16().float(), wt.bfloat16().float(), top.bfloat16().float()
+    ref = F.conv2d(x, wt, b) + F.interpolate(top, scale_factor=2, mode="nearest")
+    pc = ops().pack_conv(wt.cuda(), bias=b.cuda(), dtype=DT[dt])
+    y = ops().conv2d(to_nhwc(x, DT[dt]), pc, res=to_nhwc(top, DT[dt]), res_mode=ops().RES_UP2X)
+    torch.testing.assert_close(from_nhwc(y), ref, **TOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv2d_relu_in_and_exp_scale(dt):
+    n, cin, h, w = 1, 256, 9, 7
+    x, wt, b = rnd(n, cin, h, w, seed=1), rnd(4, cin, 3, 3, seed=2) / 48, rnd(4, seed=3) * 0.1
+    if dt == "bf16":
+        x, wt = x.bfloat16().float(), wt.bfloat16().float()
+    pc = ops().pack_conv(wt.cuda(), bias=b.cuda(), dtype=DT[dt])
+    y = ops().conv2d(to_nhwc(x, DT[dt]), pc, stride=2, pad=1, relu_in=True)          # P7 = conv(relu(P6)) fpn.py:98
+    torch.testing.assert_close(from_nhwc(y), F.conv2d(F.relu(x), wt, b, stride=2, padding=1), **TOL[dt])
+    y = ops().conv2d(to_nhwc(x, DT[dt]), pc, pad=1, act=ops().ACT_EXP_SCALE, act_scale=0.7)  # fcos.py:95-97
+    torch.testing.assert_close(from_nhwc(y), torch.exp(0.7 * F.conv2d(x, wt, b, padding=1)), **TOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("hw", [(32, 48), (63, 63), (127, 127)])
+def test_stem_conv_and_maxpool(hw, dt):
+    """BaseStem.forward resnet.py:332-337 incl. odd sizes (the 127x127 query)."""
+    from oneshotdet_amd import model
+    h, w = hw
+    x, wt = rnd(2, 3, h, w, seed=1, scale=50), rnd(64, 3, 7, 7, seed=2) / 12
+    bn = [rnd(64, seed=4).abs() + 0.5, rnd(64, seed=5), rnd(64, seed=6), rnd(64, seed=7).abs() + 0.5]
+    sd = {"conv1.weight": wt, "bn1.weight": bn[0], "bn1.bias": bn[1], "bn1.running_mean": bn[2], "bn1.running_var": bn[3]}
+    if dt == "bf16":
+        x = x.bfloat16().float()
+    ref = orc.stem(x, sd, "")
+    pc = ops().pack_conv(wt.cuda(), bn=[t.cuda() for t in bn], dtype=DT[dt], stem=True)
+    ho, wo = ops().conv_out(h, 7, 2, 3), ops().conv_out(w, 7, 2, 3)
+    hp, wp = max(2 * (ho - 1) + 7, h + 3), max(2 * (wo - 1) + 8, w + 3)
+    wp += wp & 1
+    xi = ops().pack_image(x.cuda(), DT[dt], hp, wp)
+    y = ops().maxpool3x3s2(ops().conv2d(xi, pc, act=ops().ACT_RELU, out_hw=(ho, wo)))
+    # +-150-valued pixels through a 147-tap dot product: outputs reach 1e2-1e3
+    tol = dict(rtol=1e-4, atol=1e-3) if dt == "f32" else dict(rtol=5e-2, atol=0.5)
+    torch.testing.assert_close(from_nhwc(y), ref, **tol)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 256, 7, 8), (1, 256, 25, 32), (3, 256, 13, 16)])
+def test_groupnorm_relu(shape, dt):
+    """nn.GroupNorm(32, 256) + ReLU, fcos.py:37-38."""
+    x, g, b = rnd(*shape, seed=1, scale=3) + 0.5, rnd(shape[1], seed=2).abs() + 0.5, rnd(shape[1], seed=3)
+    if dt == "bf16":
+        x = x.bfloat16().float()
+    ref = F.relu(F.group_norm(x, 32, g, b, eps=1e-5))
+    y = ops().groupnorm_relu(to_nhwc(x, DT[dt]), g.cuda(), b.cuda(), 32, 1e-5)
+    torch.testing.assert_close(from_nhwc(y), ref, **(TOL[dt] if dt == "bf16" else dict(rtol=1e-4, atol=1e-4)))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_roi_align_reference_vectors(dt):
+    """Vectors recorded through the reference's _C.roi_align_forward (tests/golden/roialign.npz)."""
+    f = gu.load("roialign.npz")
+    for i in range(int(f["n"])):
+        scale, ph, pw, sr = f["args.%d" % i]
+        x = torch.from_numpy(f["x.%d" % i])
+        if dt == "bf16":
+            x = x.bfloat16().float()
+            ref = orc.roi_align(x, torch.from_numpy(f["rois.%d" % i]), float(scale), int(ph), int(pw), int(sr))
+        else:
+            ref = torch.from_numpy(f["y.%d" % i])
+        y = ops().roi_align(to_nhwc(x, DT[dt]), torch.from_numpy(f["rois.%d" % i]).cuda(), float(scale), int(ph), int(pw),
+                            int(sr))
+        torch.testing.assert_close(y.cpu().permute(0, 3, 1, 2), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 256, 7, 8), (1, 256, 100, 128), (3, 64, 5, 3)])
+def test_correlate_matches_broadcast_multiply(shape, dt):
+    """generalized_rcnn.py:307-311; in bf16 the product is rounded once from the fp32 product."""
+    x, q = rnd(*shape, seed=1), rnd(shape[0], shape[1], seed=2)
+    if dt == "bf16":
+        x = x.bfloat16().float()
+    ref = orc.correlate([x], [q.view(shape[0], shape[1], 1, 1)])[0]
+    y = ops().correlate(to_nhwc(x, DT[dt]), q.cuda())
+    if dt == "bf16":
+        ref = ref.bfloat16().float()
+    torch.testing.assert_close(from_nhwc(y), ref, rtol=0, atol=0)   # one fp32 multiply: bit exact
+
+
+def test_shot_mean():
+    x = rnd(10, 256, seed=1)
+    y = ops().shot_mean(x.cuda(), 2)
+    torch.testing.assert_close(y.cpu(), x.view(2, 5, 256).mean(1), rtol=1e-6, atol=1e-6)
+
+
+def test_empty_inputs_are_noops():
+    o = ops()
+    y = o.correlate(torch.zeros(0, 4, 4, 256, device="cuda"), torch.zeros(0, 256, device="cuda"))
+    assert y.shape == (0, 4, 4, 256)
+    r = o.roi_align(torch.zeros(1, 4, 4, 8, device="cuda"), torch.zeros(0, 5, device="cuda"), 0.5, 1, 1, 2)
+    assert r.shape == (0, 1, 1, 8)
+
+
+def test_sigmoid_focal_loss_fwd_bwd():
+    """csrc/cuda/SigmoidFocalLoss_cuda.cu:21-101 vs the oracle's CUDA-formula restatement + autograd."""
+    logits = (rnd(777, 1, seed=1) * 4).requires_grad_(True)
+    targets = (torch.rand(777, generator=torch.Generator().manual_seed(2)) < 0.1).int()
+    targets[5] = -1     # ignored row: contributes to neither term
+    ref = orc.sigmoid_focal_loss_cuda_formula(logits, targets, 2.0, 0.25)
+    gup = rnd(777, 1, seed=3)
+    ref.backward(gup)
+    y = ops().sigmoid_focal_loss_fwd(logits.detach().cuda(), targets.cuda(), 2.0, 0.25)
+    torch.testing.assert_close(y.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    d = ops().sigmoid_focal_loss_bwd(logits.detach().cuda(), targets.cuda(), gup.cuda(), 2.0, 0.25)
+    torch.testing.assert_close(d.cpu(), logits.grad, rtol=1e-4, atol=1e-6)

@@ -1,0 +1,101 @@
+"""GPU (-m gpu): the HIP hot path end to end against the golden fixtures generated from the REAL reference
+(tests/golden/*.npz, see tests/golden/make_golden.py) and against the oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json: "within 1e-3 fp32"):
+  fp32 path   head outputs (logit, l, t, r, b, centerness): atol 1e-3 + rtol 1e-3 (bbox distances reach 1e2 after exp)
+              features / combined: atol 1e-3 * absmax + rtol 1e-3 on 4096 hashed samples, per-channel mean and absmax
+              pooled query vectors: rtol 1e-4, atol 1e-4
+  bf16 path   logits / centerness atol 0.15, bbox distances rtol 0.2 (8-bit mantissa through ~60 layers, then exp)
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+from oneshotdet_amd import spec, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from oneshotdet_amd import model
+    np_sd = synth.make_state_dict(spec.hot_path_shapes())
+    return {"f32": model.HotPathEngine(np_sd, dtype=torch.float32),
+            "bf16": model.HotPathEngine(np_sd, dtype=torch.bfloat16)}
+
+
+def nchw(t):
+    from oneshotdet_amd import ops
+    return ops.nhwc_to_nchw_f32(t).cpu().numpy()
+
+
+def head_of(out):
+    logits = [nchw(c)[:, 0:1] for c, _ in out["head"]]
+    ctr = [nchw(c)[:, 1:2] for c, _ in out["head"]]
+    reg = [nchw(r) for _, r in out["head"]]
+    return gu.flatten_head(logits, reg, ctr)
+
+
+@pytest.mark.parametrize("name", ["small", "nonsquare", "shots5", "tall", "config1"])
+def test_fp32_forward_matches_reference_golden(name, engines):
+    B, H, W, S, qh, qw = gu.CASES[name]
+    img, q = gu.case_inputs(name)
+    f = gu.load("case_%s.npz" % name)
+    out = engines["f32"].detect(torch.from_numpy(img).cuda(), torch.from_numpy(q).cuda(), cuda_nms=False)
+    np.testing.assert_allclose(head_of(out), f["head"], rtol=1e-3, atol=1e-3)
+    for lvl in range(5):
+        np.testing.assert_allclose(out["pooled"][lvl].cpu().numpy(), f["pooled.%d" % lvl], rtol=1e-4, atol=1e-4)
+        gu.check_against(nchw(out["features"][lvl]), f, "features.%d" % lvl, 1e-3, 1e-3)
+        gu.check_against(nchw(out["combined"][lvl]), f, "combined.%d" % lvl, 1e-3, 1e-3)
+        gu.check_against(nchw(out["query_features"][lvl]), f, "query_features.%d" % lvl, 1e-3, 1e-3)
+    ob, os_, oc = out["proposals"]
+    for i in range(B):
+        k = int(oc[i])
+        rb, rs = f["proposals.%d.boxes" % i], f["proposals.%d.scores" % i]
+        # proposals come from OUR head outputs (1e-6-level differences can flip a tie at the NMS threshold)
+        assert abs(k - len(rb)) <= max(1, len(rb) // 200)
+        assert gu.match_boxes(rb, rs, ob[i, :k].cpu().numpy(), os_[i, :k].cpu().numpy()) >= 0.99
+
+
+@pytest.mark.parametrize("name", ["small", "shots5", "config1"])
+def test_bf16_forward_close_to_reference_golden(name, engines):
+    img, q = gu.case_inputs(name)
+    f = gu.load("case_%s.npz" % name)
+    out = engines["bf16"].forward(torch.from_numpy(img).cuda(), torch.from_numpy(q).cuda())
+    head, ref = head_of(out), f["head"]
+    np.testing.assert_allclose(head[..., 0], ref[..., 0], rtol=0, atol=0.15)
+    np.testing.assert_allclose(head[..., 5], ref[..., 5], rtol=0, atol=0.15)
+    np.testing.assert_allclose(head[..., 1:5], ref[..., 1:5], rtol=0.2, atol=0.05)
+    for lvl in range(5):
+        gu.check_against(nchw(out["features"][lvl]), f, "features.%d" % lvl, 3e-2, 5e-2)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_full_size_batch8_properties(dt, engines):
+    """BASELINE.json configs[1]/[2] size (8 x 800x1024 + 8 x 127x127).  Size-independent properties:
+    (a) every image of a batch of identical (image, query) pairs gives bit-identical outputs (tiling / batching
+        invariance of every kernel), (b) image 0 equals the 1-image run bit for bit, which for fp32 is itself pinned to
+        the reference by test_fp32_forward_matches_reference_golden[config1], (c) correlation is linear in the query,
+        (d) proposals are sorted, inside the image, and NMS is idempotent on them."""
+    from oneshotdet_amd import layers, ops
+    eng = engines[dt]
+    img, q = gu.case_inputs("config1")
+    images = torch.from_numpy(img).cuda().expand(8, -1, -1, -1).contiguous()
+    queries = torch.from_numpy(q).cuda().expand(8, -1, -1, -1).contiguous()
+    out8 = eng.detect(images, queries)
+    out1 = eng.detect(images[:1], queries[:1])
+    for lvl in range(5):
+        for a, b in zip(out8["head"][lvl], out1["head"][lvl]):
+            assert torch.equal(a[0], b[0]), "batch-8 image 0 differs from the single-image run (level %d)" % lvl
+            for i in range(1, 8):
+                assert torch.equal(a[i], a[0]), "image %d differs from image 0 (level %d)" % (i, lvl)
+    x, qv = out8["features"][0], out8["pooled"][0]
+    y1, y2 = ops.correlate(x, qv), ops.correlate(x, 2.0 * qv)
+    assert torch.equal(y2.float(), 2.0 * y1.float())
+    ob, os_, oc = out8["proposals"]
+    k = int(oc[0])
+    assert k > 0 and torch.all(os_[0, :k - 1] >= os_[0, 1:k])
+    b = ob[0, :k]
+    assert b.min() >= 0 and b[:, 2].max() <= 1023 and b[:, 3].max() <= 799
+    assert layers.nms(b, os_[0, :k], spec.NMS_THRESH).numel() == k

@@ -1,0 +1,88 @@
+"""GPU (-m gpu): NMS against the reference's own known-answer vectors, the proposal pipeline against the oracle,
+and size-independent properties at full size."""
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+from oracle import hotpath_ref as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_nms_reference_known_answers():
+    """reference tests/test_nms.py:11-217 (recorded in tests/golden/nms_kat.npz); CPU rule (>=) as recorded."""
+    from oneshotdet_amd import layers
+    f = gu.load("nms_kat.npz")
+    for i in range(int(f["n"])):
+        keep = layers.nms(torch.from_numpy(f["boxes.%d" % i]).cuda(), torch.from_numpy(f["scores.%d" % i]).cuda(),
+                          float(f["thresh.%d" % i]), cuda_semantics=False)
+        np.testing.assert_array_equal(keep.cpu().numpy(), f["keep.%d" % i])
+
+
+def test_nms_rules_and_edge_cases():
+    from oneshotdet_amd import layers
+    dev = "cuda"
+    assert layers.nms(torch.zeros(0, 4, device=dev), torch.zeros(0, device=dev), 0.5).shape == (0,)
+    b = torch.tensor([[0, 0, 9, 9], [0, 0, 9, 9], [20, 20, 30, 30]], dtype=torch.float32, device=dev)
+    s = torch.tensor([0.5, 0.9, 0.1], device=dev)
+    assert layers.nms(b, s, 1.0, cuda_semantics=False).tolist() == [1, 2]     # nms_cpu.cpp:60  '>='
+    assert layers.nms(b, s, 1.0, cuda_semantics=True).tolist() == [0, 1, 2]   # nms.cu:60       '>'
+    with pytest.raises(RuntimeError):
+        layers.nms(b.cpu(), s.cpu(), 0.5)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4097])
+def test_nms_random_vs_oracle(n):
+    from oneshotdet_amd import layers
+    rng = np.random.RandomState(n)
+    xy = rng.uniform(0, 200, (n, 2)).astype(np.float32)
+    wh = rng.uniform(5, 80, (n, 2)).astype(np.float32)
+    boxes = np.concatenate([xy, xy + wh], 1)
+    scores = rng.permutation(n).astype(np.float32) / n          # distinct scores: no tie ambiguity
+    for thr, cuda in ((0.5, True), (0.8, False), (0.3, True)):
+        ref = orc.nms(boxes, scores, thr, cuda_semantics=cuda)
+        got = layers.nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thr, cuda_semantics=cuda)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    # idempotence: NMS of the survivors keeps all of them
+    keep = layers.nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 0.5)
+    again = layers.nms(torch.from_numpy(boxes).cuda()[keep], torch.from_numpy(scores).cuda()[keep], 0.5)
+    assert again.numel() == keep.numel()
+
+
+def _split_head(head, hw):
+    logits, reg, ctr, off = [], [], [], 0
+    for (h, w) in hw:
+        blk = head[:, off:off + h * w].permute(0, 2, 1).reshape(head.shape[0], 6, h, w)
+        logits.append(blk[:, 0:1]), reg.append(blk[:, 1:5]), ctr.append(blk[:, 5:6])
+        off += h * w
+    return logits, reg, ctr
+
+
+@pytest.mark.parametrize("name", ["small", "nonsquare", "config1"])
+def test_proposals_from_golden_head(name):
+    """R10/R11: score, per-level top-k, decode, clip, NMS(0.8), top-2000 from the REFERENCE's head outputs; compared
+    with the reference's proposals stored in the fixture (CPU rule)."""
+    from oneshotdet_amd import model, spec
+    B, H, W, S, qh, qw = gu.CASES[name]
+    f = gu.load("case_%s.npz" % name)
+    head = torch.from_numpy(f["head"])
+    from oneshotdet_amd import ops
+    sizes = spec.level_sizes(H, W) if (H % 32 == 0 and W % 32 == 0) else None
+    if sizes is None:
+        pytest.skip("non /32 size")
+    logits, reg, ctr = _split_head(head, sizes)
+    head_out = []
+    for lg, rg, ct in zip(logits, reg, ctr):
+        cc = torch.cat([lg, ct, torch.zeros_like(lg), torch.zeros_like(lg)], 1).permute(0, 2, 3, 1).contiguous().cuda()
+        head_out.append((cc, rg.permute(0, 2, 3, 1).contiguous().cuda()))
+    ob, os_, oc = model.run_proposals(head_out, H, W, spec.PRE_NMS_TOP_N_TEST, spec.POST_NMS_TOP_N_TEST,
+                                      spec.NMS_THRESH, cuda_nms=False)
+    for i in range(B):
+        k = int(oc[i])
+        rb, rs = f["proposals.%d.boxes" % i], f["proposals.%d.scores" % i]
+        assert k == len(rb)
+        sc = os_[i, :k].cpu().numpy()
+        assert np.all(np.diff(sc) <= 0), "scores must be descending"
+        assert gu.match_boxes(rb, rs, ob[i, :k].cpu().numpy(), sc) >= 0.999
+        np.testing.assert_allclose(sc, rs, rtol=1e-5, atol=1e-7)
