@@ -134,6 +134,7 @@ def main():
     images = torch.from_numpy(synth.make_images("bench.target", B, 800, 1024, seed=1000 + rank)).cuda()
     queries = torch.from_numpy(synth.make_images("bench.query", B, 127, 127, seed=1000 + rank)).cuda()
 
+    eng.tune(images, queries)      # per-shape conv algorithm selection by measurement (untimed, once)
     use_graph = not args.no_graph
     if use_graph:
         # production path: the whole forward captured once into a hipGraph (multi-stream branches), then replayed

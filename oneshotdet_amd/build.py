@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liboneshotdet_hip.so")
-SOURCES = ["osd_error.hip", "conv_igemm.hip", "elementwise.hip", "proposals.hip"]
+SOURCES = ["osd_error.hip", "conv_igemm.hip", "conv_igemm_dma.hip", "elementwise.hip", "proposals.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
@@ -26,7 +26,7 @@ def build_library(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "osd_common.h"), os.path.join(os.path.dirname(HERE), "include", "oneshotdet_hip.h")]
+    headers = [os.path.join(CSRC, "osd_common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(os.path.dirname(HERE), "include", "oneshotdet_hip.h")]
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -17,25 +17,11 @@
 //     stage); zero padding and the M tail are handled by predicating the 16-byte loads;
 //   * 1-D grid remapped so consecutive tiles (sharing the same pixel rows / halo) land on the same XCD's L2.
 #include "osd_common.h"
+#include "conv_params.h"
+#include <string.h>
 
 namespace {
 
-struct ConvKParams {
-  const void* x;
-  const void* w;
-  const float* bias;
-  const void* res;
-  void* y;
-  int H, W, Cin, sN, sH, sW;
-  int Ho, Wo, Cout, HoWo;
-  int R, S, sh, sw, ph, pw;
-  int w_rows, Ktot, out_stride;
-  int res_mode, res_h, res_w, res_stride;
-  int act;
-  float act_scale;
-  int relu_in;
-  int M, tilesM, tilesN, KT;
-};
 
 template <int KB> __device__ __forceinline__ int swz(int row, int chunk) {
   if constexpr (KB == 64) {
@@ -324,6 +310,8 @@ int choose_tile(int M, int cout) {
 
 }  // namespace
 
+extern "C" int osd_conv_algo_count(void) { return 32; }
+
 extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void* w, const float* bias,
                               const void* res, const float* gn_a, const float* gn_b, void* y, void* stream) {
   if (!d || !x || !w || !bias || !y) return osd_fail(OSD_ERR_INVALID_ARG, "conv: null argument");
@@ -354,7 +342,24 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
   if (M <= 0 || M > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad M");
   p.M = (int)M; p.tilesM = p.tilesN = p.KT = 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int tile = choose_tile(p.M, p.Cout);
+  int tile = choose_tile(p.M, p.Cout);
+  static int impl_env = -1;   // OSD_CONV_IMPL=regstage selects the first-generation register-staged kernel (A/B testing)
+  if (impl_env < 0) {
+    const char* e = getenv("OSD_CONV_IMPL");
+    impl_env = (e && !strcmp(e, "regstage")) ? 1 : 0;
+  }
+  if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad dtype %d", d->dtype);
+  int impl = impl_env, variant = 0;
+  if (d->algo > 0) {
+    const int a = d->algo - 1;
+    if (a >= 32) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad algo %d", d->algo);
+    impl = a >> 4;                 // 0 = LDS-DMA kernel, 1 = register-staged kernel
+    variant = (a >> 2) & 3;
+    tile = a & 3;
+    if (variant == 3 || (impl == 1 && variant != 0)) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: algo %d not built", d->algo);
+    if (p.Cout > 16 && tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: skinny tile on a wide conv");
+  }
+  if (impl == 0) return osd_conv_dma_dispatch(d->dtype, tile, variant, p, s);
   if (d->dtype == OSD_F32) {
     return dispatch_tile<float, 64>(tile, p, s);
   } else if (d->dtype == OSD_BF16) {

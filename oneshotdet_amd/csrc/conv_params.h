@@ -1,0 +1,23 @@
+// Kernel-side parameter block shared by the two implicit-GEMM convolution implementations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct ConvKParams {
+  const void* x;
+  const void* w;
+  const float* bias;
+  const void* res;
+  void* y;
+  int H, W, Cin, sN, sH, sW;
+  int Ho, Wo, Cout, HoWo;
+  int R, S, sh, sw, ph, pw;
+  int w_rows, Ktot, out_stride;
+  int res_mode, res_h, res_w, res_stride;
+  int act;
+  float act_scale;
+  int relu_in;
+  int M, tilesM, tilesN, KT;
+};
+
+// conv_igemm_dma.hip
+int osd_conv_dma_dispatch(int dtype, int tile, int variant, const ConvKParams& p, hipStream_t s);

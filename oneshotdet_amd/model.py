@@ -212,6 +212,13 @@ class HotPathEngine(object):
         self.supp_backbone = BackboneWeights(self.sd, "supp_backbone.", self.dtype)
         self.head = HeadWeights(self.sd, self.dtype)
 
+    def tune(self, images, queries):
+        """Pick, by measurement on this device, the conv algorithm (kernel generation, ring depth, tile) for every
+        distinct conv shape of this input geometry (cached in ops.ALGO_CACHE; a few ms per shape, done once)."""
+        with ops.tuning():
+            self.detect(images, queries, concurrent=False)
+        torch.cuda.synchronize()
+
     def side_streams(self):
         if getattr(self, "_streams", None) is None:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
@@ -260,6 +267,7 @@ class GraphedDetect(object):
         self.engine = engine
         self.images = images.clone()
         self.queries = queries.clone()
+        engine.tune(self.images, self.queries)
         side = torch.cuda.Stream(device=engine.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -91,8 +91,57 @@ def pack_image(images, dtype, hp, wp, pad_t=3, pad_l=3):
     return out
 
 
+# ---- per-shape algorithm selection by measurement ("measure, don't guess") ----
+# osd_conv_desc.algo = 1 + impl*16 + variant*4 + tile; impl 0 = LDS-DMA ring kernel (variants: deep / shallow ring /
+# short stages), impl 1 = register-staged kernel; tile 0..3 = 128x128, 128x64, 64x64, 256x16 (pixels x channels).
+ALGO_CACHE = {}
+_TUNING = [False]
+
+
+def conv_algo_candidates(cout_store, relu_in):
+    tiles = [3] if cout_store <= 16 else [0, 1, 2]
+    if cout_store <= 16:
+        tiles = [3, 2]
+    cands = [1 + 0 * 16 + v * 4 + t for v in (0, 1, 2) for t in tiles]
+    if not relu_in:
+        cands += [1 + 1 * 16 + t for t in tiles]
+    return cands
+
+
+class tuning(object):
+    """with ops.tuning(): ...   every conv shape met for the first time is timed over all candidate algorithms."""
+
+    def __enter__(self):
+        _TUNING[0] = True
+
+    def __exit__(self, *a):
+        _TUNING[0] = False
+
+
+def _tune(key, d, args):
+    best, best_t = 0, float("inf")
+    for algo in conv_algo_candidates(d.cout, d.relu_in):
+        d.algo = algo
+        try:
+            _lib.call("osd_conv2d_fwd", C.byref(d), *args)
+        except _lib.OsdError:
+            continue
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(3):
+            _lib.call("osd_conv2d_fwd", C.byref(d), *args)
+        ev[1].record()
+        torch.cuda.synchronize()
+        t = ev[0].elapsed_time(ev[1])
+        if t < best_t:
+            best, best_t = algo, t
+    ALGO_CACHE[key] = best
+    return best
+
+
 def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, relu_in=False, act_scale=1.0, out=None,
-           out_hw=None):
+           out_hw=None, algo=None):
     """x NHWC [N,H,W,C] -> [N,Ho,Wo,cout_store].  For the stem, x is the padded NHWC4 image from pack_image and
     out_hw gives (Ho, Wo)."""
     _chk_dev(x, res, out)
@@ -125,8 +174,14 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
         if res_mode == RES_UP2X:
             assert res.shape[1] * 2 == ho and res.shape[2] * 2 == wo, "top-down map must be exactly half size"
     d.act, d.act_scale, d.relu_in, d.gn_in = act, float(act_scale), int(relu_in), 0
-    _lib.call("osd_conv2d_fwd", C.byref(d), _ptr(x), _ptr(pc.w), _ptr(pc.bias), _ptr(res), None, None, _ptr(out),
-              _stream())
+    args = (_ptr(x), _ptr(pc.w), _ptr(pc.bias), _ptr(res), None, None, _ptr(out), _stream())
+    if algo is None:
+        key = (d.dtype, n * ho * wo, d.cout, d.cin, d.r, d.s, d.stride_h, d.pad_h, res_mode, act, int(relu_in))
+        algo = ALGO_CACHE.get(key)
+        if algo is None:
+            algo = _tune(key, d, args) if _TUNING[0] else 0
+    d.algo = algo
+    _lib.call("osd_conv2d_fwd", C.byref(d), *args)
     return out
 
 

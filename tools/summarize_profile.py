@@ -23,7 +23,7 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else line["steps"]
     stats = list(csv.DictReader(open(os.path.join(d, "run_kernel_stats.csv"))))
     trace = [r for r in csv.DictReader(open(os.path.join(d, "run_kernel_trace.csv")))]
-    convs = [r for r in trace if "conv_igemm" in r["Kernel_Name"]]
+    convs = [r for r in trace if "conv_igemm" in r["Kernel_Name"] or "conv_dma" in r["Kernel_Name"]]
     launches = workload.conv_launches(8, 800, 1024, 8, 127, 127)
     per = len(launches)
     last = convs[-steps * per:]
