@@ -139,12 +139,14 @@ int osd_fcos_score_decode(const void* cls_ctr, const void* reg, float* scores, f
 /* Per-level top-k of inference.py:97-102 (exact, by rank): within keys[img][lo .. lo+cnt) keep the `topn` largest
  * (ties: lower index first), write key -1 for the rest.  keys_in/keys_out: [n][total] fp32 (may alias). */
 int osd_level_topk(const float* keys_in, float* keys_out, int n, int total, int lo, int cnt, int topn, void* stream);
-/* Sort the live (key >= 0) candidates of each image by (key descending, index ascending) and gather their boxes:
- * boxes_sorted [n][max_count][4], scores_sorted [n][max_count], idx_sorted [n][max_count] (original index),
- * counts [n] (live candidates, written by the call).  Replaces scores.sort(descending) + index_select of
- * csrc/cuda/nms.cu:73-75. */
-int osd_rank_sort_gather(const float* keys, const float* boxes, int n, int total, int max_count, float* boxes_sorted,
-                         float* scores_sorted, int32_t* idx_sorted, int32_t* counts, void* stream);
+/* Per-level top-k (inference.py:97-102) fused with the descending sort that NMS needs (csrc/cuda/nms.cu:73-75): the
+ * candidates of each image are split into `n_levels` consecutive segments (level_lo/level_cnt, HOST arrays); within a
+ * segment only the `topn` best (score desc, index asc) survive; survivors of all segments are ordered by (score desc,
+ * index asc) and their boxes gathered: boxes_sorted [n][max_count][4], scores_sorted [n][max_count], idx_sorted
+ * [n][max_count] (original index), counts [n] (written by the call).  n_levels = 0: one segment, no cut. */
+int osd_rank_sort_gather(const float* keys, const float* boxes, int n, int total, int max_count,
+                         const int32_t* level_lo, const int32_t* level_cnt, int n_levels, int topn,
+                         float* boxes_sorted, float* scores_sorted, int32_t* idx_sorted, int32_t* counts, void* stream);
 /* Greedy NMS over boxes ALREADY SORTED by descending score, per image, stopping after max_keep survivors
  * (= boxlist_nms + the post-NMS top-n of inference.py:316-321).  mask_ws: osd_nms_workspace_bytes(n, max_count)
  * bytes.  out_boxes [n][max_keep][4], out_scores [n][max_keep], out_pos [n][max_keep] (position in the sorted

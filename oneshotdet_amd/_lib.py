@@ -44,7 +44,7 @@ SIGNATURES = {
     "osd_correlate_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "osd_fcos_score_decode": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "osd_level_topk": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
-    "osd_rank_sort_gather": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "osd_rank_sort_gather": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "osd_nms_sorted": (_i, [_p, _p, _p, _i, _i, _f, _i, _i, _p, _p, _p, _p, _p, _p]),
     "osd_nms_workspace_bytes": (_i64, [_i, _i]),
     "osd_sigmoid_focal_fwd": (_i, [_p, _p, _p, _i, _i, _f, _f, _p]),

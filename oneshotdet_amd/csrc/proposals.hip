@@ -57,25 +57,53 @@ __global__ void __launch_bounds__(256) level_topk_kernel(const float* __restrict
   if (i < cnt) keys_out[(size_t)img * total + lo + i] = (rank < topn && ki >= 0.f) ? ki : -1.f;
 }
 
-// ---- global rank sort + gather: position of element i = #elements before it; dropped elements (key < 0) skipped ----
+// ---- fused per-level top-k + global order + gather ----
+// For element i of level L let c_l = #elements of level l that come before i (score desc, index asc).  Then
+//   i survives the per-level top-k   <=>  c_L < topn            (inference.py:97-102)
+//   position of i among the survivors =  sum_l min(c_l, topn)   (the survivors of a level are a prefix of its order)
+// so ONE O(n^2) pass gives both, with a single 64-bit compare per pair: key64 = (score bits + 1) << 32 | ~index.
+struct LevelTable {
+  int n_levels;
+  int lo[8];     // first location of each level
+  int cnt[8];
+};
+
+__device__ __forceinline__ unsigned long long key64(float k, int idx) {
+  const unsigned hi = k >= 0.f ? __float_as_uint(k) + 1u : 0u;      // dropped candidates (-1) sort last
+  return ((unsigned long long)hi << 32) | (unsigned)(~idx);
+}
+
 __global__ void __launch_bounds__(256) rank_sort_gather_kernel(const float* __restrict__ keys, const float* __restrict__ boxes,
-                                                               int total, int max_count, float* __restrict__ boxes_sorted,
+                                                               int total, int max_count, int topn, LevelTable lt,
+                                                               float* __restrict__ boxes_sorted,
                                                                float* __restrict__ scores_sorted, int* __restrict__ idx_sorted,
                                                                int* __restrict__ counts) {
-  __shared__ float tile[1024];
+  __shared__ unsigned long long tile[1024];
   const int img = blockIdx.y;
   const float* k = keys + (size_t)img * total;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const float ki = i < total ? k[i] : -1.f;
-  int rank = 0;
-  for (int j0 = 0; j0 < total; j0 += 1024) {
-    const int m = min(1024, total - j0);
-    __syncthreads();
-    for (int t = threadIdx.x; t < m; t += blockDim.x) tile[t] = k[j0 + t];
-    __syncthreads();
-    for (int t = 0; t < m; ++t) rank += before(tile[t], j0 + t, ki, i);
+  const unsigned long long mine = key64(ki, i);
+  int rank = 0, own_before = 0;
+  for (int l = 0; l < lt.n_levels; ++l) {
+    const int lo = lt.lo[l], cnt = lt.cnt[l];
+    int c = 0;
+    for (int j0 = 0; j0 < cnt; j0 += 1024) {
+      const int m = min(1024, cnt - j0);
+      __syncthreads();
+      for (int t = threadIdx.x; t < 1024; t += blockDim.x)
+        tile[t] = t < m ? key64(k[lo + j0 + t], lo + j0 + t) : 0ULL;      // 0 is never "before" anything
+      __syncthreads();
+#pragma unroll 8
+      for (int t = 0; t < 1024; t += 2) {       // whole tile: the zero padding keeps the loop branch free
+        const ulonglong2 two = *reinterpret_cast<const ulonglong2*>(&tile[t]);
+        c += (two.x > mine) + (two.y > mine);
+      }
+    }
+    if (i >= lo && i < lo + cnt) own_before = c;
+    rank += min(c, topn);
   }
-  const bool live = (i < total) && (ki >= 0.f) && (rank < max_count);
+  const bool live = (i < total) && (ki >= 0.f) && (own_before < topn) && (rank < max_count);
   if (live) {
     const size_t o = (size_t)img * max_count + rank;
     *reinterpret_cast<float4*>(boxes_sorted + o * 4) =
@@ -180,12 +208,17 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
     }
     __syncthreads();
     const unsigned long long keep = s_keep;
+    // every thread owns one 64-box column word and ORs in the rows of the boxes kept in this block.  The 64 row loads
+    // are issued unconditionally and independently (8 in flight at a time), then masked by the keep bits: a
+    // data-dependent `while (bits)` walk would serialise ~60 L2/MALL round trips per block.
+    const int rows_here = min(64, n - blk * 64);
     for (int c = blk + 1 + threadIdx.x; c < nblk; c += blockDim.x) {
-      unsigned long long acc = 0ULL, bits = keep;
-      while (bits) {
-        const int l = __ffsll((long long)bits) - 1;
-        bits &= bits - 1ULL;
-        acc |= mk[(size_t)(blk * 64 + l) * col_blocks + c];
+      unsigned long long acc = 0ULL;
+      const unsigned long long* col = mk + (size_t)(blk * 64) * col_blocks + c;
+#pragma unroll 8
+      for (int l = 0; l < 64; ++l) {
+        const unsigned long long w = (l < rows_here) ? col[(size_t)l * col_blocks] : 0ULL;
+        acc |= ((keep >> l) & 1ULL) ? w : 0ULL;
       }
       remv[c] |= acc;
     }
@@ -227,16 +260,31 @@ extern "C" int osd_level_topk(const float* keys_in, float* keys_out, int n, int 
 }
 
 extern "C" int osd_rank_sort_gather(const float* keys, const float* boxes, int n, int total, int max_count,
+                                    const int32_t* level_lo, const int32_t* level_cnt, int n_levels, int topn,
                                     float* boxes_sorted, float* scores_sorted, int32_t* idx_sorted, int32_t* counts,
                                     void* stream) {
   if (!keys || !boxes || !boxes_sorted || !scores_sorted || !idx_sorted || !counts)
     return osd_fail(OSD_ERR_INVALID_ARG, "rank_sort_gather: null argument");
   if (n == 0) return OSD_OK;
+  LevelTable lt;
+  if (n_levels <= 0 || !level_lo || !level_cnt) {       // one segment, no per-level cut
+    lt.n_levels = 1; lt.lo[0] = 0; lt.cnt[0] = total; topn = total > 0 ? total : 1;
+  } else {
+    if (n_levels > 8) return osd_fail(OSD_ERR_UNSUPPORTED, "rank_sort_gather: at most 8 levels");
+    lt.n_levels = n_levels;
+    int expect = 0;
+    for (int l = 0; l < n_levels; ++l) {
+      lt.lo[l] = level_lo[l]; lt.cnt[l] = level_cnt[l];
+      if (level_lo[l] != expect) return osd_fail(OSD_ERR_INVALID_ARG, "rank_sort_gather: levels must tile [0,total)");
+      expect += level_cnt[l];
+    }
+    if (expect != total) return osd_fail(OSD_ERR_INVALID_ARG, "rank_sort_gather: levels must tile [0,total)");
+  }
   hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * n, OSD_STREAM(stream));
   if (e != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "rank_sort_gather: memset: %s", hipGetErrorString(e));
   if (total == 0) return OSD_OK;
   hipLaunchKernelGGL(rank_sort_gather_kernel, dim3(cdiv(total, 256), n), dim3(256), 0, OSD_STREAM(stream), keys, boxes,
-                     total, max_count, boxes_sorted, scores_sorted, idx_sorted, counts);
+                     total, max_count, topn, lt, boxes_sorted, scores_sorted, idx_sorted, counts);
   return osd_check_launch("rank_sort_gather");
 }
 

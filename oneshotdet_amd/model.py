@@ -180,12 +180,9 @@ def run_proposals(head_out, img_h, img_w, pre_nms_top_n, post_nms_top_n, nms_thr
         ops.fcos_score_decode(cls_ctr, reg, scores, boxes, stride, off, img_h, img_w)
         offs.append(off)
         off += cls_ctr.shape[1] * cls_ctr.shape[2]
-    max_count = 0
-    for (h, w), lo in zip(sizes, offs):
-        if h * w > pre_nms_top_n:
-            ops.level_topk(scores, lo, h * w, pre_nms_top_n)
-        max_count += min(h * w, pre_nms_top_n)
-    bs, ss, idx, cnt = ops.rank_sort_gather(scores, boxes, max_count)
+    levels = [(lo, h * w) for (h, w), lo in zip(sizes, offs)]
+    max_count = sum(min(c, pre_nms_top_n) for _, c in levels)
+    bs, ss, idx, cnt = ops.rank_sort_gather(scores, boxes, max_count, levels, pre_nms_top_n)
     ob, os_, op, oc = ops.nms_sorted(bs, ss, cnt, nms_thresh, post_nms_top_n, cuda_semantics=cuda_nms,
                                      workspace=workspace)
     return ob, os_, oc

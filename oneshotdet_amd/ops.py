@@ -271,8 +271,9 @@ def level_topk(keys, lo, cnt, topn):
     _lib.call("osd_level_topk", _ptr(keys), _ptr(keys), n, total, lo, cnt, topn, _stream())
 
 
-def rank_sort_gather(keys, boxes, max_count):
-    """keys [N,T] fp32 (dropped = -1), boxes [N,T,4] -> boxes_sorted [N,max_count,4], scores_sorted, idx_sorted, counts"""
+def rank_sort_gather(keys, boxes, max_count, levels=None, topn=0):
+    """keys [N,T] fp32 (dropped = -1), boxes [N,T,4]; levels = [(lo, cnt), ...] tiling [0,T) with a per-level top-`topn`
+    cut (None: no cut) -> boxes_sorted [N,max_count,4], scores_sorted, idx_sorted, counts."""
     _chk_dev(keys, boxes)
     n, total = keys.shape
     dev = keys.device
@@ -280,8 +281,14 @@ def rank_sort_gather(keys, boxes, max_count):
     ss = torch.empty((n, max_count), device=dev, dtype=torch.float32)
     idx = torch.empty((n, max_count), device=dev, dtype=torch.int32)
     cnt = torch.empty((n,), device=dev, dtype=torch.int32)
-    _lib.call("osd_rank_sort_gather", _ptr(keys), _ptr(boxes), n, total, max_count, _ptr(bs), _ptr(ss), _ptr(idx),
-              _ptr(cnt), _stream())
+    if levels:
+        lo = (C.c_int32 * len(levels))(*[l for l, _ in levels])
+        lc = (C.c_int32 * len(levels))(*[c for _, c in levels])
+        nl = len(levels)
+    else:
+        lo, lc, nl = None, None, 0
+    _lib.call("osd_rank_sort_gather", _ptr(keys), _ptr(boxes), n, total, max_count, lo, lc, nl, int(topn), _ptr(bs),
+              _ptr(ss), _ptr(idx), _ptr(cnt), _stream())
     return bs, ss, idx, cnt
 
 
