@@ -108,24 +108,177 @@ def cpu_baseline(dtype_name, seconds_budget=25.0):
                       "(torch CPU fp32, %d threads)" % (n, cores)}
 
 
+def dist_setup(backend):
+    """One process per GPU, launched by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def timed_steps(step, steps, warmup, world, device_sync, reduce_device):
+    """W untimed steps, then exactly K steps bracketed by barrier + device sync on both sides; MAX over ranks."""
+    def sync():
+        device_sync()
+        if world > 1:
+            dist.barrier()
+            device_sync()
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=reduce_device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def result_line(args, world, batch, elapsed, workload, launch, roofline=None, cpu=None):
+    line = {
+        "metric": METRIC, "value": round(batch * world * args.steps / elapsed, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": workload, "global_batch": batch * world,
+                   "parallelism": "dp%d (batch sharded over ranks, no collective in forward)" % world,
+                   "launch": launch},
+        "roofline": roofline,
+    }
+    if cpu is not None:
+        line["cpu_baseline"] = cpu
+    return line
+
+
+class TrainTimer(ConvTimer):
+    """ConvTimer that also brackets the weight-gradient kernel (2*M*Cout*Cin*R*S FLOP per launch)."""
+
+    def install(self, ops):
+        ConvTimer.install(self, ops)
+        self._orig_w = ops.conv2d_wgrad
+        timer = self
+
+        def timed_wgrad(x, dy, dw, r, s, stride, pad, cout, scale=None):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            timer._orig_w(x, dy, dw, r, s, stride, pad, cout, scale=scale)
+            b.record()
+            timer.records.append((a, b))
+            timer.flops += 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * cout * x.shape[-1] * r * s
+            timer.launches += 1
+        ops.conv2d_wgrad = timed_wgrad
+
+    def uninstall(self, ops):
+        ConvTimer.uninstall(self, ops)
+        ops.conv2d_wgrad = self._orig_w
+
+
+def main_train(args, rank, world):
+    """BASELINE.json configs[2]/[3]: bs=8/GPU, forward + FCOS loss + backward + gradient all-reduce (RCCL) + SGD."""
+    import numpy as np
+    from oneshotdet_amd import ops, spec, synth, train
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    eng = train.TrainEngine(synth.make_state_dict(spec.hot_path_shapes()), dtype=dtype)
+    B = args.batch
+    images = torch.from_numpy(synth.make_images("bench.target", B, 800, 1024, seed=1000 + rank)).cuda()
+    queries = torch.from_numpy(synth.make_images("bench.query", B, 127, 127, seed=1000 + rank)).cuda()
+    gts = synth.make_gt_boxes(B, 800, 1024, seed=1000 + rank, max_boxes=6)
+    gtb = np.zeros((B, 6, 4), np.float32)
+    for i, g in enumerate(gts):
+        gtb[i, :len(g)] = g
+    gt_boxes = torch.from_numpy(gtb).cuda()
+    gt_count = torch.tensor([len(g) for g in gts], dtype=torch.int32).cuda()
+    with ops.tuning():
+        eng.forward_backward(images, queries, gt_boxes, gt_count)
+    torch.cuda.synchronize()
+
+    def step():
+        return eng.train_step(images, queries, gt_boxes, gt_count)
+
+    elapsed = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, "cuda")
+    roofline = None
+    if not args.no_conv_timing:
+        timer = TrainTimer()
+        timer.install(ops)
+        torch.cuda.synchronize()
+        nst = max(2, min(args.steps, 5))
+        for _ in range(nst):
+            torch.cuda._sleep(int(150e6))
+            eng.forward_backward(images, queries, gt_boxes, gt_count)
+            torch.cuda.synchronize()
+        conv_ms = timer.total_ms()
+        tflops = timer.flops / (conv_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                    "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "kernel": "conv_dma_kernel / conv_igemm_kernel (forward + data gradient) and conv_wgrad_kernel",
+                    "avg_launch_us": round(conv_ms * 1e3 / max(timer.launches, 1), 2),
+                    "launches_per_step": timer.launches // nst,
+                    "gflop_per_step": round(timer.flops / nst / 1e9, 1),
+                    "conv_ms_per_step": round(conv_ms / nst, 3),
+                    "measured": "HIP events per launch (minus the %.1f us empty-bracket overhead), %d eager steps after "
+                                "the timed region" % (ConvTimer.bracket_overhead_ms() * 1e3, nst)}
+        timer.uninstall(ops)
+    if rank == 0:
+        workload = ("BASELINE.json configs[2]: bs=%d/GPU, 800x1024 target + 127x127 query, %s MFMA convs, forward "
+                    "(two R-50-FPN backbones, query pooling, correlation, FCOS head, training proposals) + FCOS loss + "
+                    "backward (stem/layer1 frozen) + gradient all-reduce + SGD(momentum) + weight repack" % (B, args.dtype))
+        cpu = cpu_baseline(args.dtype) if (world == 1 and not args.no_cpu_baseline) else None
+        line = result_line(args, world, B, elapsed, workload, "eager, 1 stream", roofline, cpu)
+        line["config"]["parallelism"] = "dp%d, fp32 gradient all-reduce over RCCL (%d x flat buckets)" % (world, 4)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default=os.environ.get("OSD_BENCH_DTYPE", "f32"), choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default=os.environ.get("OSD_BENCH_DTYPE", ""), choices=["f32", "bf16"])
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-timing", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--mode", default=os.environ.get("OSD_BENCH_MODE", "train"), choices=["train", "forward"],
+                    help="train = forward + loss + backward + gradient all-reduce + SGD (the headline metric); "
+                         "forward = BASELINE.json configs[1] (inference forward incl. proposals)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="exercise only the multi-process plumbing (gloo, no GPU work): used by tests/test_dist_cpu.py")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_run_cpu:
+        rank, local_rank, world = dist_setup("gloo")
+        work = torch.zeros(1)
+
+        def fake_step():
+            work.add_(1.0 + rank)
+            time.sleep(0.002 * (1 + rank))       # rank-dependent so MAX-over-ranks is observable
+        elapsed = timed_steps(fake_step, args.steps, args.warmup, world, lambda: None, "cpu")
+        if rank == 0:
+            print(json.dumps(result_line(args, world, args.batch, elapsed, "dry run (no GPU work)", "cpu dry run")),
+                  flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), \
+        int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist_setup("nccl")
+    if not args.dtype:      # configs[2] (train) is bf16, configs[1] (forward parity config) is fp32
+        args.dtype = "bf16" if args.mode == "train" else "f32"
+    if args.mode == "train":
+        return main_train(args, rank, world)
 
     from oneshotdet_amd import model, ops, spec, synth
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
@@ -146,24 +299,7 @@ def main():
         def step():
             return eng.detect(images, queries)
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, "cuda")
 
     # Roofline of the dominant kernel family (conv_igemm): HIP events around every conv launch, on the stream the
     # kernel is launched on, over `steps` further steps of the SAME workload in this process, run eagerly on one
@@ -195,21 +331,12 @@ def main():
         timer.uninstall(ops)
 
     if rank == 0:
-        line = {
-            "metric": METRIC, "value": round(B * world * args.steps / elapsed, 2), "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1] shape, FORWARD ONLY (backward not built yet): bs=%d/GPU, "
-                                   "800x1024 target + 127x127 query, two R-50-FPN backbones + query pooling + "
-                                   "correlation + FCOS head + proposals (top-k, NMS 0.8, top-2000), %s MFMA convs"
-                                   % (B, args.dtype),
-                       "global_batch": B * world, "parallelism": "dp%d (no collective in forward)" % world,
-                       "launch": "hipGraph replay, 4 streams" if use_graph else "eager, 4 streams"},
-            "roofline": roofline,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.dtype)
+        workload = ("BASELINE.json configs[1] shape, FORWARD ONLY (backward not built yet): bs=%d/GPU, 800x1024 target + "
+                    "127x127 query, two R-50-FPN backbones + query pooling + correlation + FCOS head + proposals "
+                    "(top-k, NMS 0.8, top-2000), %s MFMA convs" % (B, args.dtype))
+        cpu = cpu_baseline(args.dtype) if (world == 1 and not args.no_cpu_baseline) else None
+        line = result_line(args, world, B, elapsed, workload,
+                           "hipGraph replay, 4 streams" if use_graph else "eager, 4 streams", roofline, cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

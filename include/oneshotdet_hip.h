@@ -74,14 +74,22 @@ typedef struct osd_conv_desc {
 /* number of selectable algorithms for osd_conv_desc.algo (valid values 1..count); unsupported combinations for a
  * given shape return OSD_ERR_UNSUPPORTED */
 int osd_conv_algo_count(void);
+/* mask (optional, same geometry as y, pixel stride = out_stride): y = mask > 0 ? y : 0 after the residual add — the
+ * ReLU backward of the layer whose forward output is `mask`, fused into the data-gradient convolution.
+ * act_scale_dev (optional device scalar) overrides d->act_scale for OSD_ACT_EXP_SCALE: the learnable Scale of fcos.py:81
+ * read on the device, so training needs no host round trip.  `reserved` must be NULL. */
 int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void* w, const float* bias, const void* res,
-                   const float* gn_a, const float* gn_b, void* y, void* stream);
+                   const void* mask, const float* act_scale_dev, const void* reserved, void* y, void* stream);
 
 /* OIHW fp32 conv weight (+ optional per-Cout scale = FrozenBN weight*rsqrt(var), layers/batch_norm.py:20) ->
  * packed [w_rows][r][s][cin_pad] rows of `dtype`, zero padded. */
 int osd_pack_conv_weight(const float* w_oihw, const float* scale, void* dst, int cout, int cin, int r, int s,
                          int w_rows, int cin_pad, int dtype, void* stream);
 /* 7x7 stem weight [64][3][7][7] (BaseStem conv1, resnet.py:323-325) -> [w_rows][7][32] with (s, c) at s*4+c. */
+/* same with the source in [cout][r][s][cin] order (src_orsi != 0): the layout the training engine keeps its fp32
+ * master weights in, so the optimiser, the weight gradient and the packers share one layout */
+int osd_pack_conv_weight_ex(const float* w, const float* scale, void* dst, int cout, int cin, int r, int s, int w_rows,
+                            int cin_pad, int src_orsi, int dtype, void* stream);
 int osd_pack_stem_weight(const float* w_oihw, const float* scale, void* dst, int cout, int w_rows, int dtype,
                          void* stream);
 /* NCHW fp32 image batch -> zero-padded NHWC4 [n][hp][wp][4] of `dtype` with the image at (pad_t, pad_l). Replaces the
@@ -165,6 +173,64 @@ int osd_sigmoid_focal_fwd(const float* logits, const int32_t* targets, float* lo
                           float alpha, void* stream);
 int osd_sigmoid_focal_bwd(const float* logits, const int32_t* targets, const float* d_losses, float* d_logits, int m,
                           int classes, float gamma, float alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Backward pass (BASELINE.json configs[2..4]: forward + backward).  In the reference these are autograd's ATen
+ * kernels (conv dgrad/wgrad, group_norm backward, ...), _C.roi_align_backward (csrc/ROIAlign.h:27-45,
+ * csrc/cuda/ROIAlign_cuda.cu:178-254) and the FCOS loss of modeling/rpn/fcos/loss.py:213-276.
+ * Data gradient of a stride-1 conv = osd_conv2d_fwd on dY with osd_pack_conv_weight_dgrad weights (pad' = r-1-pad),
+ * its `mask` epilogue applying the producer's ReLU backward; stride-2 1x1 = that on the small grid + osd_scatter2x.
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* OIHW fp32 (+ FrozenBN scale) -> [rows >= cin][r][s][cout_pad] with taps flipped: Wd[ci][r'][s'][co] = w[co][ci][R-1-r'][S-1-s'] */
+int osd_pack_conv_weight_dgrad(const float* w, const float* scale, void* dst, int cout, int cin, int r, int s, int rows,
+                               int cout_pad, int src_orsi, int dtype, void* stream);
+/* dW[cout][r][s][cin] (fp32, ACCUMULATED with atomics: zero it first) += sum over pixels dy[m][co] * x[m@tap][ci].
+ * d describes the FORWARD conv (x geometry, strides, pads, cout, out_stride = pixel stride of dy); scale (nullable) is a
+ * per-Cout factor applied to the contribution (the folded FrozenBN scale). */
+int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const void* dy, const float* scale, float* dw,
+                     void* stream);
+/* packed fp32 dW [cout][r][s][cin] -> OIHW fp32 gradient, multiplied by the folded FrozenBN scale (nullable);
+ * accumulate != 0 adds to grad_oihw (weights shared over FPN levels) */
+int osd_unpack_wgrad(const float* dw_packed, const float* scale, float* grad_oihw, int cout, int cin, int r, int s,
+                     int accumulate, void* stream);
+/* db[c] (fp32, accumulated with atomics) += sum over m of dy[m][c] */
+int osd_bias_grad(const void* dy, float* db, int m, int c, int stride, int dtype, void* stream);
+/* data gradient of strided convs without the implicit-GEMM path (the two 3x3/2 convs P6/P7): forward-packed weights,
+ * optional addend (same shape as dx) and ReLU mask */
+int osd_conv2d_dgrad_naive(const osd_conv_desc* d, const void* dy, const void* w_fwd_packed, const void* mask,
+                           const void* addend, void* dx, void* stream);
+/* dst = mask>0 ? (zero-inserted src + addend) : 0, where zero-inserted src[n,2ho,2wo,:] = src[n,ho,wo,:] (dst, mask,
+ * addend [n][h][w][c]; src [n][ho][wo][c]; mask, addend nullable) */
+int osd_scatter2x(const void* src, const void* mask, const void* addend, void* dst, int n, int h, int w, int ho, int wo,
+                  int c, int dtype, void* stream);
+/* out = (a + b) * (mask > 0); b and mask nullable */
+int osd_add_mask(const void* a, const void* b, const void* mask, void* out, int64_t numel, int dtype, void* stream);
+/* top[n,y,x,:] = prev[n,y,x,:] + sum_{2x2} inner[n,2y+i,2x+j,:]  (backward of the FPN nearest-2x top-down add; prev nullable) */
+int osd_upsample2x_bwd(const void* inner, const void* prev, void* top, int n, int h, int w, int c, int dtype, void* stream);
+/* dq[n][c] = sum_p g[n,p,c] * feat[n,p,c] (correlation backward w.r.t. the pooled query; d_feat = osd_correlate_fwd(g, q)) */
+int osd_correlate_bwd_query(const void* g, const void* feat, float* dq, int n, int hw, int c, int dtype, void* stream);
+/* _C.roi_align_backward on NHWC fp32: gx [b][h][w][c] (zeroed by the call) += taps of gy [r][ph][pw][c] */
+int osd_roialign_bwd(const float* gy, const float* rois, float* gx, int b, int h, int w, int c, int num_rois,
+                     float spatial_scale, int ph, int pw, int sampling_ratio, void* stream);
+int osd_shot_mean_bwd(const float* gy, float* gx, int b, int shots, int c, void* stream);
+int osd_cast_f32(const float* src, void* dst, int64_t numel, int dtype, void* stream);
+/* backward of t = relu(GroupNorm(u)): du from dt; a, b = the forward's per-(image, channel) scale/shift
+ * (osd_groupnorm_finalize); ws: (n*OSD_GN_SPLITS*groups*2 + n*groups*2) floats; dgamma/dbeta [c] fp32 accumulated */
+int osd_groupnorm_relu_bwd(const void* u, const void* dt, const float* a, const float* b, const float* gamma,
+                           const float* beta, float* ws, float* dgamma, float* dbeta, void* du, int n, int hw, int c,
+                           int groups, int dtype, void* stream);
+/* FCOS loss (modeling/rpn/fcos/loss.py:101-276; focal term = csrc/cuda/SigmoidFocalLoss_cuda.cu) for one FPN level.
+ * phase 0 accumulates sums[5] = {num_pos, sum_w, sum_focal, sum_w*(1-giou), sum_bce} (zero them before the first
+ * level); phase 1 writes d_cls_ctr [n][hw][grad_stride] (d logit, d centerness at +0/+1; the caller zero-fills the
+ * rest, the layout the data-gradient conv consumes), d_reg [n][hw][grad_stride] (4 values) = gradient w.r.t. the
+ * bbox_pred conv output (already through exp and the Scale), and accumulates d_scale_raw (divide by scale).
+ * gt_boxes [n][max_gt][4] fp32 xyxy, gt_count [n]. */
+int osd_fcos_loss_level(int phase, const void* cls_ctr, const void* reg, const float* gt_boxes, const int32_t* gt_count,
+                        int max_gt, int n, int h, int w, int stride, float size_lo, float size_hi, float radius,
+                        float gamma, float alpha, const float* scale_dev, float* sums, void* d_cls_ctr, void* d_reg,
+                        int grad_stride, float* d_scale_raw, int dtype, void* stream);
+/* losses[4] = {loss_cls, loss_reg, loss_centerness, num_pos} */
+int osd_fcos_loss_finalize(const float* sums, float* losses, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ SIGNATURES = {
     "osd_last_error_string": (C.c_char_p, []),
     "osd_abi_version": (_i, []),
     "osd_conv_algo_count": (_i, []),
-    "osd_conv2d_fwd": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
+    "osd_conv2d_fwd": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_pack_conv_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "osd_pack_stem_weight": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "osd_pack_image": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -49,6 +49,22 @@ SIGNATURES = {
     "osd_nms_workspace_bytes": (_i64, [_i, _i]),
     "osd_sigmoid_focal_fwd": (_i, [_p, _p, _p, _i, _i, _f, _f, _p]),
     "osd_sigmoid_focal_bwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _f, _p]),
+    "osd_pack_conv_weight_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "osd_pack_conv_weight_ex": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "osd_conv2d_wgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p]),
+    "osd_unpack_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "osd_bias_grad": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "osd_conv2d_dgrad_naive": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
+    "osd_scatter2x": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "osd_add_mask": (_i, [_p, _p, _p, _p, _i64, _i, _p]),
+    "osd_upsample2x_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "osd_correlate_bwd_query": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "osd_roialign_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p]),
+    "osd_shot_mean_bwd": (_i, [_p, _p, _i, _i, _i, _p]),
+    "osd_cast_f32": (_i, [_p, _p, _i64, _i, _p]),
+    "osd_groupnorm_relu_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "osd_fcos_loss_level": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _p, _p, _p, _p, _i, _p, _i, _p]),
+    "osd_fcos_loss_finalize": (_i, [_p, _p, _i, _p]),
 }
 
 _lib = None

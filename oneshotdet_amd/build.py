@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liboneshotdet_hip.so")
-SOURCES = ["osd_error.hip", "conv_igemm.hip", "conv_igemm_dma.hip", "elementwise.hip", "proposals.hip"]
+SOURCES = ["osd_error.hip", "conv_igemm.hip", "conv_igemm_dma.hip", "conv_wgrad.hip", "backward.hip", "loss.hip", "elementwise.hip", "proposals.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 

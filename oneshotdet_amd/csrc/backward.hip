@@ -1,0 +1,535 @@
+// Backward-pass support kernels (HBM-bound, NHWC, 16 bytes per lane where the layout allows):
+// data-gradient weight packing, stride-2 scatter, ReLU masks, top-down (nearest 2x) backward, correlation backward,
+// ROIAlign backward, GroupNorm(+ReLU) backward, naive strided data gradient for the two tiny 3x3/2 convs (P6/P7),
+// weight-gradient unpacking (packed [Cout][R][S][Cin] fp32 -> OIHW, FrozenBN scale applied).
+#include "osd_common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;
+inline int grid_for(long long work, int threads) {
+  long long b = (work + threads - 1) / threads;
+  if (b < 1) b = 1;
+  return (int)(b > kMaxBlocks ? kMaxBlocks : b);
+}
+
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  float v[4];
+  __device__ __forceinline__ void load(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Chunk<__bf16> {
+  static constexpr int N = 8;
+  float v[8];
+  __device__ __forceinline__ void load(const __bf16* p) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+  }
+  __device__ __forceinline__ void store(__bf16* p) const {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (__bf16)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  }
+};
+
+// Wd[ci][r'][s'][co] = w[co][ci][R-1-r'][S-1-s'] * scale[co]   (data gradient of a stride-1 conv = conv with these)
+template <typename T>
+__global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ dst,
+                                         int cout, int cin, int R, int S, int rows, int cout_pad, int src_orsi) {
+  const long long total = (long long)rows * R * S * cout_pad;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % cout_pad);
+    long long t = i / cout_pad;
+    const int s = (int)(t % S); t /= S;
+    const int r = (int)(t % R);
+    const int ci = (int)(t / R);
+    float v = 0.f;
+    if (co < cout && ci < cin) {
+      v = src_orsi ? w[(((size_t)co * R + (R - 1 - r)) * S + (S - 1 - s)) * cin + ci]
+                   : w[(((size_t)co * cin + ci) * R + (R - 1 - r)) * S + (S - 1 - s)];
+      if (scale) v *= scale[co];
+    }
+    dst[i] = from_f32<T>(v);
+  }
+}
+
+// packed fp32 weight gradient [cout][R][S][cin] -> OIHW, times the folded FrozenBN scale (d/dw of conv(x, w*scale))
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, const float* __restrict__ scale, float* __restrict__ g,
+                                    int cout, int cin, int R, int S, int accumulate) {
+  const long long total = (long long)cout * cin * R * S;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int s = (int)(i % S);
+    long long t = i / S;
+    const int r = (int)(t % R); t /= R;
+    const int ci = (int)(t % cin);
+    const int co = (int)(t / cin);
+    float v = dwp[(((size_t)co * R + r) * S + s) * cin + ci];
+    if (scale) v *= scale[co];
+    g[i] = accumulate ? g[i] + v : v;
+  }
+}
+
+// dst[n, 2*ho, 2*wo, c] = mask > 0 ? src[n, ho, wo, c] : 0 ; every other position 0   (data gradient of a 1x1/2 conv)
+template <typename T>
+__global__ void scatter2x_kernel(const T* __restrict__ src, const T* __restrict__ mask, const T* __restrict__ addend,
+                                 T* __restrict__ dst, int n, int h, int w, int ho, int wo, int c) {
+  constexpr int E = Chunk<T>::N;
+  const int cch = c / E;
+  const long long total = (long long)n * h * w * cch;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cch);
+    long long t = i / cch;
+    const int x = (int)(t % w); t /= w;
+    const int y = (int)(t % h);
+    const int b = (int)(t / h);
+    Chunk<T> v;
+#pragma unroll
+    for (int e = 0; e < E; ++e) v.v[e] = 0.f;
+    if (!(x & 1) && !(y & 1) && (y >> 1) < ho && (x >> 1) < wo)
+      v.load(src + (((size_t)b * ho + (y >> 1)) * wo + (x >> 1)) * c + cc * E);
+    if (addend) {
+      Chunk<T> a;
+      a.load(addend + i * E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) v.v[e] += a.v[e];
+    }
+    if (mask) {
+      Chunk<T> m;
+      m.load(mask + i * E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) v.v[e] = m.v[e] > 0.f ? v.v[e] : 0.f;
+    }
+    v.store(dst + i * E);
+  }
+}
+
+// out = (a [+ b]) masked by (mask > 0)      (ReLU backward, optionally summing two gradient branches)
+template <typename T>
+__global__ void add_mask_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ mask, T* __restrict__ out,
+                                long long chunks) {
+  constexpr int E = Chunk<T>::N;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < chunks; i += (long long)gridDim.x * blockDim.x) {
+    Chunk<T> v;
+    v.load(a + i * E);
+    if (b) {
+      Chunk<T> w;
+      w.load(b + i * E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) v.v[e] += w.v[e];
+    }
+    if (mask) {
+      Chunk<T> m;
+      m.load(mask + i * E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) v.v[e] = m.v[e] > 0.f ? v.v[e] : 0.f;
+    }
+    v.store(out + i * E);
+  }
+}
+
+// nearest-2x upsample backward: top[n,y,x,c] (+)= sum_{i,j<2} inner[n,2y+i,2x+j,c]      (fpn.py:59-64)
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ inner, const T* __restrict__ prev, T* __restrict__ top, int n,
+                                      int h, int w, int c) {
+  constexpr int E = Chunk<T>::N;
+  const int cch = c / E;
+  const long long total = (long long)n * h * w * cch;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cch);
+    long long t = i / cch;
+    const int x = (int)(t % w); t /= w;
+    const int y = (int)(t % h);
+    const int b = (int)(t / h);
+    Chunk<T> s;
+    if (prev) s.load(prev + i * E);
+    else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) s.v[e] = 0.f;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        Chunk<T> v;
+        v.load(inner + (((size_t)b * 2 * h + 2 * y + dy) * 2 * w + 2 * x + dx) * c + cc * E);
+#pragma unroll
+        for (int e = 0; e < E; ++e) s.v[e] += v.v[e];
+      }
+    s.store(top + i * E);
+  }
+}
+
+// correlation backward wrt the query: dq[n][c] = sum_p g[n,p,c] * feat[n,p,c]   (one workgroup per (image, slab); atomics)
+template <typename T>
+__global__ void __launch_bounds__(256) correlate_bwd_q_kernel(const T* __restrict__ g, const T* __restrict__ feat,
+                                                              float* __restrict__ dq, int hw, int c) {
+  constexpr int E = Chunk<T>::N;
+  const int cch = c / E;
+  const int lanes = 256 / cch;
+  const int img = blockIdx.y;
+  const int cc = threadIdx.x % cch, pl = threadIdx.x / cch;
+  const int per = (hw + gridDim.x - 1) / gridDim.x;
+  const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
+  float s[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s[e] = 0.f;
+  if (pl < lanes)
+    for (int p = p0 + pl; p < p1; p += lanes) {
+      Chunk<T> a, b;
+      const size_t off = ((size_t)img * hw + p) * c + cc * E;
+      a.load(g + off);
+      b.load(feat + off);
+#pragma unroll
+      for (int e = 0; e < E; ++e) s[e] += a.v[e] * b.v[e];
+    }
+  if (pl < lanes) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) atomicAdd(dq + (size_t)img * c + cc * E + e, s[e]);
+  }
+}
+
+// ROIAlign backward (csrc/cuda/ROIAlign_cuda.cu:125-254) on NHWC, fp32 gradient of the (tiny) query feature map
+__global__ void roialign_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ rois, float* __restrict__ gx, int h,
+                                    int w, int c, int num_rois, float scale, int ph, int pw, int sampling) {
+  const long long total = (long long)num_rois * ph * pw * c;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    long long t = i / c;
+    const int px = (int)(t % pw); t /= pw;
+    const int py = (int)(t % ph);
+    const int r = (int)(t / ph);
+    const float* roi = rois + (size_t)r * 5;
+    const int b = (int)roi[0];
+    const float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
+    const float roi_w = fmaxf(rew - rsw, 1.f), roi_h = fmaxf(reh - rsh, 1.f);
+    const float bin_h = roi_h / (float)ph, bin_w = roi_w / (float)pw;
+    const int gh = sampling > 0 ? sampling : (int)ceilf(roi_h / ph);
+    const int gw = sampling > 0 ? sampling : (int)ceilf(roi_w / pw);
+    const float g = gy[i] / (float)(gh * gw);
+    float* base = gx + (size_t)b * h * w * c + ch;
+    for (int iy = 0; iy < gh; ++iy) {
+      const float yy = rsh + py * bin_h + (iy + .5f) * bin_h / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        const float xx = rsw + px * bin_w + (ix + .5f) * bin_w / (float)gw;
+        float yv = yy, xv = xx;
+        if (yv < -1.0f || yv > (float)h || xv < -1.0f || xv > (float)w) continue;
+        if (yv <= 0.f) yv = 0.f;
+        if (xv <= 0.f) xv = 0.f;
+        int yl = (int)yv, xl = (int)xv, yh, xh;
+        if (yl >= h - 1) { yh = yl = h - 1; yv = (float)yl; } else { yh = yl + 1; }
+        if (xl >= w - 1) { xh = xl = w - 1; xv = (float)xl; } else { xh = xl + 1; }
+        const float ly = yv - yl, lx = xv - xl, hy = 1.f - ly, hx = 1.f - lx;
+        atomicAdd(base + ((size_t)yl * w + xl) * c, g * hy * hx);
+        atomicAdd(base + ((size_t)yl * w + xh) * c, g * hy * lx);
+        atomicAdd(base + ((size_t)yh * w + xl) * c, g * ly * hx);
+        atomicAdd(base + ((size_t)yh * w + xh) * c, g * ly * lx);
+      }
+    }
+  }
+}
+
+__global__ void shot_mean_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int b, int shots, int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b * shots * c) return;
+  const int ch = i % c, q = i / c;
+  gx[i] = gy[(size_t)(q / shots) * c + ch] / (float)shots;
+}
+
+template <typename T> __global__ void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = from_f32<T>(src[i]);
+}
+
+// ---- GroupNorm + ReLU backward.  Forward: z = u*a[n,c] + b[n,c], t = relu(z), a = gamma*rstd, b = beta - mean*a.
+// With dz = dt*(z>0), xhat = (u-mean)*rstd and m = hw*cpg:  du = rstd*(dz*gamma - S1/m - xhat*S2/m),
+// S1 = sum_g dz*gamma, S2 = sum_g dz*gamma*xhat; dgamma_c = sum dz*xhat, dbeta_c = sum dz.
+// pass 1: per (image, slab) partial S1,S2 per group (two-stage, deterministic) and per-channel dgamma/dbeta (atomics).
+constexpr int kGnSplits = 64;
+template <typename T>
+__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__ u, const T* __restrict__ dt,
+                                                           const float* __restrict__ a, const float* __restrict__ bb,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ ws, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int hw, int c, int groups) {
+  constexpr int E = Chunk<T>::N;
+  const int cch = c / E, lanes = 256 / cch;
+  const int img = blockIdx.y, split = blockIdx.x;
+  const int cc = threadIdx.x % cch, pl = threadIdx.x / cch;
+  const int per = (hw + kGnSplits - 1) / kGnSplits;
+  const int p0 = split * per, p1 = min(hw, p0 + per);
+  float av[E], bv[E], gm[E], bt[E], s1 = 0.f, s2 = 0.f, dg[E], db[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    av[e] = a[(size_t)img * c + cc * E + e];
+    bv[e] = bb[(size_t)img * c + cc * E + e];
+    gm[e] = gamma[cc * E + e];
+    bt[e] = beta[cc * E + e];
+    dg[e] = 0.f; db[e] = 0.f;
+  }
+  if (pl < lanes)
+    for (int p = p0 + pl; p < p1; p += lanes) {
+      Chunk<T> uu, gg;
+      const size_t off = ((size_t)img * hw + p) * c + cc * E;
+      uu.load(u + off);
+      gg.load(dt + off);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float z = fmaf(uu.v[e], av[e], bv[e]);
+        const float dz = z > 0.f ? gg.v[e] : 0.f;
+        const float xhat = (z - bt[e]) / gm[e];          // gamma != 0 (synthetic and trained GN scales are positive)
+        s1 += dz * gm[e];
+        s2 += dz * gm[e] * xhat;
+        dg[e] += dz * xhat;
+        db[e] += dz;
+      }
+    }
+  __shared__ float red[2][256];
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  const int cpg_chunks = (c / groups) / E > 0 ? (c / groups) / E : 1;
+  if (threadIdx.x < groups) {
+    const int g = threadIdx.x;
+    float t1 = 0.f, t2 = 0.f;
+    for (int l = 0; l < lanes; ++l)
+      for (int k = 0; k < cpg_chunks; ++k) {
+        const int idx = l * cch + g * cpg_chunks + k;
+        t1 += red[0][idx];
+        t2 += red[1][idx];
+      }
+    float* o = ws + (((size_t)img * kGnSplits + split) * groups + g) * 2;
+    o[0] = t1;
+    o[1] = t2;
+  }
+  if (pl < lanes) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      atomicAdd(dgamma + cc * E + e, dg[e]);
+      atomicAdd(dbeta + cc * E + e, db[e]);
+    }
+  }
+}
+
+__global__ void gn_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ sums, int n, int groups) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * groups) return;
+  const int img = i / groups, g = i % groups;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < kGnSplits; ++k) {
+    const float* o = ws + (((size_t)img * kGnSplits + k) * groups + g) * 2;
+    s1 += o[0];
+    s2 += o[1];
+  }
+  sums[i * 2] = s1;
+  sums[i * 2 + 1] = s2;
+}
+
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ u, const T* __restrict__ dt, const float* __restrict__ a,
+                                    const float* __restrict__ bb, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ ws, T* __restrict__ du, int n, int hw, int c, int groups) {
+  constexpr int E = Chunk<T>::N;
+  const int cch = c / E;
+  const int cpg = c / groups;
+  const long long total = (long long)n * hw * cch;
+  const float inv_m = 1.f / ((float)hw * cpg);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cch);
+    const int img = (int)(i / ((long long)cch * hw));
+    const int g = (cc * E) / cpg;
+    const float s1 = ws[((size_t)img * groups + g) * 2], s2 = ws[((size_t)img * groups + g) * 2 + 1];
+    Chunk<T> uu, gg;
+    uu.load(u + i * E);
+    gg.load(dt + i * E);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int ch = cc * E + e;
+      const float av = a[(size_t)img * c + ch], bv = bb[(size_t)img * c + ch], gm = gamma[ch];
+      const float z = fmaf(uu.v[e], av, bv);
+      const float dz = z > 0.f ? gg.v[e] : 0.f;
+      const float xhat = (z - beta[ch]) / gm;
+      const float rstd = av / gm;
+      uu.v[e] = rstd * (dz * gm - s1 * inv_m - xhat * s2 * inv_m);
+    }
+    uu.store(du + i * E);
+  }
+}
+
+// naive data gradient for strided convs (used for the two 3x3/2 convs P6, P7: M <= 1664 pixels):
+// dx[n,hi,wi,ci] = sum_{r,s,co : (hi+pad-r) % stride == 0 ...} dy[n,ho,wo,co] * w[co][r][s][ci]  (forward-packed weights)
+template <typename T>
+__global__ void dgrad_naive_kernel(const T* __restrict__ dy, const T* __restrict__ wp, const T* __restrict__ mask,
+                                   const T* __restrict__ addend, T* __restrict__ dx, int n, int h, int w, int cin, int ho,
+                                   int wo, int cout, int R, int S, int stride, int pad, int ktot, int dy_stride) {
+  const long long total = (long long)n * h * w * cin;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cin);
+    long long t = i / cin;
+    const int x = (int)(t % w); t /= w;
+    const int y = (int)(t % h);
+    const int b = (int)(t / h);
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r) {
+      const int yy = y + pad - r;
+      if (yy < 0 || yy % stride) continue;
+      const int oy = yy / stride;
+      if (oy >= ho) continue;
+      for (int s = 0; s < S; ++s) {
+        const int xx = x + pad - s;
+        if (xx < 0 || xx % stride) continue;
+        const int ox = xx / stride;
+        if (ox >= wo) continue;
+        const T* g = dy + (((size_t)b * ho + oy) * wo + ox) * dy_stride;
+        const T* wr = wp + (size_t)(r * S + s) * cin + ci;
+        for (int co = 0; co < cout; ++co) acc += to_f32(g[co]) * to_f32(wr[(size_t)co * ktot]);
+      }
+    }
+    if (mask) acc = to_f32(mask[i]) > 0.f ? acc : 0.f;      // ReLU backward of the conv's own input ...
+    if (addend) acc += to_f32(addend[i]);                   // ... then the other gradient branch of that tensor
+    dx[i] = from_f32<T>(acc);
+  }
+}
+
+}  // namespace
+
+#define OSD_STREAM(s) reinterpret_cast<hipStream_t>(s)
+#define OSD_DISPATCH_DTYPE(dtype, CALL_F32, CALL_BF16)                            \
+  do {                                                                           \
+    if ((dtype) == OSD_F32) { CALL_F32; }                                        \
+    else if ((dtype) == OSD_BF16) { CALL_BF16; }                                 \
+    else return osd_fail(OSD_ERR_INVALID_ARG, "bad dtype %d", (int)(dtype));     \
+  } while (0)
+
+extern "C" int osd_pack_conv_weight_dgrad(const float* w, const float* scale, void* dst, int cout, int cin, int r, int s,
+                                          int rows, int cout_pad, int src_orsi, int dtype, void* stream) {
+  if (!w || !dst || rows < cin || cout_pad < cout) return osd_fail(OSD_ERR_INVALID_ARG, "pack_dgrad: bad args");
+  const int g = grid_for((long long)rows * r * s * cout_pad, 256);
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(pack_dgrad_weight_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), w, scale, (float*)dst, cout, cin, r, s, rows, cout_pad, src_orsi),
+      hipLaunchKernelGGL(pack_dgrad_weight_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), w, scale, (__bf16*)dst, cout, cin, r, s, rows, cout_pad, src_orsi));
+  return osd_check_launch("pack_dgrad_weight");
+}
+
+extern "C" int osd_unpack_wgrad(const float* dw_packed, const float* scale, float* grad_oihw, int cout, int cin, int r, int s,
+                                int accumulate, void* stream) {
+  if (!dw_packed || !grad_oihw) return osd_fail(OSD_ERR_INVALID_ARG, "unpack_wgrad: null argument");
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for((long long)cout * cin * r * s, 256)), dim3(256), 0, OSD_STREAM(stream),
+                     dw_packed, scale, grad_oihw, cout, cin, r, s, accumulate);
+  return osd_check_launch("unpack_wgrad");
+}
+
+extern "C" int osd_scatter2x(const void* src, const void* mask, const void* addend, void* dst, int n, int h, int w, int ho,
+                             int wo, int c, int dtype, void* stream) {
+  const int e = dtype == OSD_BF16 ? 8 : 4;
+  if (!src || !dst || c % e) return osd_fail(OSD_ERR_INVALID_ARG, "scatter2x: bad args");
+  const int g = grid_for((long long)n * h * w * (c / e), 256);
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(scatter2x_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const float*)src, (const float*)mask, (const float*)addend, (float*)dst, n, h, w, ho, wo, c),
+      hipLaunchKernelGGL(scatter2x_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const __bf16*)src, (const __bf16*)mask, (const __bf16*)addend, (__bf16*)dst, n, h, w, ho, wo, c));
+  return osd_check_launch("scatter2x");
+}
+
+extern "C" int osd_add_mask(const void* a, const void* b, const void* mask, void* out, int64_t numel, int dtype, void* stream) {
+  const int e = dtype == OSD_BF16 ? 8 : 4;
+  if (!a || !out || numel % e) return osd_fail(OSD_ERR_INVALID_ARG, "add_mask: bad args");
+  if (numel == 0) return OSD_OK;
+  const int g = grid_for(numel / e, 256);
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(add_mask_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const float*)a, (const float*)b, (const float*)mask, (float*)out, (long long)(numel / e)),
+      hipLaunchKernelGGL(add_mask_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const __bf16*)a, (const __bf16*)b, (const __bf16*)mask, (__bf16*)out, (long long)(numel / e)));
+  return osd_check_launch("add_mask");
+}
+
+extern "C" int osd_upsample2x_bwd(const void* inner, const void* prev, void* top, int n, int h, int w, int c, int dtype,
+                                  void* stream) {
+  const int e = dtype == OSD_BF16 ? 8 : 4;
+  if (!inner || !top || c % e) return osd_fail(OSD_ERR_INVALID_ARG, "upsample2x_bwd: bad args");
+  const int g = grid_for((long long)n * h * w * (c / e), 256);
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const float*)inner, (const float*)prev, (float*)top, n, h, w, c),
+      hipLaunchKernelGGL(upsample2x_bwd_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const __bf16*)inner, (const __bf16*)prev, (__bf16*)top, n, h, w, c));
+  return osd_check_launch("upsample2x_bwd");
+}
+
+extern "C" int osd_correlate_bwd_query(const void* g, const void* feat, float* dq, int n, int hw, int c, int dtype, void* stream) {
+  const int e = dtype == OSD_BF16 ? 8 : 4;
+  if (!g || !feat || !dq || c % e || 256 % (c / e)) return osd_fail(OSD_ERR_INVALID_ARG, "correlate_bwd_query: bad args");
+  hipError_t er = hipMemsetAsync(dq, 0, sizeof(float) * (size_t)n * c, OSD_STREAM(stream));
+  if (er != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "correlate_bwd_query: memset failed");
+  if (n == 0 || hw == 0) return OSD_OK;
+  int slabs = (hw + 255) / 256;
+  if (slabs > 128) slabs = 128;
+  dim3 grid(slabs, n);
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(correlate_bwd_q_kernel<float>, grid, dim3(256), 0, OSD_STREAM(stream), (const float*)g, (const float*)feat, dq, hw, c),
+      hipLaunchKernelGGL(correlate_bwd_q_kernel<__bf16>, grid, dim3(256), 0, OSD_STREAM(stream), (const __bf16*)g, (const __bf16*)feat, dq, hw, c));
+  return osd_check_launch("correlate_bwd_query");
+}
+
+extern "C" int osd_roialign_bwd(const float* gy, const float* rois, float* gx, int b, int h, int w, int c, int num_rois,
+                                float spatial_scale, int ph, int pw, int sampling_ratio, void* stream) {
+  if (!gy || !rois || !gx) return osd_fail(OSD_ERR_INVALID_ARG, "roialign_bwd: null argument");
+  hipError_t er = hipMemsetAsync(gx, 0, sizeof(float) * (size_t)b * h * w * c, OSD_STREAM(stream));
+  if (er != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "roialign_bwd: memset failed");
+  if (num_rois == 0) return OSD_OK;
+  hipLaunchKernelGGL(roialign_bwd_kernel, dim3(grid_for((long long)num_rois * ph * pw * c, 256)), dim3(256), 0, OSD_STREAM(stream),
+                     gy, rois, gx, h, w, c, num_rois, spatial_scale, ph, pw, sampling_ratio);
+  return osd_check_launch("roialign_bwd");
+}
+
+extern "C" int osd_shot_mean_bwd(const float* gy, float* gx, int b, int shots, int c, void* stream) {
+  if (!gy || !gx || shots < 1) return osd_fail(OSD_ERR_INVALID_ARG, "shot_mean_bwd: bad args");
+  hipLaunchKernelGGL(shot_mean_bwd_kernel, dim3(cdiv(b * shots * c, 256)), dim3(256), 0, OSD_STREAM(stream), gy, gx, b, shots, c);
+  return osd_check_launch("shot_mean_bwd");
+}
+
+extern "C" int osd_cast_f32(const float* src, void* dst, int64_t numel, int dtype, void* stream) {
+  if (!src || !dst) return osd_fail(OSD_ERR_INVALID_ARG, "cast_f32: null argument");
+  if (numel == 0) return OSD_OK;
+  const int g = grid_for(numel, 256);
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), src, (float*)dst, (long long)numel),
+      hipLaunchKernelGGL(cast_from_f32_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), src, (__bf16*)dst, (long long)numel));
+  return osd_check_launch("cast_f32");
+}
+
+extern "C" int osd_groupnorm_relu_bwd(const void* u, const void* dt, const float* a, const float* b, const float* gamma,
+                                      const float* beta, float* ws, float* dgamma, float* dbeta, void* du, int n, int hw, int c,
+                                      int groups, int dtype, void* stream) {
+  const int e = dtype == OSD_BF16 ? 8 : 4;
+  if (!u || !dt || !a || !b || !gamma || !beta || !ws || !dgamma || !dbeta || !du)
+    return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_relu_bwd: null argument");
+  if (c % e != 0 || c / e > 256 || 256 % (c / e) != 0 || groups > 256 || c % groups != 0 || (c / groups) % e != 0)
+    return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_relu_bwd: unsupported shape c=%d groups=%d", c, groups);
+  dim3 grid(kGnSplits, n);
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, grid, dim3(256), 0, OSD_STREAM(stream), (const float*)u, (const float*)dt, a, b, gamma, beta, ws, dgamma, dbeta, hw, c, groups),
+      hipLaunchKernelGGL(gn_bwd_stats_kernel<__bf16>, grid, dim3(256), 0, OSD_STREAM(stream), (const __bf16*)u, (const __bf16*)dt, a, b, gamma, beta, ws, dgamma, dbeta, hw, c, groups));
+  int rc = osd_check_launch("gn_bwd_stats");
+  if (rc) return rc;
+  float* sums = ws + (size_t)n * kGnSplits * groups * 2;     // reduced [n][groups][2] behind the partial slabs
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(cdiv(n * groups, 256)), dim3(256), 0, OSD_STREAM(stream), ws, sums, n, groups);
+  const int g = grid_for((long long)n * hw * (c / e), 256);
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const float*)u, (const float*)dt, a, b, gamma, beta, sums, (float*)du, n, hw, c, groups),
+      hipLaunchKernelGGL(gn_bwd_apply_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const __bf16*)u, (const __bf16*)dt, a, b, gamma, beta, sums, (__bf16*)du, n, hw, c, groups));
+  return osd_check_launch("gn_bwd_apply");
+}
+
+extern "C" int osd_conv2d_dgrad_naive(const osd_conv_desc* d, const void* dy, const void* w_fwd_packed, const void* mask,
+                                      const void* addend, void* dx, void* stream) {
+  if (!d || !dy || !w_fwd_packed || !dx) return osd_fail(OSD_ERR_INVALID_ARG, "dgrad_naive: null argument");
+  const int g = grid_for((long long)d->n * d->h * d->w * d->cin, 256);
+  const int ktot = d->r * d->s * d->cin;
+  OSD_DISPATCH_DTYPE(d->dtype,
+      hipLaunchKernelGGL(dgrad_naive_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const float*)dy, (const float*)w_fwd_packed, (const float*)mask, (const float*)addend, (float*)dx, d->n, d->h, d->w, d->cin, d->ho, d->wo, d->cout, d->r, d->s, d->stride_h, d->pad_h, ktot, d->out_stride),
+      hipLaunchKernelGGL(dgrad_naive_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const __bf16*)dy, (const __bf16*)w_fwd_packed, (const __bf16*)mask, (const __bf16*)addend, (__bf16*)dx, d->n, d->h, d->w, d->cin, d->ho, d->wo, d->cout, d->r, d->s, d->stride_h, d->pad_h, ktot, d->out_stride));
+  return osd_check_launch("dgrad_naive");
+}

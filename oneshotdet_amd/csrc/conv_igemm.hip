@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvKParams p) {
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       } else if (p.act == OSD_ACT_EXP_SCALE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = expf(v[e] * p.act_scale);
+        for (int e = 0; e < 4; ++e) v[e] = expf(v[e] * (p.act_scale_dev ? *p.act_scale_dev : p.act_scale));
       }
       T* dst = yg + (size_t)m * p.out_stride + c;
       if constexpr (sizeof(T) == 2) {
@@ -313,10 +313,11 @@ int choose_tile(int M, int cout) {
 extern "C" int osd_conv_algo_count(void) { return 32; }
 
 extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void* w, const float* bias,
-                              const void* res, const float* gn_a, const float* gn_b, void* y, void* stream) {
+                              const void* res, const void* mask, const float* act_scale_dev, const void* reserved,
+                              void* y, void* stream) {
   if (!d || !x || !w || !bias || !y) return osd_fail(OSD_ERR_INVALID_ARG, "conv: null argument");
   if (d->gn_in) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: gn_in fusion not available in this build");
-  (void)gn_a; (void)gn_b;
+  if (reserved) return osd_fail(OSD_ERR_INVALID_ARG, "conv: reserved argument must be null");
   if (d->cout % 4 != 0 || d->out_stride % 4 != 0)
     return osd_fail(OSD_ERR_INVALID_ARG, "conv: cout/out_stride must be multiples of 4 (got %d/%d)", d->cout,
                     d->out_stride);
@@ -331,13 +332,13 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
   if (!w_ok || d->in_stride_h % epc || d->in_stride_n % epc || d->cin % epc)
     return osd_fail(OSD_ERR_INVALID_ARG, "conv: input strides must keep 16-byte alignment");
   ConvKParams p;
-  p.x = x; p.w = w; p.bias = bias; p.res = res; p.y = y;
+  p.x = x; p.w = w; p.bias = bias; p.res = res; p.mask = mask; p.y = y;
   p.H = d->h; p.W = d->w; p.Cin = d->cin; p.sN = d->in_stride_n; p.sH = d->in_stride_h; p.sW = d->in_stride_w;
   p.Ho = d->ho; p.Wo = d->wo; p.Cout = d->cout; p.HoWo = d->ho * d->wo;
   p.R = d->r; p.S = d->s; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
   p.w_rows = d->w_rows; p.Ktot = d->r * d->s * d->cin; p.out_stride = d->out_stride;
   p.res_mode = d->res_mode; p.res_h = d->res_h; p.res_w = d->res_w; p.res_stride = d->res_stride;
-  p.act = d->act; p.act_scale = d->act_scale; p.relu_in = d->relu_in;
+  p.act = d->act; p.act_scale = d->act_scale; p.act_scale_dev = act_scale_dev; p.relu_in = d->relu_in;
   const long long M = (long long)d->n * d->ho * d->wo;
   if (M <= 0 || M > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad M");
   p.M = (int)M; p.tilesM = p.tilesN = p.KT = 0;
@@ -360,6 +361,7 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
     if (p.Cout > 16 && tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: skinny tile on a wide conv");
   }
   if (impl == 0) return osd_conv_dma_dispatch(d->dtype, tile, variant, p, s);
+  if (mask) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: mask epilogue only in the LDS-DMA kernel");
   if (d->dtype == OSD_F32) {
     return dispatch_tile<float, 64>(tile, p, s);
   } else if (d->dtype == OSD_BF16) {

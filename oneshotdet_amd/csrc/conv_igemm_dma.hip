@@ -289,12 +289,28 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(ConvKParams p) {
         v[it][e + 2] = (a4[2] + b4.z) + v[it][e + 2];
         v[it][e + 3] = (a4[3] + b4.w) + v[it][e + 3];
       }
+      if (p.mask) {     // ReLU backward of the producer layer: zero where its forward output was not positive
+        const T* mk = reinterpret_cast<const T*>(p.mask) + ooff[it];
+        if constexpr (sizeof(T) == 2) {
+          if (vec_ok && nval[it] == EPC) {
+            const bf16x8 m8 = *reinterpret_cast<const bf16x8*>(mk);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[it][e] = (float)m8[e] > 0.f ? v[it][e] : 0.f;
+          } else {
+            for (int e = 0; e < nval[it]; ++e) v[it][e] = (float)mk[e] > 0.f ? v[it][e] : 0.f;
+          }
+        } else {
+          const float4 m4 = *reinterpret_cast<const float4*>(mk);
+          v[it][0] = m4.x > 0.f ? v[it][0] : 0.f; v[it][1] = m4.y > 0.f ? v[it][1] : 0.f;
+          v[it][2] = m4.z > 0.f ? v[it][2] : 0.f; v[it][3] = m4.w > 0.f ? v[it][3] : 0.f;
+        }
+      }
       if (p.act == OSD_ACT_RELU) {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) v[it][e] = fmaxf(v[it][e], 0.f);
       } else if (p.act == OSD_ACT_EXP_SCALE) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[it][e] = expf(v[it][e] * p.act_scale);
+        for (int e = 0; e < EPC; ++e) v[it][e] = expf(v[it][e] * (p.act_scale_dev ? *p.act_scale_dev : p.act_scale));
       }
       T* dst = yg + ooff[it];
       if constexpr (sizeof(T) == 2) {

@@ -7,6 +7,7 @@ struct ConvKParams {
   const void* w;
   const float* bias;
   const void* res;
+  const void* mask;   // optional: y = (mask[m][c] > 0) ? y : 0   (ReLU backward fused into a dgrad epilogue)
   void* y;
   int H, W, Cin, sN, sH, sW;
   int Ho, Wo, Cout, HoWo;
@@ -15,6 +16,7 @@ struct ConvKParams {
   int res_mode, res_h, res_w, res_stride;
   int act;
   float act_scale;
+  const float* act_scale_dev;   // optional device scalar overriding act_scale (the learnable Scale of fcos.py:81)
   int relu_in;
   int M, tilesM, tilesN, KT;
 };

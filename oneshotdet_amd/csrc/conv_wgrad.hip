@@ -1,0 +1,340 @@
+// conv_wgrad — weight gradient of an NHWC convolution on MFMA (gfx950):
+//     dW[co][r][s][ci] += sum_m dY[m][co] * X[m @ tap(r,s)][ci]          m = (n, ho, wo)
+// GEMM view: rows = output channels, columns = (tap, input channel), reduction over PIXELS.  Both operands are stored
+// pixel-major (NHWC), i.e. the reduction index is the slow index, so the MFMA fragments need a transpose:
+//   * bf16: tiles are staged as [32 pixels][128 channels] (256-byte rows) by LDS-DMA and read with
+//     ds_read_b64_tr_b16 (hardware transpose): a lane receives 4 consecutive pixels of one channel per read.  The
+//     k slots of v_mfma_f32_16x16x32_bf16 are mapped to tile rows (4g+j | 16+4g+j-4) for both operands, so one
+//     32-lane half reads 8 consecutive rows; with the 16-byte-chunk swizzle chunk ^= 2*(row&7) (applied on the DMA
+//     source, the destination is lane-linear) every transposed read is bank-conflict free;
+//   * fp32: tiles [32 pixels][64 channels] (256-byte rows), v_mfma_f32_16x16x4_f32 takes ONE float per lane so the
+//     fragments are plain ds_read_b32 of [pixel][channel]; swizzle chunk ^= 4*(row&3).
+// Pixels are split over `splits` workgroups per output tile (the reduction is 1e5..1e6 long while there are only
+// tens of output tiles); partial tiles are accumulated with fp32 atomics (no-return global_atomic_add_f32).
+// A 3-deep LDS ring with counted vmcnt and one raw barrier per stage, as in conv_igemm_dma.hip.
+#include "osd_common.h"
+
+namespace {
+
+__device__ __attribute__((aligned(256))) unsigned g_wzero[64];
+
+struct WgradParams {
+  const void* x;
+  const void* dy;
+  float* dw;
+  const float* scale;   // optional per-Cout factor (folded FrozenBN scale: d/dw of conv(x, w*scale))
+  int H, W, Cin, Ho, Wo, Cout, HoWo;
+  int R, S, sh, sw, ph, pw;
+  int dy_stride, M;
+  int tilesCo, tilesCi, splits, rows_per_split, Ktot;
+};
+
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void wg_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+template <typename T> __device__ __forceinline__ int wg_swz(int row) {
+  if constexpr (sizeof(T) == 2) return 2 * (row & 7);
+  else return 4 * (row & 3);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams p) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int TW = 256 / (int)sizeof(T);    // tile width (channels) of both operands: 256-byte rows
+  constexpr int BKP = 32;                     // pixels per stage
+  constexpr int NST = 3;
+  constexpr int OPB = BKP * 256;              // bytes of one operand tile
+  constexpr int STAGE = 2 * OPB;
+  constexpr int LPS = 4;                      // DMA instructions per wave per stage (2 per operand)
+  constexpr int TA = TW / 2 / 16;             // 16-wide MFMA tiles per wave along co (and along ci)
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int bid = blockIdx.x;
+  const int co_tile = bid % p.tilesCo;
+  bid /= p.tilesCo;
+  const int ntile = p.R * p.S * p.tilesCi;
+  const int nt = bid % ntile;
+  const int split = bid / ntile;
+  const int tap = nt / p.tilesCi, ci_tile = nt % p.tilesCi;
+  const int fr = tap / p.S, fs = tap % p.S;
+  const int co0 = co_tile * TW, ci0 = ci_tile * TW;
+  const int p_lo = split * p.rows_per_split;
+  const int p_hi = min(p.M, p_lo + p.rows_per_split);
+  if (p_lo >= p_hi) return;
+  const int KT = (p_hi - p_lo + BKP - 1) / BKP;
+
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
+  const T* zero = reinterpret_cast<const T*>(g_wzero) + (lane & 15) * EPC;
+
+  // ---- per-lane DMA coordinates: 2 instructions per operand per stage, 4 tile rows per instruction ----
+  const int lrow = lane >> 4, lpos = lane & 15;
+  int a_row[2], a_col[2];          // dY: tile row, channel offset (swizzled source chunk)
+  int b_row[2], b_col[2];          // X
+  int b_n[2], b_ho[2], b_wo[2];    // output-pixel coordinates of the lane's row (advanced by BKP per stage)
+  bool a_cok[2], b_cok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 4 + lrow;
+    const int chunk = lpos ^ wg_swz<T>(row);
+    a_row[i] = row; b_row[i] = row;
+    a_col[i] = co0 + chunk * EPC; b_col[i] = ci0 + chunk * EPC;
+    a_cok[i] = a_col[i] < p.Cout; b_cok[i] = b_col[i] < p.Cin;
+    const int m = p_lo + row;
+    const int n_img = m / p.HoWo;
+    const int rem = m - n_img * p.HoWo;
+    b_n[i] = n_img; b_ho[i] = rem / p.Wo; b_wo[i] = rem - (rem / p.Wo) * p.Wo;
+  }
+
+  int stage_m = p_lo;   // first pixel of the NEXT stage to issue
+  auto issue_stage = [&](int buf) {
+    const unsigned sa = lds0 + buf * STAGE, sb = sa + OPB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = stage_m + a_row[i];
+      const T* src = (m < p_hi && a_cok[i]) ? dyg + (size_t)m * p.dy_stride + a_col[i] : zero;
+      wg_dma16(src, sa + (wave * 2 + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = stage_m + b_row[i];
+      const int hi = b_ho[i] * p.sh - p.ph + fr, wi = b_wo[i] * p.sw - p.pw + fs;
+      const bool ok = (m < p_hi) && b_cok[i] && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+      const T* src = ok ? xg + ((size_t)(b_n[i] * p.H + hi) * p.W + wi) * p.Cin + b_col[i] : zero;
+      wg_dma16(src, sb + (wave * 2 + i) * 1024);
+      // advance this lane's pixel by BKP rows
+      b_wo[i] += BKP;
+      while (b_wo[i] >= p.Wo) { b_wo[i] -= p.Wo; ++b_ho[i]; }
+      while (b_ho[i] >= p.Ho) { b_ho[i] -= p.Ho; ++b_n[i]; }
+    }
+    stage_m += BKP;
+  };
+
+  f32x4 acc[TA][TA];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TA; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute_stage = [&](int buf) {
+    const char* sa = smem + buf * STAGE;
+    const char* sb = sa + OPB;
+    if constexpr (sizeof(T) == 2) {
+      // one 32-deep k step; k slot (g, j) <-> tile row (j < 4 ? 4g + j : 16 + 4g + j - 4)
+      const int g = lane >> 4, t = lane & 15, q = t >> 2, pp = t & 3;
+      const int r1 = 4 * g + q, r2 = 16 + 4 * g + q;
+      typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+      typedef __attribute__((address_space(3))) bf4* lds_bf4_ptr;
+      bf16x8 af[TA], bfr[TA];
+#pragma unroll
+      for (int i = 0; i < TA; ++i) {
+        const int chunk_a = ((wm * (TW / 2) + i * 16) >> 3) + (pp >> 1);
+        const int chunk_b = ((wn * (TW / 2) + i * 16) >> 3) + (pp >> 1);
+        const int h8 = (pp & 1) * 8;
+        const bf4 a_lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (lds_bf4_ptr)(sa + r1 * 256 + ((chunk_a ^ wg_swz<T>(r1)) << 4) + h8));
+        const bf4 a_hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (lds_bf4_ptr)(sa + r2 * 256 + ((chunk_a ^ wg_swz<T>(r2)) << 4) + h8));
+        const bf4 b_lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (lds_bf4_ptr)(sb + r1 * 256 + ((chunk_b ^ wg_swz<T>(r1)) << 4) + h8));
+        const bf4 b_hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (lds_bf4_ptr)(sb + r2 * 256 + ((chunk_b ^ wg_swz<T>(r2)) << 4) + h8));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          af[i][e] = a_lo[e]; af[i][e + 4] = a_hi[e];
+          bfr[i][e] = b_lo[e]; bfr[i][e + 4] = b_hi[e];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TA; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    } else {
+      const int k = lane >> 4, e16 = lane & 15;
+#pragma unroll
+      for (int kb = 0; kb < BKP / 4; ++kb) {
+        const int row = kb * 4 + k;
+        const int sw = wg_swz<T>(row);
+        float af[TA], bfr[TA];
+#pragma unroll
+        for (int i = 0; i < TA; ++i) {
+          const int col_a = wm * (TW / 2) + i * 16 + e16, col_b = wn * (TW / 2) + i * 16 + e16;
+          af[i] = *reinterpret_cast<const float*>(sa + row * 256 + (((col_a >> 2) ^ sw) << 4) + (col_a & 3) * 4);
+          bfr[i] = *reinterpret_cast<const float*>(sb + row * 256 + (((col_b >> 2) ^ sw) << 4) + (col_b & 3) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+          for (int j = 0; j < TA; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < KT) issue_stage(s);
+  int cur = 0, nxt = NST - 1;
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + NST - 2 < KT) wg_wait_vmcnt<LPS * (NST - 2)>();
+    else wg_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NST - 1 < KT) issue_stage(nxt);
+    compute_stage(cur);
+    cur = cur + 1 == NST ? 0 : cur + 1;
+    nxt = nxt + 1 == NST ? 0 : nxt + 1;
+  }
+
+  // ---- accumulate the partial tile into dW (fp32 atomics; rows = co, 16 consecutive ci per 16 lanes) ----
+  float* __restrict__ dw = p.dw;
+#pragma unroll
+  for (int i = 0; i < TA; ++i) {
+#pragma unroll
+    for (int j = 0; j < TA; ++j) {
+      const int ci = ci0 + wn * (TW / 2) + j * 16 + (lane & 15);
+      if (ci >= p.Cin) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + wm * (TW / 2) + i * 16 + (lane >> 4) * 4 + e;
+        if (co < p.Cout) {
+          const float sc = p.scale ? p.scale[co] : 1.f;
+          atomicAdd(dw + (size_t)co * p.Ktot + tap * p.Cin + ci, acc[i][j][e] * sc);
+        }
+      }
+    }
+  }
+}
+
+// ---- skinny weight gradient for the prediction convs (Cout <= 8): dW[co][tap][ci] with one thread per ci ----
+template <typename T>
+__global__ void __launch_bounds__(256) conv_wgrad_skinny_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                float* __restrict__ dw, int H, int W, int Cin, int Ho,
+                                                                int Wo, int Cout, int R, int S, int stride, int pad,
+                                                                int dy_stride, int M, int rows_per_block) {
+  const int ci = blockIdx.y * blockDim.x + threadIdx.x;
+  const int p_lo = blockIdx.x * rows_per_block, p_hi = min(M, p_lo + rows_per_block);
+  if (ci >= Cin || p_lo >= p_hi) return;
+  float acc[4][9];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+  const int HoWo = Ho * Wo;
+  for (int m = p_lo; m < p_hi; ++m) {
+    const int n = m / HoWo, rem = m - n * HoWo, ho = rem / Wo, wo = rem - (rem / Wo) * Wo;
+    float g[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) g[c] = c < Cout ? to_f32(dy[(size_t)m * dy_stride + c]) : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t >= R * S) break;
+      const int r = t / S, s = t - (t / S) * S;
+      const int hi = ho * stride - pad + r, wi = wo * stride - pad + s;
+      if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
+      const float xv = to_f32(x[((size_t)(n * H + hi) * W + wi) * Cin + ci]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c][t] += g[c] * xv;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c >= Cout) break;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      if (t < R * S) atomicAdd(dw + ((size_t)c * R * S + t) * Cin + ci, acc[c][t]);
+  }
+}
+
+// ---- bias gradient: db[c] += sum over pixels of dy[m][c] ----
+template <typename T>
+__global__ void __launch_bounds__(256) bias_grad_kernel(const T* __restrict__ dy, float* __restrict__ db, int M, int C,
+                                                        int stride, int rows_per_block) {
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  const int p_lo = blockIdx.x * rows_per_block, p_hi = min(M, p_lo + rows_per_block);
+  if (c >= C || p_lo >= p_hi) return;
+  float s = 0.f;
+  for (int m = p_lo; m < p_hi; ++m) s += to_f32(dy[(size_t)m * stride + c]);
+  atomicAdd(db + c, s);
+}
+
+}  // namespace
+
+#define OSD_STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const void* dy, const float* scale, float* dw,
+                                void* stream) {
+  if (!d || !x || !dy || !dw) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: null argument");
+  if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad dtype");
+  const int epc = d->dtype == OSD_BF16 ? 8 : 4;
+  const long long M = (long long)d->n * d->ho * d->wo;
+  if (M <= 0 || M > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad M");
+  if (d->in_stride_w != d->cin || d->in_stride_h != d->w * d->cin)
+    return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: dense NHWC input required");
+  hipStream_t s = OSD_STREAM(stream);
+  if (d->cout <= 8) {   // prediction convs
+    if (d->r * d->s > 9) return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: skinny kernel supports up to 9 taps");
+    const int rows = 512;
+    dim3 grid(cdiv((int)M, rows), cdiv(d->cin, 256));
+    if (d->dtype == OSD_F32)
+      hipLaunchKernelGGL(conv_wgrad_skinny_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)dy, dw, d->h,
+                         d->w, d->cin, d->ho, d->wo, d->cout, d->r, d->s, d->stride_h, d->pad_h, d->out_stride, (int)M, rows);
+    else
+      hipLaunchKernelGGL(conv_wgrad_skinny_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dy, dw,
+                         d->h, d->w, d->cin, d->ho, d->wo, d->cout, d->r, d->s, d->stride_h, d->pad_h, d->out_stride, (int)M,
+                         rows);
+    return osd_check_launch("conv_wgrad_skinny");
+  }
+  if (d->cin % epc || d->out_stride % epc) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: channel counts must keep 16-byte alignment");
+  WgradParams p;
+  p.x = x; p.dy = dy; p.dw = dw; p.scale = scale;
+  p.H = d->h; p.W = d->w; p.Cin = d->cin; p.Ho = d->ho; p.Wo = d->wo; p.Cout = d->cout; p.HoWo = d->ho * d->wo;
+  p.R = d->r; p.S = d->s; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
+  p.dy_stride = d->out_stride; p.M = (int)M; p.Ktot = d->r * d->s * d->cin;
+  const int tw = d->dtype == OSD_BF16 ? 128 : 64;
+  p.tilesCo = cdiv(d->cout, tw);
+  p.tilesCi = cdiv(d->cin, tw);
+  const long long tiles = (long long)p.tilesCo * p.tilesCi * d->r * d->s;
+  int splits = (int)((1536 + tiles - 1) / tiles);
+  const int max_splits = (int)((M + 127) / 128);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.rows_per_split = cdiv(cdiv((int)M, splits), 32) * 32;
+  p.splits = cdiv((int)M, p.rows_per_split);
+  const long long nblocks = tiles * p.splits;
+  if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
+  const int lds = 3 * 2 * 32 * 256;
+  if (d->dtype == OSD_F32)
+    hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3((unsigned)nblocks), dim3(256), lds, s, p);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<__bf16>, dim3((unsigned)nblocks), dim3(256), lds, s, p);
+  return osd_check_launch("conv_wgrad");
+}
+
+extern "C" int osd_bias_grad(const void* dy, float* db, int m, int c, int stride, int dtype, void* stream) {
+  if (!dy || !db) return osd_fail(OSD_ERR_INVALID_ARG, "bias_grad: null argument");
+  if (m == 0 || c == 0) return OSD_OK;
+  const int rows = 256;
+  dim3 grid(cdiv(m, rows), cdiv(c, 256));
+  if (dtype == OSD_F32)
+    hipLaunchKernelGGL(bias_grad_kernel<float>, grid, dim3(256), 0, OSD_STREAM(stream), (const float*)dy, db, m, c, stride, rows);
+  else if (dtype == OSD_BF16)
+    hipLaunchKernelGGL(bias_grad_kernel<__bf16>, grid, dim3(256), 0, OSD_STREAM(stream), (const __bf16*)dy, db, m, c, stride,
+                       rows);
+  else
+    return osd_fail(OSD_ERR_INVALID_ARG, "bias_grad: bad dtype");
+  return osd_check_launch("bias_grad");
+}

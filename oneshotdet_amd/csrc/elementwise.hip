@@ -15,7 +15,7 @@ inline int grid_for(long long work, int threads) {
 // ------------------------------------------------------------------------------------------------ weight / image packs
 template <typename T>
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ dst,
-                                        int cout, int cin, int R, int S, int w_rows, int cin_pad) {
+                                        int cout, int cin, int R, int S, int w_rows, int cin_pad, int src_orsi) {
   const long long total = (long long)w_rows * R * S * cin_pad;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int ci = (int)(i % cin_pad);
@@ -25,7 +25,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float
     const int co = (int)(t / R);
     float v = 0.f;
     if (co < cout && ci < cin) {
-      v = w[(((size_t)co * cin + ci) * R + r) * S + s];
+      v = src_orsi ? w[(((size_t)co * R + r) * S + s) * cin + ci] : w[(((size_t)co * cin + ci) * R + r) * S + s];
       if (scale) v *= scale[co];
     }
     dst[i] = from_f32<T>(v);
@@ -384,12 +384,17 @@ __global__ void sigmoid_focal_bwd_kernel(const float* __restrict__ logits, const
 
 extern "C" int osd_pack_conv_weight(const float* w, const float* scale, void* dst, int cout, int cin, int r, int s,
                                     int w_rows, int cin_pad, int dtype, void* stream) {
+  return osd_pack_conv_weight_ex(w, scale, dst, cout, cin, r, s, w_rows, cin_pad, 0, dtype, stream);
+}
+
+extern "C" int osd_pack_conv_weight_ex(const float* w, const float* scale, void* dst, int cout, int cin, int r, int s,
+                                       int w_rows, int cin_pad, int src_orsi, int dtype, void* stream) {
   if (!w || !dst || w_rows < cout || cin_pad < cin) return osd_fail(OSD_ERR_INVALID_ARG, "pack_conv_weight: bad args");
   const long long total = (long long)w_rows * r * s * cin_pad;
   const int g = grid_for(total, 256);
   OSD_DISPATCH_DTYPE(dtype,
-      hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), w, scale, (float*)dst, cout, cin, r, s, w_rows, cin_pad),
-      hipLaunchKernelGGL(pack_conv_weight_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), w, scale, (__bf16*)dst, cout, cin, r, s, w_rows, cin_pad));
+      hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), w, scale, (float*)dst, cout, cin, r, s, w_rows, cin_pad, src_orsi),
+      hipLaunchKernelGGL(pack_conv_weight_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), w, scale, (__bf16*)dst, cout, cin, r, s, w_rows, cin_pad, src_orsi));
   return osd_check_launch("pack_conv_weight");
 }
 

@@ -98,12 +98,12 @@ ALGO_CACHE = {}
 _TUNING = [False]
 
 
-def conv_algo_candidates(cout_store, relu_in):
+def conv_algo_candidates(cout_store, relu_in, has_mask=False):
     tiles = [3] if cout_store <= 16 else [0, 1, 2]
     if cout_store <= 16:
         tiles = [3, 2]
     cands = [1 + 0 * 16 + v * 4 + t for v in (0, 1, 2) for t in tiles]
-    if not relu_in:
+    if not relu_in and not has_mask:
         cands += [1 + 1 * 16 + t for t in tiles]
     return cands
 
@@ -120,7 +120,7 @@ class tuning(object):
 
 def _tune(key, d, args):
     best, best_t = 0, float("inf")
-    for algo in conv_algo_candidates(d.cout, d.relu_in):
+    for algo in conv_algo_candidates(d.cout, d.relu_in, has_mask=bool(key[-1])):
         d.algo = algo
         try:
             _lib.call("osd_conv2d_fwd", C.byref(d), *args)
@@ -141,7 +141,7 @@ def _tune(key, d, args):
 
 
 def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, relu_in=False, act_scale=1.0, out=None,
-           out_hw=None, algo=None):
+           out_hw=None, algo=None, mask=None, act_scale_dev=None):
     """x NHWC [N,H,W,C] -> [N,Ho,Wo,cout_store].  For the stem, x is the padded NHWC4 image from pack_image and
     out_hw gives (Ho, Wo)."""
     _chk_dev(x, res, out)
@@ -174,9 +174,12 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
         if res_mode == RES_UP2X:
             assert res.shape[1] * 2 == ho and res.shape[2] * 2 == wo, "top-down map must be exactly half size"
     d.act, d.act_scale, d.relu_in, d.gn_in = act, float(act_scale), int(relu_in), 0
-    args = (_ptr(x), _ptr(pc.w), _ptr(pc.bias), _ptr(res), None, None, _ptr(out), _stream())
+    if mask is not None:
+        assert mask.shape == out.shape and mask.dtype == out.dtype
+    args = (_ptr(x), _ptr(pc.w), _ptr(pc.bias), _ptr(res), _ptr(mask), _ptr(act_scale_dev), None, _ptr(out), _stream())
     if algo is None:
-        key = (d.dtype, n * ho * wo, d.cout, d.cin, d.r, d.s, d.stride_h, d.pad_h, res_mode, act, int(relu_in))
+        key = (d.dtype, n * ho * wo, d.cout, d.cin, d.r, d.s, d.stride_h, d.pad_h, res_mode, act, int(relu_in),
+               mask is not None)
         algo = ALGO_CACHE.get(key)
         if algo is None:
             algo = _tune(key, d, args) if _TUNING[0] else 0
@@ -323,3 +326,144 @@ def sigmoid_focal_loss_bwd(logits, targets, d_losses, gamma, alpha):
     _lib.call("osd_sigmoid_focal_bwd", _ptr(logits.contiguous()), _ptr(targets.contiguous()),
               _ptr(d_losses.contiguous()), _ptr(d_logits), m, classes, float(gamma), float(alpha), _stream())
     return d_logits
+
+
+# ---------------------------------------------------------------------------------------------- backward wrappers
+def _conv_desc(x_shape, dtype_code, cout_store, r, s, stride, pad, out_stride):
+    n, h, w, c = x_shape
+    d = ConvDesc()
+    d.dtype = dtype_code
+    d.n, d.h, d.w, d.cin = n, h, w, c
+    d.in_stride_n, d.in_stride_h, d.in_stride_w = h * w * c, w * c, c
+    d.ho, d.wo = conv_out(h, r, stride, pad), conv_out(w, s, stride, pad)
+    d.cout, d.r, d.s = cout_store, r, s
+    d.stride_h = d.stride_w = stride
+    d.pad_h = d.pad_w = pad
+    d.out_stride = out_stride
+    return d
+
+
+def pack_conv_master(w_orsi, scale, dtype, w_rows=None):
+    """fp32 master weight in [cout][r][s][cin] order (+ optional FrozenBN scale) -> forward PackedConv layout."""
+    cout, r, s, cin = w_orsi.shape
+    w_rows = _round_up(cout, 16) if w_rows is None else w_rows
+    mult = 64 if dtype == torch.bfloat16 else 16
+    cin_pad = _round_up(cin, mult)
+    wp = torch.empty((w_rows, r, s, cin_pad), device=w_orsi.device, dtype=dtype)
+    _lib.call("osd_pack_conv_weight_ex", _ptr(w_orsi), _ptr(scale), _ptr(wp), cout, cin, r, s, w_rows, cin_pad, 1, _dt(wp),
+              _stream())
+    return wp
+
+
+def pack_conv_master_dgrad(w_orsi, scale, dtype):
+    """-> [cin_pad16][r][s][cout_pad] (taps flipped): the weights of the data-gradient convolution."""
+    cout, r, s, cin = w_orsi.shape
+    rows = _round_up(cin, 16)
+    mult = 64 if dtype == torch.bfloat16 else 16
+    cout_pad = _round_up(cout, mult)
+    wp = torch.empty((rows, r, s, cout_pad), device=w_orsi.device, dtype=dtype)
+    _lib.call("osd_pack_conv_weight_dgrad", _ptr(w_orsi), _ptr(scale), _ptr(wp), cout, cin, r, s, rows, cout_pad, 1,
+              _dt(wp), _stream())
+    return wp
+
+
+def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None):
+    """dw_packed [cout][r][s][cin] fp32 += wgrad(x NHWC, dy NHWC [N,Ho,Wo,>=cout])."""
+    _chk_dev(x, dy, dw_packed)
+    d = _conv_desc(x.shape, _dt(x), cout, r, s, stride, pad, dy.shape[-1])
+    assert (dy.shape[1], dy.shape[2]) == (d.ho, d.wo), (dy.shape, d.ho, d.wo)
+    _lib.call("osd_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(scale), _ptr(dw_packed), _stream())
+
+
+def bias_grad(dy, db, c):
+    n, h, w, stride = dy.shape
+    _lib.call("osd_bias_grad", _ptr(dy), _ptr(db), n * h * w, c, stride, _dt(dy), _stream())
+
+
+def conv2d_dgrad_naive(dy, w_fwd_packed, x_shape, r, s, stride, pad, cout, mask=None, addend=None):
+    d = _conv_desc(x_shape, _dt(dy), cout, r, s, stride, pad, dy.shape[-1])
+    dx = torch.empty(x_shape, device=dy.device, dtype=dy.dtype)
+    _lib.call("osd_conv2d_dgrad_naive", C.byref(d), _ptr(dy), _ptr(w_fwd_packed), _ptr(mask), _ptr(addend), _ptr(dx),
+              _stream())
+    return dx
+
+
+def scatter2x(src, out_hw, mask=None, addend=None):
+    n, ho, wo, c = src.shape
+    h, w = out_hw
+    dst = torch.empty((n, h, w, c), device=src.device, dtype=src.dtype)
+    _lib.call("osd_scatter2x", _ptr(src), _ptr(mask), _ptr(addend), _ptr(dst), n, h, w, ho, wo, c, _dt(src), _stream())
+    return dst
+
+
+def add_mask(a, b=None, mask=None, out=None):
+    out = torch.empty_like(a) if out is None else out
+    _lib.call("osd_add_mask", _ptr(a), _ptr(b), _ptr(mask), _ptr(out), a.numel(), _dt(a), _stream())
+    return out
+
+
+def upsample2x_bwd(inner, prev=None):
+    n, h2, w2, c = inner.shape
+    top = torch.empty((n, h2 // 2, w2 // 2, c), device=inner.device, dtype=inner.dtype)
+    _lib.call("osd_upsample2x_bwd", _ptr(inner), _ptr(prev), _ptr(top), n, h2 // 2, w2 // 2, c, _dt(inner), _stream())
+    return top
+
+
+def correlate_bwd_query(g, feat):
+    n, h, w, c = g.shape
+    dq = torch.empty((n, c), device=g.device, dtype=torch.float32)
+    _lib.call("osd_correlate_bwd_query", _ptr(g), _ptr(feat), _ptr(dq), n, h * w, c, _dt(g), _stream())
+    return dq
+
+
+def roi_align_bwd(gy, rois, x_shape, spatial_scale, ph, pw, sampling_ratio):
+    b, h, w, c = x_shape
+    gx = torch.empty(x_shape, device=gy.device, dtype=torch.float32)
+    _lib.call("osd_roialign_bwd", _ptr(gy.contiguous()), _ptr(rois), _ptr(gx), b, h, w, c, rois.shape[0],
+              float(spatial_scale), ph, pw, sampling_ratio, _stream())
+    return gx
+
+
+def shot_mean_bwd(gy, shots):
+    b, c = gy.shape
+    gx = torch.empty((b * shots, c), device=gy.device, dtype=torch.float32)
+    _lib.call("osd_shot_mean_bwd", _ptr(gy.contiguous()), _ptr(gx), b, shots, c, _stream())
+    return gx
+
+
+def cast_f32(x, dtype):
+    y = torch.empty(x.shape, device=x.device, dtype=dtype)
+    _lib.call("osd_cast_f32", _ptr(x.contiguous()), _ptr(y), x.numel(), _dt(y), _stream())
+    return y
+
+
+def groupnorm_relu_train(x, gamma, beta, groups=32, eps=1e-5):
+    """relu(GroupNorm(x)) keeping x and the per-(image, channel) scale/shift for the backward pass."""
+    n, h, w, c = x.shape
+    ws = torch.empty((n, GN_SPLITS, groups, 2), device=x.device, dtype=torch.float32)
+    ab = torch.empty((2, n, c), device=x.device, dtype=torch.float32)
+    st = _stream()
+    _lib.call("osd_groupnorm_stats", _ptr(x), _ptr(ws), n, h * w, c, groups, _dt(x), st)
+    _lib.call("osd_groupnorm_finalize", _ptr(ws), _ptr(gamma), _ptr(beta), _ptr(ab[0]), _ptr(ab[1]), n, h * w, c, groups,
+              float(eps), st)
+    out = torch.empty_like(x)
+    _lib.call("osd_groupnorm_relu_apply", _ptr(x), _ptr(ab[0]), _ptr(ab[1]), _ptr(out), n, h * w, c, _dt(x), st)
+    return out, ab
+
+
+def groupnorm_relu_bwd(u, dt, ab, gamma, beta, dgamma, dbeta, groups=32):
+    n, h, w, c = u.shape
+    ws = torch.empty((n * GN_SPLITS * groups * 2 + n * groups * 2,), device=u.device, dtype=torch.float32)
+    du = torch.empty_like(u)
+    _lib.call("osd_groupnorm_relu_bwd", _ptr(u), _ptr(dt), _ptr(ab[0]), _ptr(ab[1]), _ptr(gamma), _ptr(beta), _ptr(ws),
+              _ptr(dgamma), _ptr(dbeta), _ptr(du), n, h * w, c, groups, _dt(u), _stream())
+    return du
+
+
+def fcos_loss_level(phase, cls_ctr, reg, gt_boxes, gt_count, stride, size_lo, size_hi, radius, gamma, alpha, scale_dev,
+                    sums, d_cls_ctr=None, d_reg=None, d_scale_raw=None):
+    n, h, w, _ = cls_ctr.shape
+    gs = d_cls_ctr.shape[-1] if d_cls_ctr is not None else 4
+    _lib.call("osd_fcos_loss_level", phase, _ptr(cls_ctr), _ptr(reg), _ptr(gt_boxes), _ptr(gt_count), gt_boxes.shape[1], n,
+              h, w, stride, float(size_lo), float(size_hi), float(radius), float(gamma), float(alpha), _ptr(scale_dev),
+              _ptr(sums), _ptr(d_cls_ctr), _ptr(d_reg), gs, _ptr(d_scale_raw), _dt(cls_ctr), _stream())

@@ -1,0 +1,431 @@
+"""Training step of the siamese-FCOS hot path on MI355X: forward with saved activations, FCOS loss, hand-scheduled
+backward (data gradients on the forward implicit-GEMM kernel with flipped weights, weight gradients on the MFMA
+wgrad kernel, GroupNorm / ROIAlign / correlation backward), gradient all-reduce over RCCL and SGD.
+
+Reference call stack: engine/trainer.py:62-96 -> GeneralizedRCNN.forward (train) ->
+FCOSModule._forward_train (fcos.py:178-200) -> FCOSLossComputation.__call__ (fcos/loss.py:213-276); autograd does the
+backward there.  Stem and layer1 are frozen (resnet.py:127-136, FREEZE_CONV_BODY_AT=2) and FrozenBN has no parameters,
+so gradients stop at the input of layer2.
+
+Master weights are fp32 and live, like their gradients, in ONE flat buffer each, conv weights in the kernels' own
+[Cout][R][S][Cin] order: the optimiser (elementwise), the weight-gradient kernel (atomics into that layout) and the
+bf16/fp32 packers all share it, and the gradient all-reduce is a handful of large contiguous RCCL calls.
+`state_dict()` converts back to the reference's OIHW names/shapes.
+"""
+import math
+
+import torch
+
+from . import ops, spec
+from .ops import ACT_EXP_SCALE, ACT_NONE, ACT_RELU, RES_NONE, RES_SAME, RES_UP2X, PackedConv
+
+SIZE_RANGES = ((-1.0, 64.0), (64.0, 128.0), (128.0, 256.0), (256.0, 512.0), (512.0, float(spec.INF)))
+
+
+class TConv(object):
+    """One convolution of the training graph."""
+
+    def __init__(self, name, cout, cin, r, s, trainable, has_bias):
+        self.name, self.cout, self.cin, self.r, self.s = name, cout, cin, r, s
+        self.trainable, self.has_bias = trainable, has_bias
+        self.w = self.gw = self.b = self.gb = None       # views into the flat master / gradient buffers
+        self.bn_scale = self.bn_shift = None             # folded FrozenBN (fp32 device tensors)
+        self.pc = None                                   # forward PackedConv
+        self.pd = None                                   # data-gradient PackedConv (flipped, transposed weights)
+        self.need_dgrad = True
+
+
+class TrainEngine(object):
+    def __init__(self, state_dict, dtype=torch.bfloat16, device="cuda", lr=0.0005, momentum=0.9, weight_decay=0.0001,
+                 process_group=None):
+        if not torch.cuda.is_available():
+            raise ops._lib.OsdError("TrainEngine needs an MI355X: no GPU visible and there is no CPU fallback")
+        ops._lib.load()
+        self.device, self.dtype = torch.device(device), dtype
+        self.pg = process_group
+        sd = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state_dict.items()}
+        self._frozen_sd = sd
+        self.convs = {}          # name -> TConv
+        self.extra = {}          # name -> (param view, grad view) for GN affine and Scale parameters
+        self._plan = []          # (name, shape) of every trainable tensor, in registration order
+        self._build(sd)
+        self._allocate(sd)
+        self.repack()
+        self.zero_bias = torch.zeros(4096, device=self.device, dtype=torch.float32)
+        # SGD with the reference's parameter groups (solver/build.py:8-26: bias lr x2, bias weight decay 0)
+        weights = [c.w for c in self.convs.values() if c.trainable] + \
+                  [p for n, (p, _) in self.extra.items() if n.endswith(".weight")]
+        biases = [c.b for c in self.convs.values() if c.trainable and c.has_bias] + \
+                 [p for n, (p, _) in self.extra.items() if not n.endswith(".weight")]
+        self.opt = torch.optim.SGD([{"params": weights, "lr": lr, "weight_decay": weight_decay},
+                                    {"params": biases, "lr": 2 * lr, "weight_decay": 0.0}], lr=lr, momentum=momentum)
+
+    # ------------------------------------------------------------------------------------------------ construction
+    def _add_conv(self, name, sd, bn=None, bias=None, trainable=True):
+        w = sd[name + ".weight"]
+        cout, cin, r, s = w.shape
+        c = TConv(name, cout, cin, r, s, trainable, bias is not None)
+        if bn is not None:
+            g, b, mean, var = (sd[bn + k] for k in (".weight", ".bias", ".running_mean", ".running_var"))
+            c.bn_scale = (g * var.rsqrt()).contiguous()          # layers/batch_norm.py:20 (no eps)
+            c.bn_shift = (b - mean * c.bn_scale).contiguous()
+        self.convs[name] = c
+        if trainable:
+            self._plan.append((name + ".weight", (cout, r, s, cin)))
+            if bias is not None:
+                self._plan.append((name + ".bias", (cout,)))
+        return c
+
+    def _build(self, sd):
+        for bb in ("backbone.", "supp_backbone."):
+            b = bb + "body."
+            self._add_conv(b + "stem.conv1", sd, bn=b + "stem.bn1", trainable=False)
+            for si, nblocks in enumerate(spec.STAGE_BLOCKS):
+                for bi in range(nblocks):
+                    p = "%slayer%d.%d." % (b, si + 1, bi)
+                    tr = si >= 1
+                    if (p + "downsample.0.weight") in sd:
+                        self._add_conv(p + "downsample.0", sd, bn=p + "downsample.1", trainable=tr)
+                    for i in (1, 2, 3):
+                        self._add_conv("%sconv%d" % (p, i), sd, bn="%sbn%d" % (p, i), trainable=tr)
+            f = bb + "fpn."
+            for nm in ("fpn_inner2", "fpn_inner3", "fpn_inner4", "fpn_layer2", "fpn_layer3", "fpn_layer4", "top_blocks.p6",
+                       "top_blocks.p7"):
+                self._add_conv(f + nm, sd, bias=True)
+        h = "rpn.head."
+        for tower in ("cls_tower", "bbox_tower"):
+            for i in range(spec.NUM_CONVS):
+                self._add_conv("%s%s.%d" % (h, tower, 3 * i), sd, bias=True)
+                self._plan.append(("%s%s.%d.weight" % (h, tower, 3 * i + 1), (spec.FPN_OUT,)))
+                self._plan.append(("%s%s.%d.bias" % (h, tower, 3 * i + 1), (spec.FPN_OUT,)))
+        # cls_logits + centerness fused into one 2-output conv (both read the cls tower, fcos.py:91-92)
+        c = TConv(h + "cls_ctr", 2, spec.FPN_OUT, 3, 3, True, True)
+        self.convs[h + "cls_ctr"] = c
+        self._plan.append((h + "cls_ctr.weight", (2, 3, 3, spec.FPN_OUT)))
+        self._plan.append((h + "cls_ctr.bias", (2,)))
+        self._add_conv(h + "bbox_pred", sd, bias=True)
+        self._plan.append((h + "scales", (5,)))
+
+    def _allocate(self, sd):
+        total = sum(int(math.prod(s)) for _, s in self._plan)
+        total = (total + 63) // 64 * 64
+        self.flat_w = torch.zeros(total, device=self.device, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=self.device, dtype=torch.float32)
+        off = 0
+        h = "rpn.head."
+        for name, shape in self._plan:
+            n = int(math.prod(shape))
+            wv, gv = self.flat_w[off:off + n].view(shape), self.flat_g[off:off + n].view(shape)
+            off += n
+            wv.grad = gv
+            base, leaf = name.rsplit(".", 1)
+            if name == h + "scales":
+                wv.copy_(torch.cat([sd["%sscales.%d.scale" % (h, i)] for i in range(5)]))
+                self.extra[name] = (wv, gv)
+            elif base == h + "cls_ctr":
+                if leaf == "weight":
+                    src = torch.cat([sd[h + "cls_logits.weight"], sd[h + "centerness.weight"]], 0)
+                    wv.copy_(src.permute(0, 2, 3, 1))
+                    self.convs[base].w, self.convs[base].gw = wv, gv
+                else:
+                    wv.copy_(torch.cat([sd[h + "cls_logits.bias"], sd[h + "centerness.bias"]], 0))
+                    self.convs[base].b, self.convs[base].gb = wv, gv
+            elif base in self.convs:
+                if leaf == "weight":
+                    wv.copy_(sd[name].permute(0, 2, 3, 1))              # OIHW -> [O][R][S][I]
+                    self.convs[base].w, self.convs[base].gw = wv, gv
+                else:
+                    wv.copy_(sd[name])
+                    self.convs[base].b, self.convs[base].gb = wv, gv
+            else:                                                        # GroupNorm affine
+                wv.copy_(sd[name])
+                self.extra[name] = (wv, gv)
+
+    def repack(self):
+        """fp32 masters -> kernel-layout weights of the compute dtype (forward + data-gradient forms)."""
+        for c in self.convs.values():
+            if not c.trainable:
+                if c.pc is None:
+                    c.pc = ops.pack_conv(self._frozen_sd[c.name + ".weight"], bn=None if c.bn_scale is None else tuple(
+                        self._frozen_sd[c.name.replace("conv", "bn").replace("downsample.0", "downsample.1") + k]
+                        for k in (".weight", ".bias", ".running_mean", ".running_var")), dtype=self.dtype,
+                        stem=c.name.endswith("stem.conv1"))
+                continue
+            cout_store = ops._round_up(c.cout, 4)
+            w_rows = ops._round_up(c.cout, 16)
+            wp = ops.pack_conv_master(c.w, c.bn_scale, self.dtype, w_rows)
+            if c.pc is None:
+                bias = torch.zeros(ops._round_up(cout_store, 16), device=self.device, dtype=torch.float32)
+                c.pc = PackedConv(wp, bias, c.cout, cout_store, w_rows, wp.shape[-1], c.r, c.s, cin_real=c.cin)
+            else:
+                c.pc.w = wp
+            c.pc.bias[:c.cout] = c.b if c.has_bias else c.bn_shift
+            if c.need_dgrad:
+                wd = ops.pack_conv_master_dgrad(c.w, c.bn_scale, self.dtype)
+                if c.pd is None:
+                    zb = torch.zeros(ops._round_up(c.cin, 16), device=self.device, dtype=torch.float32)
+                    c.pd = PackedConv(wd, zb, c.cin, c.cin, wd.shape[0], wd.shape[-1], c.r, c.s, cin_real=c.cout)
+                else:
+                    c.pd.w = wd
+
+    def gn(self, name):
+        return self.extra[name + ".weight"], self.extra[name + ".bias"]
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def backbone_forward(self, bb, images):
+        cv, dt = self.convs, self.dtype
+        n, _, h, w = images.shape
+        ho, wo = ops.conv_out(h, 7, 2, 3), ops.conv_out(w, 7, 2, 3)
+        hp, wp = max(2 * (ho - 1) + 7, h + 3), max(2 * (wo - 1) + 8, w + 3)
+        wp += wp & 1
+        b = bb + "body."
+        x = ops.pack_image(images, dt, hp, wp)
+        x = ops.conv2d(x, cv[b + "stem.conv1"].pc, act=ACT_RELU, out_hw=(ho, wo))
+        x = ops.maxpool3x3s2(x)
+        blocks, stage_out = [], []
+        for si, nblocks in enumerate(spec.STAGE_BLOCKS):
+            for bi in range(nblocks):
+                p = "%slayer%d.%d." % (b, si + 1, bi)
+                s = 2 if (bi == 0 and si > 0) else 1
+                has_ds = (p + "downsample.0") in cv
+                identity = ops.conv2d(x, cv[p + "downsample.0"].pc, stride=s) if has_ds else x
+                o1 = ops.conv2d(x, cv[p + "conv1"].pc, stride=s, act=ACT_RELU)
+                o2 = ops.conv2d(o1, cv[p + "conv2"].pc, pad=1, act=ACT_RELU)
+                y = ops.conv2d(o2, cv[p + "conv3"].pc, act=ACT_RELU, res=identity, res_mode=RES_SAME)
+                if si >= 1:
+                    blocks.append(dict(p=p, s=s, ds=has_ds, x=x, o1=o1, o2=o2, y=y, first=(si == 1 and bi == 0)))
+                x = y
+            stage_out.append(x)
+        c3, c4, c5 = stage_out[1], stage_out[2], stage_out[3]
+        f = bb + "fpn."
+        inner4 = ops.conv2d(c5, cv[f + "fpn_inner4"].pc)
+        p5 = ops.conv2d(inner4, cv[f + "fpn_layer4"].pc, pad=1)
+        inner3 = ops.conv2d(c4, cv[f + "fpn_inner3"].pc, res=inner4, res_mode=RES_UP2X)
+        p4 = ops.conv2d(inner3, cv[f + "fpn_layer3"].pc, pad=1)
+        inner2 = ops.conv2d(c3, cv[f + "fpn_inner2"].pc, res=inner3, res_mode=RES_UP2X)
+        p3 = ops.conv2d(inner2, cv[f + "fpn_layer2"].pc, pad=1)
+        p6 = ops.conv2d(p5, cv[f + "top_blocks.p6"].pc, stride=2, pad=1)
+        p6r = ops.add_mask(p6, None, p6)                    # relu(P6), materialised: the P7 weight gradient reads it
+        p7 = ops.conv2d(p6r, cv[f + "top_blocks.p7"].pc, stride=2, pad=1)
+        ctx = dict(bb=bb, blocks=blocks, c3=c3, c4=c4, c5=c5, inner4=inner4, inner3=inner3, inner2=inner2, p5=p5, p6=p6,
+                   p6r=p6r)
+        return [p3, p4, p5, p6, p7], ctx
+
+    def head_forward(self, feats):
+        cv = self.convs
+        h = "rpn.head."
+        scales = self.extra[h + "scales"][0]
+        outs, ctxs = [], []
+        for lvl, f in enumerate(feats):
+            lctx = {}
+            res = {}
+            for tower in ("cls_tower", "bbox_tower"):
+                t, layers = f, []
+                for i in range(spec.NUM_CONVS):
+                    (gw, _), (gbeta, _) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
+                    u = ops.conv2d(t, cv["%s%s.%d" % (h, tower, 3 * i)].pc, pad=1)
+                    t2, ab = ops.groupnorm_relu_train(u, gw, gbeta, spec.GN_GROUPS, spec.GN_EPS)
+                    layers.append((t, u, ab))
+                    t = t2
+                lctx[tower] = (layers, t)
+                if tower == "cls_tower":
+                    res[tower] = ops.conv2d(t, cv[h + "cls_ctr"].pc, pad=1)
+                else:
+                    res[tower] = ops.conv2d(t, cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE,
+                                            act_scale_dev=scales[lvl:lvl + 1])
+            outs.append((res["cls_tower"], res["bbox_tower"]))
+            ctxs.append(lctx)
+        return outs, ctxs
+
+    # ------------------------------------------------------------------------------------------------ loss
+    def loss_and_grads(self, head_out, gt_boxes, gt_count):
+        """-> losses [4] (cls, reg, centerness, num_pos) on the device, per-level gradients w.r.t. the prediction convs."""
+        h = "rpn.head."
+        scales, gscales = self.extra[h + "scales"]
+        n = head_out[0][0].shape[0]
+        sums = torch.zeros(8, device=self.device, dtype=torch.float32)
+        for lvl, (cc, rg) in enumerate(head_out):
+            ops.fcos_loss_level(0, cc, rg, gt_boxes, gt_count, spec.FPN_STRIDES[lvl], SIZE_RANGES[lvl][0],
+                                SIZE_RANGES[lvl][1], spec.POS_RADIUS, spec.LOSS_GAMMA, spec.LOSS_ALPHA, None, sums)
+        gstride = self.convs[h + "bbox_pred"].pd.cin_k
+        grads = []
+        raw = torch.zeros(5, device=self.device, dtype=torch.float32)
+        for lvl, (cc, rg) in enumerate(head_out):
+            shape = cc.shape[:3] + (gstride,)
+            dcc = torch.zeros(shape, device=self.device, dtype=self.dtype)
+            drg = torch.zeros(shape, device=self.device, dtype=self.dtype)
+            ops.fcos_loss_level(1, cc, rg, gt_boxes, gt_count, spec.FPN_STRIDES[lvl], SIZE_RANGES[lvl][0],
+                                SIZE_RANGES[lvl][1], spec.POS_RADIUS, spec.LOSS_GAMMA, spec.LOSS_ALPHA,
+                                scales[lvl:lvl + 1], sums, dcc, drg, raw[lvl:lvl + 1])
+            grads.append((dcc, drg))
+        gscales.add_(raw / scales)      # d loss / d scale_l = sum ds * x, x = log(reg) / scale_l
+        losses = torch.empty(4, device=self.device, dtype=torch.float32)
+        ops._lib.call("osd_fcos_loss_finalize", ops._ptr(sums), ops._ptr(losses), n, ops._stream())
+        return losses, grads
+
+    # ------------------------------------------------------------------------------------------------ backward
+    def _wgrad(self, c, x, dy, stride=1, pad=0):
+        ops.conv2d_wgrad(x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale)
+        if c.has_bias:
+            ops.bias_grad(dy, c.gb, c.cout)
+
+    def _dgrad(self, c, dy, res=None, mask=None):
+        """Data gradient of a stride-1 conv: the forward kernel on dy with flipped/transposed weights."""
+        return ops.conv2d(dy, c.pd, stride=1, pad=c.r - 1 - (c.r // 2), res=res,
+                          res_mode=RES_SAME if res is not None else RES_NONE, mask=mask)
+
+    def head_backward(self, feats, ctxs, pred_grads):
+        cv = self.convs
+        h = "rpn.head."
+        d_feats = []
+        for lvl, (f, lctx, (dcc, drg)) in enumerate(zip(feats, ctxs, pred_grads)):
+            d_f = None
+            for tower, dpred, pname in (("cls_tower", dcc, h + "cls_ctr"), ("bbox_tower", drg, h + "bbox_pred")):
+                layers, t_last = lctx[tower]
+                pc = cv[pname]
+                self._wgrad(pc, t_last, dpred, 1, 1)
+                d_t = self._dgrad(pc, dpred)
+                for i in range(spec.NUM_CONVS - 1, -1, -1):
+                    t_in, u, ab = layers[i]
+                    (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
+                    du = ops.groupnorm_relu_bwd(u, d_t, ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
+                    c = cv["%s%s.%d" % (h, tower, 3 * i)]
+                    self._wgrad(c, t_in, du, 1, 1)
+                    d_t = self._dgrad(c, du, res=d_f if (i == 0 and d_f is not None) else None)
+                d_f = d_t
+            d_feats.append(d_f)
+        return d_feats
+
+    def backbone_backward(self, ctx, dP, need_input_grad=False):
+        cv, bb = self.convs, ctx["bb"]
+        f = bb + "fpn."
+        dp3, dp4, dp5, dp6, dp7 = dP
+        # P7 = conv(relu(P6)), P6 = conv(P5), both 3x3 stride 2 (fpn.py:95-99)
+        c7, c6 = cv[f + "top_blocks.p7"], cv[f + "top_blocks.p6"]
+        self._wgrad(c7, ctx["p6r"], dp7, 2, 1)
+        d_p6 = ops.conv2d_dgrad_naive(dp7, c7.pc.w, ctx["p6"].shape, 3, 3, 2, 1, c7.cout, mask=ctx["p6"], addend=dp6)
+        self._wgrad(c6, ctx["p5"], d_p6, 2, 1)
+        d_p5 = ops.conv2d_dgrad_naive(d_p6, c6.pc.w, ctx["p5"].shape, 3, 3, 2, 1, c6.cout, mask=None, addend=dp5)
+        l4, l3, l2 = cv[f + "fpn_layer4"], cv[f + "fpn_layer3"], cv[f + "fpn_layer2"]
+        self._wgrad(l4, ctx["inner4"], d_p5, 1, 1)
+        self._wgrad(l3, ctx["inner3"], dp4, 1, 1)
+        self._wgrad(l2, ctx["inner2"], dp3, 1, 1)
+        d_inner2 = self._dgrad(l2, dp3)
+        d_inner3 = self._dgrad(l3, dp4)
+        d_inner3 = ops.upsample2x_bwd(d_inner2, d_inner3)
+        d_inner4 = self._dgrad(l4, d_p5)
+        d_inner4 = ops.upsample2x_bwd(d_inner3, d_inner4)
+        i4, i3, i2 = cv[f + "fpn_inner4"], cv[f + "fpn_inner3"], cv[f + "fpn_inner2"]
+        self._wgrad(i4, ctx["c5"], d_inner4)
+        self._wgrad(i3, ctx["c4"], d_inner3)
+        self._wgrad(i2, ctx["c3"], d_inner2)
+        # gradients w.r.t. C5 / C4 / C3 from the laterals; C5's is complete, so its ReLU mask is applied here
+        g = self._dgrad(i4, d_inner4, mask=ctx["c5"])
+        lateral = {id(ctx["c4"]): self._dgrad(i3, d_inner3), id(ctx["c3"]): self._dgrad(i2, d_inner2)}
+        # body, last block first.  `g` = gradient w.r.t. the block output, already masked by its ReLU.
+        for blk in reversed(ctx["blocks"]):
+            p, s = blk["p"], blk["s"]
+            c1, c2, c3 = cv[p + "conv1"], cv[p + "conv2"], cv[p + "conv3"]
+            self._wgrad(c3, blk["o2"], g)
+            d_o2 = self._dgrad(c3, g, mask=blk["o2"])
+            self._wgrad(c2, blk["o1"], d_o2, 1, 1)
+            d_o1 = self._dgrad(c2, d_o2, mask=blk["o1"])
+            self._wgrad(c1, blk["x"], d_o1, s, 0)
+            if blk["ds"]:
+                self._wgrad(cv[p + "downsample.0"], blk["x"], g, s, 0)
+            if blk["first"]:
+                break                                   # input of layer2 = frozen layer1 output: no data gradient
+            extra = lateral.get(id(blk["x"]))            # block input is C3/C4: add the FPN lateral's gradient
+            if s == 1:
+                a = self._dgrad(cv[p + "downsample.0"], g, res=extra) if blk["ds"] else \
+                    (g if extra is None else ops.add_mask(g, extra))
+                g = self._dgrad(c1, d_o1, res=a, mask=blk["x"])
+            else:                                        # 1x1 stride 2: small-grid GEMM, then zero-insert
+                a = self._dgrad(cv[p + "downsample.0"], g)
+                bsm = self._dgrad(c1, d_o1, res=a)
+                g = ops.scatter2x(bsm, blk["x"].shape[1:3], mask=blk["x"], addend=extra)
+        return None
+
+    # ------------------------------------------------------------------------------------------------ step
+    def forward_backward(self, images, queries, gt_boxes, gt_count, with_proposals=True):
+        """One training forward + backward.  images [B,3,H,W], queries [B*S,3,h,w] fp32 NCHW on the device;
+        gt_boxes [B, G, 4] fp32 xyxy, gt_count [B] int32.  Returns losses [4] = (cls, reg, centerness, num_pos)."""
+        from . import model
+        self.flat_g.zero_()
+        batch = images.shape[0]
+        shots = queries.shape[0] // batch
+        feats, tctx = self.backbone_forward("backbone.", images)
+        qfeats, qctx = self.backbone_forward("supp_backbone.", queries)
+        q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0]
+        rois = model.whole_image_rois(q_sizes, self.device)
+        pooled = []
+        for feat, scale in zip(qfeats, spec.POOLER_SCALES):
+            v = ops.roi_align(feat, rois, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
+            pooled.append(ops.shot_mean(v.view(v.shape[0], -1), batch))
+        combined = [ops.correlate(f, q) for f, q in zip(feats, pooled)]
+        head_out, hctx = self.head_forward(combined)
+        if with_proposals:      # box_selector_train under no_grad (fcos.py:196-199): proposals for the second stage
+            self.proposals = model.run_proposals(head_out, images.shape[-2], images.shape[-1],
+                                                 spec.PRE_NMS_TOP_N_TRAIN, spec.POST_NMS_TOP_N_TRAIN, spec.NMS_THRESH)
+        losses, pred_grads = self.loss_and_grads(head_out, gt_boxes, gt_count)
+        d_comb = self.head_backward(combined, hctx, pred_grads)
+        # correlation backward (generalized_rcnn.py:307-311): d feat = g * q, d q = sum_hw g * feat
+        dP = [ops.correlate(g, q) for g, q in zip(d_comb, pooled)]
+        dQ = []
+        for g, feat, qf, scale in zip(d_comb, feats, qfeats, spec.POOLER_SCALES):
+            dq = ops.correlate_bwd_query(g, feat)
+            dv = ops.shot_mean_bwd(dq, shots)
+            gx = ops.roi_align_bwd(dv.view(-1, 1, 1, dv.shape[-1]), rois, qf.shape, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
+            dQ.append(ops.cast_f32(gx, self.dtype))
+        self.backbone_backward(tctx, dP)
+        self.backbone_backward(qctx, dQ)
+        self.debug = dict(head_out=head_out, dP=dP, dQ=dQ, d_comb=d_comb)
+        return losses
+
+    def reduce_gradients(self):
+        """DDP gradient averaging (tools/train_net.py:83-88): one flat fp32 buffer, a few large RCCL all-reduces."""
+        import torch.distributed as dist
+        if self.pg is None and not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(self.pg)
+        if world == 1:
+            return
+        n = self.flat_g.numel()
+        chunk = (n + 3) // 4
+        for i in range(0, n, chunk):
+            dist.all_reduce(self.flat_g[i:i + chunk], group=self.pg)
+        self.flat_g.mul_(1.0 / world)
+
+    def optimizer_step(self):
+        self.opt.step()
+        self.repack()
+
+    def train_step(self, images, queries, gt_boxes, gt_count):
+        losses = self.forward_backward(images, queries, gt_boxes, gt_count)
+        self.reduce_gradients()
+        self.optimizer_step()
+        return losses
+
+    # ------------------------------------------------------------------------------------------------ state
+    def named_grads(self):
+        """Reference-named gradients (OIHW) for parity tests."""
+        out = {}
+        h = "rpn.head."
+        for name, c in self.convs.items():
+            if not c.trainable:
+                continue
+            g = c.gw.permute(0, 3, 1, 2).contiguous()
+            if name == h + "cls_ctr":
+                out[h + "cls_logits.weight"], out[h + "centerness.weight"] = g[0:1], g[1:2]
+                out[h + "cls_logits.bias"], out[h + "centerness.bias"] = c.gb[0:1], c.gb[1:2]
+                continue
+            out[name + ".weight"] = g
+            if c.has_bias:
+                out[name + ".bias"] = c.gb
+        for name, (p, g) in self.extra.items():
+            if name == h + "scales":
+                for i in range(5):
+                    out["%sscales.%d.scale" % (h, i)] = g[i:i + 1]
+            else:
+                out[name] = g
+        return out

@@ -53,7 +53,7 @@ def test_invalid_arguments_return_error_codes(lib_path):
     lib = _lib.load()
     d = _lib.ConvDesc()
     d.cout = 3
-    rc = lib.osd_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None)
+    rc = lib.osd_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None, None)
     assert rc == -1 and b"null" in lib.osd_last_error_string()
     rc = lib.osd_correlate_fwd(None, None, None, 1, 1, 8, 0, None)
     assert rc == -1

@@ -1,0 +1,42 @@
+"""CPU, world_size 2, gloo: the multi-process plumbing of bench.py (rank env, barrier-bracketed timing, MAX over ranks,
+whole-job value, one JSON line from rank 0).  The data path itself needs no collective in forward."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_gloo():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5",
+           "--warmup", "1", "--dry-run-cpu", "--batch", "8"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and r["scaling"] == "weak"
+    assert r["config"]["global_batch"] == 16
+    # rank 1 sleeps 4 ms per step, rank 0 2 ms: MAX over ranks -> >= 4 ms/step; whole-job value = 16 images / step time
+    assert r["ms_per_step"] >= 3.9
+    assert abs(r["value"] - 16 * 1e3 / r["ms_per_step"]) / r["value"] < 0.01
+
+
+def test_bench_single_process_dry_run():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--dry-run-cpu"],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 1 and r["metric"].startswith("images/sec/GPU")
