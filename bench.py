@@ -167,10 +167,10 @@ class TrainTimer(ConvTimer):
         self._orig_w = ops.conv2d_wgrad
         timer = self
 
-        def timed_wgrad(x, dy, dw, r, s, stride, pad, cout, scale=None):
+        def timed_wgrad(x, dy, dw, r, s, stride, pad, cout, scale=None, db=None):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            timer._orig_w(x, dy, dw, r, s, stride, pad, cout, scale=scale)
+            timer._orig_w(x, dy, dw, r, s, stride, pad, cout, scale=scale, db=db)
             b.record()
             timer.records.append((a, b))
             timer.flops += 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * cout * x.shape[-1] * r * s

@@ -186,8 +186,9 @@ int osd_pack_conv_weight_dgrad(const float* w, const float* scale, void* dst, in
                                int cout_pad, int src_orsi, int dtype, void* stream);
 /* dW[cout][r][s][cin] (fp32, ACCUMULATED with atomics: zero it first) += sum over pixels dy[m][co] * x[m@tap][ci].
  * d describes the FORWARD conv (x geometry, strides, pads, cout, out_stride = pixel stride of dy); scale (nullable) is a
- * per-Cout factor applied to the contribution (the folded FrozenBN scale). */
-int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const void* dy, const float* scale, float* dw,
+ * per-Cout factor applied to the contribution (the folded FrozenBN scale); db (nullable, fp32 [cout], accumulated) also
+ * receives the bias gradient sum_m dy[m][co] from the same pass over dy. */
+int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const void* dy, const float* scale, float* dw, float* db,
                      void* stream);
 /* packed fp32 dW [cout][r][s][cin] -> OIHW fp32 gradient, multiplied by the folded FrozenBN scale (nullable);
  * accumulate != 0 adds to grad_oihw (weights shared over FPN levels) */

@@ -308,12 +308,29 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__
     o[0] = t1;
     o[1] = t2;
   }
-  if (pl < lanes) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      atomicAdd(dgamma + cc * E + e, dg[e]);
-      atomicAdd(dbeta + cc * E + e, db[e]);
+  // per-channel dgamma / dbeta: reduce over the block's pixel lanes in LDS first, then ONE atomic per channel and block
+  // (every workgroup adding 256 x lanes values to the same 256 addresses is an order of magnitude slower)
+  __syncthreads();
+  __shared__ float redc[2][256 * 8 / 8];   // [2][c <= 256]
+  for (int e = 0; e < E; ++e) {
+    __syncthreads();
+    red[0][threadIdx.x] = dg[e];
+    red[1][threadIdx.x] = db[e];
+    __syncthreads();
+    if (threadIdx.x < cch) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int l = 0; l < lanes; ++l) {
+        t1 += red[0][l * cch + threadIdx.x];
+        t2 += red[1][l * cch + threadIdx.x];
+      }
+      redc[0][threadIdx.x * E + e] = t1;
+      redc[1][threadIdx.x * E + e] = t2;
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < c) {
+    atomicAdd(dgamma + threadIdx.x, redc[0][threadIdx.x]);
+    atomicAdd(dbeta + threadIdx.x, redc[1][threadIdx.x]);
   }
 }
 

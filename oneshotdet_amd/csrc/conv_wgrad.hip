@@ -23,6 +23,7 @@ struct WgradParams {
   const void* dy;
   float* dw;
   const float* scale;   // optional per-Cout factor (folded FrozenBN scale: d/dw of conv(x, w*scale))
+  float* db;            // optional bias gradient: db[co] += sum over pixels of dy (done by the tap-0 / ci-tile-0 blocks)
   int H, W, Cin, Ho, Wo, Cout, HoWo;
   int R, S, sh, sw, ph, pw;
   int dy_stride, M;
@@ -185,6 +186,17 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams p) {
     }
   };
 
+  // bias gradient: the blocks that own (tap 0, ci tile 0) also sum their dY tile over its pixels, one column per thread
+  const bool do_bias = (p.db != nullptr) && (nt == 0) && (tid < TW);
+  float bsum = 0.f;
+  auto bias_stage = [&](int buf) {
+    const char* sa = smem + buf * STAGE;
+    const int chunk = tid / EPC, within = tid % EPC;
+#pragma unroll 8
+    for (int row = 0; row < BKP; ++row)
+      bsum += to_f32(*reinterpret_cast<const T*>(sa + row * 256 + ((chunk ^ wg_swz<T>(row)) << 4) + within * (int)sizeof(T)));
+  };
+
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (s < KT) issue_stage(s);
@@ -194,11 +206,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams p) {
     else wg_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (kt + NST - 1 < KT) issue_stage(nxt);
+    if (do_bias) bias_stage(cur);
     compute_stage(cur);
     cur = cur + 1 == NST ? 0 : cur + 1;
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
 
+  if (do_bias && co0 + tid < p.Cout) atomicAdd(p.db + co0 + tid, bsum);
   // ---- accumulate the partial tile into dW (fp32 atomics; rows = co, 16 consecutive ci per 16 lanes) ----
   float* __restrict__ dw = p.dw;
 #pragma unroll
@@ -275,8 +289,10 @@ __global__ void __launch_bounds__(256) bias_grad_kernel(const T* __restrict__ dy
 
 #define OSD_STREAM(s) reinterpret_cast<hipStream_t>(s)
 
+extern "C" int osd_bias_grad(const void* dy, float* db, int m, int c, int stride, int dtype, void* stream);
+
 extern "C" int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const void* dy, const float* scale, float* dw,
-                                void* stream) {
+                                float* db, void* stream) {
   if (!d || !x || !dy || !dw) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: null argument");
   if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad dtype");
   const int epc = d->dtype == OSD_BF16 ? 8 : 4;
@@ -285,7 +301,7 @@ extern "C" int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const voi
   if (d->in_stride_w != d->cin || d->in_stride_h != d->w * d->cin)
     return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: dense NHWC input required");
   hipStream_t s = OSD_STREAM(stream);
-  if (d->cout <= 8) {   // prediction convs
+  if (d->cout <= 8 && (d->out_stride % epc != 0 || d->cin % epc != 0)) {   // prediction convs whose dy is not padded
     if (d->r * d->s > 9) return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: skinny kernel supports up to 9 taps");
     const int rows = 512;
     dim3 grid(cdiv((int)M, rows), cdiv(d->cin, 256));
@@ -296,11 +312,13 @@ extern "C" int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const voi
       hipLaunchKernelGGL(conv_wgrad_skinny_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dy, dw,
                          d->h, d->w, d->cin, d->ho, d->wo, d->cout, d->r, d->s, d->stride_h, d->pad_h, d->out_stride, (int)M,
                          rows);
-    return osd_check_launch("conv_wgrad_skinny");
+    int rc = osd_check_launch("conv_wgrad_skinny");
+    if (rc || !db) return rc;
+    return osd_bias_grad(dy, db, (int)M, d->cout, d->out_stride, d->dtype, stream);
   }
   if (d->cin % epc || d->out_stride % epc) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: channel counts must keep 16-byte alignment");
   WgradParams p;
-  p.x = x; p.dy = dy; p.dw = dw; p.scale = scale;
+  p.x = x; p.dy = dy; p.dw = dw; p.scale = scale; p.db = db;
   p.H = d->h; p.W = d->w; p.Cin = d->cin; p.Ho = d->ho; p.Wo = d->wo; p.Cout = d->cout; p.HoWo = d->ho * d->wo;
   p.R = d->r; p.S = d->s; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
   p.dy_stride = d->out_stride; p.M = (int)M; p.Ktot = d->r * d->s * d->cin;
@@ -327,7 +345,7 @@ extern "C" int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const voi
 extern "C" int osd_bias_grad(const void* dy, float* db, int m, int c, int stride, int dtype, void* stream) {
   if (!dy || !db) return osd_fail(OSD_ERR_INVALID_ARG, "bias_grad: null argument");
   if (m == 0 || c == 0) return OSD_OK;
-  const int rows = 256;
+  const int rows = m > 65536 ? 2048 : 512;
   dim3 grid(cdiv(m, rows), cdiv(c, 256));
   if (dtype == OSD_F32)
     hipLaunchKernelGGL(bias_grad_kernel<float>, grid, dim3(256), 0, OSD_STREAM(stream), (const float*)dy, db, m, c, stride, rows);

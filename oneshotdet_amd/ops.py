@@ -367,12 +367,12 @@ def pack_conv_master_dgrad(w_orsi, scale, dtype):
     return wp
 
 
-def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None):
-    """dw_packed [cout][r][s][cin] fp32 += wgrad(x NHWC, dy NHWC [N,Ho,Wo,>=cout])."""
+def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None, db=None):
+    """dw_packed [cout][r][s][cin] fp32 += wgrad(x NHWC, dy NHWC [N,Ho,Wo,>=cout]); db [cout] fp32 += sum_m dy (optional)."""
     _chk_dev(x, dy, dw_packed)
     d = _conv_desc(x.shape, _dt(x), cout, r, s, stride, pad, dy.shape[-1])
     assert (dy.shape[1], dy.shape[2]) == (d.ho, d.wo), (dy.shape, d.ho, d.wo)
-    _lib.call("osd_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(scale), _ptr(dw_packed), _stream())
+    _lib.call("osd_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(scale), _ptr(dw_packed), _ptr(db), _stream())
 
 
 def bias_grad(dy, db, c):

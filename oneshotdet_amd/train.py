@@ -265,9 +265,7 @@ class TrainEngine(object):
 
     # ------------------------------------------------------------------------------------------------ backward
     def _wgrad(self, c, x, dy, stride=1, pad=0):
-        ops.conv2d_wgrad(x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale)
-        if c.has_bias:
-            ops.bias_grad(dy, c.gb, c.cout)
+        ops.conv2d_wgrad(x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale, db=c.gb if c.has_bias else None)
 
     def _dgrad(self, c, dy, res=None, mask=None):
         """Data gradient of a stride-1 conv: the forward kernel on dy with flipped/transposed weights."""

@@ -59,8 +59,7 @@ def test_conv_wgrad_skinny_and_bias(dt):
     dyp = torch.zeros(n, h, w, 16, dtype=DT[dt], device="cuda")
     dyp[..., :cout] = to_nhwc(dy, DT[dt])
     dw, db = torch.zeros(cout, 3, 3, cin, device="cuda"), torch.zeros(cout, device="cuda")
-    ops.conv2d_wgrad(to_nhwc(x, DT[dt]), dyp, dw, 3, 3, 1, 1, cout)
-    ops.bias_grad(dyp, db, cout)
+    ops.conv2d_wgrad(to_nhwc(x, DT[dt]), dyp, dw, 3, 3, 1, 1, cout, db=db)
     torch.testing.assert_close(dw.cpu(), wt.grad.permute(0, 2, 3, 1), rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3)
 
