@@ -190,6 +190,11 @@ int osd_pack_conv_weight_dgrad(const float* w, const float* scale, void* dst, in
  * receives the bias gradient sum_m dy[m][co] from the same pass over dy. */
 int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const void* dy, const float* scale, float* dw, float* db,
                      void* stream);
+/* the same over n_seg <= 8 (x, dy) pairs that share the weights (the FPN levels of the FCOS towers): d gives the conv
+ * geometry, ns/hs/ws (HOST arrays) the batch and input size of each pair; one launch, the atomic traffic into dW is paid once */
+int osd_conv2d_wgrad_grouped(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
+                             const int32_t* ns, const int32_t* hs, const int32_t* ws, const float* scale, float* dw,
+                             float* db, void* stream);
 /* packed fp32 dW [cout][r][s][cin] -> OIHW fp32 gradient, multiplied by the folded FrozenBN scale (nullable);
  * accumulate != 0 adds to grad_oihw (weights shared over FPN levels) */
 int osd_unpack_wgrad(const float* dw_packed, const float* scale, float* grad_oihw, int cout, int cin, int r, int s,

@@ -18,16 +18,27 @@ namespace {
 
 __device__ __attribute__((aligned(256))) unsigned g_wzero[64];
 
-struct WgradParams {
+constexpr int kMaxSeg = 8;
+
+// One launch can reduce over several (x, dy) pairs that share the weights (the FPN levels of the FCOS towers): the
+// pixel splits are distributed over the segments, every workgroup works inside one segment, and all of them add into
+// the same dW, so the atomic traffic is paid once instead of once per level.
+struct WgradSeg {
   const void* x;
   const void* dy;
+  int H, W, Ho, Wo, M, rows_per_split, split_begin;
+};
+
+struct WgradParams {
+  WgradSeg seg[kMaxSeg];
+  int n_seg;
   float* dw;
   const float* scale;   // optional per-Cout factor (folded FrozenBN scale: d/dw of conv(x, w*scale))
   float* db;            // optional bias gradient: db[co] += sum over pixels of dy (done by the tap-0 / ci-tile-0 blocks)
-  int H, W, Cin, Ho, Wo, Cout, HoWo;
+  int Cin, Cout;
   int R, S, sh, sw, ph, pw;
-  int dy_stride, M;
-  int tilesCo, tilesCi, splits, rows_per_split, Ktot;
+  int dy_stride;
+  int tilesCo, tilesCi, splits, Ktot;
 };
 
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -47,7 +58,7 @@ template <typename T> __device__ __forceinline__ int wg_swz(int row) {
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams p) {
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int TW = 256 / (int)sizeof(T);    // tile width (channels) of both operands: 256-byte rows
   constexpr int BKP = 32;                     // pixels per stage
@@ -64,11 +75,26 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   int bid = blockIdx.x;
-  const int co_tile = bid % p.tilesCo;
-  bid /= p.tilesCo;
-  const int ntile = p.R * p.S * p.tilesCi;
+  const int co_tile = bid % gp.tilesCo;
+  bid /= gp.tilesCo;
+  const int ntile = gp.R * gp.S * gp.tilesCi;
   const int nt = bid % ntile;
-  const int split = bid / ntile;
+  int split = bid / ntile;
+  int sidx = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxSeg; ++i)
+    if (i < gp.n_seg && split >= gp.seg[i].split_begin) sidx = i;
+  // flatten the chosen segment into the single-problem view the rest of the kernel uses
+  struct {
+    const void* x; const void* dy; float* dw; const float* scale; float* db;
+    int H, W, Cin, Ho, Wo, Cout, HoWo, R, S, sh, sw, ph, pw, dy_stride, M, tilesCo, tilesCi, rows_per_split, Ktot;
+  } p;
+  p.x = gp.seg[sidx].x; p.dy = gp.seg[sidx].dy; p.dw = gp.dw; p.scale = gp.scale; p.db = gp.db;
+  p.H = gp.seg[sidx].H; p.W = gp.seg[sidx].W; p.Ho = gp.seg[sidx].Ho; p.Wo = gp.seg[sidx].Wo; p.HoWo = p.Ho * p.Wo;
+  p.M = gp.seg[sidx].M; p.rows_per_split = gp.seg[sidx].rows_per_split;
+  p.Cin = gp.Cin; p.Cout = gp.Cout; p.R = gp.R; p.S = gp.S; p.sh = gp.sh; p.sw = gp.sw; p.ph = gp.ph; p.pw = gp.pw;
+  p.dy_stride = gp.dy_stride; p.tilesCo = gp.tilesCo; p.tilesCi = gp.tilesCi; p.Ktot = gp.Ktot;
+  split -= gp.seg[sidx].split_begin;
   const int tap = nt / p.tilesCi, ci_tile = nt % p.tilesCi;
   const int fr = tap / p.S, fs = tap % p.S;
   const int co0 = co_tile * TW, ci0 = ci_tile * TW;
@@ -291,6 +317,52 @@ __global__ void __launch_bounds__(256) bias_grad_kernel(const T* __restrict__ dy
 
 extern "C" int osd_bias_grad(const void* dy, float* db, int m, int c, int stride, int dtype, void* stream);
 
+static int wgrad_launch(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys, const int* ns,
+                        const int* hs, const int* ws, const float* scale, float* dw, float* db, hipStream_t s) {
+  WgradParams p;
+  p.n_seg = n_seg; p.dw = dw; p.scale = scale; p.db = db;
+  p.Cin = d->cin; p.Cout = d->cout;
+  p.R = d->r; p.S = d->s; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
+  p.dy_stride = d->out_stride; p.Ktot = d->r * d->s * d->cin;
+  const int tw = d->dtype == OSD_BF16 ? 128 : 64;
+  p.tilesCo = cdiv(d->cout, tw);
+  p.tilesCi = cdiv(d->cin, tw);
+  const long long tiles = (long long)p.tilesCo * p.tilesCi * d->r * d->s;
+  long long Mtot = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    const int ho = (hs[i] + 2 * d->pad_h - d->r) / d->stride_h + 1, wo = (ws[i] + 2 * d->pad_w - d->s) / d->stride_w + 1;
+    const long long M = (long long)ns[i] * ho * wo;
+    if (M <= 0 || M > 0x7fffffffLL || !xs[i] || !dys[i]) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad segment %d", i);
+    p.seg[i].x = xs[i]; p.seg[i].dy = dys[i]; p.seg[i].H = hs[i]; p.seg[i].W = ws[i]; p.seg[i].Ho = ho; p.seg[i].Wo = wo;
+    p.seg[i].M = (int)M;
+    Mtot += M;
+  }
+  // pixel splits: enough workgroups to fill the chip (~1536), at least 128 pixels each, shared out over the segments
+  long long want = (1536 + tiles - 1) / tiles;
+  const long long max_splits = (Mtot + 127) / 128;
+  if (want > max_splits) want = max_splits;
+  if (want < 1) want = 1;
+  const long long rows = ((Mtot + want - 1) / want + 31) / 32 * 32;
+  int total_splits = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    int sp = (int)((p.seg[i].M + rows - 1) / rows);
+    if (sp < 1) sp = 1;
+    p.seg[i].rows_per_split = cdiv(cdiv(p.seg[i].M, sp), 32) * 32;
+    p.seg[i].split_begin = total_splits;
+    total_splits += cdiv(p.seg[i].M, p.seg[i].rows_per_split);
+  }
+  for (int i = n_seg; i < kMaxSeg; ++i) p.seg[i] = p.seg[0];
+  p.splits = total_splits;
+  const long long nblocks = tiles * total_splits;
+  if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
+  const int lds = 3 * 2 * 32 * 256;
+  if (d->dtype == OSD_F32)
+    hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3((unsigned)nblocks), dim3(256), lds, s, p);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<__bf16>, dim3((unsigned)nblocks), dim3(256), lds, s, p);
+  return osd_check_launch("conv_wgrad");
+}
+
 extern "C" int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const void* dy, const float* scale, float* dw,
                                 float* db, void* stream) {
   if (!d || !x || !dy || !dw) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: null argument");
@@ -317,29 +389,22 @@ extern "C" int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const voi
     return osd_bias_grad(dy, db, (int)M, d->cout, d->out_stride, d->dtype, stream);
   }
   if (d->cin % epc || d->out_stride % epc) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: channel counts must keep 16-byte alignment");
-  WgradParams p;
-  p.x = x; p.dy = dy; p.dw = dw; p.scale = scale; p.db = db;
-  p.H = d->h; p.W = d->w; p.Cin = d->cin; p.Ho = d->ho; p.Wo = d->wo; p.Cout = d->cout; p.HoWo = d->ho * d->wo;
-  p.R = d->r; p.S = d->s; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
-  p.dy_stride = d->out_stride; p.M = (int)M; p.Ktot = d->r * d->s * d->cin;
-  const int tw = d->dtype == OSD_BF16 ? 128 : 64;
-  p.tilesCo = cdiv(d->cout, tw);
-  p.tilesCi = cdiv(d->cin, tw);
-  const long long tiles = (long long)p.tilesCo * p.tilesCi * d->r * d->s;
-  int splits = (int)((1536 + tiles - 1) / tiles);
-  const int max_splits = (int)((M + 127) / 128);
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  p.rows_per_split = cdiv(cdiv((int)M, splits), 32) * 32;
-  p.splits = cdiv((int)M, p.rows_per_split);
-  const long long nblocks = tiles * p.splits;
-  if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
-  const int lds = 3 * 2 * 32 * 256;
-  if (d->dtype == OSD_F32)
-    hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3((unsigned)nblocks), dim3(256), lds, s, p);
-  else
-    hipLaunchKernelGGL(conv_wgrad_kernel<__bf16>, dim3((unsigned)nblocks), dim3(256), lds, s, p);
-  return osd_check_launch("conv_wgrad");
+  const void* xs[1] = {x};
+  const void* dys[1] = {dy};
+  const int hs[1] = {d->h}, ws[1] = {d->w}, ns[1] = {d->n};
+  return wgrad_launch(d, 1, xs, dys, ns, hs, ws, scale, dw, db, s);
+}
+
+// several (x, dy) pairs with the same conv geometry except batch / spatial size, sharing dW (weights shared over FPN levels)
+extern "C" int osd_conv2d_wgrad_grouped(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
+                                        const int32_t* ns, const int32_t* hs, const int32_t* ws, const float* scale,
+                                        float* dw, float* db, void* stream) {
+  if (!d || !xs || !dys || !ns || !hs || !ws || !dw || n_seg < 1 || n_seg > kMaxSeg)
+    return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_grouped: bad arguments");
+  const int epc = d->dtype == OSD_BF16 ? 8 : 4;
+  if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad dtype");
+  if (d->cin % epc || d->out_stride % epc) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_grouped: channel alignment");
+  return wgrad_launch(d, n_seg, xs, dys, ns, hs, ws, scale, dw, db, OSD_STREAM(stream));
 }
 
 extern "C" int osd_bias_grad(const void* dy, float* db, int m, int c, int stride, int dtype, void* stream) {

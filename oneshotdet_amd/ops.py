@@ -375,6 +375,20 @@ def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None, db=None)
     _lib.call("osd_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(scale), _ptr(dw_packed), _ptr(db), _stream())
 
 
+def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, db=None):
+    """One launch over several (x, dy) pairs sharing the weights (FPN levels): dw_packed += sum over pairs."""
+    x0, dy0 = pairs[0]
+    d = _conv_desc(x0.shape, _dt(x0), cout, r, s, stride, pad, dy0.shape[-1])
+    k = len(pairs)
+    xs = (C.c_void_p * k)(*[x.data_ptr() for x, _ in pairs])
+    dys = (C.c_void_p * k)(*[dy.data_ptr() for _, dy in pairs])
+    ns = (C.c_int32 * k)(*[x.shape[0] for x, _ in pairs])
+    hs = (C.c_int32 * k)(*[x.shape[1] for x, _ in pairs])
+    ws = (C.c_int32 * k)(*[x.shape[2] for x, _ in pairs])
+    _lib.call("osd_conv2d_wgrad_grouped", C.byref(d), k, xs, dys, ns, hs, ws, _ptr(scale), _ptr(dw_packed), _ptr(db),
+              _stream())
+
+
 def bias_grad(dy, db, c):
     n, h, w, stride = dy.shape
     _lib.call("osd_bias_grad", _ptr(dy), _ptr(db), n * h * w, c, stride, _dt(dy), _stream())

@@ -273,26 +273,30 @@ class TrainEngine(object):
                           res_mode=RES_SAME if res is not None else RES_NONE, mask=mask)
 
     def head_backward(self, feats, ctxs, pred_grads):
+        """Loops: tower -> layer (last first) -> level, so that the weight gradient of each (shared) conv is ONE grouped
+        launch over the five FPN levels."""
         cv = self.convs
         h = "rpn.head."
-        d_feats = []
-        for lvl, (f, lctx, (dcc, drg)) in enumerate(zip(feats, ctxs, pred_grads)):
-            d_f = None
-            for tower, dpred, pname in (("cls_tower", dcc, h + "cls_ctr"), ("bbox_tower", drg, h + "bbox_pred")):
-                layers, t_last = lctx[tower]
-                pc = cv[pname]
-                self._wgrad(pc, t_last, dpred, 1, 1)
-                d_t = self._dgrad(pc, dpred)
-                for i in range(spec.NUM_CONVS - 1, -1, -1):
-                    t_in, u, ab = layers[i]
-                    (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
-                    du = ops.groupnorm_relu_bwd(u, d_t, ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
-                    c = cv["%s%s.%d" % (h, tower, 3 * i)]
-                    self._wgrad(c, t_in, du, 1, 1)
-                    d_t = self._dgrad(c, du, res=d_f if (i == 0 and d_f is not None) else None)
-                d_f = d_t
-            d_feats.append(d_f)
-        return d_feats
+        nl = len(feats)
+        d_f = [None] * nl
+        for tower, pname, gi in (("cls_tower", h + "cls_ctr", 0), ("bbox_tower", h + "bbox_pred", 1)):
+            pc = cv[pname]
+            dpred = [pred_grads[l][gi] for l in range(nl)]
+            ops.conv2d_wgrad_grouped([(ctxs[l][tower][1], dpred[l]) for l in range(nl)], pc.gw, 3, 3, 1, 1, pc.cout,
+                                     db=pc.gb)
+            d_t = [self._dgrad(pc, dpred[l]) for l in range(nl)]
+            for i in range(spec.NUM_CONVS - 1, -1, -1):
+                (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
+                c = cv["%s%s.%d" % (h, tower, 3 * i)]
+                du = []
+                for l in range(nl):
+                    t_in, u, ab = ctxs[l][tower][0][i]
+                    du.append(ops.groupnorm_relu_bwd(u, d_t[l], ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS))
+                ops.conv2d_wgrad_grouped([(ctxs[l][tower][0][i][0], du[l]) for l in range(nl)], c.gw, 3, 3, 1, 1, c.cout,
+                                         db=c.gb)
+                d_t = [self._dgrad(c, du[l], res=d_f[l] if (i == 0 and d_f[l] is not None) else None) for l in range(nl)]
+            d_f = d_t
+        return d_f
 
     def backbone_backward(self, ctx, dP, need_input_grad=False):
         cv, bb = self.convs, ctx["bb"]
@@ -301,9 +305,11 @@ class TrainEngine(object):
         # P7 = conv(relu(P6)), P6 = conv(P5), both 3x3 stride 2 (fpn.py:95-99)
         c7, c6 = cv[f + "top_blocks.p7"], cv[f + "top_blocks.p6"]
         self._wgrad(c7, ctx["p6r"], dp7, 2, 1)
-        d_p6 = ops.conv2d_dgrad_naive(dp7, c7.pc.w, ctx["p6"].shape, 3, 3, 2, 1, c7.cout, mask=ctx["p6"], addend=dp6)
+        # 3x3 stride-2 data gradient = zero-insert dY to the input grid, then the stride-1 flipped-weight conv
+        t = self._dgrad(c7, ops.scatter2x(dp7, ctx["p6"].shape[1:3]), mask=ctx["p6"])
+        d_p6 = ops.add_mask(t, dp6)
         self._wgrad(c6, ctx["p5"], d_p6, 2, 1)
-        d_p5 = ops.conv2d_dgrad_naive(d_p6, c6.pc.w, ctx["p5"].shape, 3, 3, 2, 1, c6.cout, mask=None, addend=dp5)
+        d_p5 = self._dgrad(c6, ops.scatter2x(d_p6, ctx["p5"].shape[1:3]), res=dp5)
         l4, l3, l2 = cv[f + "fpn_layer4"], cv[f + "fpn_layer3"], cv[f + "fpn_layer2"]
         self._wgrad(l4, ctx["inner4"], d_p5, 1, 1)
         self._wgrad(l3, ctx["inner3"], dp4, 1, 1)
