@@ -176,10 +176,23 @@ class TrainTimer(ConvTimer):
             timer.flops += 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * cout * x.shape[-1] * r * s
             timer.launches += 1
         ops.conv2d_wgrad = timed_wgrad
+        self._orig_g = ops.conv2d_wgrad_grouped
+
+        def timed_grouped(pairs, dw, r, s, stride, pad, cout, scale=None, db=None):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            timer._orig_g(pairs, dw, r, s, stride, pad, cout, scale=scale, db=db)
+            b.record()
+            timer.records.append((a, b))
+            for x, dy in pairs:
+                timer.flops += 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * cout * x.shape[-1] * r * s
+            timer.launches += 1
+        ops.conv2d_wgrad_grouped = timed_grouped
 
     def uninstall(self, ops):
         ConvTimer.uninstall(self, ops)
         ops.conv2d_wgrad = self._orig_w
+        ops.conv2d_wgrad_grouped = self._orig_g
 
 
 def main_train(args, rank, world):
@@ -201,8 +214,16 @@ def main_train(args, rank, world):
         eng.forward_backward(images, queries, gt_boxes, gt_count)
     torch.cuda.synchronize()
 
-    def step():
-        return eng.train_step(images, queries, gt_boxes, gt_count)
+    launch = "eager, 2 streams"
+    step = lambda: eng.train_step(images, queries, gt_boxes, gt_count)     # noqa: E731
+    if args.graph:
+        try:
+            eng.capture(images, queries, gt_boxes, gt_count)
+            step = lambda: eng.replay_step()                                # noqa: E731
+            launch = "hipGraph replay (forward+backward graph, RCCL all-reduce, optimiser graph), 2 streams"
+        except Exception as e:     # capture is an optimisation: report and fall back to eager launches
+            print("graph capture failed, running eagerly: %r" % (e,), file=sys.stderr)
+            torch.cuda.synchronize()
 
     elapsed = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, "cuda")
     roofline = None
@@ -211,6 +232,7 @@ def main_train(args, rank, world):
         timer.install(ops)
         torch.cuda.synchronize()
         nst = max(2, min(args.steps, 5))
+        eng.wstream = None           # one stream: concurrent kernels would stretch each other's durations
         for _ in range(nst):
             torch.cuda._sleep(int(150e6))
             eng.forward_backward(images, queries, gt_boxes, gt_count)
@@ -232,7 +254,7 @@ def main_train(args, rank, world):
                     "(two R-50-FPN backbones, query pooling, correlation, FCOS head, training proposals) + FCOS loss + "
                     "backward (stem/layer1 frozen) + gradient all-reduce + SGD(momentum) + weight repack" % (B, args.dtype))
         cpu = cpu_baseline(args.dtype) if (world == 1 and not args.no_cpu_baseline) else None
-        line = result_line(args, world, B, elapsed, workload, "eager, 1 stream", roofline, cpu)
+        line = result_line(args, world, B, elapsed, workload, launch, roofline, cpu)
         line["config"]["parallelism"] = "dp%d, fp32 gradient all-reduce over RCCL (%d x flat buckets)" % (world, 4)
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -248,7 +270,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-timing", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-graph", action="store_true", help="forward mode: eager launches instead of hipGraph replay")
+    ap.add_argument("--graph", action="store_true",
+                    help="train mode: replay the step from hipGraphs (measured slower than eager 2-stream launches: the "
+                         "step is GPU-bound, so eager is the default)")
     ap.add_argument("--mode", default=os.environ.get("OSD_BENCH_MODE", "train"), choices=["train", "forward"],
                     help="train = forward + loss + backward + gradient all-reduce + SGD (the headline metric); "
                          "forward = BASELINE.json configs[1] (inference forward incl. proposals)")

@@ -338,7 +338,9 @@ static int wgrad_launch(const osd_conv_desc* d, int n_seg, const void* const* xs
     Mtot += M;
   }
   // pixel splits: enough workgroups to fill the chip (~1536), at least 128 pixels each, shared out over the segments
-  long long want = (1536 + tiles - 1) / tiles;
+  static int target = -1;
+  if (target < 0) { const char* e = getenv("OSD_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; }
+  long long want = (target + tiles - 1) / tiles;
   const long long max_splits = (Mtot + 127) / 128;
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;

@@ -37,12 +37,15 @@ class TConv(object):
 
 class TrainEngine(object):
     def __init__(self, state_dict, dtype=torch.bfloat16, device="cuda", lr=0.0005, momentum=0.9, weight_decay=0.0001,
-                 process_group=None):
+                 process_group=None, wgrad_side_stream=True):
         if not torch.cuda.is_available():
             raise ops._lib.OsdError("TrainEngine needs an MI355X: no GPU visible and there is no CPU fallback")
         ops._lib.load()
         self.device, self.dtype = torch.device(device), dtype
         self.pg = process_group
+        # weight gradients feed nothing but the optimiser: they run on a side stream, beside the data-gradient chain
+        self.wstream = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None
+        self._keep = []
         sd = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state_dict.items()}
         self._frozen_sd = sd
         self.convs = {}          # name -> TConv
@@ -264,8 +267,23 @@ class TrainEngine(object):
         return losses, grads
 
     # ------------------------------------------------------------------------------------------------ backward
+    def _on_wstream(self, fn, tensors):
+        if self.wstream is None:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record()
+        self.wstream.wait_event(ev)
+        with torch.cuda.stream(self.wstream):
+            fn()
+        self._keep.append(tensors)        # keep the operands alive until the side stream has been joined
+
     def _wgrad(self, c, x, dy, stride=1, pad=0):
-        ops.conv2d_wgrad(x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale, db=c.gb if c.has_bias else None)
+        self._on_wstream(lambda: ops.conv2d_wgrad(x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale,
+                                                  db=c.gb if c.has_bias else None), (x, dy))
+
+    def _wgrad_grouped(self, c, pairs):
+        self._on_wstream(lambda: ops.conv2d_wgrad_grouped(pairs, c.gw, c.r, c.s, 1, c.r // 2, c.cout, scale=c.bn_scale,
+                                                          db=c.gb if c.has_bias else None), pairs)
 
     def _dgrad(self, c, dy, res=None, mask=None):
         """Data gradient of a stride-1 conv: the forward kernel on dy with flipped/transposed weights."""
@@ -282,8 +300,7 @@ class TrainEngine(object):
         for tower, pname, gi in (("cls_tower", h + "cls_ctr", 0), ("bbox_tower", h + "bbox_pred", 1)):
             pc = cv[pname]
             dpred = [pred_grads[l][gi] for l in range(nl)]
-            ops.conv2d_wgrad_grouped([(ctxs[l][tower][1], dpred[l]) for l in range(nl)], pc.gw, 3, 3, 1, 1, pc.cout,
-                                     db=pc.gb)
+            self._wgrad_grouped(pc, [(ctxs[l][tower][1], dpred[l]) for l in range(nl)])
             d_t = [self._dgrad(pc, dpred[l]) for l in range(nl)]
             for i in range(spec.NUM_CONVS - 1, -1, -1):
                 (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
@@ -292,8 +309,7 @@ class TrainEngine(object):
                 for l in range(nl):
                     t_in, u, ab = ctxs[l][tower][0][i]
                     du.append(ops.groupnorm_relu_bwd(u, d_t[l], ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS))
-                ops.conv2d_wgrad_grouped([(ctxs[l][tower][0][i][0], du[l]) for l in range(nl)], c.gw, 3, 3, 1, 1, c.cout,
-                                         db=c.gb)
+                self._wgrad_grouped(c, [(ctxs[l][tower][0][i][0], du[l]) for l in range(nl)])
                 d_t = [self._dgrad(c, du[l], res=d_f[l] if (i == 0 and d_f[l] is not None) else None) for l in range(nl)]
             d_f = d_t
         return d_f
@@ -355,6 +371,7 @@ class TrainEngine(object):
         """One training forward + backward.  images [B,3,H,W], queries [B*S,3,h,w] fp32 NCHW on the device;
         gt_boxes [B, G, 4] fp32 xyxy, gt_count [B] int32.  Returns losses [4] = (cls, reg, centerness, num_pos)."""
         from . import model
+        self._keep = []
         self.flat_g.zero_()
         batch = images.shape[0]
         shots = queries.shape[0] // batch
@@ -383,7 +400,8 @@ class TrainEngine(object):
             dQ.append(ops.cast_f32(gx, self.dtype))
         self.backbone_backward(tctx, dP)
         self.backbone_backward(qctx, dQ)
-        self.debug = dict(head_out=head_out, dP=dP, dQ=dQ, d_comb=d_comb)
+        if self.wstream is not None:
+            torch.cuda.current_stream().wait_stream(self.wstream)
         return losses
 
     def reduce_gradients(self):
@@ -409,6 +427,35 @@ class TrainEngine(object):
         self.reduce_gradients()
         self.optimizer_step()
         return losses
+
+    def capture(self, images, queries, gt_boxes, gt_count, warmup=2):
+        """Capture the training step into hipGraphs (forward+loss+backward as one graph, SGD + repack as another, with the
+        RCCL all-reduce between them launched normally): ~1500 launches per step become two graph launches.  The learning
+        rate is baked in at capture time; call capture() again after changing it."""
+        self._static = [t.clone() for t in (images, queries, gt_boxes, gt_count)]
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.train_step(*self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fb):
+            self._static_losses = self.forward_backward(*self._static)
+        self._g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_opt):
+            self.optimizer_step()
+        return self
+
+    def replay_step(self, images=None, queries=None, gt_boxes=None, gt_count=None):
+        for dst, src in zip(self._static, (images, queries, gt_boxes, gt_count)):
+            if src is not None:
+                dst.copy_(src, non_blocking=True)
+        self._g_fb.replay()
+        self.reduce_gradients()
+        self._g_opt.replay()
+        return self._static_losses
 
     # ------------------------------------------------------------------------------------------------ state
     def named_grads(self):
