@@ -356,7 +356,7 @@ def main():
         timer.uninstall(ops)
 
     if rank == 0:
-        workload = ("BASELINE.json configs[1] shape, FORWARD ONLY (backward not built yet): bs=%d/GPU, 800x1024 target + "
+        workload = ("BASELINE.json configs[1] (forward-only parity/inference config; --mode train is the headline): bs=%d/GPU, 800x1024 target + "
                     "127x127 query, two R-50-FPN backbones + query pooling + correlation + FCOS head + proposals "
                     "(top-k, NMS 0.8, top-2000), %s MFMA convs" % (B, args.dtype))
         cpu = cpu_baseline(args.dtype) if (world == 1 and not args.no_cpu_baseline) else None
