@@ -406,17 +406,8 @@ class TrainEngine(object):
 
     def reduce_gradients(self):
         """DDP gradient averaging (tools/train_net.py:83-88): one flat fp32 buffer, a few large RCCL all-reduces."""
-        import torch.distributed as dist
-        if self.pg is None and not (dist.is_available() and dist.is_initialized()):
-            return
-        world = dist.get_world_size(self.pg)
-        if world == 1:
-            return
-        n = self.flat_g.numel()
-        chunk = (n + 3) // 4
-        for i in range(0, n, chunk):
-            dist.all_reduce(self.flat_g[i:i + chunk], group=self.pg)
-        self.flat_g.mul_(1.0 / world)
+        from .dist_utils import average_flat_
+        average_flat_(self.flat_g, self.pg, 4)
 
     def optimizer_step(self):
         self.opt.step()

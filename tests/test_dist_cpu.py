@@ -40,3 +40,13 @@ def test_bench_single_process_dry_run():
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert r["n_gpus"] == 1 and r["metric"].startswith("images/sec/GPU")
+
+
+def test_gradient_average_two_ranks():
+    """The training step's one collective (TrainEngine.reduce_gradients -> dist_utils.average_flat_) on 2 gloo ranks:
+    bucketed contiguous all-reduce of a flat buffer, ragged last bucket, empty buffer."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "RANK 0 OK=True" in out.stdout and "RANK 1 OK=True" in out.stdout
