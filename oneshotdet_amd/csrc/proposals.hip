@@ -128,28 +128,36 @@ __device__ __forceinline__ float iou_plus1(const float4 a, const float4 b) {
 
 __global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
                                                       int max_count, int col_blocks, float thresh, int gt_rule,
-                                                      unsigned long long* __restrict__ mask) {
-  const int img = blockIdx.z, row_b = blockIdx.y, col_b = blockIdx.x;
-  if (col_b < row_b) return;                     // lower triangle is never read by the scan
-  const int n = counts[img];
-  if (row_b * 64 >= n || col_b * 64 >= n) return;
+                                                      unsigned long long* __restrict__ mask, int limit,
+                                                      const int* __restrict__ need_full) {
+  const int img = blockIdx.y;
+  if (need_full && !need_full[img]) return;      // phase 2 runs only for images phase 1 could not finish
+  const int n = min(counts[img], limit);
+  const int nb = (n + 63) / 64;
   __shared__ float4 cb[64];
   const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)img * max_count;
   const int lane = threadIdx.x;
-  const int col_size = min(64, n - col_b * 64);
-  if (lane < col_size) cb[lane] = bx[col_b * 64 + lane];
-  __syncthreads();
-  const int i = row_b * 64 + lane;
-  if (i < n) {
-    const float4 me = bx[i];
-    unsigned long long bits = 0;
-    const int start = (row_b == col_b) ? lane + 1 : 0;
-    for (int j = start; j < col_size; ++j) {
-      const float v = iou_plus1(me, cb[j]);
-      const bool hit = gt_rule ? (v > thresh) : (v >= thresh);
-      if (hit) bits |= 1ULL << j;
+  // grid-stride over the tiles of the upper triangle (a fixed, small grid: an idle phase costs a few hundred
+  // workgroups, not (n/64)^2 of them)
+  for (int tile = blockIdx.x; tile < nb * nb; tile += gridDim.x) {
+    const int row_b = tile / nb, col_b = tile - row_b * nb;
+    if (col_b < row_b) continue;                 // lower triangle is never read by the scan
+    const int col_size = min(64, n - col_b * 64);
+    __syncthreads();
+    if (lane < col_size) cb[lane] = bx[col_b * 64 + lane];
+    __syncthreads();
+    const int i = row_b * 64 + lane;
+    if (i < n) {
+      const float4 me = bx[i];
+      unsigned long long bits = 0;
+      const int start = (row_b == col_b) ? lane + 1 : 0;
+      for (int j = start; j < col_size; ++j) {
+        const float v = iou_plus1(me, cb[j]);
+        const bool hit = gt_rule ? (v > thresh) : (v >= thresh);
+        if (hit) bits |= 1ULL << j;
+      }
+      mask[((size_t)img * max_count + i) * col_blocks + col_b] = bits;
     }
-    mask[((size_t)img * max_count + i) * col_blocks + col_b] = bits;
   }
 }
 
@@ -158,13 +166,16 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
                                                        const int* __restrict__ counts, int max_count, int col_blocks,
                                                        int max_keep, const unsigned long long* __restrict__ mask,
                                                        float* __restrict__ out_boxes, float* __restrict__ out_scores,
-                                                       int* __restrict__ out_pos, int* __restrict__ out_count) {
+                                                       int* __restrict__ out_pos, int* __restrict__ out_count, int limit,
+                                                       int* __restrict__ need_full, int phase) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* remv = reinterpret_cast<unsigned long long*>(smem);   // [col_blocks]
   __shared__ unsigned long long s_keep;
   __shared__ int s_kept[2];   // double-buffered so the next block's writer cannot race this block's readers
   const int img = blockIdx.x;
-  const int n = counts[img];
+  if (phase == 2 && !need_full[img]) return;
+  const int n_all = counts[img];
+  const int n = min(n_all, limit);
   const int nblk = (n + 63) / 64;
   const unsigned long long* mk = mask + (size_t)img * max_count * col_blocks;
   for (int c = threadIdx.x; c < col_blocks; c += blockDim.x) remv[c] = 0ULL;
@@ -224,7 +235,12 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out_count[img] = s_kept[blk & 1];
+  if (threadIdx.x == 0) {
+    out_count[img] = s_kept[blk & 1];
+    // phase 1 looked at the first `limit` candidates only: if that did not yield max_keep survivors and there are
+    // more candidates, the full problem is redone by the (otherwise idle) phase-2 launches
+    if (phase == 1) need_full[img] = (s_kept[blk & 1] < max_keep && n_all > limit) ? 1 : 0;
+  }
 }
 
 }  // namespace
@@ -289,7 +305,7 @@ extern "C" int osd_rank_sort_gather(const float* keys, const float* boxes, int n
 }
 
 extern "C" int64_t osd_nms_workspace_bytes(int n, int max_count) {
-  return (int64_t)n * max_count * cdiv(max_count, 64) * 8;
+  return (int64_t)n * max_count * cdiv(max_count, 64) * 8 + ((int64_t)cdiv(n, 2) + 8) * 8;   // mask + per-image flags
 }
 
 extern "C" int osd_nms_sorted(const float* boxes_sorted, const float* scores_sorted, const int32_t* counts, int n,
@@ -304,12 +320,27 @@ extern "C" int osd_nms_sorted(const float* boxes_sorted, const float* scores_sor
   }
   const int col_blocks = cdiv(max_count, 64);
   if ((size_t)col_blocks * 8 > 60000) return osd_fail(OSD_ERR_UNSUPPORTED, "nms_sorted: max_count %d too large", max_count);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks, n), dim3(64), 0, OSD_STREAM(stream), boxes_sorted, counts,
-                     max_count, col_blocks, thresh, cuda_semantics, reinterpret_cast<unsigned long long*>(mask_ws));
+  // Phase 1: only the first `limit` candidates (in score order) — greedy NMS needs no more than that whenever they yield
+  // max_keep survivors, the common case: IoU tiles drop from (n/64)^2/2 to (limit/64)^2/2.  Phase 2 (full problem)
+  // is launched unconditionally but exits at once unless phase 1 flagged the image: no host round trip.
+  int limit = cdiv(max_keep * 5 / 4 + 64, 64) * 64;
+  if (limit > max_count) limit = max_count;
+  int* need_full = reinterpret_cast<int*>(mask_ws);                 // n ints at the head of the workspace
+  unsigned long long* mk = reinterpret_cast<unsigned long long*>(mask_ws) + cdiv(n, 2) + 8;
+  const int lim_blocks = cdiv(limit, 64);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(min(lim_blocks * lim_blocks, 4096), n), dim3(64), 0, OSD_STREAM(stream),
+                     boxes_sorted, counts, max_count, col_blocks, thresh, cuda_semantics, mk, limit, (const int*)nullptr);
   int rc = osd_check_launch("nms_mask");
   if (rc) return rc;
   hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8, OSD_STREAM(stream), boxes_sorted, scores_sorted,
-                     counts, max_count, col_blocks, max_keep, reinterpret_cast<const unsigned long long*>(mask_ws), out_boxes,
-                     out_scores, out_pos, out_count);
-  return osd_check_launch("nms_scan");
+                     counts, max_count, col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, limit, need_full, 1);
+  rc = osd_check_launch("nms_scan");
+  if (rc || limit >= max_count) return rc;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(min(col_blocks * col_blocks, 4096), n), dim3(64), 0, OSD_STREAM(stream),
+                     boxes_sorted, counts, max_count, col_blocks, thresh, cuda_semantics, mk, max_count, (const int*)need_full);
+  rc = osd_check_launch("nms_mask(full)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8, OSD_STREAM(stream), boxes_sorted, scores_sorted,
+                     counts, max_count, col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, max_count, need_full, 2);
+  return osd_check_launch("nms_scan(full)");
 }

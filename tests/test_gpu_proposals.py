@@ -50,6 +50,31 @@ def test_nms_random_vs_oracle(n):
     assert again.numel() == keep.numel()
 
 
+def test_nms_second_phase_when_first_candidates_do_not_suffice():
+    """Heavy overlap among the best-scoring boxes: the first `limit` candidates yield fewer than max_keep survivors, so
+    the device-side fallback (full mask + full scan) must produce the answer; an image of the same batch that needs no
+    fallback must be unaffected."""
+    from oneshotdet_amd import ops
+    rng = np.random.RandomState(0)
+    n, max_keep = 3000, 100
+    centers = rng.uniform(50, 150, (8, 2)).astype(np.float32)
+    boxes = np.zeros((2, n, 4), np.float32)
+    for img in range(2):
+        xy = rng.uniform(0, 900, (n, 2)).astype(np.float32)
+        if img == 0:      # the 2000 best boxes are jittered copies of 8 clusters
+            xy[:2000] = centers[rng.randint(0, 8, 2000)] + rng.uniform(-1, 1, (2000, 2)).astype(np.float32)
+        boxes[img] = np.concatenate([xy, xy + 60], 1)
+    scores = np.tile(np.linspace(1.0, 0.01, n, dtype=np.float32), (2, 1))      # already sorted, distinct
+    bs, ss, idx, cnt = ops.rank_sort_gather(torch.from_numpy(scores).cuda(), torch.from_numpy(boxes).cuda(), n)
+    ob, os_, op, oc = ops.nms_sorted(bs, ss, cnt, 0.5, max_keep, cuda_semantics=True)
+    for img in range(2):
+        ref = orc.nms(boxes[img], scores[img], 0.5, cuda_semantics=True)[:max_keep]
+        k = int(oc[img])
+        assert k == len(ref) == max_keep
+        np.testing.assert_array_equal(op[img, :k].cpu().numpy(), ref)
+        np.testing.assert_array_equal(ob[img, :k].cpu().numpy(), boxes[img][ref])
+
+
 def _split_head(head, hw):
     logits, reg, ctr, off = [], [], [], 0
     for (h, w) in hw:
