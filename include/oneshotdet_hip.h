@@ -90,6 +90,13 @@ int osd_pack_conv_weight(const float* w_oihw, const float* scale, void* dst, int
  * master weights in, so the optimiser, the weight gradient and the packers share one layout */
 int osd_pack_conv_weight_ex(const float* w, const float* scale, void* dst, int cout, int cin, int r, int s, int w_rows,
                             int cin_pad, int src_orsi, int dtype, void* stream);
+/* Repack MANY convs in one launch (training: every step after the optimiser).  table: device array of
+ * struct { int64 src_off, dst_off, scale_off; int32 cout, cin, r, s, rows, kpad, first_block, n_blocks; } (56 bytes),
+ * src = flat fp32 masters in [cout][r][s][cin] order, scales = flat per-Cout factors (scale_off -1: none), dst = flat
+ * packed buffer of `dtype`; block_entry[b] = table index served by workgroup b; dgrad != 0 writes the flipped /
+ * transposed data-gradient form ([rows >= cin][r][s][kpad >= cout]). */
+int osd_pack_multi(const void* table, const int32_t* block_entry, int n_blocks, const float* src, const float* scales,
+                   void* dst, int dgrad, int dtype, void* stream);
 int osd_pack_stem_weight(const float* w_oihw, const float* scale, void* dst, int cout, int w_rows, int dtype,
                          void* stream);
 /* NCHW fp32 image batch -> zero-padded NHWC4 [n][hp][wp][4] of `dtype` with the image at (pad_t, pad_l). Replaces the

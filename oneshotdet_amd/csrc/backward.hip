@@ -60,6 +60,48 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, const floa
   }
 }
 
+// ---- all weights of the model repacked by ONE launch per form (forward / data-gradient): table driven ----
+struct PackEntry {
+  long long src_off;     // floats into the flat fp32 master buffer ([cout][R][S][cin] order)
+  long long dst_off;     // elements into the flat packed buffer
+  long long scale_off;   // floats into the flat scale buffer, -1: none
+  int cout, cin, R, S;
+  int rows, kpad;        // packed geometry: forward [rows >= cout][R][S][kpad >= cin]; dgrad [rows >= cin][R][S][kpad >= cout]
+  int first_block, n_blocks;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) pack_multi_kernel(const PackEntry* __restrict__ table, const int* __restrict__ block_entry,
+                                                         const float* __restrict__ src, const float* __restrict__ scales,
+                                                         T* __restrict__ dst, int dgrad) {
+  const PackEntry e = table[block_entry[blockIdx.x]];
+  const float* w = src + e.src_off;
+  const float* sc = e.scale_off >= 0 ? scales + e.scale_off : nullptr;
+  T* out = dst + e.dst_off;
+  const long long total = (long long)e.rows * e.R * e.S * e.kpad;
+  const long long stride = (long long)e.n_blocks * blockDim.x;
+  for (long long i = (long long)(blockIdx.x - e.first_block) * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int k = (int)(i % e.kpad);
+    long long t = i / e.kpad;
+    const int s = (int)(t % e.S); t /= e.S;
+    const int r = (int)(t % e.R);
+    const int row = (int)(t / e.R);
+    float v = 0.f;
+    if (!dgrad) {            // forward: row = co, k = ci
+      if (row < e.cout && k < e.cin) {
+        v = w[(((size_t)row * e.R + r) * e.S + s) * e.cin + k];
+        if (sc) v *= sc[row];
+      }
+    } else {                 // data gradient: row = ci, k = co, taps flipped
+      if (row < e.cin && k < e.cout) {
+        v = w[(((size_t)k * e.R + (e.R - 1 - r)) * e.S + (e.S - 1 - s)) * e.cin + row];
+        if (sc) v *= sc[k];
+      }
+    }
+    out[i] = from_f32<T>(v);
+  }
+}
+
 // packed fp32 weight gradient [cout][R][S][cin] -> OIHW, times the folded FrozenBN scale (d/dw of conv(x, w*scale))
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, const float* __restrict__ scale, float* __restrict__ g,
                                     int cout, int cin, int R, int S, int accumulate) {
@@ -432,6 +474,16 @@ extern "C" int osd_pack_conv_weight_dgrad(const float* w, const float* scale, vo
       hipLaunchKernelGGL(pack_dgrad_weight_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), w, scale, (float*)dst, cout, cin, r, s, rows, cout_pad, src_orsi),
       hipLaunchKernelGGL(pack_dgrad_weight_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), w, scale, (__bf16*)dst, cout, cin, r, s, rows, cout_pad, src_orsi));
   return osd_check_launch("pack_dgrad_weight");
+}
+
+extern "C" int osd_pack_multi(const void* table, const int32_t* block_entry, int n_blocks, const float* src,
+                              const float* scales, void* dst, int dgrad, int dtype, void* stream) {
+  if (!table || !block_entry || !src || !dst) return osd_fail(OSD_ERR_INVALID_ARG, "pack_multi: null argument");
+  if (n_blocks <= 0) return OSD_OK;
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(n_blocks), dim3(256), 0, OSD_STREAM(stream), (const PackEntry*)table, block_entry, src, scales, (float*)dst, dgrad),
+      hipLaunchKernelGGL(pack_multi_kernel<__bf16>, dim3(n_blocks), dim3(256), 0, OSD_STREAM(stream), (const PackEntry*)table, block_entry, src, scales, (__bf16*)dst, dgrad));
+  return osd_check_launch("pack_multi");
 }
 
 extern "C" int osd_unpack_wgrad(const float* dw_packed, const float* scale, float* grad_oihw, int cout, int cin, int r, int s,

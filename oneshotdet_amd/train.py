@@ -144,32 +144,76 @@ class TrainEngine(object):
                 wv.copy_(sd[name])
                 self.extra[name] = (wv, gv)
 
-    def repack(self):
-        """fp32 masters -> kernel-layout weights of the compute dtype (forward + data-gradient forms)."""
-        for c in self.convs.values():
-            if not c.trainable:
-                if c.pc is None:
-                    c.pc = ops.pack_conv(self._frozen_sd[c.name + ".weight"], bn=None if c.bn_scale is None else tuple(
-                        self._frozen_sd[c.name.replace("conv", "bn").replace("downsample.0", "downsample.1") + k]
-                        for k in (".weight", ".bias", ".running_mean", ".running_var")), dtype=self.dtype,
-                        stem=c.name.endswith("stem.conv1"))
-                continue
-            cout_store = ops._round_up(c.cout, 4)
-            w_rows = ops._round_up(c.cout, 16)
-            wp = ops.pack_conv_master(c.w, c.bn_scale, self.dtype, w_rows)
-            if c.pc is None:
-                bias = torch.zeros(ops._round_up(cout_store, 16), device=self.device, dtype=torch.float32)
-                c.pc = PackedConv(wp, bias, c.cout, cout_store, w_rows, wp.shape[-1], c.r, c.s, cin_real=c.cin)
-            else:
-                c.pc.w = wp
-            c.pc.bias[:c.cout] = c.b if c.has_bias else c.bn_shift
-            if c.need_dgrad:
-                wd = ops.pack_conv_master_dgrad(c.w, c.bn_scale, self.dtype)
-                if c.pd is None:
-                    zb = torch.zeros(ops._round_up(c.cin, 16), device=self.device, dtype=torch.float32)
-                    c.pd = PackedConv(wd, zb, c.cin, c.cin, wd.shape[0], wd.shape[-1], c.r, c.s, cin_real=c.cout)
+    def _build_pack_tables(self):
+        """Allocate ONE flat packed buffer per form (forward, data gradient) and the tables that let a single launch
+        repack every trainable conv from the flat fp32 masters (osd_pack_multi)."""
+        import numpy as np
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        mult = 64 if self.dtype == torch.bfloat16 else 16
+        tr = [c for c in self.convs.values() if c.trainable]
+        scale_off, scales = {}, []
+        off = 0
+        for c in tr:
+            if c.bn_scale is not None:
+                scale_off[c.name] = off
+                scales.append(c.bn_scale)
+                off += c.cout
+        self._flat_scale = torch.cat(scales) if scales else torch.zeros(1, device=self.device)
+        base = self.flat_w.data_ptr()
+        self._pack = {}
+        for form in (0, 1):
+            entries, dst_off, blocks = [], 0, []
+            for ci, c in enumerate(tr):
+                if form == 0:
+                    rows, kpad = ops._round_up(c.cout, 16), ops._round_up(c.cin, mult)
                 else:
-                    c.pd.w = wd
+                    rows, kpad = ops._round_up(c.cin, 16), ops._round_up(c.cout, mult)
+                numel = rows * c.r * c.s * kpad
+                nb = max(1, min(64, (numel + 256 * 16 - 1) // (256 * 16)))
+                entries.append(((c.w.data_ptr() - base) // 4, dst_off, scale_off.get(c.name, -1), c.cout, c.cin, c.r, c.s, rows,
+                                kpad, len(blocks), nb, numel))
+                blocks += [ci] * nb
+                dst_off += (numel + 63) // 64 * 64
+            flat = torch.zeros(dst_off, device=self.device, dtype=self.dtype)
+            # 3 int64 offsets + 8 int32 (cout, cin, r, s, rows, kpad, first_block, n_blocks) = 7 x 8 bytes per entry
+            tab = np.zeros((len(entries), 7), dtype=np.int64)
+            for i, e in enumerate(entries):
+                tab[i, 0:3] = e[0:3]
+                tab[i, 3:7] = np.frombuffer(np.array(e[3:11], dtype=np.int32).tobytes(), dtype=np.int64)
+            self._pack[form] = dict(flat=flat, table=torch.from_numpy(tab).to(self.device),
+                                    blocks=torch.tensor(blocks, dtype=torch.int32, device=self.device), n=len(blocks))
+            for e, c in zip(entries, tr):
+                view = flat[e[1]:e[1] + e[11]].view(e[7], c.r, c.s, e[8])
+                if form == 0:
+                    cout_store = ops._round_up(c.cout, 4)
+                    if c.has_bias and c.cout % 16 == 0:
+                        bias = c.b                                   # the fp32 master bias IS the epilogue's bias vector
+                    else:
+                        bias = torch.zeros(ops._round_up(cout_store, 16), device=self.device, dtype=torch.float32)
+                        if c.bn_shift is not None:
+                            bias[:c.cout] = c.bn_shift
+                    c.pc = PackedConv(view, bias, c.cout, cout_store, e[7], e[8], c.r, c.s, cin_real=c.cin)
+                else:
+                    zb = torch.zeros(ops._round_up(c.cin, 16), device=self.device, dtype=torch.float32)
+                    c.pd = PackedConv(view, zb, c.cin, c.cin, e[7], e[8], c.r, c.s, cin_real=c.cout)
+
+    def repack(self):
+        """fp32 masters -> kernel-layout weights of the compute dtype: two launches (forward and data-gradient forms)."""
+        for c in self.convs.values():
+            if not c.trainable and c.pc is None:
+                c.pc = ops.pack_conv(self._frozen_sd[c.name + ".weight"], bn=None if c.bn_scale is None else tuple(
+                    self._frozen_sd[c.name.replace("conv", "bn").replace("downsample.0", "downsample.1") + k]
+                    for k in (".weight", ".bias", ".running_mean", ".running_var")), dtype=self.dtype,
+                    stem=c.name.endswith("stem.conv1"))
+        if not hasattr(self, "_pack"):
+            self._build_pack_tables()
+        for form in (0, 1):
+            pk = self._pack[form]
+            ops._lib.call("osd_pack_multi", ops._ptr(pk["table"]), ops._ptr(pk["blocks"]), pk["n"], ops._ptr(self.flat_w),
+                          ops._ptr(self._flat_scale), ops._ptr(pk["flat"]), form, ops._dt(pk["flat"]), ops._stream())
+        for c in self.convs.values():       # the two prediction convs keep a padded copy of their 2 / 4 biases
+            if c.trainable and c.has_bias and c.cout % 16 != 0:
+                c.pc.bias[:c.cout] = c.b
 
     def gn(self, name):
         return self.extra[name + ".weight"], self.extra[name + ".bias"]
