@@ -65,7 +65,7 @@ typedef struct osd_conv_desc {
   int32_t act;            /* OSD_ACT_* */
   float act_scale;
   int32_t relu_in;        /* 1: apply ReLU to x while staging (P7 = conv(relu(P6)), fpn.py:98) */
-  int32_t algo;           /* 0 = library heuristic; otherwise 1 + impl*16 + variant*4 + tile (see osd_conv_algo_count /
+  int32_t algo;           /* 0 = library heuristic; otherwise 1 + impl*32 + variant*8 + tile (see osd_conv_algo_count /
                              DESIGN.md 4.1): lets the host autotune per layer shape by measurement */
   int32_t gn_in;          /* 1: x' = relu(x * gn_a[n,c] + gn_b[n,c]) while staging (GroupNorm+ReLU of the previous tower conv,
                              fcos.py:37-38 fused into the consumer); gn_a/gn_b are [n][cin] fp32 from osd_groupnorm_finalize */

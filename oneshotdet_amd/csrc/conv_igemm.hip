@@ -310,7 +310,7 @@ int choose_tile(int M, int cout) {
 
 }  // namespace
 
-extern "C" int osd_conv_algo_count(void) { return 32; }
+extern "C" int osd_conv_algo_count(void) { return 64; }
 
 extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void* w, const float* bias,
                               const void* res, const void* mask, const float* act_scale_dev, const void* reserved,
@@ -353,11 +353,12 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
   int impl = impl_env, variant = 0;
   if (d->algo > 0) {
     const int a = d->algo - 1;
-    if (a >= 32) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad algo %d", d->algo);
-    impl = a >> 4;                 // 0 = LDS-DMA kernel, 1 = register-staged kernel
-    variant = (a >> 2) & 3;
-    tile = a & 3;
-    if (variant == 3 || (impl == 1 && variant != 0)) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: algo %d not built", d->algo);
+    if (a >= 64) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad algo %d", d->algo);
+    impl = a >> 5;                 // 0 = LDS-DMA kernel, 1 = register-staged kernel
+    variant = (a >> 3) & 3;
+    tile = a & 7;
+    if (variant == 3 || tile > 4 || (impl == 1 && (variant != 0 || tile > 3)))
+      return osd_fail(OSD_ERR_UNSUPPORTED, "conv: algo %d not built", d->algo);
     if (p.Cout > 16 && tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: skinny tile on a wide conv");
   }
   if (impl == 0) return osd_conv_dma_dispatch(d->dtype, tile, variant, p, s);

@@ -12,6 +12,7 @@
 //     coalesced stores (and 16-byte residual loads): one output pixel's BN channels are one contiguous run.
 #include "osd_common.h"
 #include "conv_params.h"
+#include <type_traits>
 
 namespace {
 
@@ -51,20 +52,21 @@ __device__ __forceinline__ uint4 relu_frag(uint4 v, __bf16) {
 }
 
 template <typename T, int BM, int BN, int KB, int WM, int WN, int NST, bool RELU_IN>
-__global__ void __launch_bounds__(256) conv_dma_kernel(ConvKParams p) {
+__global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
+  constexpr int NWV = WM * WN;            // waves per workgroup: 4 (256 threads) or 8 (512 threads, the 256x256 tile)
   constexpr int CH = KB / 16;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BKE = KB / (int)sizeof(T);
   constexpr int RPI = 1024 / KB;          // tile rows covered by one wave-instruction
   constexpr int IA = BM / RPI, IB = BN / RPI;
-  static_assert(IA % 4 == 0, "pixel tile must give every wave the same number of DMA instructions");
-  constexpr int PA = IA / 4;
-  constexpr int PB = IB >= 4 ? IB / 4 : 1;
-  static_assert(IB >= 4 ? (IB % 4 == 0) : (4 % IB == 0), "weight tile / wave split");
+  static_assert(IA % NWV == 0, "pixel tile must give every wave the same number of DMA instructions");
+  constexpr int PA = IA / NWV;
+  constexpr int PB = IB >= NWV ? IB / NWV : 1;
+  static_assert(IB >= NWV ? (IB % NWV == 0) : (NWV % IB == 0), "weight tile / wave split");
   constexpr int LPS = PA + PB;            // DMA instructions per wave per stage
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   constexpr int STAGE = (BM + BN) * KB;
-  static_assert(WM * WN == 4, "4 waves");
+  static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(size_t)smem;   // LDS byte offset of the dynamic segment (low 32 bits of the flat address)
@@ -113,7 +115,7 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(ConvKParams p) {
   int b_instr[PB];
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
-    const int jb = IB >= 4 ? wave * PB + i : wave % IB;   // tiles narrower than 4 instructions: waves duplicate a load
+    const int jb = IB >= NWV ? wave * PB + i : wave % IB;   // tiles narrower than NWV instructions: waves duplicate a load
     const int row = jb * RPI + lrow;
     const bool ok = n0 + row < p.w_rows;
     b_instr[i] = jb;
@@ -122,26 +124,32 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(ConvKParams p) {
   }
 
   int kr = 0, ks = 0, kc = 0;
-  auto issue_stage = [&](int buf) {
+  // one DMA instruction of the stage being fetched: j < PA -> pixel operand, else weight operand
+  auto issue_one = [&](int buf, int j) {
     const unsigned xs = lds0 + buf * STAGE;
     const unsigned ws = xs + BM * KB;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int hi = a_hi0[i] + kr, wi = a_wi0[i] + ks;
+    if (j < PA) {
+      const int hi = a_hi0[j] + kr, wi = a_wi0[j] + ks;
       const bool ok = ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
-      const T* src = ok ? a_base[i] + (hi * p.sH + wi * p.sW + kc) : zero;
-      dma16(src, xs + (wave * PA + i) * 1024);
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
+      const T* src = ok ? a_base[j] + (hi * p.sH + wi * p.sW + kc) : zero;
+      dma16(src, xs + (wave * PA + j) * 1024);
+    } else {
+      const int i = j - PA;
       dma16(b_ptr[i], ws + b_instr[i] * 1024);
       b_ptr[i] += b_step[i];
     }
+  };
+  auto advance_k = [&]() {
     kc += BKE;
     if (kc >= p.Cin) {
       kc = 0;
       if (++ks >= p.S) { ks = 0; ++kr; }
     }
+  };
+  auto issue_stage = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) issue_one(buf, j);
+    advance_k();
   };
 
   f32x4 acc[TN][TM];
@@ -152,9 +160,19 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(ConvKParams p) {
 
   const int frow = lane & 15, fkq = lane >> 4;
 
-  auto compute_stage = [&](int buf) {
+  // MFMAs of stage `buf`; when `fetch` is set the LPS DMA instructions of the next stage are spread between the MFMA
+  // row groups instead of being issued as one burst after the barrier (all waves leave the barrier together, so a
+  // burst would leave the matrix pipe idle on every SIMD at the same time)
+  constexpr int SLOTS = (KB / 64) * TN;
+  // (measured: spreading helps the 8-wave 256x256 tile, 877 -> 939 TFLOP/s; the 4-wave tiles run two workgroups per CU
+  // that cover each other's bursts and are faster with the burst, 760 vs 635 TFLOP/s)
+  constexpr bool SPREAD = NWV == 8;
+  auto compute_stage = [&](int buf, int nbuf, auto fetch_tag) {
+    constexpr bool fetch = decltype(fetch_tag)::value && SPREAD;
+    if constexpr (decltype(fetch_tag)::value && !SPREAD) issue_stage(nbuf);
     const char* xs = smem + buf * STAGE;
     const char* ws = xs + BM * KB;
+    int issued = 0;
 #pragma unroll
     for (int kb = 0; kb < KB / 64; ++kb) {
       uint4 wf[TN], xf[TM];
@@ -182,8 +200,18 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(ConvKParams p) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[i][j], 0, 0, 0);
           }
         }
+        // DMA instructions due by the end of this slot
+        const int slot = kb * TN + i;
+        const int due = ((slot + 1) * LPS) / SLOTS;
+        if constexpr (fetch) {
+#pragma unroll
+          for (int j = 0; j < LPS; ++j)
+            if (j >= issued && j < due) issue_one(nbuf, j);
+        }
+        issued = due;
       }
     }
+    if constexpr (fetch) advance_k();
   };
 
   // ---- main loop: NST-1 stages in flight, one barrier per stage ----
@@ -192,14 +220,19 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(ConvKParams p) {
   for (int s = 0; s < NST - 1; ++s)
     if (s < KT) issue_stage(s);
   int cur = 0, nxt = NST - 1;
-  for (int kt = 0; kt < KT; ++kt) {
-    if (kt + NST - 2 < KT) wait_vmcnt<LPS * (NST - 2)>();   // stage kt has landed; later stages stay in flight
-    else wait_vmcnt<0>();
+  int kt = 0;
+  for (; kt + NST - 1 < KT; ++kt) {                        // steady state: fetch stage kt+NST-1 while computing stage kt
+    wait_vmcnt<LPS * (NST - 2)>();                         // stage kt has landed; later stages stay in flight
     __builtin_amdgcn_s_barrier();                          // every wave's part of stage kt is visible; buffer `nxt` is free
-    if (kt + NST - 1 < KT) issue_stage(nxt);
-    compute_stage(cur);
+    compute_stage(cur, nxt, std::true_type());
     cur = cur + 1 == NST ? 0 : cur + 1;
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
+  }
+  for (; kt < KT; ++kt) {                                  // drain: nothing left to fetch
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    compute_stage(cur, nxt, std::false_type());
+    cur = cur + 1 == NST ? 0 : cur + 1;
   }
 
   // ---- epilogue: each wave stages its accumulator sub-tile through a private LDS region (fp32, two passes of TM/2
@@ -210,7 +243,7 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(ConvKParams p) {
   const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
   constexpr int WC = TN * 16;                    // channels of a wave tile
   constexpr int CSW = WC * 4 + 16;               // staging row stride (bytes); +16 keeps ds_write_b128 conflict free
-  constexpr int NPASS = TM >= 2 ? 2 : 1;
+  constexpr int NPASS = TM >= 8 ? TM / 2 : (TM >= 2 ? 2 : 1);
   constexpr int TMP = TM / NPASS;                // 16-pixel tiles per pass
   constexpr int ROWS = TMP * 16;
   constexpr int CPR = WC / EPC;                  // 16-byte output chunks per row
@@ -344,7 +377,8 @@ int launch_dma(const ConvKParams& pin, hipStream_t stream) {
   p.KT = p.Ktot / BKE;
   constexpr int ring = NST * (BM + BN) * KB;
   constexpr int TMx = BM / WM / 16, TNx = BN / WN / 16;
-  constexpr int stagec = 4 * ((TMx >= 2 ? TMx / 2 : 1) * 16) * (TNx * 16 * 4 + 16);
+  constexpr int npass = TMx >= 8 ? TMx / 2 : (TMx >= 2 ? 2 : 1);
+  constexpr int stagec = WM * WN * ((TMx / npass) * 16) * (TNx * 16 * 4 + 16);
   constexpr int lds = ring > stagec ? ring : stagec;
   auto kern = conv_dma_kernel<T, BM, BN, KB, WM, WN, NST, RELU_IN>;
   static bool attr_done = false;
@@ -354,7 +388,7 @@ int launch_dma(const ConvKParams& pin, hipStream_t stream) {
   }
   const long long nblocks = (long long)p.tilesM * p.tilesN;
   if (nblocks <= 0 || nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad grid");
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * WM * WN), lds, stream, p);
   return osd_check_launch("conv_igemm_dma");
 }
 
@@ -366,6 +400,9 @@ int dispatch_tile_dma(int tile, const ConvKParams& p, hipStream_t s) {
     case 1: return launch_dma<T, 128, 64, KB, 4, 1, NST>(p, s);
     case 2: return launch_dma<T, 64, 64, KB, 2, 2, NST>(p, s);
     case 3: return launch_dma<T, 256, 16, KB, 4, 1, NST>(p, s);
+    case 4:   // 256 x 256, 8 waves: half the operand bytes per MFMA of the 128 x 128 tile (the L1/TA path is the bound there)
+      if constexpr (NST == 2 || (sizeof(T) == 4 && NST <= 3)) return launch_dma<T, 256, 256, KB, 2, 4, NST>(p, s);
+      else return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the 256x256 tile exists for the shallow ring only");
   }
   return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad tile id %d", tile);
 }

@@ -92,8 +92,9 @@ def pack_image(images, dtype, hp, wp, pad_t=3, pad_l=3):
 
 
 # ---- per-shape algorithm selection by measurement ("measure, don't guess") ----
-# osd_conv_desc.algo = 1 + impl*16 + variant*4 + tile; impl 0 = LDS-DMA ring kernel (variants: deep / shallow ring /
-# short stages), impl 1 = register-staged kernel; tile 0..3 = 128x128, 128x64, 64x64, 256x16 (pixels x channels).
+# osd_conv_desc.algo = 1 + impl*32 + variant*8 + tile; impl 0 = LDS-DMA ring kernel (variants: deep / shallow ring /
+# short stages), impl 1 = register-staged kernel; tile 0..4 = 128x128, 128x64, 64x64, 256x16, 256x256/8 waves
+# (pixels x channels).
 ALGO_CACHE = {}
 _TUNING = [False]
 
@@ -102,9 +103,11 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
     tiles = [3] if cout_store <= 16 else [0, 1, 2]
     if cout_store <= 16:
         tiles = [3, 2]
-    cands = [1 + 0 * 16 + v * 4 + t for v in (0, 1, 2) for t in tiles]
+    cands = [1 + 0 * 32 + v * 8 + t for v in (0, 1, 2) for t in tiles]
+    if cout_store >= 256 and not relu_in:
+        cands.append(1 + 0 * 32 + 1 * 8 + 4)          # 256x256 tile, shallow ring
     if not relu_in and not has_mask:
-        cands += [1 + 1 * 16 + t for t in tiles]
+        cands += [1 + 1 * 32 + t for t in tiles]
     return cands
 
 

@@ -192,3 +192,26 @@ def test_sigmoid_focal_loss_fwd_bwd():
     torch.testing.assert_close(y.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
     d = ops().sigmoid_focal_loss_bwd(logits.detach().cuda(), targets.cuda(), gup.cuda(), 2.0, 0.25)
     torch.testing.assert_close(d.cpu(), logits.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv2d_every_algorithm_gives_the_same_answer(dt):
+    """Every kernel generation x ring depth x tile the autotuner may pick (osd_conv_desc.algo), incl. the 8-wave
+    256x256 tile, on a 3x3 conv with a ragged M tail, residual and ReLU."""
+    from oneshotdet_amd import _lib
+    n, cin, h, w, cout = 2, 256, 23, 19, 256
+    x, wt, b, idn = rnd(n, cin, h, w, seed=1), rnd(cout, cin, 3, 3, seed=2) / 48, rnd(cout, seed=3), rnd(n, cout, h, w, seed=4)
+    if dt == "bf16":
+        x, wt, idn = x.bfloat16().float(), wt.bfloat16().float(), idn.bfloat16().float()
+    ref = F.relu(F.conv2d(x, wt, b, padding=1) + idn)
+    pc = ops().pack_conv(wt.cuda(), bias=b.cuda(), dtype=DT[dt])
+    xx, rr = to_nhwc(x, DT[dt]), to_nhwc(idn, DT[dt])
+    ran = 0
+    for algo in ops().conv_algo_candidates(cout, False):
+        try:
+            y = ops().conv2d(xx, pc, pad=1, act=ops().ACT_RELU, res=rr, res_mode=ops().RES_SAME, algo=algo)
+        except _lib.OsdError:
+            continue
+        torch.testing.assert_close(from_nhwc(y), ref, **TOL[dt], msg=lambda m: "algo %d: %s" % (algo, m))
+        ran += 1
+    assert ran >= 10

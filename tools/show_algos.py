@@ -11,4 +11,4 @@ eng.tune(images, queries)
 names = {0: "dma", 1: "reg"}
 for k, a in sorted(ops.ALGO_CACHE.items(), key=lambda kv: -kv[0][1]):
     a0 = a - 1
-    print("M=%8d N=%5d cin=%5d %dx%d s%d res%d act%d -> %s v%d tile%d" % (k[1], k[2], k[3], k[4], k[5], k[6], k[8], k[9], names[a0 >> 4], (a0 >> 2) & 3, a0 & 3))
+    print("M=%8d N=%5d cin=%5d %dx%d s%d res%d act%d -> %s v%d tile%d" % (k[1], k[2], k[3], k[4], k[5], k[6], k[8], k[9], names[a0 >> 5], (a0 >> 3) & 3, a0 & 7))
