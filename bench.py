@@ -159,11 +159,37 @@ def result_line(args, world, batch, elapsed, workload, launch, roofline=None, cp
     return line
 
 
+def measured_traffic(mode, dtype):
+    """HBM bytes per conv-family launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections), collected
+    offline by tools/prof_pmc.sh + tools/summarize_pmc.py in separate rocprofv3 --pmc passes and committed under
+    profiles/ (counters cannot be read from inside the process).  None when no profile exists for this mode."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic_%s_%s.json" % (mode, dtype))
+    try:
+        with open(path) as f:
+            return round(json.load(f)["conv_family"]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 class TrainTimer(ConvTimer):
-    """ConvTimer that also brackets the weight-gradient kernel (2*M*Cout*Cin*R*S FLOP per launch)."""
+    """ConvTimer that also brackets the weight-gradient kernel (2*M*Cout*Cin*R*S FLOP per launch) and, separately, the
+    correlation kernel (HBM-bound: elements * (read + write) bytes per launch)."""
 
     def install(self, ops):
         ConvTimer.install(self, ops)
+        self.corr, self.corr_bytes = [], 0.0
+        self._orig_c = ops.correlate
+        tm = self
+
+        def timed_correlate(x, q, out=None):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            y = tm._orig_c(x, q, out=out)
+            b.record()
+            tm.corr.append((a, b))
+            tm.corr_bytes += 2.0 * x.numel() * x.element_size() + q.numel() * 4
+            return y
+        ops.correlate = timed_correlate
         self._orig_w = ops.conv2d_wgrad
         timer = self
 
@@ -193,6 +219,15 @@ class TrainTimer(ConvTimer):
         ConvTimer.uninstall(self, ops)
         ops.conv2d_wgrad = self._orig_w
         ops.conv2d_wgrad_grouped = self._orig_g
+        ops.correlate = self._orig_c
+
+    def correlation_roofline(self):
+        ms = sum(a.elapsed_time(b) for a, b in self.corr) - self.bracket_overhead_ms() * len(self.corr)
+        gbs = self.corr_bytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                "kernel": "correlate_kernel (forward y = x*q and backward d_feat = g*q, 5 FPN levels each)",
+                "avg_launch_us": round(ms * 1e3 / max(len(self.corr), 1), 2), "launches": len(self.corr),
+                "bytes_per_launch": round(self.corr_bytes / max(len(self.corr), 1))}
 
 
 def main_train(args, rank, world):
@@ -239,8 +274,10 @@ def main_train(args, rank, world):
             torch.cuda.synchronize()
         conv_ms = timer.total_ms()
         tflops = timer.flops / (conv_ms * 1e-3) / 1e12
+        corr_roofline = timer.correlation_roofline()
         roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                    "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4), "traffic": measured_traffic("train", args.dtype),
+                    "traffic_source": "profiles/r1_pmc_traffic_train_%s.json (rocprofv3 --pmc, bytes per launch)" % args.dtype,
                     "kernel": "conv_dma_kernel / conv_igemm_kernel (forward + data gradient) and conv_wgrad_kernel",
                     "avg_launch_us": round(conv_ms * 1e3 / max(timer.launches, 1), 2),
                     "launches_per_step": timer.launches // nst,
@@ -255,6 +292,8 @@ def main_train(args, rank, world):
                     "backward (stem/layer1 frozen) + gradient all-reduce + SGD(momentum) + weight repack" % (B, args.dtype))
         cpu = cpu_baseline(args.dtype) if (world == 1 and not args.no_cpu_baseline) else None
         line = result_line(args, world, B, elapsed, workload, launch, roofline, cpu)
+        if roofline is not None:
+            line["roofline_correlation"] = corr_roofline
         line["config"]["parallelism"] = "dp%d, fp32 gradient all-reduce over RCCL (%d x flat buckets)" % (world, 4)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -74,7 +74,14 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  int bid = blockIdx.x;
+  // XCD-aware bijective remap (blocks b, b+8 share an XCD): all output tiles of one pixel split — they re-read the same
+  // dY / X rows — become consecutive logical ids and therefore land on ONE XCD's L2 instead of being fetched by all 8
+  int bid;
+  {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   const int co_tile = bid % gp.tilesCo;
   bid /= gp.tilesCo;
   const int ntile = gp.R * gp.S * gp.tilesCi;

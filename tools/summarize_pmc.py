@@ -1,0 +1,67 @@
+"""Summarise tools/prof_pmc.sh output (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the training bench)
+into profiles/<name>.json + .md: HBM bytes per launch of the conv family in ONE training step.
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE counts a wide coalesced
+(16 B/lane) streaming read at exactly 1/2 of its bytes -> doubled; WRITE_SIZE is exact for 16-B/lane stores and float
+atomics.  Calibration on correlate_kernel (known bytes: read = write = elements * 2 B) is printed beside it."""
+import csv
+import json
+import sys
+
+
+def last_step(rows):
+    rows = sorted(rows, key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(rows) if "pack_multi" in r["Kernel_Name"]]
+    ends = idx[1::2]
+    return rows[ends[-2] + 1:ends[-1] + 1]
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    res = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        rows = last_step(list(csv.DictReader(open("%s/%s/run_counter_collection.csv" % (d, c)))))
+        for r in rows:
+            n = r["Kernel_Name"]
+            k = "conv_fwd_dgrad" if ("conv_dma" in n or "conv_igemm" in n) else (
+                "conv_wgrad" if "conv_wgrad_kernel" in n else ("correlate" if "correlate_kernel" in n else None))
+            if k is None:
+                continue
+            e = res.setdefault(k, {"launches": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+            e[c] += float(r["Counter_Value"]) * 1024.0
+            if c == "FETCH_SIZE":
+                e["launches"] += 1
+    for k, e in res.items():
+        e["hbm_read_bytes"] = 2.0 * e["FETCH_SIZE"]         # gfx950: FETCH_SIZE = 1/2 of a wide coalesced read
+        e["hbm_write_bytes"] = e["WRITE_SIZE"]
+        e["hbm_bytes_per_launch"] = (e["hbm_read_bytes"] + e["hbm_write_bytes"]) / max(e["launches"], 1)
+    fam = {"launches": 0, "hbm_read_bytes": 0.0, "hbm_write_bytes": 0.0}
+    for k in ("conv_fwd_dgrad", "conv_wgrad"):
+        for f in fam:
+            fam[f] += res[k][f]
+    fam["hbm_bytes_per_launch"] = (fam["hbm_read_bytes"] + fam["hbm_write_bytes"]) / fam["launches"]
+    res["conv_family"] = fam
+    # calibration: correlation over 5 FPN levels of 8 x 800x1024 in bf16: 8*17064*256 elements, 2 B read + 2 B written
+    cal = 8 * 17064 * 256 * 2.0
+    res["calibration"] = {"kernel": "correlate_kernel (forward + backward d_feat)", "expected_read_bytes_per_pass": cal,
+                          "measured_read_bytes": res["correlate"]["hbm_read_bytes"],
+                          "measured_write_bytes": res["correlate"]["hbm_write_bytes"],
+                          "launches": res["correlate"]["launches"]}
+    json.dump(res, open(out + ".json", "w"), indent=1)
+    with open(out + ".md", "w") as f:
+        f.write("# HBM traffic from PMC counters (rocprofv3 --pmc, separate passes), one training step, bf16, bs=8\n\n")
+        f.write("FETCH_SIZE doubled (gfx950 counts wide coalesced reads at 1/2), WRITE_SIZE as is; KiB -> bytes.\n\n")
+        f.write("| kernel group | launches/step | HBM read MB | HBM write MB | MB per launch |\n|---|---|---|---|---|\n")
+        for k in ("conv_fwd_dgrad", "conv_wgrad", "conv_family", "correlate"):
+            e = res[k]
+            f.write("| %s | %d | %.1f | %.1f | %.2f |\n" % (k, e["launches"], e["hbm_read_bytes"] / 1e6,
+                                                           e["hbm_write_bytes"] / 1e6, e["hbm_bytes_per_launch"] / 1e6))
+        c = res["calibration"]
+        f.write("\nCalibration: %d correlate launches (5 forward + 5 backward levels) should read and write %.1f MB each "
+                "per pass (x2 passes); measured read %.1f MB, write %.1f MB.\n" % (
+                    c["launches"], cal / 1e6, c["measured_read_bytes"] / 1e6, c["measured_write_bytes"] / 1e6))
+    print(open(out + ".md").read())
+
+
+if __name__ == "__main__":
+    main()
