@@ -57,15 +57,14 @@ template <typename T> __device__ __forceinline__ int wg_swz(int row) {
   else return 4 * (row & 3);
 }
 
-template <typename T>
+template <typename T, int BKP, int NST>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int TW = 256 / (int)sizeof(T);    // tile width (channels) of both operands: 256-byte rows
-  constexpr int BKP = 32;                     // pixels per stage
-  constexpr int NST = 3;
-  constexpr int OPB = BKP * 256;              // bytes of one operand tile
+  constexpr int OPB = BKP * 256;              // bytes of one operand tile (BKP pixels per stage)
   constexpr int STAGE = 2 * OPB;
-  constexpr int LPS = 4;                      // DMA instructions per wave per stage (2 per operand)
+  constexpr int IPO = BKP / 16;               // DMA instructions per wave per operand per stage (4 rows each, 4 waves)
+  constexpr int LPS = 2 * IPO;                // DMA instructions per wave per stage
   constexpr int TA = TW / 2 / 16;             // 16-wide MFMA tiles per wave along co (and along ci)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -116,13 +115,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
 
   // ---- per-lane DMA coordinates: 2 instructions per operand per stage, 4 tile rows per instruction ----
   const int lrow = lane >> 4, lpos = lane & 15;
-  int a_row[2], a_col[2];          // dY: tile row, channel offset (swizzled source chunk)
-  int b_row[2], b_col[2];          // X
-  int b_n[2], b_ho[2], b_wo[2];    // output-pixel coordinates of the lane's row (advanced by BKP per stage)
-  bool a_cok[2], b_cok[2];
+  int a_row[IPO], a_col[IPO];          // dY: tile row, channel offset (swizzled source chunk)
+  int b_row[IPO], b_col[IPO];          // X
+  int b_n[IPO], b_ho[IPO], b_wo[IPO];  // output-pixel coordinates of the lane's row (advanced by BKP per stage)
+  bool a_cok[IPO], b_cok[IPO];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wave * 2 + i) * 4 + lrow;
+  for (int i = 0; i < IPO; ++i) {
+    const int row = (wave * IPO + i) * 4 + lrow;
     const int chunk = lpos ^ wg_swz<T>(row);
     a_row[i] = row; b_row[i] = row;
     a_col[i] = co0 + chunk * EPC; b_col[i] = ci0 + chunk * EPC;
@@ -137,18 +136,18 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
   auto issue_stage = [&](int buf) {
     const unsigned sa = lds0 + buf * STAGE, sb = sa + OPB;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < IPO; ++i) {
       const int m = stage_m + a_row[i];
       const T* src = (m < p_hi && a_cok[i]) ? dyg + (size_t)m * p.dy_stride + a_col[i] : zero;
-      wg_dma16(src, sa + (wave * 2 + i) * 1024);
+      wg_dma16(src, sa + (wave * IPO + i) * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < IPO; ++i) {
       const int m = stage_m + b_row[i];
       const int hi = b_ho[i] * p.sh - p.ph + fr, wi = b_wo[i] * p.sw - p.pw + fs;
       const bool ok = (m < p_hi) && b_cok[i] && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
       const T* src = ok ? xg + ((size_t)(b_n[i] * p.H + hi) * p.W + wi) * p.Cin + b_col[i] : zero;
-      wg_dma16(src, sb + (wave * 2 + i) * 1024);
+      wg_dma16(src, sb + (wave * IPO + i) * 1024);
       // advance this lane's pixel by BKP rows
       b_wo[i] += BKP;
       while (b_wo[i] >= p.Wo) { b_wo[i] -= p.Wo; ++b_ho[i]; }
@@ -167,9 +166,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
     const char* sa = smem + buf * STAGE;
     const char* sb = sa + OPB;
     if constexpr (sizeof(T) == 2) {
+#pragma unroll
+     for (int k32 = 0; k32 < BKP / 32; ++k32) {
       // one 32-deep k step; k slot (g, j) <-> tile row (j < 4 ? 4g + j : 16 + 4g + j - 4)
       const int g = lane >> 4, t = lane & 15, q = t >> 2, pp = t & 3;
-      const int r1 = 4 * g + q, r2 = 16 + 4 * g + q;
+      const int r1 = k32 * 32 + 4 * g + q, r2 = k32 * 32 + 16 + 4 * g + q;
       typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
       typedef __attribute__((address_space(3))) bf4* lds_bf4_ptr;
       bf16x8 af[TA], bfr[TA];
@@ -197,6 +198,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
 #pragma unroll
         for (int j = 0; j < TA; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+     }
     } else {
       const int k = lane >> 4, e16 = lane & 15;
 #pragma unroll
@@ -364,11 +366,27 @@ static int wgrad_launch(const osd_conv_desc* d, int n_seg, const void* const* xs
   p.splits = total_splits;
   const long long nblocks = tiles * total_splits;
   if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
-  const int lds = 3 * 2 * 32 * 256;
-  if (d->dtype == OSD_F32)
-    hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3((unsigned)nblocks), dim3(256), lds, s, p);
-  else
-    hipLaunchKernelGGL(conv_wgrad_kernel<__bf16>, dim3((unsigned)nblocks), dim3(256), lds, s, p);
+  static int variant = -1;   // OSD_WGRAD_VARIANT: 0 = 32 px x 3 stages, 1 = 64 px x 2, 2 = 32 px x 4, 3 = 64 px x 3
+  if (variant < 0) { const char* e = getenv("OSD_WGRAD_VARIANT"); variant = e ? atoi(e) : 0; }
+#define OSD_WG_LAUNCH(TT, BK, NS)                                                                                   \
+  do {                                                                                                               \
+    auto kern = conv_wgrad_kernel<TT, BK, NS>;                                                                       \
+    constexpr int lds = NS * 2 * BK * 256;                                                                           \
+    static bool attr = false;                                                                                        \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; } \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds, s, p);                                        \
+  } while (0)
+  if (d->dtype == OSD_F32) {
+    OSD_WG_LAUNCH(float, 32, 3);
+  } else {
+    switch (variant) {
+      case 1: OSD_WG_LAUNCH(__bf16, 64, 2); break;
+      case 2: OSD_WG_LAUNCH(__bf16, 32, 4); break;
+      case 3: OSD_WG_LAUNCH(__bf16, 64, 3); break;
+      default: OSD_WG_LAUNCH(__bf16, 32, 3); break;
+    }
+  }
+#undef OSD_WG_LAUNCH
   return osd_check_launch("conv_wgrad");
 }
 

@@ -132,3 +132,34 @@ def test_sgd_steps_reduce_the_loss():
         last = eng.train_step(img, q, gtb, cnt)[:3].sum().item()
     assert not torch.equal(w0, eng.flat_w)
     assert np.isfinite(last) and last < first
+
+
+def test_forward_backward_five_shots_vs_oracle_autograd():
+    """BASELINE.json configs[4] structure (S = 5 queries per image, mean-pooled: generalized_rcnn.py:100-104): the query
+    branch gradient flows through shot-mean backward and ROIAlign backward.  Oracle autograd computed here on the CPU."""
+    from oneshotdet_amd import train
+    name = "shots5"
+    B, H, W, S, qh, qw = gu.CASES[name]
+    img, q = gu.case_inputs(name)
+    gts = synth.make_gt_boxes(B, H, W, seed=5, max_boxes=3)
+    np_sd = synth.make_state_dict(spec.hot_path_shapes())
+    sd = {k: v.clone().requires_grad_(not spec.is_frozen(k)) for k, v in orc.to_torch_state_dict(np_sd).items()}
+    o = orc.hot_path_forward(torch.from_numpy(img), torch.from_numpy(q), sd, shots=S)
+    c, r, t, info = orc.fcos_loss(o["logits"], o["bbox_reg"], o["centerness"], gts, focal="cuda")
+    (c + r + t).backward()
+    eng = train.TrainEngine(np_sd, dtype=torch.float32)
+    G = max(len(g) for g in gts)
+    gtb = torch.zeros(B, G, 4)
+    for i, g in enumerate(gts):
+        gtb[i, :len(g)] = torch.from_numpy(g)
+    cnt = torch.tensor([len(g) for g in gts], dtype=torch.int32)
+    losses = eng.forward_backward(torch.from_numpy(img).cuda(), torch.from_numpy(q).cuda(), gtb.cuda(), cnt.cuda()).cpu()
+    assert int(losses[3]) == info["num_pos"]
+    np.testing.assert_allclose(losses[:3].numpy(), [c.item(), r.item(), t.item()], rtol=1e-4)
+    grads = eng.named_grads()
+    for k in ("supp_backbone.body.layer2.0.conv1.weight", "supp_backbone.body.layer4.2.conv3.weight",
+              "supp_backbone.fpn.fpn_inner2.weight", "supp_backbone.fpn.top_blocks.p7.weight",
+              "backbone.body.layer3.2.conv2.weight", "rpn.head.cls_tower.0.weight"):
+        ref = sd[k].grad
+        err = (grads[k].float().cpu() - ref).abs().max().item()
+        assert err <= 2e-2 * ref.abs().max().item(), (k, err, ref.abs().max().item())
