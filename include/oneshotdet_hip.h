@@ -232,6 +232,14 @@ int osd_cast_f32(const float* src, void* dst, int64_t numel, int dtype, void* st
 int osd_groupnorm_relu_bwd(const void* u, const void* dt, const float* a, const float* b, const float* gamma,
                            const float* beta, float* ws, float* dgamma, float* dbeta, void* du, int n, int hw, int c,
                            int groups, int dtype, void* stream);
+/* SGD with momentum over the flat fp32 master / gradient / momentum buffers in ONE launch (the reference uses
+ * torch.optim.SGD with per-parameter groups, solver/build.py:8-26; same update rule: g += wd*p; buf = momentum*buf + g
+ * (buf = g on the first step); p -= lr*lr_mult*buf).  table: device array of
+ * struct { int64 off, numel; float lr_mult, wd; int32 first_block, n_blocks; } (32 bytes); block_entry[b] = entry of
+ * workgroup b. */
+int osd_sgd_momentum_multi(const void* table, const int32_t* block_entry, int n_blocks, float* params,
+                           const float* grads, float* momentum_buf, float lr, float momentum, int first_step,
+                           void* stream);
 /* FCOS loss (modeling/rpn/fcos/loss.py:101-276; focal term = csrc/cuda/SigmoidFocalLoss_cuda.cu) for one FPN level.
  * phase 0 accumulates sums[5] = {num_pos, sum_w, sum_focal, sum_w*(1-giou), sum_bce} (zero them before the first
  * level); phase 1 writes d_cls_ctr [n][hw][grad_stride] (d logit, d centerness at +0/+1; the caller zero-fills the

@@ -102,6 +102,31 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackEntry* __rest
   }
 }
 
+// ---- SGD with momentum over the flat master buffer, ONE launch (torch.optim.SGD semantics, dampening 0, no nesterov:
+// g += wd*p; buf = first ? g : momentum*buf + g; p -= lr*buf), per-tensor lr multiplier and weight decay from a table
+// (solver/build.py:8-26: biases get lr x2 and no weight decay) ----
+struct SgdEntry {
+  long long off, numel;
+  float lr_mult, wd;
+  int first_block, n_blocks;
+};
+
+__global__ void __launch_bounds__(256) sgd_multi_kernel(const SgdEntry* __restrict__ table, const int* __restrict__ block_entry,
+                                                        float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ buf, float lr, float momentum, int first) {
+  const SgdEntry e = table[block_entry[blockIdx.x]];
+  const float step = lr * e.lr_mult;
+  const long long stride = (long long)e.n_blocks * blockDim.x;
+  for (long long i = (long long)(blockIdx.x - e.first_block) * blockDim.x + threadIdx.x; i < e.numel; i += stride) {
+    const long long k = e.off + i;
+    const float w = p[k];
+    const float d = g[k] + e.wd * w;
+    const float m = first ? d : momentum * buf[k] + d;
+    buf[k] = m;
+    p[k] = w - step * m;
+  }
+}
+
 // packed fp32 weight gradient [cout][R][S][cin] -> OIHW, times the folded FrozenBN scale (d/dw of conv(x, w*scale))
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, const float* __restrict__ scale, float* __restrict__ g,
                                     int cout, int cin, int R, int S, int accumulate) {
@@ -484,6 +509,16 @@ extern "C" int osd_pack_multi(const void* table, const int32_t* block_entry, int
       hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(n_blocks), dim3(256), 0, OSD_STREAM(stream), (const PackEntry*)table, block_entry, src, scales, (float*)dst, dgrad),
       hipLaunchKernelGGL(pack_multi_kernel<__bf16>, dim3(n_blocks), dim3(256), 0, OSD_STREAM(stream), (const PackEntry*)table, block_entry, src, scales, (__bf16*)dst, dgrad));
   return osd_check_launch("pack_multi");
+}
+
+extern "C" int osd_sgd_momentum_multi(const void* table, const int32_t* block_entry, int n_blocks, float* params,
+                                      const float* grads, float* momentum_buf, float lr, float momentum, int first_step,
+                                      void* stream) {
+  if (!table || !block_entry || !params || !grads || !momentum_buf) return osd_fail(OSD_ERR_INVALID_ARG, "sgd: null argument");
+  if (n_blocks <= 0) return OSD_OK;
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_blocks), dim3(256), 0, OSD_STREAM(stream), (const SgdEntry*)table, block_entry,
+                     params, grads, momentum_buf, lr, momentum, first_step);
+  return osd_check_launch("sgd_multi");
 }
 
 extern "C" int osd_unpack_wgrad(const float* dw_packed, const float* scale, float* grad_oihw, int cout, int cin, int r, int s,

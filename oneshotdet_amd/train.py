@@ -37,7 +37,7 @@ class TConv(object):
 
 class TrainEngine(object):
     def __init__(self, state_dict, dtype=torch.bfloat16, device="cuda", lr=0.0005, momentum=0.9, weight_decay=0.0001,
-                 process_group=None, wgrad_side_stream=True):
+                 process_group=None, wgrad_side_stream=True, optimizer="fused"):
         if not torch.cuda.is_available():
             raise ops._lib.OsdError("TrainEngine needs an MI355X: no GPU visible and there is no CPU fallback")
         ops._lib.load()
@@ -60,8 +60,13 @@ class TrainEngine(object):
                   [p for n, (p, _) in self.extra.items() if n.endswith(".weight")]
         biases = [c.b for c in self.convs.values() if c.trainable and c.has_bias] + \
                  [p for n, (p, _) in self.extra.items() if not n.endswith(".weight")]
-        self.opt = torch.optim.SGD([{"params": weights, "lr": lr, "weight_decay": weight_decay},
-                                    {"params": biases, "lr": 2 * lr, "weight_decay": 0.0}], lr=lr, momentum=momentum)
+        self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        self.opt = None
+        if optimizer == "torch":     # the reference's optimiser object, kept for A/B tests of the fused kernel
+            self.opt = torch.optim.SGD([{"params": weights, "lr": lr, "weight_decay": weight_decay},
+                                        {"params": biases, "lr": 2 * lr, "weight_decay": 0.0}], lr=lr, momentum=momentum)
+        else:
+            self._build_sgd_table(weights, biases)
 
     # ------------------------------------------------------------------------------------------------ construction
     def _add_conv(self, name, sd, bn=None, bias=None, trainable=True):
@@ -453,8 +458,33 @@ class TrainEngine(object):
         from .dist_utils import average_flat_
         average_flat_(self.flat_g, self.pg, 4)
 
+    def _build_sgd_table(self, weights, biases):
+        import numpy as np
+        base = self.flat_w.data_ptr()
+        rows, blocks = [], []
+        for group, lr_mult, wd in ((weights, 1.0, self.weight_decay), (biases, 2.0, 0.0)):
+            for t in group:
+                nb = max(1, min(64, (t.numel() + 256 * 16 - 1) // (256 * 16)))
+                rows.append(((t.data_ptr() - base) // 4, t.numel(), lr_mult, wd, len(blocks), nb))
+                blocks += [len(rows) - 1] * nb
+        tab = np.zeros((len(rows), 4), dtype=np.int64)         # 32 bytes per entry
+        for i, (off, n, lm, wd, fb, nb) in enumerate(rows):
+            tab[i, 0], tab[i, 1] = off, n
+            tab[i, 2] = np.frombuffer(np.array([lm, wd], dtype=np.float32).tobytes(), dtype=np.int64)[0]
+            tab[i, 3] = np.frombuffer(np.array([fb, nb], dtype=np.int32).tobytes(), dtype=np.int64)[0]
+        self._sgd = dict(table=torch.from_numpy(tab).to(self.device),
+                         blocks=torch.tensor(blocks, dtype=torch.int32, device=self.device), n=len(blocks),
+                         buf=torch.zeros_like(self.flat_w), steps=0)
+
     def optimizer_step(self):
-        self.opt.step()
+        if self.opt is not None:
+            self.opt.step()
+        else:
+            sg = self._sgd
+            ops._lib.call("osd_sgd_momentum_multi", ops._ptr(sg["table"]), ops._ptr(sg["blocks"]), sg["n"],
+                          ops._ptr(self.flat_w), ops._ptr(self.flat_g), ops._ptr(sg["buf"]), float(self.lr),
+                          float(self.momentum), int(sg["steps"] == 0), ops._stream())
+            sg["steps"] += 1
         self.repack()
 
     def train_step(self, images, queries, gt_boxes, gt_count):
