@@ -78,27 +78,51 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackEntry* __rest
   const float* w = src + e.src_off;
   const float* sc = e.scale_off >= 0 ? scales + e.scale_off : nullptr;
   T* out = dst + e.dst_off;
-  const long long total = (long long)e.rows * e.R * e.S * e.kpad;
-  const long long stride = (long long)e.n_blocks * blockDim.x;
-  for (long long i = (long long)(blockIdx.x - e.first_block) * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int k = (int)(i % e.kpad);
-    long long t = i / e.kpad;
-    const int s = (int)(t % e.S); t /= e.S;
-    const int r = (int)(t % e.R);
-    const int row = (int)(t / e.R);
-    float v = 0.f;
-    if (!dgrad) {            // forward: row = co, k = ci
+  if (!dgrad) {              // forward form: same [row = co][r][s][k = ci] order as the master -> a scaled, padded copy
+    const int total = e.rows * e.R * e.S * e.kpad;
+    const int stride = e.n_blocks * blockDim.x;
+    const int rs_k = e.R * e.S * e.kpad;
+    for (int i = (blockIdx.x - e.first_block) * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const int row = i / rs_k, rem = i - row * rs_k;
+      const int tap = rem / e.kpad, k = rem - tap * e.kpad;
+      float v = 0.f;
       if (row < e.cout && k < e.cin) {
-        v = w[(((size_t)row * e.R + r) * e.S + s) * e.cin + k];
+        v = w[((size_t)row * e.R * e.S + tap) * e.cin + k];
         if (sc) v *= sc[row];
       }
-    } else {                 // data gradient: row = ci, k = co, taps flipped
-      if (row < e.cin && k < e.cout) {
-        v = w[(((size_t)k * e.R + (e.R - 1 - r)) * e.S + (e.S - 1 - s)) * e.cin + row];
-        if (sc) v *= sc[k];
-      }
+      out[i] = from_f32<T>(v);
     }
-    out[i] = from_f32<T>(v);
+    return;
+  }
+  // data-gradient form [row = ci][r'][s'][k = co] with flipped taps: a transpose of the master per tap, done through
+  // LDS in 32 x 32 tiles so both the reads (along ci) and the writes (along co) are coalesced
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int tci = (e.rows + 31) / 32, tco = (e.kpad + 31) / 32;
+  const int ntiles = e.R * e.S * tci * tco;
+  for (int t = blockIdx.x - e.first_block; t < ntiles; t += e.n_blocks) {
+    const int cot = t % tco;
+    int u = t / tco;
+    const int cit = u % tci; u /= tci;
+    const int s = u % e.S, r = u / e.S;
+    const int co0 = cot * 32, ci0 = cit * 32;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = co0 + ty + 8 * j, ci = ci0 + tx;
+      float v = 0.f;
+      if (co < e.cout && ci < e.cin) {
+        v = w[(((size_t)co * e.R + (e.R - 1 - r)) * e.S + (e.S - 1 - s)) * e.cin + ci];
+        if (sc) v *= sc[co];
+      }
+      tile[ty + 8 * j][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ci = ci0 + ty + 8 * j, co = co0 + tx;
+      if (ci < e.rows && co < e.kpad) out[(((size_t)ci * e.R + r) * e.S + s) * e.kpad + co] = from_f32<T>(tile[tx][ty + 8 * j]);
+    }
   }
 }
 
