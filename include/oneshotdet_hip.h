@@ -240,6 +240,16 @@ int osd_groupnorm_relu_bwd(const void* u, const void* dt, const float* a, const 
 int osd_sgd_momentum_multi(const void* table, const int32_t* block_entry, int n_blocks, float* params,
                            const float* grads, float* momentum_buf, float lr, float momentum, int first_step,
                            void* stream);
+/* GroupNorm + ReLU of one tower layer over ALL FPN levels (separate tensors sharing gamma/beta) in two launches, and
+ * its backward in two launches: statistics per (level, image, slab), finalised inside the apply kernels.
+ * xs/ys/us/dts/dus: HOST arrays of n_levels device pointers to [n][hw_l][c] tensors; hws: HOST array;
+ * ab [n_levels][2][n][c] fp32 (written by fwd, read by bwd); ws n_levels*n*OSD_GN_SPLITS*groups*2 floats. */
+int osd_groupnorm_relu_fwd_levels(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
+                                  const float* gamma, const float* beta, float* ab, float* ws, int n, int c, int groups,
+                                  float eps, int dtype, void* stream);
+int osd_groupnorm_relu_bwd_levels(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
+                                  const int32_t* hws, const float* ab, const float* gamma, const float* beta, float* ws,
+                                  float* dgamma, float* dbeta, int n, int c, int groups, int dtype, void* stream);
 /* FCOS loss (modeling/rpn/fcos/loss.py:101-276; focal term = csrc/cuda/SigmoidFocalLoss_cuda.cu) for one FPN level.
  * phase 0 accumulates sums[5] = {num_pos, sum_w, sum_focal, sum_w*(1-giou), sum_bce} (zero them before the first
  * level); phase 1 writes d_cls_ctr [n][hw][grad_stride] (d logit, d centerness at +0/+1; the caller zero-fills the

@@ -52,6 +52,8 @@ SIGNATURES = {
     "osd_pack_conv_weight_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "osd_pack_conv_weight_ex": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "osd_conv2d_wgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
+    "osd_groupnorm_relu_fwd_levels": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
+    "osd_groupnorm_relu_bwd_levels": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "osd_sgd_momentum_multi": (_i, [_p, _p, _i, _p, _p, _p, _f, _f, _i, _p]),
     "osd_pack_multi": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _p]),
     "osd_conv2d_wgrad_grouped": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

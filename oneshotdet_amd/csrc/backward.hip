@@ -661,3 +661,299 @@ extern "C" int osd_conv2d_dgrad_naive(const osd_conv_desc* d, const void* dy, co
       hipLaunchKernelGGL(dgrad_naive_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const __bf16*)dy, (const __bf16*)w_fwd_packed, (const __bf16*)mask, (const __bf16*)addend, (__bf16*)dx, d->n, d->h, d->w, d->cin, d->ho, d->wo, d->cout, d->r, d->s, d->stride_h, d->pad_h, ktot, d->out_stride));
   return osd_check_launch("dgrad_naive");
 }
+
+// ====================================================================================================================
+// GroupNorm + ReLU over ALL FPN levels of one tower layer in two launches (forward) / two launches (backward).
+// The five levels share gamma/beta but are separate tensors; blockIdx.z = level, blockIdx.y = image, blockIdx.x = slab.
+// The per-(image, channel) scale/shift (forward) and the per-(image, group) sums (backward) are finalised INSIDE the
+// apply kernels from the slab partials (each workgroup redoes the tiny reduction for its image in LDS), so there is no
+// finalize / reduce launch.
+// ====================================================================================================================
+namespace {
+
+constexpr int kGnL = 8;
+struct GnLevels {
+  const void* x[kGnL];      // forward: conv output u; backward: u
+  const void* dy[kGnL];     // backward: dt
+  void* y[kGnL];            // forward: t = relu(gn(u)); backward: du
+  int hw[kGnL];
+  int n_levels;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) gnl_stats_kernel(GnLevels L, float* __restrict__ ws, int n, int c, int groups) {
+  constexpr int E = Chunk<T>::N;
+  const int lvl = blockIdx.z, img = blockIdx.y, split = blockIdx.x;
+  const int hw = L.hw[lvl];
+  const T* x = reinterpret_cast<const T*>(L.x[lvl]);
+  const int cch = c / E, lanes = 256 / cch;
+  const int cc = threadIdx.x % cch, pl = threadIdx.x / cch;
+  const int per = (hw + kGnSplits - 1) / kGnSplits;
+  const int p0 = split * per, p1 = min(hw, p0 + per);
+  float s = 0.f, ss = 0.f;
+  if (pl < lanes)
+    for (int p = p0 + pl; p < p1; p += lanes) {
+      Chunk<T> v;
+      v.load(x + ((size_t)img * hw + p) * c + cc * E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) { s += v.v[e]; ss += v.v[e] * v.v[e]; }
+    }
+  __shared__ float red[2][256];
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = ss;
+  __syncthreads();
+  const int cpg_chunks = (c / groups) / E > 0 ? (c / groups) / E : 1;
+  if (threadIdx.x < groups) {
+    const int g = threadIdx.x;
+    float ts = 0.f, tss = 0.f;
+    for (int l = 0; l < lanes; ++l)
+      for (int k = 0; k < cpg_chunks; ++k) {
+        ts += red[0][l * cch + g * cpg_chunks + k];
+        tss += red[1][l * cch + g * cpg_chunks + k];
+      }
+    float* o = ws + ((((size_t)lvl * n + img) * kGnSplits + split) * groups + g) * 2;
+    o[0] = ts;
+    o[1] = tss;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gnl_apply_kernel(GnLevels L, const float* __restrict__ ws, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ ab, int n, int c,
+                                                        int groups, float eps) {
+  constexpr int E = Chunk<T>::N;
+  const int lvl = blockIdx.z, img = blockIdx.y;
+  const int hw = L.hw[lvl];
+  __shared__ float sm[2][64];        // mean, rstd per group
+  __shared__ float sa[512], sb[512];
+  if (threadIdx.x < groups) {
+    const int g = threadIdx.x;
+    double s = 0.0, ss = 0.0;
+    const float* o = ws + (((size_t)lvl * n + img) * kGnSplits) * groups * 2;
+    for (int k = 0; k < kGnSplits; ++k) {
+      s += o[((size_t)k * groups + g) * 2];
+      ss += o[((size_t)k * groups + g) * 2 + 1];
+    }
+    const double cnt = (double)hw * (c / groups);
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    sm[0][g] = (float)mean;
+    sm[1][g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+    const int g = ch / (c / groups);
+    const float av = gamma[ch] * sm[1][g];
+    const float bv = beta[ch] - sm[0][g] * av;
+    sa[ch] = av;
+    sb[ch] = bv;
+    if (blockIdx.x == 0) {          // saved for the backward pass: ab[level][2][n][c]
+      ab[(((size_t)lvl * 2 + 0) * n + img) * c + ch] = av;
+      ab[(((size_t)lvl * 2 + 1) * n + img) * c + ch] = bv;
+    }
+  }
+  __syncthreads();
+  const T* x = reinterpret_cast<const T*>(L.x[lvl]);
+  T* y = reinterpret_cast<T*>(L.y[lvl]);
+  const int cch = c / E;
+  const long long chunks = (long long)hw * cch;
+  const long long per = (chunks + gridDim.x - 1) / gridDim.x;
+  const long long i0 = blockIdx.x * per, i1 = min(chunks, i0 + per);
+  for (long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const int cc = (int)(i % cch);
+    Chunk<T> v;
+    v.load(x + (size_t)img * hw * c + i * E);
+#pragma unroll
+    for (int e = 0; e < E; ++e) v.v[e] = fmaxf(fmaf(v.v[e], sa[cc * E + e], sb[cc * E + e]), 0.f);
+    v.store(y + (size_t)img * hw * c + i * E);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const float* __restrict__ ab, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ ws,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int n, int c,
+                                                            int groups) {
+  constexpr int E = Chunk<T>::N;
+  const int lvl = blockIdx.z, img = blockIdx.y, split = blockIdx.x;
+  const int hw = L.hw[lvl];
+  const T* u = reinterpret_cast<const T*>(L.x[lvl]);
+  const T* dt = reinterpret_cast<const T*>(L.dy[lvl]);
+  const int cch = c / E, lanes = 256 / cch;
+  const int cc = threadIdx.x % cch, pl = threadIdx.x / cch;
+  const int per = (hw + kGnSplits - 1) / kGnSplits;
+  const int p0 = split * per, p1 = min(hw, p0 + per);
+  float av[E], bv[E], gm[E], bt[E], s1 = 0.f, s2 = 0.f, dg[E], db[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    av[e] = ab[(((size_t)lvl * 2 + 0) * n + img) * c + cc * E + e];
+    bv[e] = ab[(((size_t)lvl * 2 + 1) * n + img) * c + cc * E + e];
+    gm[e] = gamma[cc * E + e];
+    bt[e] = beta[cc * E + e];
+    dg[e] = 0.f; db[e] = 0.f;
+  }
+  if (pl < lanes)
+    for (int p = p0 + pl; p < p1; p += lanes) {
+      Chunk<T> uu, gg;
+      const size_t off = ((size_t)img * hw + p) * c + cc * E;
+      uu.load(u + off);
+      gg.load(dt + off);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float z = fmaf(uu.v[e], av[e], bv[e]);
+        const float dz = z > 0.f ? gg.v[e] : 0.f;
+        const float xhat = (z - bt[e]) / gm[e];
+        s1 += dz * gm[e];
+        s2 += dz * gm[e] * xhat;
+        dg[e] += dz * xhat;
+        db[e] += dz;
+      }
+    }
+  __shared__ float red[2][256];
+  __shared__ float redc[2][512];
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  const int cpg_chunks = (c / groups) / E > 0 ? (c / groups) / E : 1;
+  if (threadIdx.x < groups) {
+    const int g = threadIdx.x;
+    float t1 = 0.f, t2 = 0.f;
+    for (int l = 0; l < lanes; ++l)
+      for (int k = 0; k < cpg_chunks; ++k) {
+        t1 += red[0][l * cch + g * cpg_chunks + k];
+        t2 += red[1][l * cch + g * cpg_chunks + k];
+      }
+    float* o = ws + ((((size_t)lvl * n + img) * kGnSplits + split) * groups + g) * 2;
+    o[0] = t1;
+    o[1] = t2;
+  }
+  for (int e = 0; e < E; ++e) {
+    __syncthreads();
+    red[0][threadIdx.x] = dg[e];
+    red[1][threadIdx.x] = db[e];
+    __syncthreads();
+    if (threadIdx.x < cch) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int l = 0; l < lanes; ++l) {
+        t1 += red[0][l * cch + threadIdx.x];
+        t2 += red[1][l * cch + threadIdx.x];
+      }
+      redc[0][threadIdx.x * E + e] = t1;
+      redc[1][threadIdx.x * E + e] = t2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < c && p0 < p1) {
+    atomicAdd(dgamma + threadIdx.x, redc[0][threadIdx.x]);
+    atomicAdd(dbeta + threadIdx.x, redc[1][threadIdx.x]);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const float* __restrict__ ab, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ ws, int n,
+                                                            int c, int groups) {
+  constexpr int E = Chunk<T>::N;
+  const int lvl = blockIdx.z, img = blockIdx.y;
+  const int hw = L.hw[lvl];
+  __shared__ float ssum[2][64];
+  if (threadIdx.x < groups) {
+    const int g = threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    const float* o = ws + (((size_t)lvl * n + img) * kGnSplits) * groups * 2;
+    for (int k = 0; k < kGnSplits; ++k) {
+      s1 += o[((size_t)k * groups + g) * 2];
+      s2 += o[((size_t)k * groups + g) * 2 + 1];
+    }
+    ssum[0][g] = s1;
+    ssum[1][g] = s2;
+  }
+  __syncthreads();
+  const T* u = reinterpret_cast<const T*>(L.x[lvl]);
+  const T* dt = reinterpret_cast<const T*>(L.dy[lvl]);
+  T* du = reinterpret_cast<T*>(L.y[lvl]);
+  const int cch = c / E, cpg = c / groups;
+  const float inv_m = 1.f / ((float)hw * cpg);
+  const long long chunks = (long long)hw * cch;
+  const long long per = (chunks + gridDim.x - 1) / gridDim.x;
+  const long long i0 = blockIdx.x * per, i1 = min(chunks, i0 + per);
+  for (long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const int cc = (int)(i % cch);
+    const int g = (cc * E) / cpg;
+    const float s1 = ssum[0][g], s2 = ssum[1][g];
+    Chunk<T> uu, gg;
+    uu.load(u + (size_t)img * hw * c + i * E);
+    gg.load(dt + (size_t)img * hw * c + i * E);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int ch = cc * E + e;
+      const float av = ab[(((size_t)lvl * 2 + 0) * n + img) * c + ch], bv = ab[(((size_t)lvl * 2 + 1) * n + img) * c + ch];
+      const float gm = gamma[ch];
+      const float z = fmaf(uu.v[e], av, bv);
+      const float dz = z > 0.f ? gg.v[e] : 0.f;
+      const float xhat = (z - beta[ch]) / gm;
+      const float rstd = av / gm;
+      uu.v[e] = rstd * (dz * gm - s1 * inv_m - xhat * s2 * inv_m);
+    }
+    uu.store(du + (size_t)img * hw * c + i * E);
+  }
+}
+
+int gn_levels_fill(GnLevels& L, int n_levels, const void* const* xs, const void* const* dys, void* const* ys, const int32_t* hws) {
+  if (n_levels < 1 || n_levels > kGnL || !xs || !ys || !hws) return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_levels: bad arguments");
+  L.n_levels = n_levels;
+  for (int i = 0; i < kGnL; ++i) {
+    const int j = i < n_levels ? i : 0;
+    L.x[i] = xs[j]; L.dy[i] = dys ? dys[j] : nullptr; L.y[i] = ys[j]; L.hw[i] = hws[j];
+  }
+  return OSD_OK;
+}
+
+}  // namespace
+
+// ws: n_levels * n * OSD_GN_SPLITS * groups * 2 floats; ab (out): [n_levels][2][n][c] fp32 scale / shift per image, channel
+extern "C" int osd_groupnorm_relu_fwd_levels(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
+                                             const float* gamma, const float* beta, float* ab, float* ws, int n, int c,
+                                             int groups, float eps, int dtype, void* stream) {
+  const int e = dtype == OSD_BF16 ? 8 : 4;
+  if (!gamma || !beta || !ab || !ws || c % e != 0 || c > 512 || c / e > 256 || 256 % (c / e) != 0 || groups > 64 ||
+      c % groups != 0 || (c / groups) % e != 0)
+    return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_levels: unsupported shape c=%d groups=%d", c, groups);
+  GnLevels L;
+  int rc = gn_levels_fill(L, n_levels, xs, nullptr, ys, hws);
+  if (rc) return rc;
+  dim3 g1(kGnSplits, n, n_levels), g2(64, n, n_levels);
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(gnl_stats_kernel<float>, g1, dim3(256), 0, OSD_STREAM(stream), L, ws, n, c, groups),
+      hipLaunchKernelGGL(gnl_stats_kernel<__bf16>, g1, dim3(256), 0, OSD_STREAM(stream), L, ws, n, c, groups));
+  rc = osd_check_launch("gnl_stats");
+  if (rc) return rc;
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(gnl_apply_kernel<float>, g2, dim3(256), 0, OSD_STREAM(stream), L, ws, gamma, beta, ab, n, c, groups, eps),
+      hipLaunchKernelGGL(gnl_apply_kernel<__bf16>, g2, dim3(256), 0, OSD_STREAM(stream), L, ws, gamma, beta, ab, n, c, groups, eps));
+  return osd_check_launch("gnl_apply");
+}
+
+extern "C" int osd_groupnorm_relu_bwd_levels(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
+                                             const int32_t* hws, const float* ab, const float* gamma, const float* beta,
+                                             float* ws, float* dgamma, float* dbeta, int n, int c, int groups, int dtype,
+                                             void* stream) {
+  const int e = dtype == OSD_BF16 ? 8 : 4;
+  if (!gamma || !beta || !ab || !ws || !dgamma || !dbeta || !dts || c % e != 0 || c > 512 || c / e > 256 ||
+      256 % (c / e) != 0 || groups > 64 || c % groups != 0 || (c / groups) % e != 0)
+    return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_bwd_levels: unsupported shape c=%d groups=%d", c, groups);
+  GnLevels L;
+  int rc = gn_levels_fill(L, n_levels, us, dts, dus, hws);
+  if (rc) return rc;
+  dim3 g1(kGnSplits, n, n_levels), g2(64, n, n_levels);
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(gnl_bwd_stats_kernel<float>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups),
+      hipLaunchKernelGGL(gnl_bwd_stats_kernel<__bf16>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups));
+  rc = osd_check_launch("gnl_bwd_stats");
+  if (rc) return rc;
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(gnl_bwd_apply_kernel<float>, g2, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, n, c, groups),
+      hipLaunchKernelGGL(gnl_bwd_apply_kernel<__bf16>, g2, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, n, c, groups));
+  return osd_check_launch("gnl_bwd_apply");
+}

@@ -484,3 +484,34 @@ def fcos_loss_level(phase, cls_ctr, reg, gt_boxes, gt_count, stride, size_lo, si
     _lib.call("osd_fcos_loss_level", phase, _ptr(cls_ctr), _ptr(reg), _ptr(gt_boxes), _ptr(gt_count), gt_boxes.shape[1], n,
               h, w, stride, float(size_lo), float(size_hi), float(radius), float(gamma), float(alpha), _ptr(scale_dev),
               _ptr(sums), _ptr(d_cls_ctr), _ptr(d_reg), gs, _ptr(d_scale_raw), _dt(cls_ctr), _stream())
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5):
+    """relu(GroupNorm(x_l)) for the FPN levels of one tower layer in two launches.  Returns (ys, ab) with
+    ab [L][2][N][C] fp32 (per-image scale/shift, kept for the backward pass)."""
+    n, _, _, c = xs[0].shape
+    k = len(xs)
+    dev = xs[0].device
+    ys = [torch.empty_like(x) for x in xs]
+    ab = torch.empty((k, 2, n, c), device=dev, dtype=torch.float32)
+    ws = torch.empty((k * n * GN_SPLITS * groups * 2,), device=dev, dtype=torch.float32)
+    hws = (C.c_int32 * k)(*[x.shape[1] * x.shape[2] for x in xs])
+    _lib.call("osd_groupnorm_relu_fwd_levels", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),
+              _ptr(ws), n, c, groups, float(eps), _dt(xs[0]), _stream())
+    return ys, ab
+
+
+def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32):
+    n, _, _, c = us[0].shape
+    k = len(us)
+    dev = us[0].device
+    dus = [torch.empty_like(u) for u in us]
+    ws = torch.empty((k * n * GN_SPLITS * groups * 2,), device=dev, dtype=torch.float32)
+    hws = (C.c_int32 * k)(*[u.shape[1] * u.shape[2] for u in us])
+    _lib.call("osd_groupnorm_relu_bwd_levels", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
+              _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), _stream())
+    return dus

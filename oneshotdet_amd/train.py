@@ -264,30 +264,29 @@ class TrainEngine(object):
         return [p3, p4, p5, p6, p7], ctx
 
     def head_forward(self, feats):
+        """FCOSHead.forward (fcos.py:83-99), tower -> layer -> level so that GroupNorm+ReLU of a layer is two launches for
+        all five levels.  ctx[tower] = ([per layer: (inputs per level, conv outputs per level, ab)], last activations)."""
         cv = self.convs
         h = "rpn.head."
         scales = self.extra[h + "scales"][0]
-        outs, ctxs = [], []
-        for lvl, f in enumerate(feats):
-            lctx = {}
-            res = {}
-            for tower in ("cls_tower", "bbox_tower"):
-                t, layers = f, []
-                for i in range(spec.NUM_CONVS):
-                    (gw, _), (gbeta, _) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
-                    u = ops.conv2d(t, cv["%s%s.%d" % (h, tower, 3 * i)].pc, pad=1)
-                    t2, ab = ops.groupnorm_relu_train(u, gw, gbeta, spec.GN_GROUPS, spec.GN_EPS)
-                    layers.append((t, u, ab))
-                    t = t2
-                lctx[tower] = (layers, t)
-                if tower == "cls_tower":
-                    res[tower] = ops.conv2d(t, cv[h + "cls_ctr"].pc, pad=1)
-                else:
-                    res[tower] = ops.conv2d(t, cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE,
-                                            act_scale_dev=scales[lvl:lvl + 1])
-            outs.append((res["cls_tower"], res["bbox_tower"]))
-            ctxs.append(lctx)
-        return outs, ctxs
+        nl = len(feats)
+        res, ctxs = {}, {}
+        for tower in ("cls_tower", "bbox_tower"):
+            t, layers = list(feats), []
+            for i in range(spec.NUM_CONVS):
+                (gw, _), (gbeta, _) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
+                c = cv["%s%s.%d" % (h, tower, 3 * i)]
+                u = [ops.conv2d(t[l], c.pc, pad=1) for l in range(nl)]
+                t2, ab = ops.groupnorm_relu_levels(u, gw, gbeta, spec.GN_GROUPS, spec.GN_EPS)
+                layers.append((t, u, ab))
+                t = t2
+            ctxs[tower] = (layers, t)
+            if tower == "cls_tower":
+                res[tower] = [ops.conv2d(t[l], cv[h + "cls_ctr"].pc, pad=1) for l in range(nl)]
+            else:
+                res[tower] = [ops.conv2d(t[l], cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE,
+                                         act_scale_dev=scales[l:l + 1]) for l in range(nl)]
+        return list(zip(res["cls_tower"], res["bbox_tower"])), ctxs
 
     # ------------------------------------------------------------------------------------------------ loss
     def loss_and_grads(self, head_out, gt_boxes, gt_count):
@@ -340,25 +339,24 @@ class TrainEngine(object):
                           res_mode=RES_SAME if res is not None else RES_NONE, mask=mask)
 
     def head_backward(self, feats, ctxs, pred_grads):
-        """Loops: tower -> layer (last first) -> level, so that the weight gradient of each (shared) conv is ONE grouped
-        launch over the five FPN levels."""
+        """Loops: tower -> layer (last first) -> level: the weight gradient of each (shared) conv is ONE grouped launch
+        over the five FPN levels, GroupNorm+ReLU backward two launches."""
         cv = self.convs
         h = "rpn.head."
         nl = len(feats)
         d_f = [None] * nl
         for tower, pname, gi in (("cls_tower", h + "cls_ctr", 0), ("bbox_tower", h + "bbox_pred", 1)):
+            layers, t_last = ctxs[tower]
             pc = cv[pname]
             dpred = [pred_grads[l][gi] for l in range(nl)]
-            self._wgrad_grouped(pc, [(ctxs[l][tower][1], dpred[l]) for l in range(nl)])
+            self._wgrad_grouped(pc, [(t_last[l], dpred[l]) for l in range(nl)])
             d_t = [self._dgrad(pc, dpred[l]) for l in range(nl)]
             for i in range(spec.NUM_CONVS - 1, -1, -1):
                 (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
                 c = cv["%s%s.%d" % (h, tower, 3 * i)]
-                du = []
-                for l in range(nl):
-                    t_in, u, ab = ctxs[l][tower][0][i]
-                    du.append(ops.groupnorm_relu_bwd(u, d_t[l], ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS))
-                self._wgrad_grouped(c, [(ctxs[l][tower][0][i][0], du[l]) for l in range(nl)])
+                t_in, u, ab = layers[i]
+                du = ops.groupnorm_relu_bwd_levels(u, d_t, ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
+                self._wgrad_grouped(c, [(t_in[l], du[l]) for l in range(nl)])
                 d_t = [self._dgrad(c, du[l], res=d_f[l] if (i == 0 and d_f[l] is not None) else None) for l in range(nl)]
             d_f = d_t
         return d_f
