@@ -126,41 +126,31 @@ def run_correlate(feats, pooled):
     return [ops.correlate(f, q) for f, q in zip(feats, pooled)]
 
 
-def run_head_tower(hw, f, lvl, tower):
-    """One tower + its prediction conv for one level (fcos.py:89-97)."""
-    t = f
+def run_head_tower(hw, feats, tower):
+    """One tower + its prediction conv over all levels (fcos.py:89-97): per layer one conv launch per level, then
+    GroupNorm+ReLU of all levels in two launches."""
+    t = list(feats)
     for conv, gamma, beta in hw.towers[tower]:
-        t = ops.conv2d(t, conv, pad=1)
-        t = ops.groupnorm_relu(t, gamma, beta, spec.GN_GROUPS, spec.GN_EPS, out=t)
+        u = [ops.conv2d(x, conv, pad=1) for x in t]
+        t, _ = ops.groupnorm_relu_levels(u, gamma, beta, spec.GN_GROUPS, spec.GN_EPS)
     if tower == "cls_tower":
-        return ops.conv2d(t, hw.pred_cls_ctr, pad=1)
-    return ops.conv2d(t, hw.pred_box, pad=1, act=ACT_EXP_SCALE, act_scale=hw.scales[lvl])
+        return [ops.conv2d(x, hw.pred_cls_ctr, pad=1) for x in t]
+    return [ops.conv2d(x, hw.pred_box, pad=1, act=ACT_EXP_SCALE, act_scale=hw.scales[l]) for l, x in enumerate(t)]
 
 
 def run_head(hw, feats, streams=None):
     """FCOSHead.forward (fcos.py:83-99).  Per level returns (cls_ctr [N,H,W,4] = (logit, centerness, 0, 0),
-    reg [N,H,W,4] = exp(scale_l * bbox_pred)).  The two towers and the five levels are independent: with `streams`
-    (3 side streams) P3/cls runs on the current stream, P3/bbox, P4-P7/cls and P4-P7/bbox on the side streams, so the
-    small levels' launch-latency-bound kernels fill the CUs the P3 GEMMs leave idle."""
-    n = len(feats)
+    reg [N,H,W,4] = exp(scale_l * bbox_pred)).  The two towers are independent: with `streams` the bbox tower runs on a
+    side stream beside the cls tower, so the small levels' launch-latency-bound kernels fill the CUs the P3 GEMMs leave
+    idle."""
     if not streams:
-        return [(run_head_tower(hw, f, l, "cls_tower"), run_head_tower(hw, f, l, "bbox_tower"))
-                for l, f in enumerate(feats)]
+        return list(zip(run_head_tower(hw, feats, "cls_tower"), run_head_tower(hw, feats, "bbox_tower")))
     main = torch.cuda.current_stream()
-    cls_out, box_out = [None] * n, [None] * n
-    for st in streams[:3]:
-        st.wait_stream(main)
+    streams[0].wait_stream(main)
     with torch.cuda.stream(streams[0]):
-        box_out[0] = run_head_tower(hw, feats[0], 0, "bbox_tower")
-    with torch.cuda.stream(streams[1]):
-        for l in range(1, n):
-            cls_out[l] = run_head_tower(hw, feats[l], l, "cls_tower")
-    with torch.cuda.stream(streams[2]):
-        for l in range(1, n):
-            box_out[l] = run_head_tower(hw, feats[l], l, "bbox_tower")
-    cls_out[0] = run_head_tower(hw, feats[0], 0, "cls_tower")
-    for st in streams[:3]:
-        main.wait_stream(st)
+        box_out = run_head_tower(hw, feats, "bbox_tower")
+    cls_out = run_head_tower(hw, feats, "cls_tower")
+    main.wait_stream(streams[0])
     return list(zip(cls_out, box_out))
 
 
