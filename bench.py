@@ -249,7 +249,7 @@ def main_train(args, rank, world):
         eng.forward_backward(images, queries, gt_boxes, gt_count)
     torch.cuda.synchronize()
 
-    launch = "eager, 2 streams"
+    launch = "eager, 4 streams (main, query/bbox branch, 2 x weight gradients)"
     step = lambda: eng.train_step(images, queries, gt_boxes, gt_count)     # noqa: E731
     if args.graph:
         try:
@@ -267,7 +267,7 @@ def main_train(args, rank, world):
         timer.install(ops)
         torch.cuda.synchronize()
         nst = max(2, min(args.steps, 5))
-        eng.wstream = None           # one stream: concurrent kernels would stretch each other's durations
+        eng.wstream = eng.wstream2 = eng.s1 = None    # one stream: concurrent kernels would stretch each other's durations
         for _ in range(nst):
             torch.cuda._sleep(int(150e6))
             eng.forward_backward(images, queries, gt_boxes, gt_count)

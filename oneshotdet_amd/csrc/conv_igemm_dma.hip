@@ -13,6 +13,9 @@
 #include "osd_common.h"
 #include "conv_params.h"
 #include <type_traits>
+#ifndef OSD_DMA_FRONT
+#define OSD_DMA_FRONT 1   // issue the next stage's DMA in the first half of the MFMA groups (more time to land)
+#endif
 
 namespace {
 
@@ -202,7 +205,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
         }
         // DMA instructions due by the end of this slot
         const int slot = kb * TN + i;
-        const int due = ((slot + 1) * LPS) / SLOTS;
+        const int due = OSD_DMA_FRONT ? min(LPS, ((slot + 1) * LPS * 2) / SLOTS) : ((slot + 1) * LPS) / SLOTS;
         if constexpr (fetch) {
 #pragma unroll
           for (int j = 0; j < LPS; ++j)
@@ -401,8 +404,8 @@ int dispatch_tile_dma(int tile, const ConvKParams& p, hipStream_t s) {
     case 2: return launch_dma<T, 64, 64, KB, 2, 2, NST>(p, s);
     case 3: return launch_dma<T, 256, 16, KB, 4, 1, NST>(p, s);
     case 4:   // 256 x 256, 8 waves: half the operand bytes per MFMA of the 128 x 128 tile (the L1/TA path is the bound there)
-      if constexpr (NST == 2 || (sizeof(T) == 4 && NST <= 3)) return launch_dma<T, 256, 256, KB, 2, 4, NST>(p, s);
-      else return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the 256x256 tile exists for the shallow ring only");
+      if constexpr (NST * 512 * KB <= 131072) return launch_dma<T, 256, 256, KB, 2, 4, NST>(p, s);
+      else return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the 256x256 tile does not fit LDS with this ring");
   }
   return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad tile id %d", tile);
 }

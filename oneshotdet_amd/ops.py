@@ -106,6 +106,7 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
     cands = [1 + 0 * 32 + v * 8 + t for v in (0, 1, 2) for t in tiles]
     if cout_store >= 256 and not relu_in:
         cands.append(1 + 0 * 32 + 1 * 8 + 4)          # 256x256 tile, shallow ring
+        cands.append(1 + 0 * 32 + 2 * 8 + 4)          # 256x256 tile, short stages x 4
     if not relu_in and not has_mask:
         cands += [1 + 1 * 32 + t for t in tiles]
     return cands

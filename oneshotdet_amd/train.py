@@ -45,6 +45,10 @@ class TrainEngine(object):
         self.pg = process_group
         # weight gradients feed nothing but the optimiser: they run on a side stream, beside the data-gradient chain
         self.wstream = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None
+        # second compute stream: the query backbone, the bbox tower and the training proposals are independent of the
+        # target backbone / cls tower / loss, so they run beside them and fill the tails of the large kernels
+        self.s1 = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None
+        self.wstream2 = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None   # weight gradients of the s1 branch
         self._keep = []
         sd = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state_dict.items()}
         self._frozen_sd = sd
@@ -265,28 +269,40 @@ class TrainEngine(object):
 
     def head_forward(self, feats):
         """FCOSHead.forward (fcos.py:83-99), tower -> layer -> level so that GroupNorm+ReLU of a layer is two launches for
-        all five levels.  ctx[tower] = ([per layer: (inputs per level, conv outputs per level, ab)], last activations)."""
+        all five levels; the bbox tower runs on the second stream beside the cls tower.
+        ctx[tower] = ([per layer: (inputs per level, conv outputs per level, ab)], last activations)."""
+        main = torch.cuda.current_stream()
+        res, ctxs = {}, {}
+        if self.s1 is not None:
+            self.s1.wait_stream(main)
+            with torch.cuda.stream(self.s1):
+                res["bbox_tower"], ctxs["bbox_tower"] = self._tower_forward(feats, "bbox_tower")
+        else:
+            res["bbox_tower"], ctxs["bbox_tower"] = self._tower_forward(feats, "bbox_tower")
+        res["cls_tower"], ctxs["cls_tower"] = self._tower_forward(feats, "cls_tower")
+        if self.s1 is not None:
+            main.wait_stream(self.s1)
+        return list(zip(res["cls_tower"], res["bbox_tower"])), ctxs
+
+    def _tower_forward(self, feats, tower):
         cv = self.convs
         h = "rpn.head."
         scales = self.extra[h + "scales"][0]
         nl = len(feats)
-        res, ctxs = {}, {}
-        for tower in ("cls_tower", "bbox_tower"):
-            t, layers = list(feats), []
-            for i in range(spec.NUM_CONVS):
-                (gw, _), (gbeta, _) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
-                c = cv["%s%s.%d" % (h, tower, 3 * i)]
-                u = [ops.conv2d(t[l], c.pc, pad=1) for l in range(nl)]
-                t2, ab = ops.groupnorm_relu_levels(u, gw, gbeta, spec.GN_GROUPS, spec.GN_EPS)
-                layers.append((t, u, ab))
-                t = t2
-            ctxs[tower] = (layers, t)
-            if tower == "cls_tower":
-                res[tower] = [ops.conv2d(t[l], cv[h + "cls_ctr"].pc, pad=1) for l in range(nl)]
-            else:
-                res[tower] = [ops.conv2d(t[l], cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE,
-                                         act_scale_dev=scales[l:l + 1]) for l in range(nl)]
-        return list(zip(res["cls_tower"], res["bbox_tower"])), ctxs
+        t, layers = list(feats), []
+        for i in range(spec.NUM_CONVS):
+            (gw, _), (gbeta, _) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
+            c = cv["%s%s.%d" % (h, tower, 3 * i)]
+            u = [ops.conv2d(t[l], c.pc, pad=1) for l in range(nl)]
+            t2, ab = ops.groupnorm_relu_levels(u, gw, gbeta, spec.GN_GROUPS, spec.GN_EPS)
+            layers.append((t, u, ab))
+            t = t2
+        if tower == "cls_tower":
+            out = [ops.conv2d(t[l], cv[h + "cls_ctr"].pc, pad=1) for l in range(nl)]
+        else:
+            out = [ops.conv2d(t[l], cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE, act_scale_dev=scales[l:l + 1])
+                   for l in range(nl)]
+        return out, (layers, t)
 
     # ------------------------------------------------------------------------------------------------ loss
     def loss_and_grads(self, head_out, gt_boxes, gt_count):
@@ -318,10 +334,11 @@ class TrainEngine(object):
     def _on_wstream(self, fn, tensors):
         if self.wstream is None:
             return fn()
+        ws = self.wstream2 if (self.wstream2 is not None and torch.cuda.current_stream() == self.s1) else self.wstream
         ev = torch.cuda.Event()
         ev.record()
-        self.wstream.wait_event(ev)
-        with torch.cuda.stream(self.wstream):
+        ws.wait_event(ev)
+        with torch.cuda.stream(ws):
             fn()
         self._keep.append(tensors)        # keep the operands alive until the side stream has been joined
 
@@ -340,26 +357,37 @@ class TrainEngine(object):
 
     def head_backward(self, feats, ctxs, pred_grads):
         """Loops: tower -> layer (last first) -> level: the weight gradient of each (shared) conv is ONE grouped launch
-        over the five FPN levels, GroupNorm+ReLU backward two launches."""
+        over the five FPN levels, GroupNorm+ReLU backward two launches.  The two towers' chains are independent until
+        their gradients w.r.t. the shared input are summed: the bbox chain runs on the second stream."""
+        nl = len(feats)
+        main = torch.cuda.current_stream()
+        if self.s1 is not None:
+            self.s1.wait_stream(main)
+            with torch.cuda.stream(self.s1):
+                d_box = self._tower_backward(ctxs, pred_grads, "bbox_tower", 1, nl)
+        else:
+            d_box = self._tower_backward(ctxs, pred_grads, "bbox_tower", 1, nl)
+        d_cls = self._tower_backward(ctxs, pred_grads, "cls_tower", 0, nl)
+        if self.s1 is not None:
+            main.wait_stream(self.s1)
+        return [ops.add_mask(d_cls[l], d_box[l]) for l in range(nl)]
+
+    def _tower_backward(self, ctxs, pred_grads, tower, gi, nl):
         cv = self.convs
         h = "rpn.head."
-        nl = len(feats)
-        d_f = [None] * nl
-        for tower, pname, gi in (("cls_tower", h + "cls_ctr", 0), ("bbox_tower", h + "bbox_pred", 1)):
-            layers, t_last = ctxs[tower]
-            pc = cv[pname]
-            dpred = [pred_grads[l][gi] for l in range(nl)]
-            self._wgrad_grouped(pc, [(t_last[l], dpred[l]) for l in range(nl)])
-            d_t = [self._dgrad(pc, dpred[l]) for l in range(nl)]
-            for i in range(spec.NUM_CONVS - 1, -1, -1):
-                (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
-                c = cv["%s%s.%d" % (h, tower, 3 * i)]
-                t_in, u, ab = layers[i]
-                du = ops.groupnorm_relu_bwd_levels(u, d_t, ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
-                self._wgrad_grouped(c, [(t_in[l], du[l]) for l in range(nl)])
-                d_t = [self._dgrad(c, du[l], res=d_f[l] if (i == 0 and d_f[l] is not None) else None) for l in range(nl)]
-            d_f = d_t
-        return d_f
+        layers, t_last = ctxs[tower]
+        pc = cv[h + ("cls_ctr" if tower == "cls_tower" else "bbox_pred")]
+        dpred = [pred_grads[l][gi] for l in range(nl)]
+        self._wgrad_grouped(pc, [(t_last[l], dpred[l]) for l in range(nl)])
+        d_t = [self._dgrad(pc, dpred[l]) for l in range(nl)]
+        for i in range(spec.NUM_CONVS - 1, -1, -1):
+            (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
+            c = cv["%s%s.%d" % (h, tower, 3 * i)]
+            t_in, u, ab = layers[i]
+            du = ops.groupnorm_relu_bwd_levels(u, d_t, ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
+            self._wgrad_grouped(c, [(t_in[l], du[l]) for l in range(nl)])
+            d_t = [self._dgrad(c, du[l]) for l in range(nl)]
+        return d_t
 
     def backbone_backward(self, ctx, dP, need_input_grad=False):
         cv, bb = self.convs, ctx["bb"]
@@ -420,35 +448,56 @@ class TrainEngine(object):
         from . import model
         self._keep = []
         self.flat_g.zero_()
+        main, s1 = torch.cuda.current_stream(), self.s1
+        side = s1 if s1 is not None else main
         batch = images.shape[0]
         shots = queries.shape[0] // batch
-        feats, tctx = self.backbone_forward("backbone.", images)
-        qfeats, qctx = self.backbone_forward("supp_backbone.", queries)
         q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0]
         rois = model.whole_image_rois(q_sizes, self.device)
-        pooled = []
-        for feat, scale in zip(qfeats, spec.POOLER_SCALES):
-            v = ops.roi_align(feat, rois, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
-            pooled.append(ops.shot_mean(v.view(v.shape[0], -1), batch))
+        # ---- forward: query backbone + pooling beside the target backbone
+        if s1 is not None:
+            s1.wait_stream(main)
+        with torch.cuda.stream(side):
+            qfeats, qctx = self.backbone_forward("supp_backbone.", queries)
+            pooled = []
+            for feat, scale in zip(qfeats, spec.POOLER_SCALES):
+                v = ops.roi_align(feat, rois, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
+                pooled.append(ops.shot_mean(v.view(v.shape[0], -1), batch))
+        feats, tctx = self.backbone_forward("backbone.", images)
+        if s1 is not None:
+            main.wait_stream(s1)
         combined = [ops.correlate(f, q) for f, q in zip(feats, pooled)]
         head_out, hctx = self.head_forward(combined)
-        if with_proposals:      # box_selector_train under no_grad (fcos.py:196-199): proposals for the second stage
-            self.proposals = model.run_proposals(head_out, images.shape[-2], images.shape[-1],
-                                                 spec.PRE_NMS_TOP_N_TRAIN, spec.POST_NMS_TOP_N_TRAIN, spec.NMS_THRESH)
+        if with_proposals:      # box_selector_train under no_grad (fcos.py:196-199): proposals for the second stage,
+            if s1 is not None:  # independent of the loss and the backward pass -> second stream
+                s1.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.proposals = model.run_proposals(head_out, images.shape[-2], images.shape[-1],
+                                                     spec.PRE_NMS_TOP_N_TRAIN, spec.POST_NMS_TOP_N_TRAIN, spec.NMS_THRESH)
+        # ---- loss + backward
         losses, pred_grads = self.loss_and_grads(head_out, gt_boxes, gt_count)
         d_comb = self.head_backward(combined, hctx, pred_grads)
         # correlation backward (generalized_rcnn.py:307-311): d feat = g * q, d q = sum_hw g * feat
         dP = [ops.correlate(g, q) for g, q in zip(d_comb, pooled)]
-        dQ = []
-        for g, feat, qf, scale in zip(d_comb, feats, qfeats, spec.POOLER_SCALES):
-            dq = ops.correlate_bwd_query(g, feat)
-            dv = ops.shot_mean_bwd(dq, shots)
-            gx = ops.roi_align_bwd(dv.view(-1, 1, 1, dv.shape[-1]), rois, qf.shape, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
-            dQ.append(ops.cast_f32(gx, self.dtype))
+        dq = [ops.correlate_bwd_query(g, feat) for g, feat in zip(d_comb, feats)]
+        if s1 is not None:
+            s1.wait_stream(main)
+        with torch.cuda.stream(side):      # query branch backward beside the target backbone's
+            dQ = []
+            for dql, qf, scale in zip(dq, qfeats, spec.POOLER_SCALES):
+                dv = ops.shot_mean_bwd(dql, shots)
+                gx = ops.roi_align_bwd(dv.view(-1, 1, 1, dv.shape[-1]), rois, qf.shape, scale, 1, 1,
+                                       spec.POOLER_SAMPLING_RATIO)
+                dQ.append(ops.cast_f32(gx, self.dtype))
+            self.backbone_backward(qctx, dQ)
         self.backbone_backward(tctx, dP)
-        self.backbone_backward(qctx, dQ)
+        if s1 is not None:
+            main.wait_stream(s1)
         if self.wstream is not None:
-            torch.cuda.current_stream().wait_stream(self.wstream)
+            main.wait_stream(self.wstream)
+        if self.wstream2 is not None:
+            main.wait_stream(self.wstream2)
+        self._keep.append((dq, dP, d_comb, pred_grads))
         return losses
 
     def reduce_gradients(self):
