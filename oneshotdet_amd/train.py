@@ -570,6 +570,31 @@ class TrainEngine(object):
         return self._static_losses
 
     # ------------------------------------------------------------------------------------------------ state
+    def state_dict(self):
+        """The reference's state_dict (same names, OIHW shapes) with the current fp32 master weights: what
+        `DetectronCheckpointer.save` (utils/checkpoint.py:35-52) would write for the hot-path modules.  Frozen tensors
+        (stem, layer1, every FrozenBN buffer) are returned unchanged."""
+        out = {k: v.clone() for k, v in self._frozen_sd.items()}
+        h = "rpn.head."
+        for name, c in self.convs.items():
+            if not c.trainable:
+                continue
+            w = c.w.permute(0, 3, 1, 2).contiguous()
+            if name == h + "cls_ctr":
+                out[h + "cls_logits.weight"], out[h + "centerness.weight"] = w[0:1].clone(), w[1:2].clone()
+                out[h + "cls_logits.bias"], out[h + "centerness.bias"] = c.b[0:1].clone(), c.b[1:2].clone()
+                continue
+            out[name + ".weight"] = w
+            if c.has_bias:
+                out[name + ".bias"] = c.b.clone()
+        for name, (p, _) in self.extra.items():
+            if name == h + "scales":
+                for i in range(5):
+                    out["%sscales.%d.scale" % (h, i)] = p[i:i + 1].clone()
+            else:
+                out[name] = p.clone()
+        return out
+
     def named_grads(self):
         """Reference-named gradients (OIHW) for parity tests."""
         out = {}

@@ -180,3 +180,24 @@ def test_fused_sgd_matches_torch_optim():
         a.optimizer_step()
         b.optimizer_step()
     torch.testing.assert_close(a.flat_w, b.flat_w, rtol=1e-6, atol=1e-7)
+
+
+def test_state_dict_round_trip_and_update():
+    """TrainEngine.state_dict() returns the reference's names/shapes (tests/golden/state_dict_keys.json); untouched it
+    equals the input bit for bit; after an SGD step exactly the trainable tensors have moved."""
+    import json
+    import os
+    from oneshotdet_amd import train
+    np_sd = synth.make_state_dict(spec.hot_path_shapes())
+    eng = train.TrainEngine(np_sd, dtype=torch.float32)
+    sd0 = eng.state_dict()
+    keys = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_keys.json")))["shapes"]
+    for k, shape in spec.hot_path_shapes().items():
+        assert tuple(keys[k]) == tuple(sd0[k].shape) == tuple(shape), k
+        assert np.array_equal(sd0[k].cpu().numpy(), np_sd[k]), k
+    _, img, q, gtb, cnt = _engine_and_inputs("f32")
+    eng.train_step(img, q, gtb, cnt)
+    sd1 = eng.state_dict()
+    moved = {k for k in sd0 if not torch.equal(sd0[k], sd1[k])}
+    assert moved and all(not spec.is_frozen(k) for k in moved)
+    assert {k for k in sd0 if not spec.is_frozen(k)} - moved == set()
