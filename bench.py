@@ -34,6 +34,7 @@ class ConvTimer(object):
         self.records = []
         self.flops = 0.0
         self.launches = 0
+        self.labels = []         # (kind, M, Cout, K) per record, for --layer-table
 
     def install(self, ops):
         self._orig = ops.conv2d
@@ -48,6 +49,7 @@ class ConvTimer(object):
             m = y.shape[0] * y.shape[1] * y.shape[2]
             k_real = 147 if pc.stem else pc.r * pc.s * getattr(pc, "cin_real", pc.cin_k)
             timer.records.append((s, e))
+            timer.labels.append(("conv%dx%d" % (pc.r, pc.s), m, pc.cout, k_real, 2.0 * m * pc.cout * k_real))
             timer.flops += 2.0 * m * pc.cout * k_real
             timer.launches += 1
             return y
@@ -57,7 +59,20 @@ class ConvTimer(object):
         ops.conv2d = self._orig
 
     def reset(self):
-        self.records, self.flops, self.launches = [], 0.0, 0
+        self.records, self.flops, self.launches, self.labels = [], 0.0, 0, []
+
+    def layer_table(self, steps):
+        """Per-shape totals of the bracketed launches: rows (kind, M, Cout, K, launches/step, us/launch, TFLOP/s, ms/step)."""
+        ov = self.bracket_overhead_ms()
+        agg = {}
+        for (s, e), lab in zip(self.records, self.labels):
+            a = agg.setdefault(lab[:4], [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += s.elapsed_time(e) - ov
+            a[2] += lab[4]
+        rows = [(k[0], k[1], k[2], k[3], v[0] / steps, v[1] * 1e3 / v[0], v[2] / (v[1] * 1e-3) / 1e12, v[1] / steps)
+                for k, v in agg.items()]
+        return sorted(rows, key=lambda r: -r[7])
 
     def total_ms(self):
         return sum(s.elapsed_time(e) for s, e in self.records) - self.bracket_overhead_ms() * len(self.records)
@@ -199,7 +214,9 @@ class TrainTimer(ConvTimer):
             timer._orig_w(x, dy, dw, r, s, stride, pad, cout, scale=scale, db=db)
             b.record()
             timer.records.append((a, b))
-            timer.flops += 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * cout * x.shape[-1] * r * s
+            fl = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * cout * x.shape[-1] * r * s
+            timer.labels.append(("wgrad%dx%d" % (r, s), dy.shape[0] * dy.shape[1] * dy.shape[2], cout, x.shape[-1] * r * s, fl))
+            timer.flops += fl
             timer.launches += 1
         ops.conv2d_wgrad = timed_wgrad
         self._orig_g = ops.conv2d_wgrad_grouped
@@ -210,8 +227,10 @@ class TrainTimer(ConvTimer):
             timer._orig_g(pairs, dw, r, s, stride, pad, cout, scale=scale, db=db)
             b.record()
             timer.records.append((a, b))
-            for x, dy in pairs:
-                timer.flops += 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * cout * x.shape[-1] * r * s
+            mm = sum(dy.shape[0] * dy.shape[1] * dy.shape[2] for x, dy in pairs)
+            fl = 2.0 * mm * cout * pairs[0][0].shape[-1] * r * s
+            timer.labels.append(("wgrad%dx%d_grouped" % (r, s), mm, cout, pairs[0][0].shape[-1] * r * s, fl))
+            timer.flops += fl
             timer.launches += 1
         ops.conv2d_wgrad_grouped = timed_grouped
 
@@ -248,6 +267,12 @@ def main_train(args, rank, world):
     with ops.tuning():
         eng.forward_backward(images, queries, gt_boxes, gt_count)
     torch.cuda.synchronize()
+    if os.environ.get("OSD_DUMP_ALGOS") and rank == 0:
+        with open(os.environ["OSD_DUMP_ALGOS"], "w") as f:
+            for k, a in ops.WGRAD_ALGO_CACHE.items():
+                f.write("wgrad %s -> variant %d target_code %d\n" % (k, (a - 1) & 3, (a - 1) >> 2))
+            for k, a in ops.ALGO_CACHE.items():
+                f.write("conv %s -> %d\n" % (k, a))
 
     launch = "eager, 4 streams (main, query/bbox branch, 2 x weight gradients)"
     step = lambda: eng.train_step(images, queries, gt_boxes, gt_count)     # noqa: E731
@@ -285,6 +310,11 @@ def main_train(args, rank, world):
                     "conv_ms_per_step": round(conv_ms / nst, 3),
                     "measured": "HIP events per launch (minus the %.1f us empty-bracket overhead), %d eager steps after "
                                 "the timed region" % (ConvTimer.bracket_overhead_ms() * 1e3, nst)}
+        if args.layer_table and rank == 0:
+            with open(args.layer_table, "w") as f:
+                f.write("| kind | M (pixels) | Cout | K | launches/step | us/launch | TFLOP/s | ms/step |\n|---|---|---|---|---|---|---|---|\n")
+                for r in timer.layer_table(nst):
+                    f.write("| %s | %d | %d | %d | %.0f | %.1f | %.0f | %.3f |\n" % r)
         timer.uninstall(ops)
     if rank == 0:
         workload = ("BASELINE.json configs[2]: bs=%d/GPU, 800x1024 target + 127x127 query, %s MFMA convs, forward "
@@ -309,6 +339,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-timing", action="store_true")
+    ap.add_argument("--layer-table", default="", help="train mode: write the per-shape conv table (markdown) here")
     ap.add_argument("--no-graph", action="store_true", help="forward mode: eager launches instead of hipGraph replay")
     ap.add_argument("--graph", action="store_true",
                     help="train mode: replay the step from hipGraphs (measured slower than eager 2-stream launches: the "

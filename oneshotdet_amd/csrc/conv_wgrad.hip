@@ -346,9 +346,19 @@ static int wgrad_launch(const osd_conv_desc* d, int n_seg, const void* const* xs
     p.seg[i].M = (int)M;
     Mtot += M;
   }
-  // pixel splits: enough workgroups to fill the chip (~1536), at least 128 pixels each, shared out over the segments
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("OSD_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; }
+  // pixel splits: enough workgroups to fill the chip, at least 128 pixels each, shared out over the segments.
+  // d->algo (0 = default) = 1 + variant + 4 * target_code: per-shape choice made by the host-side tuner.
+  static int env_target = -1, env_variant = -1;
+  if (env_target < 0) { const char* e = getenv("OSD_WGRAD_BLOCKS"); env_target = e ? atoi(e) : 512; }
+  if (env_variant < 0) { const char* e = getenv("OSD_WGRAD_VARIANT"); env_variant = e ? atoi(e) : 0; }
+  static const int kTargets[8] = {512, 256, 128, 64, 1024, 768, 384, 32};
+  int target = env_target, variant = env_variant;
+  if (d->algo > 0) {
+    const int a = d->algo - 1;
+    if (a >= 32) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d->algo);
+    variant = a & 3;
+    target = kTargets[a >> 2];
+  }
   long long want = (target + tiles - 1) / tiles;
   const long long max_splits = (Mtot + 127) / 128;
   if (want > max_splits) want = max_splits;
@@ -366,8 +376,7 @@ static int wgrad_launch(const osd_conv_desc* d, int n_seg, const void* const* xs
   p.splits = total_splits;
   const long long nblocks = tiles * total_splits;
   if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
-  static int variant = -1;   // OSD_WGRAD_VARIANT: 0 = 32 px x 3 stages, 1 = 64 px x 2, 2 = 32 px x 4, 3 = 64 px x 3
-  if (variant < 0) { const char* e = getenv("OSD_WGRAD_VARIANT"); variant = e ? atoi(e) : 0; }
+  // variant: 0 = 32 px x 3 stages, 1 = 64 px x 2, 2 = 32 px x 4, 3 = 64 px x 3 (bf16; fp32 always 32 x 3)
 #define OSD_WG_LAUNCH(TT, BK, NS)                                                                                   \
   do {                                                                                                               \
     auto kern = conv_wgrad_kernel<TT, BK, NS>;                                                                       \

@@ -371,12 +371,52 @@ def pack_conv_master_dgrad(w_orsi, scale, dtype):
     return wp
 
 
+WGRAD_ALGO_CACHE = {}
+
+
+def wgrad_algo_candidates(dtype):
+    """(variant, split-target code) pairs of osd_conv2d_wgrad's algo field; fp32 has one variant."""
+    variants = (0, 1, 2, 3) if dtype == OSD_BF16 else (0,)
+    return [1 + v + 4 * t for t in (0, 1, 2, 3, 4) for v in variants]
+
+
+def _tune_wgrad(key, d, launch, dw, db):
+    """Time every candidate on scratch outputs (the kernel accumulates) and cache the winner for this shape."""
+    sdw = torch.empty_like(dw)
+    sdb = None if db is None else torch.empty_like(db)
+    best, best_t = 0, float("inf")
+    for algo in wgrad_algo_candidates(d.dtype):
+        d.algo = algo
+        launch(sdw, sdb)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(3):
+            launch(sdw, sdb)
+        ev[1].record()
+        torch.cuda.synchronize()
+        t = ev[0].elapsed_time(ev[1])
+        if t < best_t:
+            best, best_t = algo, t
+    WGRAD_ALGO_CACHE[key] = best
+    return best
+
+
 def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None, db=None):
     """dw_packed [cout][r][s][cin] fp32 += wgrad(x NHWC, dy NHWC [N,Ho,Wo,>=cout]); db [cout] fp32 += sum_m dy (optional)."""
     _chk_dev(x, dy, dw_packed)
     d = _conv_desc(x.shape, _dt(x), cout, r, s, stride, pad, dy.shape[-1])
     assert (dy.shape[1], dy.shape[2]) == (d.ho, d.wo), (dy.shape, d.ho, d.wo)
-    _lib.call("osd_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(scale), _ptr(dw_packed), _ptr(db), _stream())
+    st = _stream()
+
+    def launch(dw, dbias):
+        _lib.call("osd_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(scale), _ptr(dw), _ptr(dbias), st)
+    key = (d.dtype, tuple(x.shape), cout, r, s, stride, pad, dy.shape[-1], db is not None)
+    algo = WGRAD_ALGO_CACHE.get(key)
+    if algo is None:
+        algo = _tune_wgrad(key, d, launch, dw_packed, db) if _TUNING[0] else 0
+    d.algo = algo
+    launch(dw_packed, db)
 
 
 def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, db=None):
@@ -389,8 +429,16 @@ def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, 
     ns = (C.c_int32 * k)(*[x.shape[0] for x, _ in pairs])
     hs = (C.c_int32 * k)(*[x.shape[1] for x, _ in pairs])
     ws = (C.c_int32 * k)(*[x.shape[2] for x, _ in pairs])
-    _lib.call("osd_conv2d_wgrad_grouped", C.byref(d), k, xs, dys, ns, hs, ws, _ptr(scale), _ptr(dw_packed), _ptr(db),
-              _stream())
+    st = _stream()
+
+    def launch(dw, dbias):
+        _lib.call("osd_conv2d_wgrad_grouped", C.byref(d), k, xs, dys, ns, hs, ws, _ptr(scale), _ptr(dw), _ptr(dbias), st)
+    key = (d.dtype, tuple(tuple(x.shape) for x, _ in pairs), cout, r, s, stride, pad, dy0.shape[-1], db is not None)
+    algo = WGRAD_ALGO_CACHE.get(key)
+    if algo is None:
+        algo = _tune_wgrad(key, d, launch, dw_packed, db) if _TUNING[0] else 0
+    d.algo = algo
+    launch(dw_packed, db)
 
 
 def bias_grad(dy, db, c):

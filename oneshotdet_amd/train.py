@@ -579,7 +579,7 @@ class TrainEngine(object):
         for name, c in self.convs.items():
             if not c.trainable:
                 continue
-            w = c.w.permute(0, 3, 1, 2).contiguous()
+            w = c.w.permute(0, 3, 1, 2).clone(memory_format=torch.contiguous_format)   # never a view of the master
             if name == h + "cls_ctr":
                 out[h + "cls_logits.weight"], out[h + "centerness.weight"] = w[0:1].clone(), w[1:2].clone()
                 out[h + "cls_logits.bias"], out[h + "centerness.bias"] = c.b[0:1].clone(), c.b[1:2].clone()
