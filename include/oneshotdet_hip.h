@@ -245,7 +245,8 @@ int osd_sgd_momentum_multi(const void* table, const int32_t* block_entry, int n_
 /* GroupNorm + ReLU of one tower layer over ALL FPN levels (separate tensors sharing gamma/beta) in two launches, and
  * its backward in two launches: statistics per (level, image, slab), finalised inside the apply kernels.
  * xs/ys/us/dts/dus: HOST arrays of n_levels device pointers to [n][hw_l][c] tensors; hws: HOST array;
- * ab [n_levels][2][n][c] fp32 (written by fwd, read by bwd); ws n_levels*n*OSD_GN_SPLITS*groups*2 floats. */
+ * ab [n_levels][2][n][c] fp32 (written by fwd, read by bwd); ws: fwd n_levels*n*OSD_GN_SPLITS*groups*2 floats,
+ * bwd n_levels*n*OSD_GN_SPLITS*(groups*2 + 2*c) floats (group sums + per-slab d gamma / d beta partials). */
 int osd_groupnorm_relu_fwd_levels(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
                                   const float* gamma, const float* beta, float* ab, float* ws, int n, int c, int groups,
                                   float eps, int dtype, void* stream);

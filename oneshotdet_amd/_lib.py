@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liboneshotdet_hip.so")
+# OSD_LIB_PATH: another build of the SAME library (A/B timing of two kernel versions on one box); never a fallback
+LIB_PATH = os.environ.get("OSD_LIB_PATH") or os.path.join(_HERE, "lib", "liboneshotdet_hip.so")
 
 OSD_F32, OSD_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_EXP_SCALE = 0, 1, 2

@@ -793,23 +793,38 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
     bt[e] = beta[cc * E + e];
     dg[e] = 0.f; db[e] = 0.f;
   }
-  if (pl < lanes)
-    for (int p = p0 + pl; p < p1; p += lanes) {
-      Chunk<T> uu, gg;
-      const size_t off = ((size_t)img * hw + p) * c + cc * E;
-      uu.load(u + off);
-      gg.load(dt + off);
+  float igm[E];
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const float z = fmaf(uu.v[e], av[e], bv[e]);
-        const float dz = z > 0.f ? gg.v[e] : 0.f;
-        const float xhat = (z - bt[e]) / gm[e];
-        s1 += dz * gm[e];
-        s2 += dz * gm[e] * xhat;
-        dg[e] += dz * xhat;
-        db[e] += dz;
+  for (int e = 0; e < E; ++e) igm[e] = 1.f / gm[e];
+  if (pl < lanes) {
+    constexpr int U = 4;          // pixels in flight per thread: 2 * U 16-byte loads issued before the arithmetic
+    for (int p = p0 + pl; p < p1; p += U * lanes) {
+      Chunk<T> uu[U], gg[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int pk = p + k * lanes;
+        if (pk < p1) {
+          const size_t off = ((size_t)img * hw + pk) * c + cc * E;
+          uu[k].load(u + off);
+          gg[k].load(dt + off);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        if (p + k * lanes >= p1) break;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float z = fmaf(uu[k].v[e], av[e], bv[e]);
+          const float dz = z > 0.f ? gg[k].v[e] : 0.f;
+          const float xhat = (z - bt[e]) * igm[e];
+          s1 += dz * gm[e];
+          s2 += dz * gm[e] * xhat;
+          dg[e] += dz * xhat;
+          db[e] += dz;
+        }
       }
     }
+  }
   __shared__ float red[2][256];
   __shared__ float redc[2][512];
   red[0][threadIdx.x] = s1;
@@ -844,15 +859,20 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
     }
   }
   __syncthreads();
-  if (threadIdx.x < c && p0 < p1) {
-    atomicAdd(dgamma + threadIdx.x, redc[0][threadIdx.x]);
-    atomicAdd(dbeta + threadIdx.x, redc[1][threadIdx.x]);
+  // per-(level, image, slab) partial d gamma / d beta: plain stores (2,560 workgroups adding atomically into the same
+  // 2 x c words ran at the contended-atomic rate and cost more than the whole data pass); summed by the apply kernel
+  float* pw = ws + (size_t)gridDim.z * n * kGnSplits * groups * 2 +
+              ((((size_t)lvl * n + img) * kGnSplits + split) * 2) * c;
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+    pw[ch] = redc[0][ch];
+    pw[c + ch] = redc[1][ch];
   }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const float* __restrict__ ab, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, const float* __restrict__ ws, int n,
+                                                            const float* __restrict__ beta, const float* __restrict__ ws,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int n,
                                                             int c, int groups) {
   constexpr int E = Chunk<T>::N;
   const int lvl = blockIdx.z, img = blockIdx.y;
@@ -869,6 +889,19 @@ __global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const fl
     ssum[0][g] = s1;
     ssum[1][g] = s2;
   }
+  if (blockIdx.x == 0) {     // one workgroup per (level, image) folds the slabs' d gamma / d beta partials
+    const float* pw = ws + (size_t)gridDim.z * n * kGnSplits * groups * 2 + (((size_t)lvl * n + img) * kGnSplits * 2) * c;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll 16
+      for (int k = 0; k < kGnSplits; ++k) {      // 32 independent loads in flight per thread
+        t1 += pw[(size_t)k * 2 * c + ch];
+        t2 += pw[(size_t)k * 2 * c + c + ch];
+      }
+      atomicAdd(dgamma + ch, t1);
+      atomicAdd(dbeta + ch, t2);
+    }
+  }
   __syncthreads();
   const T* u = reinterpret_cast<const T*>(L.x[lvl]);
   const T* dt = reinterpret_cast<const T*>(L.dy[lvl]);
@@ -878,25 +911,46 @@ __global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const fl
   const long long chunks = (long long)hw * cch;
   const long long per = (chunks + gridDim.x - 1) / gridDim.x;
   const long long i0 = blockIdx.x * per, i1 = min(chunks, i0 + per);
-  for (long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-    const int cc = (int)(i % cch);
-    const int g = (cc * E) / cpg;
-    const float s1 = ssum[0][g], s2 = ssum[1][g];
-    Chunk<T> uu, gg;
-    uu.load(u + (size_t)img * hw * c + i * E);
-    gg.load(dt + (size_t)img * hw * c + i * E);
+  // blockDim.x is a multiple of cch, so a thread's channel chunk never changes: per-channel constants live in registers
+  const int cc = (int)((i0 + threadIdx.x) % cch);
+  const int g = (cc * E) / cpg;
+  const float c1 = ssum[0][g] * inv_m, c2 = ssum[1][g] * inv_m;
+  float av[E], bv[E], gm[E], bt[E], igm[E], rstd[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int ch = cc * E + e;
-      const float av = ab[(((size_t)lvl * 2 + 0) * n + img) * c + ch], bv = ab[(((size_t)lvl * 2 + 1) * n + img) * c + ch];
-      const float gm = gamma[ch];
-      const float z = fmaf(uu.v[e], av, bv);
-      const float dz = z > 0.f ? gg.v[e] : 0.f;
-      const float xhat = (z - beta[ch]) / gm;
-      const float rstd = av / gm;
-      uu.v[e] = rstd * (dz * gm - s1 * inv_m - xhat * s2 * inv_m);
+  for (int e = 0; e < E; ++e) {
+    const int ch = cc * E + e;
+    av[e] = ab[(((size_t)lvl * 2 + 0) * n + img) * c + ch];
+    bv[e] = ab[(((size_t)lvl * 2 + 1) * n + img) * c + ch];
+    gm[e] = gamma[ch];
+    bt[e] = beta[ch];
+    igm[e] = 1.f / gm[e];
+    rstd[e] = av[e] * igm[e];
+  }
+  constexpr int U = 4;
+  const size_t base = (size_t)img * hw * c;
+  for (long long i = i0 + threadIdx.x; i < i1; i += (long long)U * blockDim.x) {
+    Chunk<T> uu[U], gg[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const long long ik = i + (long long)k * blockDim.x;
+      if (ik < i1) {
+        uu[k].load(u + base + ik * E);
+        gg[k].load(dt + base + ik * E);
+      }
     }
-    uu.store(du + (size_t)img * hw * c + i * E);
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const long long ik = i + (long long)k * blockDim.x;
+      if (ik >= i1) break;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float z = fmaf(uu[k].v[e], av[e], bv[e]);
+        const float dz = z > 0.f ? gg[k].v[e] : 0.f;
+        const float xhat = (z - bt[e]) * igm[e];
+        uu[k].v[e] = rstd[e] * (dz * gm[e] - c1 - xhat * c2);
+      }
+      uu[k].store(du + base + ik * E);
+    }
   }
 }
 
@@ -953,7 +1007,7 @@ extern "C" int osd_groupnorm_relu_bwd_levels(int n_levels, const void* const* us
   rc = osd_check_launch("gnl_bwd_stats");
   if (rc) return rc;
   OSD_DISPATCH_DTYPE(dtype,
-      hipLaunchKernelGGL(gnl_bwd_apply_kernel<float>, g2, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, n, c, groups),
-      hipLaunchKernelGGL(gnl_bwd_apply_kernel<__bf16>, g2, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, n, c, groups));
+      hipLaunchKernelGGL(gnl_bwd_apply_kernel<float>, g2, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups),
+      hipLaunchKernelGGL(gnl_bwd_apply_kernel<__bf16>, g2, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups));
   return osd_check_launch("gnl_bwd_apply");
 }

@@ -559,7 +559,7 @@ def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32
     k = len(us)
     dev = us[0].device
     dus = [torch.empty_like(u) for u in us]
-    ws = torch.empty((k * n * GN_SPLITS * groups * 2,), device=dev, dtype=torch.float32)
+    ws = torch.empty((k * n * GN_SPLITS * (groups * 2 + 2 * c),), device=dev, dtype=torch.float32)
     hws = (C.c_int32 * k)(*[u.shape[1] * u.shape[2] for u in us])
     _lib.call("osd_groupnorm_relu_bwd_levels", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
               _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), _stream())

@@ -49,6 +49,9 @@ class TrainEngine(object):
         # target backbone / cls tower / loss, so they run beside them and fill the tails of the large kernels
         self.s1 = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None
         self.wstream2 = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None   # weight gradients of the s1 branch
+        # training proposals feed only the (out-of-path) second stage: a chain of small kernels that must not sit in
+        # front of the bbox tower's backward on s1
+        self.pstream = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None
         self._keep = []
         sd = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state_dict.items()}
         self._frozen_sd = sd
@@ -469,9 +472,10 @@ class TrainEngine(object):
         combined = [ops.correlate(f, q) for f, q in zip(feats, pooled)]
         head_out, hctx = self.head_forward(combined)
         if with_proposals:      # box_selector_train under no_grad (fcos.py:196-199): proposals for the second stage,
-            if s1 is not None:  # independent of the loss and the backward pass -> second stream
-                s1.wait_stream(main)
-            with torch.cuda.stream(side):
+            ps = self.pstream if (self.pstream is not None and s1 is not None) else main   # independent of loss/backward
+            if ps is not main:
+                ps.wait_stream(main)
+            with torch.cuda.stream(ps):
                 self.proposals = model.run_proposals(head_out, images.shape[-2], images.shape[-1],
                                                      spec.PRE_NMS_TOP_N_TRAIN, spec.POST_NMS_TOP_N_TRAIN, spec.NMS_THRESH)
         # ---- loss + backward
@@ -497,6 +501,8 @@ class TrainEngine(object):
             main.wait_stream(self.wstream)
         if self.wstream2 is not None:
             main.wait_stream(self.wstream2)
+        if with_proposals and self.pstream is not None and s1 is not None:
+            main.wait_stream(self.pstream)
         self._keep.append((dq, dP, d_comb, pred_grads))
         return losses
 
