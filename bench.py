@@ -54,9 +54,26 @@ class ConvTimer(object):
             timer.launches += 1
             return y
         ops.conv2d = timed_conv2d
+        self._orig_cg = ops.conv2d_grouped
+
+        def timed_conv2d_grouped(xs, pc, *a, **kw):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            ys = timer._orig_cg(xs, pc, *a, **kw)
+            e.record()
+            m = sum(y.shape[0] * y.shape[1] * y.shape[2] for y in ys)
+            k_real = pc.r * pc.s * getattr(pc, "cin_real", pc.cin_k)
+            timer.records.append((s, e))
+            timer.labels.append(("conv%dx%d_grouped" % (pc.r, pc.s), m, pc.cout, k_real, 2.0 * m * pc.cout * k_real))
+            timer.flops += 2.0 * m * pc.cout * k_real
+            timer.launches += 1
+            return ys
+        ops.conv2d_grouped = timed_conv2d_grouped
 
     def uninstall(self, ops):
         ops.conv2d = self._orig
+        ops.conv2d_grouped = self._orig_cg
 
     def reset(self):
         self.records, self.flops, self.launches, self.labels = [], 0.0, 0, []

@@ -81,6 +81,17 @@ int osd_conv_algo_count(void);
 int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void* w, const float* bias, const void* res,
                    const void* mask, const float* act_scale_dev, const void* reserved, void* y, void* stream);
 
+/* The same convolution applied to n_seg <= 6 dense NHWC tensors of different batch / spatial size in ONE launch: the
+ * FPN levels that share an FCOS tower or prediction conv (fcos.py:83-99 loops `for l, feature in enumerate(x)` over
+ * the same modules).  d gives dtype, cin, cout, r, s, strides, pads, w_rows, out_stride, res_mode (NONE or SAME),
+ * res_stride, act, act_scale, algo (LDS-DMA algorithms 1..32 only); xs / ys / residuals / masks / act_scale_devs are
+ * HOST arrays of n_seg device pointers (the last three nullable as a whole; act_scale_devs[l] = the level's Scale),
+ * ns / hs / ws HOST arrays with each tensor's batch, height and width. */
+int osd_conv2d_fwd_grouped(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys,
+                           const void* const* residuals, const void* const* masks, const float* const* act_scale_devs,
+                           const int32_t* ns, const int32_t* hs, const int32_t* ws, const void* w, const float* bias,
+                           void* stream);
+
 /* OIHW fp32 conv weight (+ optional per-Cout scale = FrozenBN weight*rsqrt(var), layers/batch_norm.py:20) ->
  * packed [w_rows][r][s][cin_pad] rows of `dtype`, zero padded. */
 int osd_pack_conv_weight(const float* w_oihw, const float* scale, void* dst, int cout, int cin, int r, int s,

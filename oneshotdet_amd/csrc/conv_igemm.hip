@@ -341,7 +341,7 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
   p.act = d->act; p.act_scale = d->act_scale; p.act_scale_dev = act_scale_dev; p.relu_in = d->relu_in;
   const long long M = (long long)d->n * d->ho * d->wo;
   if (M <= 0 || M > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad M");
-  p.M = (int)M; p.tilesM = p.tilesN = p.KT = 0;
+  p.M = (int)M; p.tilesM = p.tilesN = p.KT = 0; p.n_seg = 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int tile = choose_tile(p.M, p.Cout);
   static int impl_env = -1;   // OSD_CONV_IMPL=regstage selects the first-generation register-staged kernel (A/B testing)
@@ -370,4 +370,68 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
     return dispatch_tile<__bf16, 64>(tile, p, s);
   }
   return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad dtype %d", d->dtype);
+}
+
+// One launch over n_seg (x, y) pairs that share weights, bias and conv geometry but differ in batch / spatial size: the
+// five FPN levels of an FCOS tower conv (fcos.py:83-99 applies the same modules to every level).  LDS-DMA kernel only.
+extern "C" int osd_conv2d_fwd_grouped(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys,
+                                      const void* const* residuals, const void* const* masks,
+                                      const float* const* act_scale_devs, const int32_t* ns, const int32_t* hs,
+                                      const int32_t* ws, const void* w, const float* bias, void* stream) {
+  if (!d || !xs || !ys || !ns || !hs || !ws || !w || !bias || n_seg < 1 || n_seg > kConvMaxSeg)
+    return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad arguments (1..%d segments)", kConvMaxSeg);
+  if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad dtype %d", d->dtype);
+  if (d->gn_in || d->relu_in) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: input prologues not supported");
+  if (d->cout % 4 != 0 || d->out_stride % 4 != 0)
+    return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: cout/out_stride must be multiples of 4");
+  if (d->res_mode != OSD_RES_NONE && d->res_mode != OSD_RES_SAME)
+    return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: only the same-size residual is supported");
+  if (d->res_mode == OSD_RES_SAME && (!residuals || d->res_stride % 4 != 0))
+    return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: residual requested without residual tensors");
+  if (d->w_rows < d->cout) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: w_rows < cout");
+  const int epc = d->dtype == OSD_BF16 ? 8 : 4;
+  if (d->cin % epc) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: cin must keep 16-byte alignment");
+  ConvKParams p;
+  p.w = w; p.bias = bias;
+  p.Cin = d->cin; p.sW = d->cin; p.Cout = d->cout;
+  p.R = d->r; p.S = d->s; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
+  p.w_rows = d->w_rows; p.Ktot = d->r * d->s * d->cin; p.out_stride = d->out_stride;
+  p.res_mode = d->res_mode; p.res_h = 0; p.res_w = 0; p.res_stride = d->res_stride;
+  p.act = d->act; p.act_scale = d->act_scale; p.act_scale_dev = nullptr; p.relu_in = 0;
+  p.tilesM = p.tilesN = p.KT = 0;
+  p.n_seg = n_seg;
+  long long mtot = 0;
+  for (int i = 0; i < kConvMaxSeg; ++i) {
+    const int j = i < n_seg ? i : 0;
+    ConvSeg& sg = p.seg[i];
+    if (!xs[j] || !ys[j] || ns[j] <= 0 || hs[j] <= 0 || ws[j] <= 0)
+      return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad segment %d", j);
+    sg.x = xs[j]; sg.y = ys[j];
+    sg.res = d->res_mode == OSD_RES_SAME ? residuals[j] : nullptr;
+    if (d->res_mode == OSD_RES_SAME && !sg.res) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: null residual %d", j);
+    sg.mask = masks ? masks[j] : nullptr;
+    sg.act_scale_dev = act_scale_devs ? act_scale_devs[j] : nullptr;
+    sg.H = hs[j]; sg.W = ws[j];
+    sg.Ho = (hs[j] + 2 * d->pad_h - d->r) / d->stride_h + 1;
+    sg.Wo = (ws[j] + 2 * d->pad_w - d->s) / d->stride_w + 1;
+    const long long M = (long long)ns[j] * sg.Ho * sg.Wo;
+    if (sg.Ho <= 0 || sg.Wo <= 0 || M > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad M in segment %d", j);
+    sg.M = (int)M; sg.sH = ws[j] * d->cin; sg.sN = hs[j] * ws[j] * d->cin; sg.tile_begin = 0;
+    if (i < n_seg) mtot += M;
+  }
+  if (mtot > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: too many pixels");
+  // single-problem fields mirror segment 0 (unused by the kernel when n_seg > 0)
+  p.x = p.seg[0].x; p.y = p.seg[0].y; p.res = p.seg[0].res; p.mask = p.seg[0].mask;
+  p.H = p.seg[0].H; p.W = p.seg[0].W; p.Ho = p.seg[0].Ho; p.Wo = p.seg[0].Wo; p.HoWo = p.Ho * p.Wo;
+  p.sN = p.seg[0].sN; p.sH = p.seg[0].sH; p.M = (int)mtot;
+  int tile = choose_tile((int)mtot, p.Cout), variant = 0;
+  if (d->algo > 0) {
+    const int a = d->algo - 1;
+    if (a >= 32) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d is not an LDS-DMA algorithm", d->algo);
+    variant = (a >> 3) & 3;
+    tile = a & 7;
+    if (variant == 3 || tile > 4) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d not built", d->algo);
+    if (tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: skinny tile on a wide conv");
+  }
+  return osd_conv_dma_dispatch(d->dtype, tile, variant, p, reinterpret_cast<hipStream_t>(stream));
 }

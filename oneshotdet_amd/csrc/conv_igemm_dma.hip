@@ -13,6 +13,7 @@
 #include "osd_common.h"
 #include "conv_params.h"
 #include <type_traits>
+#include <cstddef>
 #ifndef OSD_DMA_FRONT
 #define OSD_DMA_FRONT 1   // issue the next stage's DMA in the first half of the MFMA groups (more time to land)
 #endif
@@ -56,6 +57,7 @@ __device__ __forceinline__ uint4 relu_frag(uint4 v, __bf16) {
 
 template <typename T, int BM, int BN, int KB, int WM, int WN, int NST, bool RELU_IN>
 __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
+  // p lives in the kernarg segment; the per-segment fields are read through the q_* locals below
   constexpr int NWV = WM * WN;            // waves per workgroup: 4 (256 threads) or 8 (512 threads, the 256x256 tile)
   constexpr int CH = KB / 16;
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -85,10 +87,34 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_n = t % p.tilesN, tile_m = t / p.tilesN;
+  const int tile_n = t % p.tilesN;
+  int tile_m = t / p.tilesN;
+  // grouped launch: the pixel tile selects its (x, y) pair; everything per-pair is uniform (SGPRs)
+  const void* q_x = p.x; void* q_y = p.y; const void* q_res = p.res; const void* q_mask = p.mask;
+  const float* q_scale_dev = p.act_scale_dev;
+  int q_H = p.H, q_W = p.W, q_Ho = p.Ho, q_Wo = p.Wo, q_M = p.M, q_sN = p.sN, q_sH = p.sH;
+  if (p.n_seg > 0) {
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < kConvMaxSeg; ++i)
+      if (i < p.n_seg && tile_m >= p.seg[i].tile_begin) si = i;
+    // read the chosen entry straight from the kernarg segment (constant address space, scalar loads): indexing the
+    // by-value struct dynamically would make the compiler copy all of it to scratch
+    typedef const __attribute__((address_space(4))) char* kptr;
+    kptr base = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ConvKParams, seg) + si * (int)sizeof(ConvSeg);
+#define OSD_KSEG(type, field) (*reinterpret_cast<const __attribute__((address_space(4))) type*>(base + offsetof(ConvSeg, field)))
+    typedef unsigned long long u64;
+    q_x = (const void*)OSD_KSEG(u64, x); q_y = (void*)OSD_KSEG(u64, y); q_res = (const void*)OSD_KSEG(u64, res);
+    q_mask = (const void*)OSD_KSEG(u64, mask); q_scale_dev = (const float*)OSD_KSEG(u64, act_scale_dev);
+    q_H = OSD_KSEG(int, H); q_W = OSD_KSEG(int, W); q_Ho = OSD_KSEG(int, Ho); q_Wo = OSD_KSEG(int, Wo);
+    q_M = OSD_KSEG(int, M); q_sN = OSD_KSEG(int, sN); q_sH = OSD_KSEG(int, sH);
+    tile_m -= OSD_KSEG(int, tile_begin);
+#undef OSD_KSEG
+  }
+  const int q_HoWo = q_Ho * q_Wo;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ xg = reinterpret_cast<const T*>(q_x);
   const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
   const T* zero = reinterpret_cast<const T*>(g_zero_page) + (lane & 15) * EPC;
 
@@ -103,12 +129,12 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
     a_base[i] = zero;
     a_hi0[i] = -0x40000000;
     a_wi0[i] = 0;
-    if (m < p.M) {
-      const int n_img = m / p.HoWo;
-      const int rem = m - n_img * p.HoWo;
-      const int ho = rem / p.Wo;
-      const int wo = rem - ho * p.Wo;
-      a_base[i] = xg + (size_t)n_img * p.sN + (lpos ^ swz_g<KB>(row)) * EPC;
+    if (m < q_M) {
+      const int n_img = m / q_HoWo;
+      const int rem = m - n_img * q_HoWo;
+      const int ho = rem / q_Wo;
+      const int wo = rem - ho * q_Wo;
+      a_base[i] = xg + (size_t)n_img * q_sN + (lpos ^ swz_g<KB>(row)) * EPC;
       a_hi0[i] = ho * p.sh - p.ph;
       a_wi0[i] = wo * p.sw - p.pw;
     }
@@ -133,8 +159,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
     const unsigned ws = xs + BM * KB;
     if (j < PA) {
       const int hi = a_hi0[j] + kr, wi = a_wi0[j] + ks;
-      const bool ok = ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
-      const T* src = ok ? a_base[j] + (hi * p.sH + wi * p.sW + kc) : zero;
+      const bool ok = ((unsigned)hi < (unsigned)q_H) && ((unsigned)wi < (unsigned)q_W);
+      const T* src = ok ? a_base[j] + (hi * q_sH + wi * p.sW + kc) : zero;
       dma16(src, xs + (wave * PA + j) * 1024);
     } else {
       const int i = j - PA;
@@ -242,8 +268,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
   // pixel tiles) and writes NHWC runs of TN*16 channels with 16-byte-per-lane accesses; all residual loads of a pass
   // are issued before any arithmetic so ~8 x 16 B per lane are in flight (the K=64 convs are HBM-bound here) ----
   __syncthreads();
-  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
-  const T* __restrict__ rg = reinterpret_cast<const T*>(p.res);
+  T* __restrict__ yg = reinterpret_cast<T*>(q_y);
+  const T* __restrict__ rg = reinterpret_cast<const T*>(q_res);
   constexpr int WC = TN * 16;                    // channels of a wave tile
   constexpr int CSW = WC * 4 + 16;               // staging row stride (bytes); +16 keeps ds_write_b128 conflict free
   constexpr int NPASS = TM >= 8 ? TM / 2 : (TM >= 2 ? 2 : 1);
@@ -275,7 +301,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
       const int idx = it * 64 + lane;
       const int row = idx / CPR, cc = idx % CPR;
       const int m = mbase + row, c = cbase + cc * EPC;
-      live[it] = (m < p.M) && (c < p.Cout);
+      live[it] = (m < q_M) && (c < p.Cout);
       nval[it] = min(EPC, p.Cout - c);
       ooff[it] = (size_t)m * p.out_stride + c;
 #pragma unroll
@@ -285,9 +311,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
         if (p.res_mode == OSD_RES_SAME) {
           res_off = (size_t)m * p.res_stride + c;
         } else {
-          const int n_img = m / p.HoWo;
-          const int rem = m - n_img * p.HoWo;
-          const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
+          const int n_img = m / q_HoWo;
+          const int rem = m - n_img * q_HoWo;
+          const int ho = rem / q_Wo, wo = rem - (rem / q_Wo) * q_Wo;
           res_off = ((size_t)(n_img * p.res_h + (ho >> 1)) * p.res_w + (wo >> 1)) * p.res_stride + c;
         }
         if constexpr (sizeof(T) == 2) {
@@ -325,8 +351,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
         v[it][e + 2] = (a4[2] + b4.z) + v[it][e + 2];
         v[it][e + 3] = (a4[3] + b4.w) + v[it][e + 3];
       }
-      if (p.mask) {     // ReLU backward of the producer layer: zero where its forward output was not positive
-        const T* mk = reinterpret_cast<const T*>(p.mask) + ooff[it];
+      if (q_mask) {     // ReLU backward of the producer layer: zero where its forward output was not positive
+        const T* mk = reinterpret_cast<const T*>(q_mask) + ooff[it];
         if constexpr (sizeof(T) == 2) {
           if (vec_ok && nval[it] == EPC) {
             const bf16x8 m8 = *reinterpret_cast<const bf16x8*>(mk);
@@ -346,7 +372,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
         for (int e = 0; e < EPC; ++e) v[it][e] = fmaxf(v[it][e], 0.f);
       } else if (p.act == OSD_ACT_EXP_SCALE) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[it][e] = expf(v[it][e] * (p.act_scale_dev ? *p.act_scale_dev : p.act_scale));
+        for (int e = 0; e < EPC; ++e) v[it][e] = expf(v[it][e] * (q_scale_dev ? *q_scale_dev : p.act_scale));
       }
       T* dst = yg + ooff[it];
       if constexpr (sizeof(T) == 2) {
@@ -374,6 +400,13 @@ template <typename T, int BM, int BN, int KB, int WM, int WN, int NST, bool RELU
 int launch_dma(const ConvKParams& pin, hipStream_t stream) {
   ConvKParams p = pin;
   p.tilesM = cdiv(p.M, BM);
+  if (p.n_seg > 0) {
+    p.tilesM = 0;
+    for (int i = 0; i < p.n_seg; ++i) {
+      p.seg[i].tile_begin = p.tilesM;
+      p.tilesM += cdiv(p.seg[i].M, BM);
+    }
+  }
   p.tilesN = cdiv(p.Cout, BN);
   constexpr int BKE = KB / (int)sizeof(T);
   if (p.Cin % BKE != 0) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: cin %d not a multiple of %d", p.Cin, BKE);

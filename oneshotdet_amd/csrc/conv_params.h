@@ -2,6 +2,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// one (input, output) pair of a grouped launch: the FPN levels of a tower conv share weights, geometry differs
+constexpr int kConvMaxSeg = 6;
+struct ConvSeg {
+  const void* x;
+  void* y;
+  const void* res;
+  const void* mask;
+  const float* act_scale_dev;
+  int H, W, Ho, Wo, M, sN, sH;
+  int tile_begin;     // first pixel tile of this segment (filled by the launcher: depends on the tile height)
+};
+
 struct ConvKParams {
   const void* x;
   const void* w;
@@ -19,6 +31,8 @@ struct ConvKParams {
   const float* act_scale_dev;   // optional device scalar overriding act_scale (the learnable Scale of fcos.py:81)
   int relu_in;
   int M, tilesM, tilesN, KT;
+  int n_seg;          // 0 = single problem (fields above); > 0: seg[] overrides x/y/res/mask/act_scale_dev/H/W/Ho/Wo/M/sN/sH
+  ConvSeg seg[kConvMaxSeg];
 };
 
 // conv_igemm_dma.hip

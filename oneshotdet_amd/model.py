@@ -62,6 +62,7 @@ class HeadWeights(object):
         self.pred_box = ops.pack_conv(sd[prefix + "bbox_pred.weight"], bias=sd[prefix + "bbox_pred.bias"], dtype=dtype)
         # Scale modules (layers/scale.py): the scalar is folded into the exp epilogue; one host read at pack time
         self.scales = [float(sd["%sscales.%d.scale" % (prefix, i)].item()) for i in range(5)]
+        self.scales_dev = torch.cat([sd["%sscales.%d.scale" % (prefix, i)].reshape(1) for i in range(5)]).float().contiguous()
 
 
 def run_backbone(wts, images, dtype, return_body=False):
@@ -127,15 +128,16 @@ def run_correlate(feats, pooled):
 
 
 def run_head_tower(hw, feats, tower):
-    """One tower + its prediction conv over all levels (fcos.py:89-97): per layer one conv launch per level, then
-    GroupNorm+ReLU of all levels in two launches."""
+    """One tower + its prediction conv over all levels (fcos.py:89-97): per layer ONE grouped conv launch over the
+    levels (they share the weights), then GroupNorm+ReLU of all levels in two launches."""
     t = list(feats)
     for conv, gamma, beta in hw.towers[tower]:
-        u = [ops.conv2d(x, conv, pad=1) for x in t]
+        u = ops.conv2d_grouped(t, conv, pad=1)
         t, _ = ops.groupnorm_relu_levels(u, gamma, beta, spec.GN_GROUPS, spec.GN_EPS)
     if tower == "cls_tower":
-        return [ops.conv2d(x, hw.pred_cls_ctr, pad=1) for x in t]
-    return [ops.conv2d(x, hw.pred_box, pad=1, act=ACT_EXP_SCALE, act_scale=hw.scales[l]) for l, x in enumerate(t)]
+        return ops.conv2d_grouped(t, hw.pred_cls_ctr, pad=1)
+    return ops.conv2d_grouped(t, hw.pred_box, pad=1, act=ACT_EXP_SCALE,
+                              act_scale_devs=[hw.scales_dev[l:l + 1] for l in range(len(t))])
 
 
 def run_head(hw, feats, streams=None):

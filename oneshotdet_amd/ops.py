@@ -122,19 +122,20 @@ class tuning(object):
         _TUNING[0] = False
 
 
-def _tune(key, d, args):
+def _tune(key, d, launch):
+    """Time every candidate algorithm for this conv shape (launch() reads d.algo) and cache the fastest."""
     best, best_t = 0, float("inf")
     for algo in conv_algo_candidates(d.cout, d.relu_in, has_mask=bool(key[-1])):
         d.algo = algo
         try:
-            _lib.call("osd_conv2d_fwd", C.byref(d), *args)
+            launch()
         except _lib.OsdError:
             continue
         torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         ev[0].record()
         for _ in range(3):
-            _lib.call("osd_conv2d_fwd", C.byref(d), *args)
+            launch()
         ev[1].record()
         torch.cuda.synchronize()
         t = ev[0].elapsed_time(ev[1])
@@ -186,10 +187,55 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
                mask is not None)
         algo = ALGO_CACHE.get(key)
         if algo is None:
-            algo = _tune(key, d, args) if _TUNING[0] else 0
+            algo = _tune(key, d, lambda: _lib.call("osd_conv2d_fwd", C.byref(d), *args)) if _TUNING[0] else 0
     d.algo = algo
     _lib.call("osd_conv2d_fwd", C.byref(d), *args)
     return out
+
+
+def conv2d_grouped(xs, pc, pad=0, act=ACT_NONE, residuals=None, masks=None, act_scale=1.0, act_scale_devs=None, algo=None):
+    """The same stride-1 convolution (shared packed weights pc) over several NHWC tensors of different size — the FPN
+    levels of an FCOS tower / prediction conv — in ONE launch.  residuals: same-size addends; masks: ReLU-backward
+    masks (data gradients); act_scale_devs: one device scalar per level (the learnable Scale).  Returns the outputs."""
+    _chk_dev(*xs)
+    k = len(xs)
+    c = xs[0].shape[-1]
+    assert c == pc.cin_k and not pc.stem, "input channels %d != packed K per tap %d" % (c, pc.cin_k)
+    d = ConvDesc()
+    d.dtype = _dt(xs[0])
+    d.cin, d.r, d.s = c, pc.r, pc.s
+    d.stride_h = d.stride_w = 1
+    d.pad_h = d.pad_w = pad
+    d.cout, d.w_rows = pc.cout_store, pc.w_rows
+    outs = [torch.empty((x.shape[0], conv_out(x.shape[1], pc.r, 1, pad), conv_out(x.shape[2], pc.s, 1, pad),
+                         pc.cout_store), device=x.device, dtype=x.dtype) for x in xs]
+    d.out_stride = pc.cout_store
+    d.res_mode = RES_NONE if residuals is None else RES_SAME
+    if residuals is not None:
+        d.res_stride = residuals[0].shape[-1]
+        assert all(r.shape == o.shape for r, o in zip(residuals, outs))
+    if masks is not None:
+        assert all(m.shape == o.shape and m.dtype == o.dtype for m, o in zip(masks, outs))
+    d.act, d.act_scale, d.relu_in, d.gn_in = act, float(act_scale), 0, 0
+    ns = (C.c_int32 * k)(*[x.shape[0] for x in xs])
+    hs = (C.c_int32 * k)(*[x.shape[1] for x in xs])
+    ws = (C.c_int32 * k)(*[x.shape[2] for x in xs])
+    args = (k, _ptr_array(xs), _ptr_array(outs), _ptr_array(residuals) if residuals is not None else None,
+            _ptr_array(masks) if masks is not None else None,
+            _ptr_array(act_scale_devs) if act_scale_devs is not None else None, ns, hs, ws, _ptr(pc.w), _ptr(pc.bias),
+            _stream())
+
+    def launch():
+        _lib.call("osd_conv2d_fwd_grouped", C.byref(d), *args)
+    if algo is None:
+        key = ("grouped", d.dtype, tuple(tuple(o.shape[:3]) for o in outs), d.cout, d.cin, d.r, d.s, pad, d.res_mode, act,
+               masks is not None)
+        algo = ALGO_CACHE.get(key)
+        if algo is None:
+            algo = _tune(key, d, launch) if _TUNING[0] else 0
+    d.algo = algo
+    launch()
+    return outs
 
 
 def maxpool3x3s2(x):

@@ -296,15 +296,15 @@ class TrainEngine(object):
         for i in range(spec.NUM_CONVS):
             (gw, _), (gbeta, _) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
             c = cv["%s%s.%d" % (h, tower, 3 * i)]
-            u = [ops.conv2d(t[l], c.pc, pad=1) for l in range(nl)]
+            u = ops.conv2d_grouped(t, c.pc, pad=1)                 # all FPN levels in one launch
             t2, ab = ops.groupnorm_relu_levels(u, gw, gbeta, spec.GN_GROUPS, spec.GN_EPS)
             layers.append((t, u, ab))
             t = t2
         if tower == "cls_tower":
-            out = [ops.conv2d(t[l], cv[h + "cls_ctr"].pc, pad=1) for l in range(nl)]
+            out = ops.conv2d_grouped(t, cv[h + "cls_ctr"].pc, pad=1)
         else:
-            out = [ops.conv2d(t[l], cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE, act_scale_dev=scales[l:l + 1])
-                   for l in range(nl)]
+            out = ops.conv2d_grouped(t, cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE,
+                                     act_scale_devs=[scales[l:l + 1] for l in range(nl)])
         return out, (layers, t)
 
     # ------------------------------------------------------------------------------------------------ loss
@@ -358,6 +358,10 @@ class TrainEngine(object):
         return ops.conv2d(dy, c.pd, stride=1, pad=c.r - 1 - (c.r // 2), res=res,
                           res_mode=RES_SAME if res is not None else RES_NONE, mask=mask)
 
+    def _dgrad_levels(self, c, dys):
+        """Data gradient of a conv shared by the FPN levels: one grouped launch."""
+        return ops.conv2d_grouped(dys, c.pd, pad=c.r - 1 - (c.r // 2))
+
     def head_backward(self, feats, ctxs, pred_grads):
         """Loops: tower -> layer (last first) -> level: the weight gradient of each (shared) conv is ONE grouped launch
         over the five FPN levels, GroupNorm+ReLU backward two launches.  The two towers' chains are independent until
@@ -382,14 +386,14 @@ class TrainEngine(object):
         pc = cv[h + ("cls_ctr" if tower == "cls_tower" else "bbox_pred")]
         dpred = [pred_grads[l][gi] for l in range(nl)]
         self._wgrad_grouped(pc, [(t_last[l], dpred[l]) for l in range(nl)])
-        d_t = [self._dgrad(pc, dpred[l]) for l in range(nl)]
+        d_t = self._dgrad_levels(pc, dpred)
         for i in range(spec.NUM_CONVS - 1, -1, -1):
             (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
             c = cv["%s%s.%d" % (h, tower, 3 * i)]
             t_in, u, ab = layers[i]
             du = ops.groupnorm_relu_bwd_levels(u, d_t, ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
             self._wgrad_grouped(c, [(t_in[l], du[l]) for l in range(nl)])
-            d_t = [self._dgrad(c, du[l]) for l in range(nl)]
+            d_t = self._dgrad_levels(c, du)
         return d_t
 
     def backbone_backward(self, ctx, dP, need_input_grad=False):

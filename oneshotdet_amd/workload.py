@@ -43,12 +43,12 @@ def conv_launches(batch, h, w, n_query, qh, qw):
     tb, levels = _backbone("backbone.", batch, h, w)
     qb, _ = _backbone("supp_backbone.", n_query, qh, qw)
     out = tb + qb
-    for lvl, (lh, lw) in enumerate(levels):
-        m = batch * lh * lw
-        for tower, pred, pn in (("cls_tower", "cls_logits+centerness", 2), ("bbox_tower", "bbox_pred", 4)):
-            for i in range(spec.NUM_CONVS):
-                out.append(("head.P%d.%s.%d" % (lvl + 3, tower, i), m, 256, 2304))
-            out.append(("head.P%d.%s" % (lvl + 3, pred), m, pn, 2304))
+    # FCOS head: the levels share the weights, so each tower layer / prediction conv is ONE grouped launch (M summed)
+    m = sum(batch * lh * lw for lh, lw in levels)
+    for tower, pred, pn in (("cls_tower", "cls_logits+centerness", 2), ("bbox_tower", "bbox_pred", 4)):
+        for i in range(spec.NUM_CONVS):
+            out.append(("head.P3-P7.%s.%d" % (tower, i), m, 256, 2304))
+        out.append(("head.P3-P7.%s" % pred, m, pn, 2304))
     return out
 
 

@@ -215,3 +215,58 @@ def test_conv2d_every_algorithm_gives_the_same_answer(dt):
         torch.testing.assert_close(from_nhwc(y), ref, **TOL[dt], msg=lambda m: "algo %d: %s" % (algo, m))
         ran += 1
     assert ran >= 10
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv2d_grouped_equals_per_level_launches(dt):
+    """osd_conv2d_fwd_grouped (one launch over the FPN levels that share a tower conv, fcos.py:83-99) against one
+    osd_conv2d_fwd launch per level with the same algorithm: the per-tile arithmetic is identical, so the outputs must
+    match BIT FOR BIT — for every LDS-DMA algorithm, with residual + mask epilogues, ragged M tails and a 1-pixel level;
+    plus the torch reference for the plain case and the per-level exp(scale_l * x) of bbox_pred."""
+    from oneshotdet_amd import _lib
+    o = ops()
+    sizes = [(2, 25, 32), (2, 13, 16), (2, 7, 8), (2, 4, 4), (2, 1, 1)]
+    cin = cout = 256
+    wt, b = rnd(cout, cin, 3, 3, seed=2) / 48, rnd(cout, seed=3)
+    xs = [rnd(n, cin, h, w, seed=10 + i) for i, (n, h, w) in enumerate(sizes)]
+    if dt == "bf16":
+        wt, xs = wt.bfloat16().float(), [x.bfloat16().float() for x in xs]
+    pc = o.pack_conv(wt.cuda(), bias=b.cuda(), dtype=DT[dt])
+    xx = [to_nhwc(x, DT[dt]) for x in xs]
+    res = [to_nhwc(rnd(n, cout, h, w, seed=20 + i), DT[dt]) for i, (n, h, w) in enumerate(sizes)]
+    msk = [to_nhwc(rnd(n, cout, h, w, seed=30 + i), DT[dt]) for i, (n, h, w) in enumerate(sizes)]
+    ran = 0
+    for algo in o.conv_algo_candidates(cout, False, has_mask=True):
+        try:
+            ys = o.conv2d_grouped(xx, pc, pad=1, residuals=res, masks=msk, algo=algo)
+        except _lib.OsdError:
+            continue
+        for x, r, m, y in zip(xx, res, msk, ys):
+            one = o.conv2d(x, pc, pad=1, res=r, res_mode=o.RES_SAME, mask=m, algo=algo)
+            assert torch.equal(one, y), "algo %d level %s" % (algo, tuple(x.shape))
+        ran += 1
+    assert ran >= 8
+    ys = o.conv2d_grouped(xx, pc, pad=1, act=o.ACT_RELU)
+    for x, y in zip(xs, ys):
+        torch.testing.assert_close(from_nhwc(y), F.relu(F.conv2d(x, wt, b, padding=1)), **TOL[dt])
+    # prediction conv: 4 outputs, per-level learnable Scale read from device memory (fcos.py:93-96)
+    w4, b4 = rnd(4, cin, 3, 3, seed=5) / 48, rnd(4, seed=6) * 0.1
+    if dt == "bf16":
+        w4 = w4.bfloat16().float()
+    p4 = o.pack_conv(w4.cuda(), bias=b4.cuda(), dtype=DT[dt])
+    scales = torch.tensor([0.5, 1.0, 1.5, 0.25, 2.0], device="cuda")
+    ys = o.conv2d_grouped(xx, p4, pad=1, act=o.ACT_EXP_SCALE, act_scale_devs=[scales[i:i + 1] for i in range(5)])
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        ref = torch.exp(F.conv2d(x, w4, b4, padding=1) * float(scales[i]))
+        torch.testing.assert_close(from_nhwc(y)[:, :4], ref, **TOL[dt])
+
+
+def test_conv2d_grouped_rejects_bad_arguments():
+    from oneshotdet_amd import _lib
+    o = ops()
+    pc = o.pack_conv((rnd(64, 64, 3, 3, seed=1) / 24).cuda(), bias=rnd(64, seed=2).cuda(), dtype=torch.float32)
+    xs = [to_nhwc(rnd(1, 64, 4, 4, seed=3), torch.float32)] * 7
+    with pytest.raises(_lib.OsdError):
+        o.conv2d_grouped(xs, pc, pad=1)               # more than 6 segments
+    with pytest.raises(_lib.OsdError):
+        o.conv2d_grouped(xs[:2], pc, pad=1, algo=40)  # register-staged algorithms cannot run grouped
