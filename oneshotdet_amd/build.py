@@ -9,10 +9,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "liboneshotdet_hip.so")
-SOURCES = ["osd_error.hip", "conv_igemm.hip", "conv_igemm_dma.hip", "conv_wgrad.hip", "backward.hip", "loss.hip", "elementwise.hip", "proposals.hip"]
+# OSD_BUILD_TAG=<name> + OSD_BUILD_FLAGS="-D..." build a second, diagnostic copy (lib/liboneshotdet_hip_<name>.so, own
+# object dir) for A/B timing through OSD_LIB_PATH; the default build is untouched
+TAG = os.environ.get("OSD_BUILD_TAG", "")
+LIB = os.path.join(LIBDIR, "liboneshotdet_hip%s.so" % ("_" + TAG if TAG else ""))
+SOURCES = ["osd_error.hip", "conv_igemm.hip", "conv_igemm_dma.hip", "conv_igemm_p8.hip", "conv_wgrad.hip", "backward.hip", "loss.hip", "elementwise.hip", "proposals.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"] + os.environ.get("OSD_BUILD_FLAGS", "").split()
 
 
 def _stale(target, deps):
@@ -24,9 +27,9 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj" + ("_" + TAG if TAG else ""))
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "osd_common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(os.path.dirname(HERE), "include", "oneshotdet_hip.h")]
+    headers = [os.path.join(CSRC, "osd_common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(CSRC, "conv_epilogue.h"), os.path.join(os.path.dirname(HERE), "include", "oneshotdet_hip.h")]
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

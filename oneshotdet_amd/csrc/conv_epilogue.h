@@ -1,0 +1,181 @@
+// Pieces shared by the LDS-DMA convolution kernels (conv_igemm_dma.hip, conv_igemm_p8.hip): the per-segment view of a
+// grouped launch and the LDS-staged NHWC epilogue.
+#pragma once
+#include "osd_common.h"
+#include "conv_params.h"
+#include <cstddef>
+
+namespace {
+
+// everything that differs between the (x, y) pairs of a grouped launch; uniform per workgroup (SGPRs)
+struct ConvView {
+  const void* x; void* y; const void* res; const void* mask; const float* scale_dev;
+  int H, W, Ho, Wo, M, sN, sH, HoWo;
+};
+
+// tile_m: global pixel-tile index of this workgroup; on return it is the index inside the selected segment
+__device__ __forceinline__ ConvView conv_select_view(const ConvKParams& p, int& tile_m) {
+  ConvView q;
+  q.x = p.x; q.y = p.y; q.res = p.res; q.mask = p.mask; q.scale_dev = p.act_scale_dev;
+  q.H = p.H; q.W = p.W; q.Ho = p.Ho; q.Wo = p.Wo; q.M = p.M; q.sN = p.sN; q.sH = p.sH;
+  if (p.n_seg > 0) {
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < kConvMaxSeg; ++i)
+      if (i < p.n_seg && tile_m >= p.seg[i].tile_begin) si = i;
+    // read the chosen entry straight from the kernarg segment (constant address space, scalar loads): indexing the
+    // by-value struct dynamically would make the compiler copy all of it to scratch
+    typedef const __attribute__((address_space(4))) char* kptr;
+    typedef unsigned long long u64;
+    kptr base = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ConvKParams, seg) + si * (int)sizeof(ConvSeg);
+#define OSD_KSEG(type, field) (*reinterpret_cast<const __attribute__((address_space(4))) type*>(base + offsetof(ConvSeg, field)))
+    q.x = (const void*)OSD_KSEG(u64, x); q.y = (void*)OSD_KSEG(u64, y); q.res = (const void*)OSD_KSEG(u64, res);
+    q.mask = (const void*)OSD_KSEG(u64, mask); q.scale_dev = (const float*)OSD_KSEG(u64, act_scale_dev);
+    q.H = OSD_KSEG(int, H); q.W = OSD_KSEG(int, W); q.Ho = OSD_KSEG(int, Ho); q.Wo = OSD_KSEG(int, Wo);
+    q.M = OSD_KSEG(int, M); q.sN = OSD_KSEG(int, sN); q.sH = OSD_KSEG(int, sH);
+    tile_m -= OSD_KSEG(int, tile_begin);
+#undef OSD_KSEG
+  }
+  q.HoWo = q.Ho * q.Wo;
+  return q;
+}
+
+// Epilogue: each wave stages its fp32 accumulator sub-tile (TN x TM MFMA tiles: acc[i][j] = channels (wn*TN+i)*16..,
+// pixels (wm*TM+j)*16..) through a private LDS region and writes NHWC runs of TN*16 channels with 16-byte-per-lane
+// accesses; all residual loads of a pass are issued before any arithmetic.  The caller has already made the LDS ring
+// reusable (barrier, no DMA in flight).
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKParams& p, const ConvView& q, char* smem,
+                                              int wave, int wm, int wn, int lane, int m0, int n0) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int q_M = q.M, q_HoWo = q.HoWo, q_Wo = q.Wo;
+  const void* q_y = q.y; const void* q_res = q.res; const void* q_mask = q.mask; const float* q_scale_dev = q.scale_dev;
+  T* __restrict__ yg = reinterpret_cast<T*>(const_cast<void*>(q_y));
+  const T* __restrict__ rg = reinterpret_cast<const T*>(q_res);
+  constexpr int WC = TN * 16;                    // channels of a wave tile
+  constexpr int CSW = WC * 4 + 16;               // staging row stride (bytes); +16 keeps ds_write_b128 conflict free
+  constexpr int NPASS = TM >= 8 ? TM / 2 : (TM >= 2 ? 2 : 1);
+  constexpr int TMP = TM / NPASS;                // 16-pixel tiles per pass
+  constexpr int ROWS = TMP * 16;
+  constexpr int CPR = WC / EPC;                  // 16-byte output chunks per row
+  constexpr int ITER = ROWS * CPR / 64;
+  static_assert((ROWS * CPR) % 64 == 0 && ITER >= 1, "epilogue chunking");
+  char* stage = smem + wave * (ROWS * CSW);
+  const bool vec_ok = (p.out_stride % EPC == 0) && (p.res_mode == OSD_RES_NONE || p.res_stride % EPC == 0);
+  const int cbase = n0 + wn * WC;
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+    for (int jj = 0; jj < TMP; ++jj) {
+      const int j = ps * TMP + jj;
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        *reinterpret_cast<f32x4*>(stage + (jj * 16 + (lane & 15)) * CSW + (i * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
+    }
+    const int mbase = m0 + (wm * TM + ps * TMP) * 16;
+    float v[ITER][EPC];
+    bool live[ITER];
+    int nval[ITER];
+    size_t ooff[ITER];
+    // pass 1: addresses + residual loads (all issued back to back)
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / CPR, cc = idx % CPR;
+      const int m = mbase + row, c = cbase + cc * EPC;
+      live[it] = (m < q_M) && (c < p.Cout);
+      nval[it] = min(EPC, p.Cout - c);
+      ooff[it] = (size_t)m * p.out_stride + c;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[it][e] = 0.f;
+      if (live[it] && p.res_mode != OSD_RES_NONE) {
+        size_t res_off;
+        if (p.res_mode == OSD_RES_SAME) {
+          res_off = (size_t)m * p.res_stride + c;
+        } else {
+          const int n_img = m / q_HoWo;
+          const int rem = m - n_img * q_HoWo;
+          const int ho = rem / q_Wo, wo = rem - (rem / q_Wo) * q_Wo;
+          res_off = ((size_t)(n_img * p.res_h + (ho >> 1)) * p.res_w + (wo >> 1)) * p.res_stride + c;
+        }
+        if constexpr (sizeof(T) == 2) {
+          if (vec_ok && nval[it] == EPC) {
+            const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(rg + res_off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[it][e] = (float)r8[e];
+          } else {
+            for (int e = 0; e < nval[it]; e += 4) {
+              const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rg + res_off + e);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[it][e + k] = (float)r4[k];
+            }
+          }
+        } else {
+          const float4 r4 = *reinterpret_cast<const float4*>(rg + res_off);
+          v[it][0] = r4.x; v[it][1] = r4.y; v[it][2] = r4.z; v[it][3] = r4.w;
+        }
+      }
+    }
+    // pass 2: accumulator + bias + residual, activation, store
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      if (!live[it]) continue;
+      const int idx = it * 64 + lane;
+      const int row = idx / CPR, cc = idx % CPR;
+      const int c = cbase + cc * EPC;
+      const char* src = stage + row * CSW + cc * EPC * 4;
+#pragma unroll
+      for (int e = 0; e < EPC; e += 4) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(src + e * 4);
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + c + e);
+        v[it][e] = (a4[0] + b4.x) + v[it][e];
+        v[it][e + 1] = (a4[1] + b4.y) + v[it][e + 1];
+        v[it][e + 2] = (a4[2] + b4.z) + v[it][e + 2];
+        v[it][e + 3] = (a4[3] + b4.w) + v[it][e + 3];
+      }
+      if (q_mask) {     // ReLU backward of the producer layer: zero where its forward output was not positive
+        const T* mk = reinterpret_cast<const T*>(q_mask) + ooff[it];
+        if constexpr (sizeof(T) == 2) {
+          if (vec_ok && nval[it] == EPC) {
+            const bf16x8 m8 = *reinterpret_cast<const bf16x8*>(mk);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[it][e] = (float)m8[e] > 0.f ? v[it][e] : 0.f;
+          } else {
+            for (int e = 0; e < nval[it]; ++e) v[it][e] = (float)mk[e] > 0.f ? v[it][e] : 0.f;
+          }
+        } else {
+          const float4 m4 = *reinterpret_cast<const float4*>(mk);
+          v[it][0] = m4.x > 0.f ? v[it][0] : 0.f; v[it][1] = m4.y > 0.f ? v[it][1] : 0.f;
+          v[it][2] = m4.z > 0.f ? v[it][2] : 0.f; v[it][3] = m4.w > 0.f ? v[it][3] : 0.f;
+        }
+      }
+      if (p.act == OSD_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[it][e] = fmaxf(v[it][e], 0.f);
+      } else if (p.act == OSD_ACT_EXP_SCALE) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[it][e] = expf(v[it][e] * (q_scale_dev ? *q_scale_dev : p.act_scale));
+      }
+      T* dst = yg + ooff[it];
+      if constexpr (sizeof(T) == 2) {
+        if (vec_ok && nval[it] == EPC) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[it][e];
+          *reinterpret_cast<bf16x8*>(dst) = o;
+        } else {
+          for (int e = 0; e < nval[it]; e += 4) {
+            bf16x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (__bf16)v[it][e + k];
+            *reinterpret_cast<bf16x4*>(dst + e) = o;
+          }
+        }
+      } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+      }
+    }
+  }
+}
+
+}  // namespace

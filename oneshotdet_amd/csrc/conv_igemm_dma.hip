@@ -12,8 +12,8 @@
 //     coalesced stores (and 16-byte residual loads): one output pixel's BN channels are one contiguous run.
 #include "osd_common.h"
 #include "conv_params.h"
+#include "conv_epilogue.h"
 #include <type_traits>
-#include <cstddef>
 #ifndef OSD_DMA_FRONT
 #define OSD_DMA_FRONT 1   // issue the next stage's DMA in the first half of the MFMA groups (more time to land)
 #endif
@@ -89,29 +89,10 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
   }
   const int tile_n = t % p.tilesN;
   int tile_m = t / p.tilesN;
-  // grouped launch: the pixel tile selects its (x, y) pair; everything per-pair is uniform (SGPRs)
-  const void* q_x = p.x; void* q_y = p.y; const void* q_res = p.res; const void* q_mask = p.mask;
-  const float* q_scale_dev = p.act_scale_dev;
-  int q_H = p.H, q_W = p.W, q_Ho = p.Ho, q_Wo = p.Wo, q_M = p.M, q_sN = p.sN, q_sH = p.sH;
-  if (p.n_seg > 0) {
-    int si = 0;
-#pragma unroll
-    for (int i = 1; i < kConvMaxSeg; ++i)
-      if (i < p.n_seg && tile_m >= p.seg[i].tile_begin) si = i;
-    // read the chosen entry straight from the kernarg segment (constant address space, scalar loads): indexing the
-    // by-value struct dynamically would make the compiler copy all of it to scratch
-    typedef const __attribute__((address_space(4))) char* kptr;
-    kptr base = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ConvKParams, seg) + si * (int)sizeof(ConvSeg);
-#define OSD_KSEG(type, field) (*reinterpret_cast<const __attribute__((address_space(4))) type*>(base + offsetof(ConvSeg, field)))
-    typedef unsigned long long u64;
-    q_x = (const void*)OSD_KSEG(u64, x); q_y = (void*)OSD_KSEG(u64, y); q_res = (const void*)OSD_KSEG(u64, res);
-    q_mask = (const void*)OSD_KSEG(u64, mask); q_scale_dev = (const float*)OSD_KSEG(u64, act_scale_dev);
-    q_H = OSD_KSEG(int, H); q_W = OSD_KSEG(int, W); q_Ho = OSD_KSEG(int, Ho); q_Wo = OSD_KSEG(int, Wo);
-    q_M = OSD_KSEG(int, M); q_sN = OSD_KSEG(int, sN); q_sH = OSD_KSEG(int, sH);
-    tile_m -= OSD_KSEG(int, tile_begin);
-#undef OSD_KSEG
-  }
-  const int q_HoWo = q_Ho * q_Wo;
+  const ConvView q = conv_select_view(p, tile_m);
+  const void* q_x = q.x;
+  const int q_H = q.H, q_W = q.W, q_Wo = q.Wo, q_M = q.M, q_sN = q.sN, q_sH = q.sH;
+  const int q_HoWo = q.HoWo;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const T* __restrict__ xg = reinterpret_cast<const T*>(q_x);
@@ -264,136 +245,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
     cur = cur + 1 == NST ? 0 : cur + 1;
   }
 
-  // ---- epilogue: each wave stages its accumulator sub-tile through a private LDS region (fp32, two passes of TM/2
-  // pixel tiles) and writes NHWC runs of TN*16 channels with 16-byte-per-lane accesses; all residual loads of a pass
-  // are issued before any arithmetic so ~8 x 16 B per lane are in flight (the K=64 convs are HBM-bound here) ----
+  // ---- epilogue (conv_epilogue.h): LDS-staged, 16-byte-per-lane NHWC stores with bias / residual / mask / activation
   __syncthreads();
-  T* __restrict__ yg = reinterpret_cast<T*>(q_y);
-  const T* __restrict__ rg = reinterpret_cast<const T*>(q_res);
-  constexpr int WC = TN * 16;                    // channels of a wave tile
-  constexpr int CSW = WC * 4 + 16;               // staging row stride (bytes); +16 keeps ds_write_b128 conflict free
-  constexpr int NPASS = TM >= 8 ? TM / 2 : (TM >= 2 ? 2 : 1);
-  constexpr int TMP = TM / NPASS;                // 16-pixel tiles per pass
-  constexpr int ROWS = TMP * 16;
-  constexpr int CPR = WC / EPC;                  // 16-byte output chunks per row
-  constexpr int ITER = ROWS * CPR / 64;
-  static_assert((ROWS * CPR) % 64 == 0 && ITER >= 1, "epilogue chunking");
-  char* stage = smem + wave * (ROWS * CSW);
-  const bool vec_ok = (p.out_stride % EPC == 0) && (p.res_mode == OSD_RES_NONE || p.res_stride % EPC == 0);
-  const int cbase = n0 + wn * WC;
-#pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-#pragma unroll
-    for (int jj = 0; jj < TMP; ++jj) {
-      const int j = ps * TMP + jj;
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-        *reinterpret_cast<f32x4*>(stage + (jj * 16 + (lane & 15)) * CSW + (i * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
-    }
-    const int mbase = m0 + (wm * TM + ps * TMP) * 16;
-    float v[ITER][EPC];
-    bool live[ITER];
-    int nval[ITER];
-    size_t ooff[ITER];
-    // pass 1: addresses + residual loads (all issued back to back)
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int idx = it * 64 + lane;
-      const int row = idx / CPR, cc = idx % CPR;
-      const int m = mbase + row, c = cbase + cc * EPC;
-      live[it] = (m < q_M) && (c < p.Cout);
-      nval[it] = min(EPC, p.Cout - c);
-      ooff[it] = (size_t)m * p.out_stride + c;
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) v[it][e] = 0.f;
-      if (live[it] && p.res_mode != OSD_RES_NONE) {
-        size_t res_off;
-        if (p.res_mode == OSD_RES_SAME) {
-          res_off = (size_t)m * p.res_stride + c;
-        } else {
-          const int n_img = m / q_HoWo;
-          const int rem = m - n_img * q_HoWo;
-          const int ho = rem / q_Wo, wo = rem - (rem / q_Wo) * q_Wo;
-          res_off = ((size_t)(n_img * p.res_h + (ho >> 1)) * p.res_w + (wo >> 1)) * p.res_stride + c;
-        }
-        if constexpr (sizeof(T) == 2) {
-          if (vec_ok && nval[it] == EPC) {
-            const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(rg + res_off);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[it][e] = (float)r8[e];
-          } else {
-            for (int e = 0; e < nval[it]; e += 4) {
-              const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rg + res_off + e);
-#pragma unroll
-              for (int k = 0; k < 4; ++k) v[it][e + k] = (float)r4[k];
-            }
-          }
-        } else {
-          const float4 r4 = *reinterpret_cast<const float4*>(rg + res_off);
-          v[it][0] = r4.x; v[it][1] = r4.y; v[it][2] = r4.z; v[it][3] = r4.w;
-        }
-      }
-    }
-    // pass 2: accumulator + bias + residual, activation, store
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      if (!live[it]) continue;
-      const int idx = it * 64 + lane;
-      const int row = idx / CPR, cc = idx % CPR;
-      const int c = cbase + cc * EPC;
-      const char* src = stage + row * CSW + cc * EPC * 4;
-#pragma unroll
-      for (int e = 0; e < EPC; e += 4) {
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(src + e * 4);
-        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + c + e);
-        v[it][e] = (a4[0] + b4.x) + v[it][e];
-        v[it][e + 1] = (a4[1] + b4.y) + v[it][e + 1];
-        v[it][e + 2] = (a4[2] + b4.z) + v[it][e + 2];
-        v[it][e + 3] = (a4[3] + b4.w) + v[it][e + 3];
-      }
-      if (q_mask) {     // ReLU backward of the producer layer: zero where its forward output was not positive
-        const T* mk = reinterpret_cast<const T*>(q_mask) + ooff[it];
-        if constexpr (sizeof(T) == 2) {
-          if (vec_ok && nval[it] == EPC) {
-            const bf16x8 m8 = *reinterpret_cast<const bf16x8*>(mk);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[it][e] = (float)m8[e] > 0.f ? v[it][e] : 0.f;
-          } else {
-            for (int e = 0; e < nval[it]; ++e) v[it][e] = (float)mk[e] > 0.f ? v[it][e] : 0.f;
-          }
-        } else {
-          const float4 m4 = *reinterpret_cast<const float4*>(mk);
-          v[it][0] = m4.x > 0.f ? v[it][0] : 0.f; v[it][1] = m4.y > 0.f ? v[it][1] : 0.f;
-          v[it][2] = m4.z > 0.f ? v[it][2] : 0.f; v[it][3] = m4.w > 0.f ? v[it][3] : 0.f;
-        }
-      }
-      if (p.act == OSD_ACT_RELU) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) v[it][e] = fmaxf(v[it][e], 0.f);
-      } else if (p.act == OSD_ACT_EXP_SCALE) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) v[it][e] = expf(v[it][e] * (q_scale_dev ? *q_scale_dev : p.act_scale));
-      }
-      T* dst = yg + ooff[it];
-      if constexpr (sizeof(T) == 2) {
-        if (vec_ok && nval[it] == EPC) {
-          bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[it][e];
-          *reinterpret_cast<bf16x8*>(dst) = o;
-        } else {
-          for (int e = 0; e < nval[it]; e += 4) {
-            bf16x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (__bf16)v[it][e + k];
-            *reinterpret_cast<bf16x4*>(dst + e) = o;
-          }
-        }
-      } else {
-        *reinterpret_cast<float4*>(dst) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
-      }
-    }
-  }
+  conv_epilogue<T, TM, TN>(acc, p, q, smem, wave, wm, wn, lane, m0, n0);
 }
 
 template <typename T, int BM, int BN, int KB, int WM, int WN, int NST, bool RELU_IN = false>

@@ -37,3 +37,5 @@ struct ConvKParams {
 
 // conv_igemm_dma.hip
 int osd_conv_dma_dispatch(int dtype, int tile, int variant, const ConvKParams& p, hipStream_t s);
+// conv_igemm_p8.hip: bf16, 256 x 256 tile, two wave groups one barrier apart (tile id 5)
+int osd_conv_p8_launch(const ConvKParams& p, hipStream_t s);

@@ -270,3 +270,21 @@ def test_conv2d_grouped_rejects_bad_arguments():
         o.conv2d_grouped(xs, pc, pad=1)               # more than 6 segments
     with pytest.raises(_lib.OsdError):
         o.conv2d_grouped(xs[:2], pc, pad=1, algo=40)  # register-staged algorithms cannot run grouped
+
+
+def test_conv2d_pingpong_kernel_is_bit_identical_to_the_dma_kernel():
+    """Race screen for conv_igemm_p8.hip (tile id 5: two wave groups one barrier apart, counted vmcnt): it accumulates in
+    the same order as the LDS-DMA 256x256 kernel, so repeated launches must reproduce that kernel's output bit for bit
+    (a DMA/ds_read race shows up as a changed tile).  Shapes: 3x3 with halo and ragged M, 1x1 deep K, KT = 1."""
+    o = ops()
+    P8, DMA = 1 + 5, 1 + 8 + 4
+    for (n, h, w, cin, cout, k, pad) in [(2, 37, 41, 256, 256, 3, 1), (4, 50, 64, 1024, 256, 1, 0), (1, 9, 7, 64, 320, 3, 1),
+                                         (2, 16, 16, 64, 256, 1, 0)]:
+        x = to_nhwc(rnd(n, cin, h, w, seed=1), torch.bfloat16)
+        wt = rnd(cout, cin, k, k, seed=2) / (cin * k * k) ** 0.5
+        pc = o.pack_conv(wt.cuda(), bias=rnd(cout, seed=3).cuda(), dtype=torch.bfloat16)
+        res = to_nhwc(rnd(n, pc.cout_store, h, w, seed=4), torch.bfloat16)
+        ref = o.conv2d(x, pc, pad=pad, res=res, res_mode=o.RES_SAME, act=o.ACT_RELU, algo=DMA)
+        for _ in range(10):
+            y = o.conv2d(x, pc, pad=pad, res=res, res_mode=o.RES_SAME, act=o.ACT_RELU, algo=P8)
+            assert torch.equal(y, ref), (n, h, w, cin, cout, k)
