@@ -341,7 +341,8 @@ def main_train(args, rank, world):
         line = result_line(args, world, B, elapsed, workload, launch, roofline, cpu)
         if roofline is not None:
             line["roofline_correlation"] = corr_roofline
-        line["config"]["parallelism"] = "dp%d, fp32 gradient all-reduce over RCCL (%d x flat buckets)" % (world, 4)
+        line["config"]["parallelism"] = ("dp%d, fp32 gradient averaging over RCCL: %d buckets of the flat buffer, each "
+                                         "all-reduced behind backward as soon as it is final" % (world, len(eng.exchange.ranges)))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

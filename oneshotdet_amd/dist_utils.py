@@ -22,3 +22,89 @@ def average_flat_(flat, group=None, n_buckets=4):
         w.wait()
     flat.mul_(1.0 / world)
     return flat
+
+
+def bucket_ranges(plan, total):
+    """Contiguous ranges of the flat gradient buffer in the order their gradients become final during backward.
+    plan: [(parameter name, shape)] in buffer order (TrainEngine._plan); total: padded length of the buffer.
+    Returns [(bucket name, lo, hi)] covering [0, total) exactly once: per backbone `layer2`, `layer3`, `layer4+fpn`
+    (the FPN and layer4 finish first, layer2 last), then the FCOS head (finishes before either backbone starts)."""
+    import math
+    out, off = [], 0
+    cur, lo = None, 0
+    for name, shape in plan:
+        if name.startswith("rpn."):
+            b = "head"
+        else:
+            bb = name.split(".", 1)[0]
+            rest = name.split(".body.", 1)[1] if ".body." in name else "fpn"
+            stage = rest.split(".", 1)[0]
+            b = "%s.%s" % (bb, "layer4+fpn" if stage in ("layer4", "fpn") else stage)
+        if b != cur:
+            if cur is not None:
+                out.append((cur, lo, off))
+            cur, lo = b, off
+        off += int(math.prod(shape))
+    if cur is not None:
+        out.append((cur, lo, total))
+    names = [n for n, _, _ in out]
+    assert len(set(names)) == len(names), "parameters of one bucket are not contiguous in the flat buffer: %s" % names
+    return out
+
+
+class GradExchange(object):
+    """Gradient averaging overlapped with backward: each bucket of the flat buffer is all-reduced on a communication
+    stream as soon as the streams that produce it have been told everything that writes it (ready()), while the rest of
+    the backward pass keeps running; finish() makes the current stream wait for all of them.  With one rank (or no
+    process group) every call is a no-op.  CPU tensors (gloo tests) take the same path without streams."""
+
+    def __init__(self, flat, ranges, group=None, single_rank_too=False):
+        self.flat, self.group = flat, group
+        self.ranges = {n: (lo, hi) for n, lo, hi in ranges}
+        # single_rank_too: run the collectives even with one rank (tests exercise the stream plumbing on one GPU)
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or single_rank_too)
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.cuda = flat.is_cuda
+        self.comm = torch.cuda.Stream(device=flat.device) if (self.active and self.cuda) else None
+        # RCCL averages natively; gloo has no AVG, so sum and scale
+        self.avg = self.active and dist.get_backend(group) == "nccl"
+        self.pending = set()
+        self.begin()
+
+    def begin(self):
+        self.pending = set(self.ranges)
+
+    def ready(self, name, producers=()):
+        """The gradients of bucket `name` are final once the work already enqueued on `producers` (streams) is done."""
+        if not self.active or name not in self.pending:
+            return
+        self.pending.discard(name)
+        lo, hi = self.ranges[name]
+        if hi <= lo:
+            return
+        view = self.flat[lo:hi]
+        if not self.cuda:
+            dist.all_reduce(view, group=self.group)
+            view.mul_(1.0 / self.world)
+            return
+        for s in producers:
+            ev = torch.cuda.Event()
+            ev.record(s)
+            self.comm.wait_event(ev)
+        with torch.cuda.stream(self.comm):
+            if self.avg:
+                dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(view, group=self.group)
+                view.mul_(1.0 / self.world)
+
+    def finish(self):
+        """Exchange whatever has not been announced yet, then order the current stream after the whole exchange."""
+        if not self.active:
+            return
+        cur = [torch.cuda.current_stream()] if self.cuda else ()
+        for name in [n for n in self.ranges if n in self.pending]:
+            self.ready(name, cur)
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.comm)
+        self.begin()

@@ -68,6 +68,10 @@ class TrainEngine(object):
         biases = [c.b for c in self.convs.values() if c.trainable and c.has_bias] + \
                  [p for n, (p, _) in self.extra.items() if not n.endswith(".weight")]
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        # gradient exchange overlapped with backward (no-op with one rank): buckets in the order they become final
+        from .dist_utils import GradExchange, bucket_ranges
+        self.exchange = GradExchange(self.flat_g, bucket_ranges(self._plan, self.flat_g.numel()), self.pg)
+        self._overlap = True
         self.opt = None
         if optimizer == "torch":     # the reference's optimiser object, kept for A/B tests of the fused kernel
             self.opt = torch.optim.SGD([{"params": weights, "lr": lr, "weight_decay": weight_decay},
@@ -345,6 +349,14 @@ class TrainEngine(object):
             fn()
         self._keep.append(tensors)        # keep the operands alive until the side stream has been joined
 
+    def _bucket_ready(self, name, extra=()):
+        """Everything that writes gradient bucket `name` has been enqueued: start its all-reduce behind those streams."""
+        if not (self._overlap and self.exchange.active):
+            return
+        cur = torch.cuda.current_stream()
+        ws = cur if self.wstream is None else (self.wstream2 if (self.wstream2 is not None and cur == self.s1) else self.wstream)
+        self.exchange.ready(name, [ws] + list(extra))
+
     def _wgrad(self, c, x, dy, stride=1, pad=0):
         self._on_wstream(lambda: ops.conv2d_wgrad(x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale,
                                                   db=c.gb if c.has_bias else None), (x, dy))
@@ -435,6 +447,9 @@ class TrainEngine(object):
             self._wgrad(c1, blk["x"], d_o1, s, 0)
             if blk["ds"]:
                 self._wgrad(cv[p + "downsample.0"], blk["x"], g, s, 0)
+            if p.endswith(".0."):                          # first block of its stage: the stage's gradients are complete
+                stage = p[len(bb + "body."):].split(".", 1)[0]
+                self._bucket_ready(bb.rstrip(".") + "." + ("layer4+fpn" if stage == "layer4" else stage))
             if blk["first"]:
                 break                                   # input of layer2 = frozen layer1 output: no data gradient
             extra = lateral.get(id(blk["x"]))            # block input is C3/C4: add the FPN lateral's gradient
@@ -455,6 +470,7 @@ class TrainEngine(object):
         from . import model
         self._keep = []
         self.flat_g.zero_()
+        self.exchange.begin()
         main, s1 = torch.cuda.current_stream(), self.s1
         side = s1 if s1 is not None else main
         batch = images.shape[0]
@@ -485,6 +501,7 @@ class TrainEngine(object):
         # ---- loss + backward
         losses, pred_grads = self.loss_and_grads(head_out, gt_boxes, gt_count)
         d_comb = self.head_backward(combined, hctx, pred_grads)
+        self._bucket_ready("head", [st for st in (main, s1, self.wstream, self.wstream2) if st is not None])
         # correlation backward (generalized_rcnn.py:307-311): d feat = g * q, d q = sum_hw g * feat
         dP = [ops.correlate(g, q) for g, q in zip(d_comb, pooled)]
         dq = [ops.correlate_bwd_query(g, feat) for g, feat in zip(d_comb, feats)]
@@ -511,9 +528,9 @@ class TrainEngine(object):
         return losses
 
     def reduce_gradients(self):
-        """DDP gradient averaging (tools/train_net.py:83-88): one flat fp32 buffer, a few large RCCL all-reduces."""
-        from .dist_utils import average_flat_
-        average_flat_(self.flat_g, self.pg, 4)
+        """DDP gradient averaging (tools/train_net.py:83-88).  The buckets of the flat fp32 buffer were handed to RCCL as
+        they became final during backward (dist_utils.GradExchange); this waits for them."""
+        self.exchange.finish()        # buckets not announced during backward (graph replay, single stream) go now
 
     def _build_sgd_table(self, weights, biases):
         import numpy as np
@@ -555,6 +572,7 @@ class TrainEngine(object):
         RCCL all-reduce between them launched normally): ~1500 launches per step become two graph launches.  The learning
         rate is baked in at capture time; call capture() again after changing it."""
         self._static = [t.clone() for t in (images, queries, gt_boxes, gt_count)]
+        self._overlap = False          # no collectives inside a captured graph: the exchange runs between the two graphs
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -6,7 +6,8 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oneshotdet_amd.dist_utils import average_flat_  # noqa: E402
+from oneshotdet_amd import spec  # noqa: E402
+from oneshotdet_amd.dist_utils import GradExchange, average_flat_, bucket_ranges  # noqa: E402
 
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -18,5 +19,39 @@ expect = base * (sum(range(1, world + 1)) / world)
 ok = torch.allclose(flat, expect, rtol=1e-6, atol=1e-6)
 empty = average_flat_(torch.zeros(0), None, 4)
 print("RANK %d OK=%s EMPTY=%d" % (rank, ok, empty.numel()), flush=True)
+
+# the overlapped exchange of TrainEngine: buckets of the real parameter plan announced in backward order (head first,
+# then per backbone layer4+fpn, layer3, layer2), one bucket deliberately never announced (finish() must pick it up), and a
+# second step to check that finish() re-arms the buckets
+plan = []
+for name, shape in spec.hot_path_shapes().items():
+    if spec.is_frozen(name) or "running_" in name or ".bn" in name or "downsample.1" in name:
+        continue
+    plan.append((name, (min(int(shape[0]), 8),) + tuple(min(int(d), 3) for d in shape[1:])))   # shrunk: structure only
+order = [n for n, _ in plan]
+plan.sort(key=lambda kv: (0 if kv[0].startswith("backbone.") else 1 if kv[0].startswith("supp_backbone.") else 2,
+                          0 if ".body." in kv[0] else 1, order.index(kv[0])))
+import math
+total = (sum(int(math.prod(s)) for _, s in plan) + 63) // 64 * 64
+ranges = bucket_ranges(plan, total)
+cover = sorted((lo, hi) for _, lo, hi in ranges)
+ok2 = cover[0][0] == 0 and cover[-1][1] == total and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+names = [n for n, _, _ in ranges]
+ok2 = ok2 and names == ["backbone.layer2", "backbone.layer3", "backbone.layer4+fpn", "supp_backbone.layer2",
+                        "supp_backbone.layer3", "supp_backbone.layer4+fpn", "head"]
+base2 = torch.randn(total, generator=g)
+for step in range(2):
+    flat2 = base2 * (rank + 1 + step)
+    ex = GradExchange(flat2, ranges) if step == 0 else ex
+    if step == 1:
+        ex.flat = flat2
+    for n in ("head", "backbone.layer4+fpn", "supp_backbone.layer4+fpn", "backbone.layer3", "supp_backbone.layer3",
+              "backbone.layer2"):
+        ex.ready(n)
+        ex.ready(n)                       # announcing twice must not reduce twice
+    ex.finish()                           # supp_backbone.layer2 was never announced
+    expect2 = base2 * (sum(r + 1 + step for r in range(world)) / world)
+    ok2 = ok2 and torch.allclose(flat2, expect2, rtol=1e-6, atol=1e-6)
+print("RANK %d EXCHANGE=%s" % (rank, ok2), flush=True)
 dist.destroy_process_group()
-sys.exit(0 if ok else 1)
+sys.exit(0 if (ok and ok2) else 1)

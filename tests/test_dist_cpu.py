@@ -50,3 +50,5 @@ def test_gradient_average_two_ranks():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     assert "RANK 0 OK=True" in out.stdout and "RANK 1 OK=True" in out.stdout
+    # dist_utils.GradExchange / bucket_ranges: the exchange overlapped with backward (same worker, second half)
+    assert "RANK 0 EXCHANGE=True" in out.stdout and "RANK 1 EXCHANGE=True" in out.stdout

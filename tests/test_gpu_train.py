@@ -202,3 +202,43 @@ def test_state_dict_round_trip_and_update():
     assert moved and all(not spec.is_frozen(k) for k in moved)
     # weights carry weight decay, so they move even where the gradient is exactly zero (biases / Scales may not)
     assert {k for k in sd0 if not spec.is_frozen(k) and k.endswith(".weight")} - moved == set()
+
+
+def test_gradient_buckets_cover_the_flat_buffer_and_overlapped_exchange_runs():
+    """dist_utils.bucket_ranges on the real parameter plan: 7 contiguous buckets covering the flat gradient buffer once,
+    in buffer order.  Then the overlapped exchange itself on ONE rank over RCCL (the hooks in backward, the events, the
+    communication stream, finish()): averaging over one rank must leave losses and gradients bit-identical."""
+    import os
+    import torch.distributed as dist
+    from oneshotdet_amd import train
+    from oneshotdet_amd.dist_utils import GradExchange, bucket_ranges
+    eng, img, q, gtb, cnt = _engine_and_inputs("bf16")
+    ranges = bucket_ranges(eng._plan, eng.flat_g.numel())
+    assert [n for n, _, _ in ranges] == ["backbone.layer2", "backbone.layer3", "backbone.layer4+fpn", "supp_backbone.layer2",
+                                         "supp_backbone.layer3", "supp_backbone.layer4+fpn", "head"]
+    assert ranges[0][1] == 0 and ranges[-1][2] == eng.flat_g.numel()
+    assert all(a[2] == b[1] for a, b in zip(ranges, ranges[1:]))
+    for name, c in eng.convs.items():
+        if c.trainable:
+            off = (c.gw.data_ptr() - eng.flat_g.data_ptr()) // 4
+            b = [n for n, lo, hi in ranges if lo <= off < hi][0]
+            assert b == ("head" if name.startswith("rpn.") else name.split(".")[0] + "." + (
+                "layer4+fpn" if (".layer4." in name or ".fpn." in name) else name.split(".")[2])), (name, b)
+    assert not eng.exchange.active
+    ref_losses = eng.forward_backward(img, q, gtb, cnt).clone()
+    ref_grads = eng.flat_g.clone()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        eng.exchange = GradExchange(eng.flat_g, ranges, None, single_rank_too=True)
+        assert eng.exchange.active and eng.exchange.avg
+        for _ in range(2):                                        # second step: finish() re-armed the buckets
+            losses = eng.forward_backward(img, q, gtb, cnt)
+            assert eng.exchange.pending == set()                  # every bucket was announced during backward
+            eng.reduce_gradients()
+            torch.cuda.synchronize()
+            assert torch.equal(losses, ref_losses)
+            torch.testing.assert_close(eng.flat_g, ref_grads, rtol=1e-3, atol=1e-5)   # atomics: order-dependent last bits
+    finally:
+        dist.destroy_process_group()
