@@ -60,6 +60,12 @@ class TrainEngine(object):
         self._plan = []          # (name, shape) of every trainable tensor, in registration order
         self._build(sd)
         self._allocate(sd)
+        # gradient exchange overlapped with backward (no-op with one rank): buckets in the order they become final; the
+        # optimiser update + weight repack of a bucket follow its exchange on the same side stream (train_step)
+        from .dist_utils import GradExchange, bucket_ranges
+        self.exchange = GradExchange(self.flat_g, bucket_ranges(self._plan, self.flat_g.numel()), self.pg)
+        self.ustream = torch.cuda.Stream(device=self.device)
+        self._overlap, self._fuse_update, self._updated = True, False, set()
         self.repack()
         self.zero_bias = torch.zeros(4096, device=self.device, dtype=torch.float32)
         # SGD with the reference's parameter groups (solver/build.py:8-26: bias lr x2, bias weight decay 0)
@@ -68,10 +74,6 @@ class TrainEngine(object):
         biases = [c.b for c in self.convs.values() if c.trainable and c.has_bias] + \
                  [p for n, (p, _) in self.extra.items() if not n.endswith(".weight")]
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
-        # gradient exchange overlapped with backward (no-op with one rank): buckets in the order they become final
-        from .dist_utils import GradExchange, bucket_ranges
-        self.exchange = GradExchange(self.flat_g, bucket_ranges(self._plan, self.flat_g.numel()), self.pg)
-        self._overlap = True
         self.opt = None
         if optimizer == "torch":     # the reference's optimiser object, kept for A/B tests of the fused kernel
             self.opt = torch.optim.SGD([{"params": weights, "lr": lr, "weight_decay": weight_decay},
@@ -160,11 +162,17 @@ class TrainEngine(object):
                 wv.copy_(sd[name])
                 self.extra[name] = (wv, gv)
 
+    def _bucket_of(self, tensor):
+        off = (tensor.data_ptr() - self.flat_w.data_ptr()) // 4
+        for name, (lo, hi) in self.exchange.ranges.items():
+            if lo <= off < hi:
+                return name
+        raise AssertionError("tensor outside the flat buffer")
+
     def _build_pack_tables(self):
-        """Allocate ONE flat packed buffer per form (forward, data gradient) and the tables that let a single launch
-        repack every trainable conv from the flat fp32 masters (osd_pack_multi)."""
+        """Allocate ONE flat packed buffer per form (forward, data gradient) and, per gradient bucket, the table that lets a
+        single launch repack all of the bucket's convs from the flat fp32 masters (osd_pack_multi)."""
         import numpy as np
-        es = 2 if self.dtype == torch.bfloat16 else 4
         mult = 64 if self.dtype == torch.bfloat16 else 16
         tr = [c for c in self.convs.values() if c.trainable]
         scale_off, scales = {}, []
@@ -178,28 +186,38 @@ class TrainEngine(object):
         base = self.flat_w.data_ptr()
         self._pack = {}
         for form in (0, 1):
-            entries, dst_off, blocks = [], 0, []
-            for ci, c in enumerate(tr):
+            entries, dst_off = [], 0
+            for c in tr:
                 if form == 0:
                     rows, kpad = ops._round_up(c.cout, 16), ops._round_up(c.cin, mult)
                 else:
                     rows, kpad = ops._round_up(c.cin, 16), ops._round_up(c.cout, mult)
                 numel = rows * c.r * c.s * kpad
                 nb = max(1, min(64, (numel + 256 * 16 - 1) // (256 * 16)))
-                entries.append(((c.w.data_ptr() - base) // 4, dst_off, scale_off.get(c.name, -1), c.cout, c.cin, c.r, c.s, rows,
-                                kpad, len(blocks), nb, numel))
-                blocks += [ci] * nb
+                entries.append(dict(c=c, src=(c.w.data_ptr() - base) // 4, dst=dst_off, scale=scale_off.get(c.name, -1), rows=rows,
+                                    kpad=kpad, nb=nb, numel=numel))
                 dst_off += (numel + 63) // 64 * 64
             flat = torch.zeros(dst_off, device=self.device, dtype=self.dtype)
-            # 3 int64 offsets + 8 int32 (cout, cin, r, s, rows, kpad, first_block, n_blocks) = 7 x 8 bytes per entry
-            tab = np.zeros((len(entries), 7), dtype=np.int64)
-            for i, e in enumerate(entries):
-                tab[i, 0:3] = e[0:3]
-                tab[i, 3:7] = np.frombuffer(np.array(e[3:11], dtype=np.int32).tobytes(), dtype=np.int64)
-            self._pack[form] = dict(flat=flat, table=torch.from_numpy(tab).to(self.device),
-                                    blocks=torch.tensor(blocks, dtype=torch.int32, device=self.device), n=len(blocks))
-            for e, c in zip(entries, tr):
-                view = flat[e[1]:e[1] + e[11]].view(e[7], c.r, c.s, e[8])
+            tables = {}
+            for bucket in self.exchange.ranges:
+                sub = [e for e in entries if self._bucket_of(e["c"].w) == bucket]
+                if not sub:
+                    continue
+                # 3 int64 offsets + 8 int32 (cout, cin, r, s, rows, kpad, first_block, n_blocks) = 7 x 8 bytes per entry
+                tab = np.zeros((len(sub), 7), dtype=np.int64)
+                blocks = []
+                for i, e in enumerate(sub):
+                    c = e["c"]
+                    tab[i, 0:3] = (e["src"], e["dst"], e["scale"])
+                    tab[i, 3:7] = np.frombuffer(np.array([c.cout, c.cin, c.r, c.s, e["rows"], e["kpad"], len(blocks), e["nb"]],
+                                                         dtype=np.int32).tobytes(), dtype=np.int64)
+                    blocks += [i] * e["nb"]
+                tables[bucket] = dict(table=torch.from_numpy(tab).to(self.device),
+                                      blocks=torch.tensor(blocks, dtype=torch.int32, device=self.device), n=len(blocks))
+            self._pack[form] = dict(flat=flat, tables=tables)
+            for e in entries:
+                c = e["c"]
+                view = flat[e["dst"]:e["dst"] + e["numel"]].view(e["rows"], c.r, c.s, e["kpad"])
                 if form == 0:
                     cout_store = ops._round_up(c.cout, 4)
                     if c.has_bias and c.cout % 16 == 0:
@@ -208,13 +226,18 @@ class TrainEngine(object):
                         bias = torch.zeros(ops._round_up(cout_store, 16), device=self.device, dtype=torch.float32)
                         if c.bn_shift is not None:
                             bias[:c.cout] = c.bn_shift
-                    c.pc = PackedConv(view, bias, c.cout, cout_store, e[7], e[8], c.r, c.s, cin_real=c.cin)
+                    c.pc = PackedConv(view, bias, c.cout, cout_store, e["rows"], e["kpad"], c.r, c.s, cin_real=c.cin)
                 else:
                     zb = torch.zeros(ops._round_up(c.cin, 16), device=self.device, dtype=torch.float32)
-                    c.pd = PackedConv(view, zb, c.cin, c.cin, e[7], e[8], c.r, c.s, cin_real=c.cout)
+                    c.pd = PackedConv(view, zb, c.cin, c.cin, e["rows"], e["kpad"], c.r, c.s, cin_real=c.cout)
+        self._padded_bias = {}
+        for c in tr:                            # the two prediction convs keep a padded copy of their 2 / 4 biases
+            if c.has_bias and c.cout % 16 != 0:
+                self._padded_bias.setdefault(self._bucket_of(c.w), []).append(c)
 
-    def repack(self):
-        """fp32 masters -> kernel-layout weights of the compute dtype: two launches (forward and data-gradient forms)."""
+    def repack(self, buckets=None):
+        """fp32 masters -> kernel-layout weights of the compute dtype: per gradient bucket two launches (forward and
+        data-gradient forms).  buckets=None: all of them."""
         for c in self.convs.values():
             if not c.trainable and c.pc is None:
                 c.pc = ops.pack_conv(self._frozen_sd[c.name + ".weight"], bn=None if c.bn_scale is None else tuple(
@@ -223,12 +246,14 @@ class TrainEngine(object):
                     stem=c.name.endswith("stem.conv1"))
         if not hasattr(self, "_pack"):
             self._build_pack_tables()
-        for form in (0, 1):
-            pk = self._pack[form]
-            ops._lib.call("osd_pack_multi", ops._ptr(pk["table"]), ops._ptr(pk["blocks"]), pk["n"], ops._ptr(self.flat_w),
-                          ops._ptr(self._flat_scale), ops._ptr(pk["flat"]), form, ops._dt(pk["flat"]), ops._stream())
-        for c in self.convs.values():       # the two prediction convs keep a padded copy of their 2 / 4 biases
-            if c.trainable and c.has_bias and c.cout % 16 != 0:
+        for bucket in (self.exchange.ranges if buckets is None else buckets):
+            for form in (0, 1):
+                pk = self._pack[form]
+                tb = pk["tables"].get(bucket)
+                if tb is not None:
+                    ops._lib.call("osd_pack_multi", ops._ptr(tb["table"]), ops._ptr(tb["blocks"]), tb["n"], ops._ptr(self.flat_w),
+                                  ops._ptr(self._flat_scale), ops._ptr(pk["flat"]), form, ops._dt(pk["flat"]), ops._stream())
+            for c in self._padded_bias.get(bucket, ()):
                 c.pc.bias[:c.cout] = c.b
 
     def gn(self, name):
@@ -350,12 +375,30 @@ class TrainEngine(object):
         self._keep.append(tensors)        # keep the operands alive until the side stream has been joined
 
     def _bucket_ready(self, name, extra=()):
-        """Everything that writes gradient bucket `name` has been enqueued: start its all-reduce behind those streams."""
-        if not (self._overlap and self.exchange.active):
+        """Everything that writes gradient bucket `name` has been enqueued (weight gradients on the side streams; for
+        the head also the GroupNorm / Scale gradients on the compute streams): start its all-reduce behind those
+        streams and, inside train_step, its SGD update + repack behind that.  The update also waits for the current
+        compute stream: the bucket's data-gradient convs (enqueued before this point) read the packed weights it
+        rewrites."""
+        if not self._overlap or name is None:
             return
         cur = torch.cuda.current_stream()
         ws = cur if self.wstream is None else (self.wstream2 if (self.wstream2 is not None and cur == self.s1) else self.wstream)
-        self.exchange.ready(name, [ws] + list(extra))
+        producers = [ws] + list(extra)
+        if self._fuse_update and cur not in producers:
+            producers.append(cur)
+        if self.exchange.active:
+            self.exchange.ready(name, producers)
+        if not self._fuse_update:
+            return
+        ust = self.exchange.comm if self.exchange.active else self.ustream
+        if not self.exchange.active:
+            for st in producers:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                ust.wait_event(ev)
+        with torch.cuda.stream(ust):
+            self._update_bucket(name)
 
     def _wgrad(self, c, x, dy, stride=1, pad=0):
         self._on_wstream(lambda: ops.conv2d_wgrad(x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale,
@@ -447,10 +490,10 @@ class TrainEngine(object):
             self._wgrad(c1, blk["x"], d_o1, s, 0)
             if blk["ds"]:
                 self._wgrad(cv[p + "downsample.0"], blk["x"], g, s, 0)
-            if p.endswith(".0."):                          # first block of its stage: the stage's gradients are complete
-                stage = p[len(bb + "body."):].split(".", 1)[0]
-                self._bucket_ready(bb.rstrip(".") + "." + ("layer4+fpn" if stage == "layer4" else stage))
+            stage = p[len(bb + "body."):].split(".", 1)[0]
+            bucket = bb.rstrip(".") + "." + ("layer4+fpn" if stage == "layer4" else stage) if p.endswith(".0.") else None
             if blk["first"]:
+                self._bucket_ready(bucket)
                 break                                   # input of layer2 = frozen layer1 output: no data gradient
             extra = lateral.get(id(blk["x"]))            # block input is C3/C4: add the FPN lateral's gradient
             if s == 1:
@@ -461,6 +504,8 @@ class TrainEngine(object):
                 a = self._dgrad(cv[p + "downsample.0"], g)
                 bsm = self._dgrad(c1, d_o1, res=a)
                 g = ops.scatter2x(bsm, blk["x"].shape[1:3], mask=blk["x"], addend=extra)
+            if bucket is not None:      # first block of its stage done (its data-gradient convs included): the stage's
+                self._bucket_ready(bucket)   # gradients are final and nothing enqueued later reads its packed weights
         return None
 
     # ------------------------------------------------------------------------------------------------ step
@@ -533,36 +578,65 @@ class TrainEngine(object):
         self.exchange.finish()        # buckets not announced during backward (graph replay, single stream) go now
 
     def _build_sgd_table(self, weights, biases):
+        """Per gradient bucket the table of osd_sgd_momentum_multi (one launch updates every tensor of the bucket)."""
         import numpy as np
         base = self.flat_w.data_ptr()
-        rows, blocks = [], []
+        rows = {name: [] for name in self.exchange.ranges}
         for group, lr_mult, wd in ((weights, 1.0, self.weight_decay), (biases, 2.0, 0.0)):
             for t in group:
-                nb = max(1, min(64, (t.numel() + 256 * 16 - 1) // (256 * 16)))
-                rows.append(((t.data_ptr() - base) // 4, t.numel(), lr_mult, wd, len(blocks), nb))
-                blocks += [len(rows) - 1] * nb
-        tab = np.zeros((len(rows), 4), dtype=np.int64)         # 32 bytes per entry
-        for i, (off, n, lm, wd, fb, nb) in enumerate(rows):
-            tab[i, 0], tab[i, 1] = off, n
-            tab[i, 2] = np.frombuffer(np.array([lm, wd], dtype=np.float32).tobytes(), dtype=np.int64)[0]
-            tab[i, 3] = np.frombuffer(np.array([fb, nb], dtype=np.int32).tobytes(), dtype=np.int64)[0]
-        self._sgd = dict(table=torch.from_numpy(tab).to(self.device),
-                         blocks=torch.tensor(blocks, dtype=torch.int32, device=self.device), n=len(blocks),
-                         buf=torch.zeros_like(self.flat_w), steps=0)
+                rows[self._bucket_of(t)].append(((t.data_ptr() - base) // 4, t.numel(), lr_mult, wd))
+        tables = {}
+        for name, rs in rows.items():
+            if not rs:
+                continue
+            tab = np.zeros((len(rs), 4), dtype=np.int64)         # 32 bytes per entry
+            blocks = []
+            for i, (off, n, lm, wd) in enumerate(rs):
+                nb = max(1, min(64, (n + 256 * 16 - 1) // (256 * 16)))
+                tab[i, 0], tab[i, 1] = off, n
+                tab[i, 2] = np.frombuffer(np.array([lm, wd], dtype=np.float32).tobytes(), dtype=np.int64)[0]
+                tab[i, 3] = np.frombuffer(np.array([len(blocks), nb], dtype=np.int32).tobytes(), dtype=np.int64)[0]
+                blocks += [i] * nb
+            tables[name] = dict(table=torch.from_numpy(tab).to(self.device),
+                                blocks=torch.tensor(blocks, dtype=torch.int32, device=self.device), n=len(blocks))
+        self._sgd = dict(tables=tables, buf=torch.zeros_like(self.flat_w), steps=0)
 
-    def optimizer_step(self):
-        if self.opt is not None:
-            self.opt.step()
-        else:
-            sg = self._sgd
-            ops._lib.call("osd_sgd_momentum_multi", ops._ptr(sg["table"]), ops._ptr(sg["blocks"]), sg["n"],
+    def _update_bucket(self, name):
+        """SGD(momentum) on the bucket's masters, then its repack, on the current stream."""
+        sg = self._sgd
+        tb = sg["tables"].get(name)
+        if tb is not None:
+            ops._lib.call("osd_sgd_momentum_multi", ops._ptr(tb["table"]), ops._ptr(tb["blocks"]), tb["n"],
                           ops._ptr(self.flat_w), ops._ptr(self.flat_g), ops._ptr(sg["buf"]), float(self.lr),
                           float(self.momentum), int(sg["steps"] == 0), ops._stream())
-            sg["steps"] += 1
-        self.repack()
+        self.repack([name])
+        self._updated.add(name)
+
+    def optimizer_step(self):
+        """Apply the update to every bucket train_step has not already updated behind the backward pass."""
+        if self.opt is not None:
+            self.opt.step()
+            self.repack()
+            return
+        if self._overlap:              # (never inside a captured graph: capture() turns the overlap off)
+            main = torch.cuda.current_stream()
+            main.wait_stream(self.ustream)
+            if self.exchange.comm is not None:
+                main.wait_stream(self.exchange.comm)
+        for name in self.exchange.ranges:
+            if name not in self._updated:
+                self._update_bucket(name)
+        self._updated = set()
+        self._sgd["steps"] += 1
 
     def train_step(self, images, queries, gt_boxes, gt_count):
-        losses = self.forward_backward(images, queries, gt_boxes, gt_count)
+        """forward + loss + backward + gradient averaging + SGD + repack.  With the fused optimiser each bucket's exchange,
+        update and repack run on a side stream as soon as the bucket is final, beside the rest of the backward pass."""
+        self._fuse_update = self.opt is None and self._overlap
+        try:
+            losses = self.forward_backward(images, queries, gt_boxes, gt_count)
+        finally:
+            self._fuse_update = False
         self.reduce_gradients()
         self.optimizer_step()
         return losses

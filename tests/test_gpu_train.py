@@ -242,3 +242,29 @@ def test_gradient_buckets_cover_the_flat_buffer_and_overlapped_exchange_runs():
             torch.testing.assert_close(eng.flat_g, ref_grads, rtol=1e-3, atol=1e-5)   # atomics: order-dependent last bits
     finally:
         dist.destroy_process_group()
+
+
+def test_train_step_with_updates_behind_backward_equals_the_sequential_step():
+    """train_step applies each bucket's SGD update + repack on a side stream as soon as the bucket's gradients are
+    final (while the rest of backward still runs).  Three steps of it against three steps of the sequential
+    forward_backward -> reduce_gradients -> optimizer_step on an identical engine: same masters, same packed weights,
+    same losses.  fp32 engines: in bf16 a single rounding flip of a repacked weight makes two runs of the SAME code
+    differ by 1 % after three steps at this learning rate (tools/race_probe.py), which would hide a real ordering bug."""
+    from oneshotdet_amd import train
+    a, img, q, gtb, cnt = _engine_and_inputs("f32")
+    b = train.TrainEngine(synth.make_state_dict(spec.hot_path_shapes()), dtype=torch.float32)
+    w0 = a.flat_w.clone()
+    a.lr = b.lr = 0.002
+    for _ in range(3):
+        la = a.train_step(img, q, gtb, cnt)
+        lb = b.forward_backward(img, q, gtb, cnt)
+        b.reduce_gradients()
+        b.optimizer_step()
+        torch.cuda.synchronize()
+        assert a._updated == set() and a._sgd["steps"] == b._sgd["steps"]
+        torch.testing.assert_close(la, lb, rtol=1e-3, atol=1e-6)
+    da, db = a.flat_w - w0, b.flat_w - w0
+    assert float(db.abs().max()) > 1e-3                                   # the steps did move the weights
+    assert float((da - db).norm() / db.norm()) < 2e-3                     # atomic-order noise only
+    for form in (0, 1):
+        torch.testing.assert_close(a._pack[form]["flat"], b._pack[form]["flat"], rtol=1e-3, atol=1e-4)

@@ -41,6 +41,20 @@ def run(label, **kw):
     print("%-40s %.2f ms/step" % (label, (time.perf_counter() - t0) / steps * 1e3), flush=True)
 
 
+def run_train_step(label):
+    for _ in range(3):
+        eng.train_step(images, queries, gt_boxes, gt_count)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.train_step(images, queries, gt_boxes, gt_count)
+    torch.cuda.synchronize()
+    print("%-40s %.2f ms/step" % (label, (time.perf_counter() - t0) / steps * 1e3), flush=True)
+
+
+run_train_step("train_step (updates behind backward)")
+run("full step")
+run_train_step("train_step (updates behind backward)")
 run("full step")
 run("no training proposals", with_proposals=False)
 orig = (ops.conv2d_wgrad, ops.conv2d_wgrad_grouped)
