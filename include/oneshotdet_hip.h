@@ -206,8 +206,9 @@ int osd_pack_conv_weight_dgrad(const float* w, const float* scale, void* dst, in
  * d describes the FORWARD conv (x geometry, strides, pads, cout, out_stride = pixel stride of dy); scale (nullable) is a
  * per-Cout factor applied to the contribution (the folded FrozenBN scale); db (nullable, fp32 [cout], accumulated) also
  * receives the bias gradient sum_m dy[m][co] from the same pass over dy.
- * d->algo: 0 = default, else 1 + variant + 4 * split_target_code (variant 0..3 = pixels per stage x ring depth
- * 32x3 / 64x2 / 32x4 / 64x3; split targets 512, 256, 128, 64, 1024, 768, 384, 32 workgroups): 1..32, all valid. */
+ * d->algo: 0 = default, else 1 + variant + 8 * split_target_code.  Variants 0..3: 128 x 128 channel tile, pixels per
+ * stage x ring depth 32x3 / 64x2 / 32x4 / 64x3; variant 4: 256 x 256 channel tile on 8 waves (bf16).  Split targets
+ * 512, 256, 128, 64, 1024, 768, 384, 32 workgroups. */
 int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const void* dy, const float* scale, float* dw, float* db,
                      void* stream);
 /* the same over n_seg <= 8 (x, dy) pairs that share the weights (the FPN levels of the FCOS towers): d gives the conv

@@ -57,21 +57,33 @@ template <typename T> __device__ __forceinline__ int wg_swz(int row) {
   else return 4 * (row & 3);
 }
 
-template <typename T, int BKP, int NST>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
+// Output tile = (WCO x WCI) sub-tiles of TWS channels (TWS = one 256-byte row: 128 bf16 / 64 fp32): 1 x 1 on 4 waves
+// (2 x 2, 64 x 64 channels each) or 2 x 2 on 8 waves (2 x 4: 128 co x 64 ci each — half the operand bytes per MFMA and
+// twice the MFMAs per barrier).  LDS stage = [dY sub-tiles | X sub-tiles], each [BKP pixels][256 B].
+template <typename T, int BKP, int NST, int WCO, int WCI, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) conv_wgrad_kernel(WgradParams gp) {
+  constexpr int NW = WM * WN;
   constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int TW = 256 / (int)sizeof(T);    // tile width (channels) of both operands: 256-byte rows
-  constexpr int OPB = BKP * 256;              // bytes of one operand tile (BKP pixels per stage)
-  constexpr int STAGE = 2 * OPB;
-  constexpr int IPO = BKP / 16;               // DMA instructions per wave per operand per stage (4 rows each, 4 waves)
-  constexpr int LPS = 2 * IPO;                // DMA instructions per wave per stage
-  constexpr int TA = TW / 2 / 16;             // 16-wide MFMA tiles per wave along co (and along ci)
+  constexpr int TWS = 256 / (int)sizeof(T);   // channels per sub-tile row (256 bytes)
+  constexpr int TCO = WCO * TWS, TCI = WCI * TWS;
+  constexpr int OPB = BKP * 256;              // bytes of one operand sub-tile (BKP pixels per stage)
+  constexpr int STAGE = (WCO + WCI) * OPB;
+  constexpr int PPS = BKP / 4;                // 1 KiB DMA pieces (4 rows) per sub-tile
+  constexpr int IPA = WCO * PPS / NW;         // DMA instructions per wave per stage, dY
+  constexpr int IPB = WCI * PPS / NW;         // ... X
+  static_assert((WCO * PPS) % NW == 0 && (WCI * PPS) % NW == 0, "DMA pieces must divide over the waves");
+  constexpr int LPS = IPA + IPB;
+  constexpr int TA = TCO / WM / 16;           // 16-wide MFMA tiles per wave along co
+  constexpr int TB = TCI / WN / 16;           // ... along ci
+  static_assert((TCO / WM) % 16 == 0 && (TCI / WN) % 16 == 0, "wave tiling");
+  static_assert(TWS % (TCO / WM) == 0 || (TCO / WM) == TWS, "a wave's co range must stay inside one sub-tile");
+  static_assert(TWS % (TCI / WN) == 0 || (TCI / WN) == TWS, "a wave's ci range must stay inside one sub-tile");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(size_t)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   // XCD-aware bijective remap (blocks b, b+8 share an XCD): all output tiles of one pixel split — they re-read the same
   // dY / X rows — become consecutive logical ids and therefore land on ONE XCD's L2 instead of being fetched by all 8
@@ -103,7 +115,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
   split -= gp.seg[sidx].split_begin;
   const int tap = nt / p.tilesCi, ci_tile = nt % p.tilesCi;
   const int fr = tap / p.S, fs = tap % p.S;
-  const int co0 = co_tile * TW, ci0 = ci_tile * TW;
+  const int co0 = co_tile * TCO, ci0 = ci_tile * TCI;
   const int p_lo = split * p.rows_per_split;
   const int p_hi = min(p.M, p_lo + p.rows_per_split);
   if (p_lo >= p_hi) return;
@@ -113,58 +125,81 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
   const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
   const T* zero = reinterpret_cast<const T*>(g_wzero) + (lane & 15) * EPC;
 
-  // ---- per-lane DMA coordinates: 2 instructions per operand per stage, 4 tile rows per instruction ----
+  // ---- per-lane DMA coordinates: piece = wave * IP + i -> (sub-tile, 4-row group); 4 tile rows per instruction ----
   const int lrow = lane >> 4, lpos = lane & 15;
-  int a_row[IPO], a_col[IPO];          // dY: tile row, channel offset (swizzled source chunk)
-  int b_row[IPO], b_col[IPO];          // X
-  int b_n[IPO], b_ho[IPO], b_wo[IPO];  // output-pixel coordinates of the lane's row (advanced by BKP per stage)
-  bool a_cok[IPO], b_cok[IPO];
+  int a_row[IPA], a_col[IPA], a_dst[IPA];    // dY: tile row, channel (swizzled source chunk), LDS byte offset in the stage
+  int b_row[IPB], b_col[IPB], b_dst[IPB];    // X
+  int b_n[IPB], b_ho[IPB], b_wo[IPB];        // output-pixel coordinates of the lane's row (advanced by BKP per stage)
+  bool a_cok[IPA], b_cok[IPB];
 #pragma unroll
-  for (int i = 0; i < IPO; ++i) {
-    const int row = (wave * IPO + i) * 4 + lrow;
-    const int chunk = lpos ^ wg_swz<T>(row);
-    a_row[i] = row; b_row[i] = row;
-    a_col[i] = co0 + chunk * EPC; b_col[i] = ci0 + chunk * EPC;
-    a_cok[i] = a_col[i] < p.Cout; b_cok[i] = b_col[i] < p.Cin;
+  for (int i = 0; i < IPA; ++i) {
+    const int piece = wave * IPA + i, sub = piece / PPS, row = (piece % PPS) * 4 + lrow;
+    a_row[i] = row;
+    a_col[i] = co0 + sub * TWS + (lpos ^ wg_swz<T>(row)) * EPC;
+    a_cok[i] = a_col[i] < p.Cout;
+    a_dst[i] = sub * OPB + (piece % PPS) * 1024;
+  }
+#pragma unroll
+  for (int i = 0; i < IPB; ++i) {
+    const int piece = wave * IPB + i, sub = piece / PPS, row = (piece % PPS) * 4 + lrow;
+    b_row[i] = row;
+    b_col[i] = ci0 + sub * TWS + (lpos ^ wg_swz<T>(row)) * EPC;
+    b_cok[i] = b_col[i] < p.Cin;
+    b_dst[i] = (WCO + sub) * OPB + (piece % PPS) * 1024;
     const int m = p_lo + row;
     const int n_img = m / p.HoWo;
     const int rem = m - n_img * p.HoWo;
     b_n[i] = n_img; b_ho[i] = rem / p.Wo; b_wo[i] = rem - (rem / p.Wo) * p.Wo;
   }
 
+  // a lane's pixel row advances by BKP output pixels per stage: (n, ho, wo) += (dn, dho, dwo) with at most one carry per
+  // digit — uniform increments and selects instead of per-lane wrap loops (those cost ~12 divergent branches per stage)
+  const int dwo = BKP % p.Wo, q_rows = BKP / p.Wo;
+  const int dho = q_rows % p.Ho, dn = q_rows / p.Ho;
+  const T* a_ptr[IPA];                       // dY source of the lane's row in the NEXT stage to issue
+  const size_t a_step = (size_t)BKP * p.dy_stride;
+#pragma unroll
+  for (int i = 0; i < IPA; ++i) a_ptr[i] = dyg + (size_t)(p_lo + a_row[i]) * p.dy_stride + a_col[i];
   int stage_m = p_lo;   // first pixel of the NEXT stage to issue
   auto issue_stage = [&](int buf) {
-    const unsigned sa = lds0 + buf * STAGE, sb = sa + OPB;
+    const unsigned st = lds0 + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < IPO; ++i) {
-      const int m = stage_m + a_row[i];
-      const T* src = (m < p_hi && a_cok[i]) ? dyg + (size_t)m * p.dy_stride + a_col[i] : zero;
-      wg_dma16(src, sa + (wave * IPO + i) * 1024);
+    for (int i = 0; i < IPA; ++i) {
+      const bool ok = (stage_m + a_row[i] < p_hi) && a_cok[i];
+      wg_dma16(ok ? a_ptr[i] : zero, st + a_dst[i]);
+      a_ptr[i] += a_step;
     }
 #pragma unroll
-    for (int i = 0; i < IPO; ++i) {
-      const int m = stage_m + b_row[i];
+    for (int i = 0; i < IPB; ++i) {
       const int hi = b_ho[i] * p.sh - p.ph + fr, wi = b_wo[i] * p.sw - p.pw + fs;
-      const bool ok = (m < p_hi) && b_cok[i] && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
-      const T* src = ok ? xg + ((size_t)(b_n[i] * p.H + hi) * p.W + wi) * p.Cin + b_col[i] : zero;
-      wg_dma16(src, sb + (wave * IPO + i) * 1024);
-      // advance this lane's pixel by BKP rows
-      b_wo[i] += BKP;
-      while (b_wo[i] >= p.Wo) { b_wo[i] -= p.Wo; ++b_ho[i]; }
-      while (b_ho[i] >= p.Ho) { b_ho[i] -= p.Ho; ++b_n[i]; }
+      const bool ok = (stage_m + b_row[i] < p_hi) && b_cok[i] && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+      const int off = ((b_n[i] * p.H + hi) * p.W + wi) * p.Cin + b_col[i];      // < 2^31 elements (checked by the host)
+      wg_dma16(ok ? xg + off : zero, st + b_dst[i]);
+      int wo = b_wo[i] + dwo, ho = b_ho[i] + dho;
+      const bool c1 = wo >= p.Wo;
+      wo -= c1 ? p.Wo : 0;
+      ho += c1 ? 1 : 0;
+      const bool c2 = ho >= p.Ho;
+      ho -= c2 ? p.Ho : 0;
+      b_wo[i] = wo; b_ho[i] = ho; b_n[i] += dn + (c2 ? 1 : 0);
     }
     stage_m += BKP;
   };
 
-  f32x4 acc[TA][TA];
+  f32x4 acc[TA][TB];
 #pragma unroll
   for (int i = 0; i < TA; ++i)
 #pragma unroll
-    for (int j = 0; j < TA; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // the wave's first channel inside the block tile -> (sub-tile, column inside the sub-tile)
+  constexpr int WCOL_A = TCO / WM, WCOL_B = TCI / WN;
+  const int a_sub = (wm * WCOL_A) / TWS, a_c0 = (wm * WCOL_A) % TWS;
+  const int b_sub = (wn * WCOL_B) / TWS, b_c0 = (wn * WCOL_B) % TWS;
 
   auto compute_stage = [&](int buf) {
-    const char* sa = smem + buf * STAGE;
-    const char* sb = sa + OPB;
+    const char* sa = smem + buf * STAGE + a_sub * OPB;
+    const char* sb = smem + buf * STAGE + (WCO + b_sub) * OPB;
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
      for (int k32 = 0; k32 < BKP / 32; ++k32) {
@@ -173,30 +208,32 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
       const int r1 = k32 * 32 + 4 * g + q, r2 = k32 * 32 + 16 + 4 * g + q;
       typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
       typedef __attribute__((address_space(3))) bf4* lds_bf4_ptr;
-      bf16x8 af[TA], bfr[TA];
+      bf16x8 af[TA], bfr[TB];
+      const int h8 = (pp & 1) * 8;
 #pragma unroll
       for (int i = 0; i < TA; ++i) {
-        const int chunk_a = ((wm * (TW / 2) + i * 16) >> 3) + (pp >> 1);
-        const int chunk_b = ((wn * (TW / 2) + i * 16) >> 3) + (pp >> 1);
-        const int h8 = (pp & 1) * 8;
+        const int chunk_a = ((a_c0 + i * 16) >> 3) + (pp >> 1);
         const bf4 a_lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
             (lds_bf4_ptr)(sa + r1 * 256 + ((chunk_a ^ wg_swz<T>(r1)) << 4) + h8));
         const bf4 a_hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
             (lds_bf4_ptr)(sa + r2 * 256 + ((chunk_a ^ wg_swz<T>(r2)) << 4) + h8));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { af[i][e] = a_lo[e]; af[i][e + 4] = a_hi[e]; }
+      }
+#pragma unroll
+      for (int j = 0; j < TB; ++j) {
+        const int chunk_b = ((b_c0 + j * 16) >> 3) + (pp >> 1);
         const bf4 b_lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
             (lds_bf4_ptr)(sb + r1 * 256 + ((chunk_b ^ wg_swz<T>(r1)) << 4) + h8));
         const bf4 b_hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
             (lds_bf4_ptr)(sb + r2 * 256 + ((chunk_b ^ wg_swz<T>(r2)) << 4) + h8));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          af[i][e] = a_lo[e]; af[i][e + 4] = a_hi[e];
-          bfr[i][e] = b_lo[e]; bfr[i][e + 4] = b_hi[e];
-        }
+        for (int e = 0; e < 4; ++e) { bfr[j][e] = b_lo[e]; bfr[j][e + 4] = b_hi[e]; }
       }
 #pragma unroll
       for (int i = 0; i < TA; ++i)
 #pragma unroll
-        for (int j = 0; j < TA; ++j)
+        for (int j = 0; j < TB; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
      }
     } else {
@@ -205,28 +242,33 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
       for (int kb = 0; kb < BKP / 4; ++kb) {
         const int row = kb * 4 + k;
         const int sw = wg_swz<T>(row);
-        float af[TA], bfr[TA];
+        float af[TA], bfr[TB];
 #pragma unroll
         for (int i = 0; i < TA; ++i) {
-          const int col_a = wm * (TW / 2) + i * 16 + e16, col_b = wn * (TW / 2) + i * 16 + e16;
+          const int col_a = a_c0 + i * 16 + e16;
           af[i] = *reinterpret_cast<const float*>(sa + row * 256 + (((col_a >> 2) ^ sw) << 4) + (col_a & 3) * 4);
-          bfr[i] = *reinterpret_cast<const float*>(sb + row * 256 + (((col_b >> 2) ^ sw) << 4) + (col_b & 3) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+          const int col_b = b_c0 + j * 16 + e16;
+          bfr[j] = *reinterpret_cast<const float*>(sb + row * 256 + (((col_b >> 2) ^ sw) << 4) + (col_b & 3) * 4);
         }
 #pragma unroll
         for (int i = 0; i < TA; ++i)
 #pragma unroll
-          for (int j = 0; j < TA; ++j)
+          for (int j = 0; j < TB; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
       }
     }
   };
 
   // bias gradient: the blocks that own (tap 0, ci tile 0) also sum their dY tile over its pixels, one column per thread
-  const bool do_bias = (p.db != nullptr) && (nt == 0) && (tid < TW);
+  const bool do_bias = (p.db != nullptr) && (nt == 0) && (tid < TCO);
   float bsum = 0.f;
   auto bias_stage = [&](int buf) {
-    const char* sa = smem + buf * STAGE;
-    const int chunk = tid / EPC, within = tid % EPC;
+    const int sub = tid / TWS, cc = tid % TWS;
+    const char* sa = smem + buf * STAGE + sub * OPB;
+    const int chunk = cc / EPC, within = cc % EPC;
 #pragma unroll 8
     for (int row = 0; row < BKP; ++row)
       bsum += to_f32(*reinterpret_cast<const T*>(sa + row * 256 + ((chunk ^ wg_swz<T>(row)) << 4) + within * (int)sizeof(T)));
@@ -253,12 +295,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradParams gp) {
 #pragma unroll
   for (int i = 0; i < TA; ++i) {
 #pragma unroll
-    for (int j = 0; j < TA; ++j) {
-      const int ci = ci0 + wn * (TW / 2) + j * 16 + (lane & 15);
+    for (int j = 0; j < TB; ++j) {
+      const int ci = ci0 + wn * WCOL_B + j * 16 + (lane & 15);
       if (ci >= p.Cin) continue;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int co = co0 + wm * (TW / 2) + i * 16 + (lane >> 4) * 4 + e;
+        const int co = co0 + wm * WCOL_A + i * 16 + (lane >> 4) * 4 + e;
         if (co < p.Cout) {
           const float sc = p.scale ? p.scale[co] : 1.f;
           atomicAdd(dw + (size_t)co * p.Ktot + tap * p.Cin + ci, acc[i][j][e] * sc);
@@ -333,7 +375,22 @@ static int wgrad_launch(const osd_conv_desc* d, int n_seg, const void* const* xs
   p.Cin = d->cin; p.Cout = d->cout;
   p.R = d->r; p.S = d->s; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
   p.dy_stride = d->out_stride; p.Ktot = d->r * d->s * d->cin;
-  const int tw = d->dtype == OSD_BF16 ? 128 : 64;
+  // d->algo (0 = default) = 1 + variant + 8 * target_code: per-shape choice made by the host-side tuner.
+  // variant 0..3: 128 x 128 channel tile on 4 waves, pixels per stage x ring depth = 32x3 / 64x2 / 32x4 / 64x3 (bf16;
+  // fp32 always 32x3); variant 4: 256 x 256 channel tile on 8 waves, 32 px x 3 stages (bf16)
+  static int env_target = -1, env_variant = -1;
+  if (env_target < 0) { const char* e = getenv("OSD_WGRAD_BLOCKS"); env_target = e ? atoi(e) : 512; }
+  if (env_variant < 0) { const char* e = getenv("OSD_WGRAD_VARIANT"); env_variant = e ? atoi(e) : 0; }
+  static const int kTargets[8] = {512, 256, 128, 64, 1024, 768, 384, 32};
+  int target = env_target, variant = env_variant;
+  if (d->algo > 0) {
+    const int a = d->algo - 1;
+    if (a >= 64 || (a & 7) > 4) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d->algo);
+    variant = a & 7;
+    target = kTargets[a >> 3];
+  }
+  const bool big = variant == 4 && d->dtype == OSD_BF16;
+  const int tw = (d->dtype == OSD_BF16 ? 128 : 64) * (big ? 2 : 1);
   p.tilesCo = cdiv(d->cout, tw);
   p.tilesCi = cdiv(d->cin, tw);
   const long long tiles = (long long)p.tilesCo * p.tilesCi * d->r * d->s;
@@ -342,23 +399,13 @@ static int wgrad_launch(const osd_conv_desc* d, int n_seg, const void* const* xs
     const int ho = (hs[i] + 2 * d->pad_h - d->r) / d->stride_h + 1, wo = (ws[i] + 2 * d->pad_w - d->s) / d->stride_w + 1;
     const long long M = (long long)ns[i] * ho * wo;
     if (M <= 0 || M > 0x7fffffffLL || !xs[i] || !dys[i]) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad segment %d", i);
+    if ((long long)ns[i] * hs[i] * ws[i] * d->cin > 0x7fffffffLL)
+      return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: input of segment %d has more than 2^31 elements", i);
     p.seg[i].x = xs[i]; p.seg[i].dy = dys[i]; p.seg[i].H = hs[i]; p.seg[i].W = ws[i]; p.seg[i].Ho = ho; p.seg[i].Wo = wo;
     p.seg[i].M = (int)M;
     Mtot += M;
   }
-  // pixel splits: enough workgroups to fill the chip, at least 128 pixels each, shared out over the segments.
-  // d->algo (0 = default) = 1 + variant + 4 * target_code: per-shape choice made by the host-side tuner.
-  static int env_target = -1, env_variant = -1;
-  if (env_target < 0) { const char* e = getenv("OSD_WGRAD_BLOCKS"); env_target = e ? atoi(e) : 512; }
-  if (env_variant < 0) { const char* e = getenv("OSD_WGRAD_VARIANT"); env_variant = e ? atoi(e) : 0; }
-  static const int kTargets[8] = {512, 256, 128, 64, 1024, 768, 384, 32};
-  int target = env_target, variant = env_variant;
-  if (d->algo > 0) {
-    const int a = d->algo - 1;
-    if (a >= 32) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d->algo);
-    variant = a & 3;
-    target = kTargets[a >> 2];
-  }
+  // pixel splits: enough workgroups to fill the chip, at least 128 pixels each, shared out over the segments
   long long want = (target + tiles - 1) / tiles;
   const long long max_splits = (Mtot + 127) / 128;
   if (want > max_splits) want = max_splits;
@@ -377,22 +424,23 @@ static int wgrad_launch(const osd_conv_desc* d, int n_seg, const void* const* xs
   const long long nblocks = tiles * total_splits;
   if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
   // variant: 0 = 32 px x 3 stages, 1 = 64 px x 2, 2 = 32 px x 4, 3 = 64 px x 3 (bf16; fp32 always 32 x 3)
-#define OSD_WG_LAUNCH(TT, BK, NS)                                                                                   \
+#define OSD_WG_LAUNCH(TT, BK, NS, WC, WMM, WNN)                                                                     \
   do {                                                                                                               \
-    auto kern = conv_wgrad_kernel<TT, BK, NS>;                                                                       \
-    constexpr int lds = NS * 2 * BK * 256;                                                                           \
+    auto kern = conv_wgrad_kernel<TT, BK, NS, WC, WC, WMM, WNN>;                                                     \
+    constexpr int lds = NS * 2 * WC * BK * 256;                                                                      \
     static bool attr = false;                                                                                        \
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; } \
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds, s, p);                                        \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * WMM * WNN), lds, s, p);                             \
   } while (0)
   if (d->dtype == OSD_F32) {
-    OSD_WG_LAUNCH(float, 32, 3);
+    OSD_WG_LAUNCH(float, 32, 3, 1, 2, 2);
   } else {
     switch (variant) {
-      case 1: OSD_WG_LAUNCH(__bf16, 64, 2); break;
-      case 2: OSD_WG_LAUNCH(__bf16, 32, 4); break;
-      case 3: OSD_WG_LAUNCH(__bf16, 64, 3); break;
-      default: OSD_WG_LAUNCH(__bf16, 32, 3); break;
+      case 1: OSD_WG_LAUNCH(__bf16, 64, 2, 1, 2, 2); break;
+      case 2: OSD_WG_LAUNCH(__bf16, 32, 4, 1, 2, 2); break;
+      case 3: OSD_WG_LAUNCH(__bf16, 64, 3, 1, 2, 2); break;
+      case 4: OSD_WG_LAUNCH(__bf16, 32, 3, 2, 2, 4); break;
+      default: OSD_WG_LAUNCH(__bf16, 32, 3, 1, 2, 2); break;
     }
   }
 #undef OSD_WG_LAUNCH

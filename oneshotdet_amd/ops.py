@@ -421,10 +421,13 @@ def pack_conv_master_dgrad(w_orsi, scale, dtype):
 WGRAD_ALGO_CACHE = {}
 
 
-def wgrad_algo_candidates(dtype):
-    """(variant, split-target code) pairs of osd_conv2d_wgrad's algo field; fp32 has one variant."""
-    variants = (0, 1, 2, 3) if dtype == OSD_BF16 else (0,)
-    return [1 + v + 4 * t for t in (0, 1, 2, 3, 4) for v in variants]
+def wgrad_algo_candidates(dtype, cout=0, cin=0):
+    """osd_conv2d_wgrad's algo field = 1 + variant + 8 * split-target code.  Variants 0..3: 128 x 128 channel tile with
+    different stage shapes (bf16; fp32 has one); variant 4: 256 x 256 channel tile on 8 waves (bf16, wide layers)."""
+    variants = [0, 1, 2, 3] if dtype == OSD_BF16 else [0]
+    if dtype == OSD_BF16 and cout >= 256 and cin >= 256:
+        variants.append(4)
+    return [1 + v + 8 * t for t in (0, 1, 2, 3, 4) for v in variants]
 
 
 def _tune_wgrad(key, d, launch, dw, db):
@@ -432,7 +435,7 @@ def _tune_wgrad(key, d, launch, dw, db):
     sdw = torch.empty_like(dw)
     sdb = None if db is None else torch.empty_like(db)
     best, best_t = 0, float("inf")
-    for algo in wgrad_algo_candidates(d.dtype):
+    for algo in wgrad_algo_candidates(d.dtype, d.cout, d.cin):
         d.algo = algo
         launch(sdw, sdb)
         torch.cuda.synchronize()
@@ -449,7 +452,7 @@ def _tune_wgrad(key, d, launch, dw, db):
     return best
 
 
-def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None, db=None):
+def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None, db=None, algo=None):
     """dw_packed [cout][r][s][cin] fp32 += wgrad(x NHWC, dy NHWC [N,Ho,Wo,>=cout]); db [cout] fp32 += sum_m dy (optional)."""
     _chk_dev(x, dy, dw_packed)
     d = _conv_desc(x.shape, _dt(x), cout, r, s, stride, pad, dy.shape[-1])
@@ -459,14 +462,15 @@ def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None, db=None)
     def launch(dw, dbias):
         _lib.call("osd_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(scale), _ptr(dw), _ptr(dbias), st)
     key = (d.dtype, tuple(x.shape), cout, r, s, stride, pad, dy.shape[-1], db is not None)
-    algo = WGRAD_ALGO_CACHE.get(key)
+    if algo is None:
+        algo = WGRAD_ALGO_CACHE.get(key)
     if algo is None:
         algo = _tune_wgrad(key, d, launch, dw_packed, db) if _TUNING[0] else 0
     d.algo = algo
     launch(dw_packed, db)
 
 
-def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, db=None):
+def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, db=None, algo=None):
     """One launch over several (x, dy) pairs sharing the weights (FPN levels): dw_packed += sum over pairs."""
     x0, dy0 = pairs[0]
     d = _conv_desc(x0.shape, _dt(x0), cout, r, s, stride, pad, dy0.shape[-1])
@@ -481,7 +485,8 @@ def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, 
     def launch(dw, dbias):
         _lib.call("osd_conv2d_wgrad_grouped", C.byref(d), k, xs, dys, ns, hs, ws, _ptr(scale), _ptr(dw), _ptr(dbias), st)
     key = (d.dtype, tuple(tuple(x.shape) for x, _ in pairs), cout, r, s, stride, pad, dy0.shape[-1], db is not None)
-    algo = WGRAD_ALGO_CACHE.get(key)
+    if algo is None:
+        algo = WGRAD_ALGO_CACHE.get(key)
     if algo is None:
         algo = _tune_wgrad(key, d, launch, dw_packed, db) if _TUNING[0] else 0
     d.algo = algo

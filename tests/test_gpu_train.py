@@ -268,3 +268,32 @@ def test_train_step_with_updates_behind_backward_equals_the_sequential_step():
     assert float((da - db).norm() / db.norm()) < 2e-3                     # atomic-order noise only
     for form in (0, 1):
         torch.testing.assert_close(a._pack[form]["flat"], b._pack[form]["flat"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", [(3, 256, 25, 32, 512, 3, 1, 1), (2, 320, 14, 10, 384, 1, 1, 0), (1, 512, 9, 7, 256, 3, 2, 1)])
+def test_conv_wgrad_every_algorithm_matches_autograd(case):
+    """Every (stage shape / tile, split target) choice of the weight-gradient tuner, incl. the 256 x 256 8-wave tile
+    (variant 4) with ragged channel tails (320 / 384 channels), a stride-2 conv, the fused bias gradient and the grouped
+    (several FPN levels) form."""
+    from oneshotdet_amd import ops
+    n, cin, h, w, cout, k, s, p = case
+    x = rnd(n, cin, h, w, seed=1).bfloat16().float()
+    wt = (rnd(cout, cin, k, k, seed=2) / np.sqrt(cin * k * k)).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    ho, wo = ops.conv_out(h, k, s, p), ops.conv_out(w, k, s, p)
+    dy = rnd(n, cout, ho, wo, seed=3).bfloat16().float()
+    (F.conv2d(x, wt, b, stride=s, padding=p) * dy).sum().backward()
+    ref, refb = wt.grad.permute(0, 2, 3, 1), b.grad
+    xx, dd = to_nhwc(x, torch.bfloat16), to_nhwc(dy, torch.bfloat16)
+    cands = ops.wgrad_algo_candidates(ops.OSD_BF16, cout, cin)
+    assert any(((a - 1) & 7) == 4 for a in cands)
+    for algo in cands:
+        dw, db = torch.zeros(cout, k, k, cin, device="cuda"), torch.zeros(cout, device="cuda")
+        ops.conv2d_wgrad(xx, dd, dw, k, k, s, p, cout, db=db, algo=algo)
+        assert (dw.cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item(), algo
+        assert (db.cpu() - refb).abs().max().item() <= 2e-2 * refb.abs().max().item(), algo
+    if s == 1:      # grouped: the same tensors as two "levels" -> twice the gradient
+        for algo in (1 + 4, 1 + 4 + 8 * 4, 1 + 0):
+            dw = torch.zeros(cout, k, k, cin, device="cuda")
+            ops.conv2d_wgrad_grouped([(xx, dd), (xx, dd)], dw, k, k, 1, p, cout, algo=algo)
+            assert (dw.cpu() - 2 * ref).abs().max().item() <= 2e-2 * 2 * ref.abs().max().item(), algo
