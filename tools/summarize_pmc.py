@@ -11,9 +11,10 @@ import sys
 
 def last_step(rows):
     rows = sorted(rows, key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "pack_multi" in r["Kernel_Name"]]
-    ends = idx[1::2]
-    return rows[ends[-2] + 1:ends[-1] + 1]
+    # exactly one fcos_loss_finalize launch per step: the dispatches between two of them are one step's worth of every
+    # kernel (second half of step k, first half of step k+1 in steady state)
+    idx = [i for i, r in enumerate(rows) if "fcos_loss_finalize" in r["Kernel_Name"]]
+    return rows[idx[-2] + 1:idx[-1] + 1]
 
 
 def main():
