@@ -275,17 +275,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default="small,nonsquare,shots5,tall,config1")
     ap.add_argument("--skip-train", action="store_true")
+    ap.add_argument("--train-cases", default="small,config1")
+    ap.add_argument("--only-train", action="store_true", help="regenerate only the training fixtures")
     args = ap.parse_args()
     torch.set_num_threads(8)
     model, cfg = rh.build_reference_model()
     np_sd = load_synth_weights(model)
-    gen_keys(model)
-    gen_nms_kat()
-    gen_roialign()
-    for name in [c for c in args.cases.split(",") if c]:
-        gen_case(model, np_sd, name)
+    if not args.only_train:
+        gen_keys(model)
+        gen_nms_kat()
+        gen_roialign()
+        for name in [c for c in args.cases.split(",") if c]:
+            gen_case(model, np_sd, name)
     if not args.skip_train:
-        gen_train_case(model, np_sd, "small")
+        for name in [c for c in args.train_cases.split(",") if c]:
+            gen_train_case(model, np_sd, name)
 
 
 if __name__ == "__main__":
