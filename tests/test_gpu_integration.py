@@ -1,0 +1,45 @@
+"""GPU: the ctypes stub INTEGRATION.md tells a reference maintainer to add (maskrcnn_benchmark/layers/_osd.py) is
+executed VERBATIM from the document (only the library path is substituted) and checked against the oracle, so the
+documented binding cannot rot."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hotpath_ref as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stub_namespace():
+    from oneshotdet_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    assert "/path/to/oneshotdet_amd/lib/liboneshotdet_hip.so" in block
+    block = block.replace("/path/to/oneshotdet_amd/lib/liboneshotdet_hip.so", _lib.LIB_PATH)
+    ns = {}
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)
+    return ns
+
+
+def test_documented_roi_align_stub_matches_the_oracle():
+    ns = _stub_namespace()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 16, 20, 24, generator=g)
+    rois = torch.tensor([[0, 1.5, 2.0, 17.0, 15.5], [1, 0.0, 0.0, 23.0, 19.0], [1, 4.2, 3.3, 9.9, 12.1]])
+    y = ns["roi_align_forward"](x.cuda(), rois.cuda(), 0.5, 3, 3, 2).cpu()
+    ref = orc.roi_align(x, rois, 0.5, 3, 3, 2)
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_documented_focal_loss_stub_matches_the_oracle():
+    ns = _stub_namespace()
+    g = torch.Generator().manual_seed(1)
+    logits = torch.randn(257, 1, generator=g) * 3
+    targets = (torch.rand(257, generator=g) > 0.7).int()
+    out = ns["sigmoid_focalloss_forward"](logits.cuda(), targets.cuda(), 1, 2.0, 0.25).cpu()
+    ref = orc.sigmoid_focal_loss_cuda_formula(logits, targets, 2.0, 0.25)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
