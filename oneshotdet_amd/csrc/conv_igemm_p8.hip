@@ -9,15 +9,16 @@
 //   * the two wave groups (wm = 0 / 1; they share every SIMD pairwise) run ONE BARRIER APART: while one group issues
 //     MFMAs at raised priority, the other does its ds_reads and its LDS-DMA issue, then they swap;
 //   * a K tile (64 k) is staged as four 16 KiB half tiles (pixel halves A0/A1, channel halves B0/B1), two LDS buffers;
-//     each phase issues ONE half tile (2 DMA wave-instructions per wave) FROM ITS MFMA SECTION, one phase after the
-//     region's last read, and there is ONE counted `s_waitcnt vmcnt(4)` per K tile (phase 3) — never 0 inside the loop;
+//     each phase issues ONE half tile (2 DMA wave-instructions per wave: one beside the fragment reads, one from the
+//     MFMA shadow) two phases after the region's last read, and there is ONE counted `s_waitcnt vmcnt(3)` per K tile
+//     (phase 3) — never 0 inside the loop;
 //   * read order per K tile: (A0,B0) -> B1 -> A1 -> B0 again; the A fragments of a pixel half stay in registers for two
 //     phases, so a K tile costs 28 ds_read_b128 per wave for 64 MFMAs.
 // Hazards (LDS-DMA is ordered for a ds_read only by the issuing waves' vmcnt followed by a barrier the reader passed):
 // with the groups one barrier apart every wave has executed the phase-3 wait before barrier instance 8t+8, group 0
-// reads K tile t+1 after 8t+8 and group 1 after 8t+9.  A region is re-staged from the matrix section one phase after
-// its last read: by then the other group's MFMAs that consumed those fragments have been issued (they precede the
-// barrier this group has just passed).
+// reads K tile t+1 after 8t+8 and group 1 after 8t+9.  A region is re-staged two phases (four barrier instances)
+// after its last read by either group (schedule 2: one phase, but only from the matrix section, i.e. after the barrier
+// that the other group's consuming MFMAs precede).
 //
 // Same operand layout, swizzle, zero page, XCD remap, grouped-launch segments and epilogue as conv_igemm_dma.hip.
 #include "osd_common.h"
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(512) conv_p8_kernel(ConvKParams p) {
   // the phase's two DMA pieces issued from the MFMA shadow (an MFMA holds the issue port for half of its 16 cycles; the
   // same two instructions issued beside the ds_reads cost the loading group ~220 cycles per phase and made it the
   // critical path)
-  auto quadrant = [&](const uint4 (&xa)[2][4], const uint4 (&wb)[2][2], int ph, int ch, auto&& dma) {
+  auto quadrant = [&](const uint4 (&xa)[2][4], const uint4 (&wb)[2][2], int ph, int ch, auto&& dma, int inside = 3) {
     P8_STAMP(s0);
     P8_ACC(0, st_phase, s0);
     __builtin_amdgcn_s_barrier();
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(512) conv_p8_kernel(ConvKParams p) {
           acc[ch * 2 + i][ph * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
               *reinterpret_cast<const bf16x8*>(&wb[kk][i]), *reinterpret_cast<const bf16x8*>(&xa[kk][j]),
               acc[ch * 2 + i][ph * 4 + j], 0, 0, 0);
-        if (kk == 0) {
+        if (kk == 0 && ((inside >> i) & 1)) {
           __builtin_amdgcn_sched_barrier(0);
           dma(i);
           __builtin_amdgcn_sched_barrier(0);
@@ -213,6 +214,59 @@ __global__ void __launch_bounds__(512) conv_p8_kernel(ConvKParams p) {
   };
 
   const int KT = p.KT;
+#if !defined(OSD_P8_SCHEDULE) || OSD_P8_SCHEDULE == 1
+  // ---- schedule 1 ("split", default): regions re-staged TWO phases after their last read, so a piece may be issued from
+  // the fragment-read section; piece 0 of a phase goes there, piece 1 into the MFMA section (balances the two sections:
+  // 843 TFLOP/s on the 3x3 256->256 P3 conv; schedule 2 below, both pieces in the MFMA section one phase after the last
+  // read, 772; both pieces in the read section 834)
+  KState k1{0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) issue_a(0, 0, k1, true, i);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) issue_b(1, 0, 0, true, i);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) issue_a(1, 0, k1, true, i);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) issue_b(0, 0, 0, true, i);
+  advance(k1);                                  // k1 = K tile 1
+#pragma unroll
+  for (int i = 0; i < 2; ++i) issue_a(0, 1, k1, 1 < KT, i);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) issue_b(1, 1, 1, 1 < KT, i);
+  KState k2 = k1;
+  advance(k2);                                  // k2 = K tile 2
+  p8_wait_vmcnt<4>();
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+
+  // per K tile kt: phase 0 stages A1 of kt+1, phase 1 B0 of kt+1, phase 2 A0 of kt+2, phase 3 B1 of kt+2; the wait in
+  // phase 3's read section leaves A0(kt+2) and the first piece of B1(kt+2) in flight (3 loads)
+  uint4 xa[2][4], wb0[2][2], wb1[2][2];
+  for (int kt = 0; kt < KT; ++kt) {
+    const int b = kt & 1;
+    const bool v1 = kt + 1 < KT, v2 = kt + 2 < KT;
+    auto d0 = [&](int i) { P8_LOOP_DMA(issue_a(1, b ^ 1, k1, v1, i)); };
+    auto d1 = [&](int i) { P8_LOOP_DMA(issue_b(0, b ^ 1, kt + 1, v1, i)); };
+    auto d2 = [&](int i) { P8_LOOP_DMA(issue_a(0, b, k2, v2, i)); };
+    auto d3 = [&](int i) { P8_LOOP_DMA(issue_b(1, b, kt + 2, v2, i)); };
+    read_a(xa, b, 0);
+    read_b(wb0, b, 0);
+    d0(0);
+    quadrant(xa, wb0, 0, 0, d0, 2);
+    read_b(wb1, b, 1);
+    d1(0);
+    quadrant(xa, wb1, 0, 1, d1, 2);
+    read_a(xa, b, 1);
+    d2(0);
+    quadrant(xa, wb1, 1, 1, d2, 2);
+    read_b(wb0, b, 0);
+    d3(0);
+    p8_wait_vmcnt<3>();
+    quadrant(xa, wb0, 1, 0, d3, 2);
+    advance(k1);
+    advance(k2);
+  }
+#else
   // ---- prologue: K tile 0 completely, then A0 / B1 / A1 of K tile 1 (issue order = retirement order of the waits)
   KState k1{0, 0, 0};
 #pragma unroll
@@ -261,6 +315,7 @@ __global__ void __launch_bounds__(512) conv_p8_kernel(ConvKParams p) {
     quadrant(xa, wb0, 1, 0, [&](int i) { P8_LOOP_DMA(issue_a(1, b, k2, v2, i)); });
     advance(k2);
   }
+#endif
 #ifdef OSD_P8_STAMPS
   if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0)
     for (int i = 0; i < 4; ++i) g_p8_stamps[wave >> 2][i] = st_acc[i];
