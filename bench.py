@@ -250,11 +250,27 @@ class TrainTimer(ConvTimer):
             timer.flops += fl
             timer.launches += 1
         ops.conv2d_wgrad_grouped = timed_grouped
+        self._orig_b = ops.conv2d_wgrad_batched
+
+        def timed_batched(items, r, s, stride, pad, cout, algo=None):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            timer._orig_b(items, r, s, stride, pad, cout, algo=algo)
+            b.record()
+            timer.records.append((a, b))
+            x, dy = items[0][0], items[0][1]
+            m = dy.shape[0] * dy.shape[1] * dy.shape[2]
+            fl = 2.0 * m * cout * x.shape[-1] * r * s * len(items)
+            timer.labels.append(("wgrad%dx%d_x%d" % (r, s, len(items)), m, cout, x.shape[-1] * r * s, fl))
+            timer.flops += fl
+            timer.launches += 1
+        ops.conv2d_wgrad_batched = timed_batched
 
     def uninstall(self, ops):
         ConvTimer.uninstall(self, ops)
         ops.conv2d_wgrad = self._orig_w
         ops.conv2d_wgrad_grouped = self._orig_g
+        ops.conv2d_wgrad_batched = self._orig_b
         ops.correlate = self._orig_c
 
     def correlation_roofline(self):

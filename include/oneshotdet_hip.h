@@ -216,6 +216,13 @@ int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const void* dy, cons
 int osd_conv2d_wgrad_grouped(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
                              const int32_t* ns, const int32_t* hs, const int32_t* ws, const float* scale, float* dw,
                              float* db, void* stream);
+/* n_seg <= 8 convs of IDENTICAL geometry (d: the shared forward descriptor incl. n, h, w) but different tensors AND
+ * different weights — the repeated bottleneck blocks of a ResNet stage (resnet.py:295-315) — in one launch; xs / dys /
+ * scales / dws / dbs: HOST arrays of per-conv device pointers (scales, dbs nullable as a whole or per entry).  The output
+ * tiles of all convs share the workgroup budget: each needs 1/n_seg of the pixel splits, and of the atomic traffic, that a
+ * launch of its own would. */
+int osd_conv2d_wgrad_batched(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
+                             const float* const* scales, float* const* dws, float* const* dbs, void* stream);
 /* packed fp32 dW [cout][r][s][cin] -> OIHW fp32 gradient, multiplied by the folded FrozenBN scale (nullable);
  * accumulate != 0 adds to grad_oihw (weights shared over FPN levels) */
 int osd_unpack_wgrad(const float* dw_packed, const float* scale, float* grad_oihw, int cout, int cin, int r, int s,

@@ -26,6 +26,9 @@ constexpr int kMaxSeg = 8;
 struct WgradSeg {
   const void* x;
   const void* dy;
+  float* dw;            // per-segment outputs (batched launch over layers of identical geometry); null: the shared ones
+  const float* scale;
+  float* db;
   int H, W, Ho, Wo, M, rows_per_split, split_begin;
 };
 
@@ -107,7 +110,10 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_wgrad_kernel(WgradParams gp
     const void* x; const void* dy; float* dw; const float* scale; float* db;
     int H, W, Cin, Ho, Wo, Cout, HoWo, R, S, sh, sw, ph, pw, dy_stride, M, tilesCo, tilesCi, rows_per_split, Ktot;
   } p;
-  p.x = gp.seg[sidx].x; p.dy = gp.seg[sidx].dy; p.dw = gp.dw; p.scale = gp.scale; p.db = gp.db;
+  p.x = gp.seg[sidx].x; p.dy = gp.seg[sidx].dy;
+  p.dw = gp.seg[sidx].dw ? gp.seg[sidx].dw : gp.dw;
+  p.scale = gp.seg[sidx].dw ? gp.seg[sidx].scale : gp.scale;
+  p.db = gp.seg[sidx].dw ? gp.seg[sidx].db : gp.db;
   p.H = gp.seg[sidx].H; p.W = gp.seg[sidx].W; p.Ho = gp.seg[sidx].Ho; p.Wo = gp.seg[sidx].Wo; p.HoWo = p.Ho * p.Wo;
   p.M = gp.seg[sidx].M; p.rows_per_split = gp.seg[sidx].rows_per_split;
   p.Cin = gp.Cin; p.Cout = gp.Cout; p.R = gp.R; p.S = gp.S; p.sh = gp.sh; p.sw = gp.sw; p.ph = gp.ph; p.pw = gp.pw;
@@ -166,22 +172,36 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_wgrad_kernel(WgradParams gp
 #pragma unroll
     for (int i = 0; i < IPA; ++i) {
       const bool ok = (stage_m + a_row[i] < p_hi) && a_cok[i];
+#ifdef OSD_WG_CHEAP_ADDR        // diagnostic: every piece reads the zero page (no address arithmetic, always cached)
+      wg_dma16(zero, st + a_dst[i]);
+#else
       wg_dma16(ok ? a_ptr[i] : zero, st + a_dst[i]);
+#endif
+#ifndef OSD_WG_SAME_ADDR        // diagnostic: every stage re-reads the first stage's rows (full address arithmetic, cached data)
       a_ptr[i] += a_step;
+#endif
     }
 #pragma unroll
     for (int i = 0; i < IPB; ++i) {
       const int hi = b_ho[i] * p.sh - p.ph + fr, wi = b_wo[i] * p.sw - p.pw + fs;
       const bool ok = (stage_m + b_row[i] < p_hi) && b_cok[i] && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
       const int off = ((b_n[i] * p.H + hi) * p.W + wi) * p.Cin + b_col[i];      // < 2^31 elements (checked by the host)
+#ifdef OSD_WG_CHEAP_ADDR
+      wg_dma16(zero, st + b_dst[i]);
+#else
       wg_dma16(ok ? xg + off : zero, st + b_dst[i]);
+#endif
       int wo = b_wo[i] + dwo, ho = b_ho[i] + dho;
       const bool c1 = wo >= p.Wo;
       wo -= c1 ? p.Wo : 0;
       ho += c1 ? 1 : 0;
       const bool c2 = ho >= p.Ho;
       ho -= c2 ? p.Ho : 0;
+#ifndef OSD_WG_SAME_ADDR
       b_wo[i] = wo; b_ho[i] = ho; b_n[i] += dn + (c2 ? 1 : 0);
+#else
+      asm volatile("" ::"v"(wo), "v"(ho), "v"(c2 ? 1 : 0));
+#endif
     }
     stage_m += BKP;
   };
@@ -282,7 +302,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_wgrad_kernel(WgradParams gp
     if (kt + NST - 2 < KT) wg_wait_vmcnt<LPS * (NST - 2)>();
     else wg_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+#ifndef OSD_WG_NO_DMA            // diagnostic builds: timing of the loop without one of its parts (results are garbage)
     if (kt + NST - 1 < KT) issue_stage(nxt);
+#endif
     if (do_bias) bias_stage(cur);
     compute_stage(cur);
     cur = cur + 1 == NST ? 0 : cur + 1;
@@ -290,6 +312,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_wgrad_kernel(WgradParams gp
   }
 
   if (do_bias && co0 + tid < p.Cout) atomicAdd(p.db + co0 + tid, bsum);
+#ifdef OSD_WG_NO_ATOMICS
+  if (acc[0][0][0] != 12345.678f) return;
+#endif
   // ---- accumulate the partial tile into dW (fp32 atomics; rows = co, 16 consecutive ci per 16 lanes) ----
   float* __restrict__ dw = p.dw;
 #pragma unroll
@@ -369,7 +394,9 @@ __global__ void __launch_bounds__(256) bias_grad_kernel(const T* __restrict__ dy
 extern "C" int osd_bias_grad(const void* dy, float* db, int m, int c, int stride, int dtype, void* stream);
 
 static int wgrad_launch(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys, const int* ns,
-                        const int* hs, const int* ws, const float* scale, float* dw, float* db, hipStream_t s) {
+                        const int* hs, const int* ws, const float* scale, float* dw, float* db, hipStream_t s,
+                        const float* const* seg_scales = nullptr, float* const* seg_dws = nullptr,
+                        float* const* seg_dbs = nullptr) {
   WgradParams p;
   p.n_seg = n_seg; p.dw = dw; p.scale = scale; p.db = db;
   p.Cin = d->cin; p.Cout = d->cout;
@@ -402,6 +429,9 @@ static int wgrad_launch(const osd_conv_desc* d, int n_seg, const void* const* xs
     if ((long long)ns[i] * hs[i] * ws[i] * d->cin > 0x7fffffffLL)
       return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: input of segment %d has more than 2^31 elements", i);
     p.seg[i].x = xs[i]; p.seg[i].dy = dys[i]; p.seg[i].H = hs[i]; p.seg[i].W = ws[i]; p.seg[i].Ho = ho; p.seg[i].Wo = wo;
+    p.seg[i].dw = seg_dws ? seg_dws[i] : nullptr;
+    p.seg[i].scale = seg_scales ? seg_scales[i] : nullptr;
+    p.seg[i].db = seg_dbs ? seg_dbs[i] : nullptr;
     p.seg[i].M = (int)M;
     Mtot += M;
   }
@@ -489,6 +519,26 @@ extern "C" int osd_conv2d_wgrad_grouped(const osd_conv_desc* d, int n_seg, const
   if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad dtype");
   if (d->cin % epc || d->out_stride % epc) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_grouped: channel alignment");
   return wgrad_launch(d, n_seg, xs, dys, ns, hs, ws, scale, dw, db, OSD_STREAM(stream));
+}
+
+// n_seg <= 8 convs of IDENTICAL geometry (same x / dy shapes, different tensors and different weights: the repeated
+// bottleneck blocks of a ResNet stage) in one launch, each with its own dW / scale / db: the output tiles of all of them
+// share the workgroup budget, so each needs 1/n_seg of the pixel splits — and of the atomic traffic — of a launch of its own
+extern "C" int osd_conv2d_wgrad_batched(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
+                                        const float* const* scales, float* const* dws, float* const* dbs, void* stream) {
+  if (!d || !xs || !dys || !dws || n_seg < 1 || n_seg > kMaxSeg)
+    return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_batched: bad arguments");
+  const int epc = d->dtype == OSD_BF16 ? 8 : 4;
+  if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad dtype");
+  if (d->cin % epc || d->out_stride % epc) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_batched: channel alignment");
+  if (d->in_stride_w != d->cin || d->in_stride_h != d->w * d->cin)
+    return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad_batched: dense NHWC input required");
+  int ns[kMaxSeg], hs[kMaxSeg], ws[kMaxSeg];
+  for (int i = 0; i < n_seg; ++i) {
+    if (!dws[i]) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_batched: null dW %d", i);
+    ns[i] = d->n; hs[i] = d->h; ws[i] = d->w;
+  }
+  return wgrad_launch(d, n_seg, xs, dys, ns, hs, ws, nullptr, dws[0], nullptr, OSD_STREAM(stream), scales, dws, dbs);
 }
 
 extern "C" int osd_bias_grad(const void* dy, float* db, int m, int c, int stride, int dtype, void* stream) {

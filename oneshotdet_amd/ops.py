@@ -493,6 +493,37 @@ def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, 
     launch(dw_packed, db)
 
 
+def conv2d_wgrad_batched(items, r, s, stride, pad, cout, algo=None):
+    """items: [(x, dy, dw, scale or None, db or None)] — convs of identical geometry with their own weights (the repeated
+    bottleneck blocks of a stage): ONE launch, dw_i += wgrad(x_i, dy_i)."""
+    x0, dy0 = items[0][0], items[0][1]
+    assert all(it[0].shape == x0.shape and it[1].shape == dy0.shape for it in items)
+    d = _conv_desc(x0.shape, _dt(x0), cout, r, s, stride, pad, dy0.shape[-1])
+    k = len(items)
+    xs = (C.c_void_p * k)(*[it[0].data_ptr() for it in items])
+    dys = (C.c_void_p * k)(*[it[1].data_ptr() for it in items])
+    scales = (C.c_void_p * k)(*[(it[3].data_ptr() if it[3] is not None else 0) for it in items])
+    st = _stream()
+    has_db = any(it[4] is not None for it in items)
+
+    def launch(dws, dbs):
+        dwp = (C.c_void_p * k)(*[t.data_ptr() for t in dws])
+        dbp = (C.c_void_p * k)(*[(t.data_ptr() if t is not None else 0) for t in dbs])
+        _lib.call("osd_conv2d_wgrad_batched", C.byref(d), k, xs, dys, scales, dwp, dbp, st)
+    key = ("batched", k, d.dtype, tuple(x0.shape), cout, r, s, stride, pad, dy0.shape[-1], has_db)
+    if algo is None:
+        algo = WGRAD_ALGO_CACHE.get(key)
+    if algo is None:
+        if _TUNING[0]:
+            sdw = [torch.empty_like(it[2]) for it in items]
+            sdb = [None if it[4] is None else torch.empty_like(it[4]) for it in items]
+            algo = _tune_wgrad(key, d, lambda a, b: launch(sdw, sdb), items[0][2], None)
+        else:
+            algo = 0
+    d.algo = algo
+    launch([it[2] for it in items], [it[4] for it in items])
+
+
 def bias_grad(dy, db, c):
     n, h, w, stride = dy.shape
     _lib.call("osd_bias_grad", _ptr(dy), _ptr(db), n * h * w, c, stride, _dt(dy), _stream())

@@ -66,6 +66,7 @@ class TrainEngine(object):
         self.exchange = GradExchange(self.flat_g, bucket_ranges(self._plan, self.flat_g.numel()), self.pg)
         self.ustream = torch.cuda.Stream(device=self.device)
         self._overlap, self._fuse_update, self._updated = True, False, set()
+        self._wq = None
         self.repack()
         self.zero_bias = torch.zeros(4096, device=self.device, dtype=torch.float32)
         # SGD with the reference's parameter groups (solver/build.py:8-26: bias lr x2, bias weight decay 0)
@@ -401,8 +402,28 @@ class TrainEngine(object):
             self._update_bucket(name)
 
     def _wgrad(self, c, x, dy, stride=1, pad=0):
+        if self._wq is not None:       # inside a backbone: queued, launched per stage with the convs of identical geometry
+            key = (tuple(x.shape), tuple(dy.shape), c.r, c.s, stride, pad, c.cout, c.has_bias, c.bn_scale is not None)
+            self._wq.setdefault(key, []).append((c, x, dy))
+            return
         self._on_wstream(lambda: ops.conv2d_wgrad(x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale,
                                                   db=c.gb if c.has_bias else None), (x, dy))
+
+    def _flush_wgrads(self):
+        """Launch the queued weight gradients: convs of identical geometry (the repeated bottleneck blocks of a stage)
+        share ONE batched launch — their output tiles split the workgroup budget, so each conv pays 1/k of the pixel
+        splits and of the atomic traffic of a launch of its own, and the query branch's tiny launches become few."""
+        q, self._wq = self._wq, {}
+        for (xs, dys, r, s, stride, pad, cout, has_bias, has_scale), lst in q.items():
+            for i in range(0, len(lst), 8):
+                part = lst[i:i + 8]
+                if len(part) == 1:
+                    c, x, dy = part[0]
+                    self._on_wstream(lambda c=c, x=x, dy=dy: ops.conv2d_wgrad(
+                        x, dy, c.gw, r, s, stride, pad, cout, scale=c.bn_scale, db=c.gb if c.has_bias else None), (x, dy))
+                else:
+                    items = [(x, dy, c.gw, c.bn_scale, c.gb if c.has_bias else None) for c, x, dy in part]
+                    self._on_wstream(lambda items=items: ops.conv2d_wgrad_batched(items, r, s, stride, pad, cout), items)
 
     def _wgrad_grouped(self, c, pairs):
         self._on_wstream(lambda: ops.conv2d_wgrad_grouped(pairs, c.gw, c.r, c.s, 1, c.r // 2, c.cout, scale=c.bn_scale,
@@ -453,6 +474,7 @@ class TrainEngine(object):
 
     def backbone_backward(self, ctx, dP, need_input_grad=False):
         cv, bb = self.convs, ctx["bb"]
+        self._wq = {}
         f = bb + "fpn."
         dp3, dp4, dp5, dp6, dp7 = dP
         # P7 = conv(relu(P6)), P6 = conv(P5), both 3x3 stride 2 (fpn.py:95-99)
@@ -493,6 +515,7 @@ class TrainEngine(object):
             stage = p[len(bb + "body."):].split(".", 1)[0]
             bucket = bb.rstrip(".") + "." + ("layer4+fpn" if stage == "layer4" else stage) if p.endswith(".0.") else None
             if blk["first"]:
+                self._flush_wgrads()
                 self._bucket_ready(bucket)
                 break                                   # input of layer2 = frozen layer1 output: no data gradient
             extra = lateral.get(id(blk["x"]))            # block input is C3/C4: add the FPN lateral's gradient
@@ -505,7 +528,10 @@ class TrainEngine(object):
                 bsm = self._dgrad(c1, d_o1, res=a)
                 g = ops.scatter2x(bsm, blk["x"].shape[1:3], mask=blk["x"], addend=extra)
             if bucket is not None:      # first block of its stage done (its data-gradient convs included): the stage's
-                self._bucket_ready(bucket)   # gradients are final and nothing enqueued later reads its packed weights
+                self._flush_wgrads()         # weight gradients go out (batched), then its gradients are final and nothing
+                self._bucket_ready(bucket)   # enqueued later reads its packed weights
+        self._flush_wgrads()
+        self._wq = None
         return None
 
     # ------------------------------------------------------------------------------------------------ step

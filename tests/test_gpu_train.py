@@ -305,3 +305,31 @@ def test_conv_wgrad_every_algorithm_matches_autograd(case):
             dw = torch.zeros(cout, k, k, cin, device="cuda")
             ops.conv2d_wgrad_grouped([(xx, dd), (xx, dd)], dw, k, k, 1, p, cout, algo=algo)
             assert (dw.cpu() - 2 * ref).abs().max().item() <= 2e-2 * 2 * ref.abs().max().item(), algo
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_wgrad_batched_equals_one_launch_per_conv(dt):
+    """osd_conv2d_wgrad_batched: k convs of identical geometry with their own weights / FrozenBN scales / bias gradients
+    in one launch vs k launches of osd_conv2d_wgrad (accumulation order differs only through the atomics)."""
+    from oneshotdet_amd import ops
+    n, cin, h, w, cout, k, stride, pad = 2, 256, 14, 18, 128, 3, 1, 1
+    items, refs = [], []
+    for i in range(5):
+        x = to_nhwc(rnd(n, cin, h, w, seed=10 + i), DT[dt])
+        dy = to_nhwc(rnd(n, cout, h, w, seed=20 + i), DT[dt])
+        scale = (rnd(cout, seed=30 + i).abs() + 0.5).cuda() if i % 2 == 0 else None
+        dw, db = torch.zeros(cout, k, k, cin, device="cuda"), (torch.zeros(cout, device="cuda") if i != 1 else None)
+        rw, rb = torch.zeros_like(dw), (torch.zeros(cout, device="cuda") if i != 1 else None)
+        ops.conv2d_wgrad(x, dy, rw, k, k, stride, pad, cout, scale=scale, db=rb)
+        items.append((x, dy, dw, scale, db))
+        refs.append((rw, rb))
+    for algo in (None, 1 + 0 + 8 * 3, 1 + 1 + 8 * 0):
+        for it in items:
+            it[2].zero_()
+            if it[4] is not None:
+                it[4].zero_()
+        ops.conv2d_wgrad_batched(items, k, k, stride, pad, cout, algo=algo)
+        for (x, dy, dw, scale, db), (rw, rb) in zip(items, refs):
+            torch.testing.assert_close(dw, rw, rtol=1e-3, atol=1e-3 * float(rw.abs().max()))
+            if db is not None:
+                torch.testing.assert_close(db, rb, rtol=1e-3, atol=1e-3 * float(rb.abs().max()))
