@@ -308,7 +308,7 @@ def main_train(args, rank, world):
             for k, a in ops.ALGO_CACHE.items():
                 f.write("conv %s -> %d\n" % (k, a))
 
-    launch = "eager, 4 streams (main, query/bbox branch, 2 x weight gradients)"
+    launch = "eager, 6 streams (main chain, query/bbox branch, 2 x weight gradients, proposals, exchange + update)"
     step = lambda: eng.train_step(images, queries, gt_boxes, gt_count)     # noqa: E731
     if args.graph:
         try:
