@@ -368,3 +368,24 @@ def test_groupnorm_relu_levels_forward_backward_at_fpn_sizes(n, dt):
         assert (du.float().cpu().permute(0, 3, 1, 2) - gref).abs().max() <= tol * gref.abs().max(), x.shape
     assert (dg.cpu() - g.grad).abs().max() <= tol * g.grad.abs().max()
     assert (db.cpu() - b.grad).abs().max() <= tol * b.grad.abs().max()
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_full_size_batch8_training_step_properties(dt):
+    """BASELINE.json configs[2] size (8 x 800x1024 targets, 8 x 127x127 queries).  A batch of 8 identical (image, query,
+    boxes) triples must give the single-image losses (the FCOS losses are normalised by the total number of positives)
+    and the single-image parameter gradients — and the single-image fp32 run is pinned to the reference by
+    test_forward_backward_matches_oracle_autograd[config1].  Exercises every training kernel at the benchmark's grid
+    sizes: batched / grouped weight gradients with many pixel splits, level-grouped GroupNorm, the loss kernels."""
+    e1, img, q, gtb, cnt = _engine_and_inputs(dt, "config1")
+    l1 = e1.forward_backward(img, q, gtb, cnt).clone()
+    g1 = e1.flat_g.clone()
+    l8 = e1.forward_backward(img.expand(8, -1, -1, -1).contiguous(), q.expand(8, -1, -1, -1).contiguous(),
+                             gtb.expand(8, -1, -1).contiguous(), cnt.expand(8).contiguous()).clone()
+    g8 = e1.flat_g
+    assert int(l8[3]) == 8 * int(l1[3])
+    torch.testing.assert_close(l8[:3], l1[:3], rtol=1e-5 if dt == "f32" else 2e-3, atol=0)
+    for name, (lo, hi) in e1.exchange.ranges.items():
+        a, b = g8[lo:hi], g1[lo:hi]
+        err = float((a - b).norm() / b.norm())
+        assert err <= (2e-4 if dt == "f32" else 3e-2), (name, err)
