@@ -128,10 +128,20 @@ __global__ void __launch_bounds__(512) conv_p8_kernel(ConvKParams p) {
     const int hi = a_hi0[h][i] + k.kr, wi = a_wi0[h][i] + k.ks;
     const bool ok = valid && ((unsigned)hi < (unsigned)q.H) && ((unsigned)wi < (unsigned)q.W);
     const T* src = ok ? a_base[h][i] + (hi * q.sH + wi * p.sW + k.kc) : zero;
+#if defined(OSD_P8_CHEAP_ADDR)      // diagnostic: every piece reads the zero page (no misses, 1 line per piece)
+    src = zero;
+#elif defined(OSD_P8_SAME_ADDR)     // diagnostic: real address arithmetic, but always K tile 0's rows (cached)
+    src = ok ? a_base[h][i] + (hi * q.sH + wi * p.sW) : zero;
+#endif
     p8_dma16(src, lds0 + buf * BUF + h * HALF + (wave * 2 + i) * 1024);
   };
   auto issue_b = [&](int h, int buf, int ktile, bool valid, int i) {
     const T* src = (valid && b_base[h][i]) ? b_base[h][i] + ktile * BKE : zero;
+#if defined(OSD_P8_CHEAP_ADDR)
+    src = zero;
+#elif defined(OSD_P8_SAME_ADDR)
+    src = (valid && b_base[h][i]) ? b_base[h][i] : zero;
+#endif
     p8_dma16(src, lds0 + buf * BUF + (2 + h) * HALF + (wave * 2 + i) * 1024);
   };
   auto advance = [&](KState& k) {
