@@ -66,8 +66,16 @@ class GradExchange(object):
         self.world = dist.get_world_size(group) if self.active else 1
         self.cuda = flat.is_cuda
         self.comm = torch.cuda.Stream(device=flat.device) if (self.active and self.cuda) else None
-        # RCCL averages natively; gloo has no AVG, so sum and scale
-        self.avg = self.active and dist.get_backend(group) == "nccl"
+        # RCCL averages natively; gloo has no AVG, so sum and scale.  Probed once with a one-element collective (every
+        # rank constructs its exchange at the same point) so an unsupported op degrades to sum + scale, not to a crash
+        self.avg = False
+        if self.active and dist.get_backend(group) == "nccl" and self.cuda:
+            try:
+                probe = torch.ones(1, device=flat.device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=group)
+                self.avg = abs(float(probe.item()) - 1.0) < 1e-6
+            except Exception:
+                self.avg = False
         self.pending = set()
         self.begin()
 
