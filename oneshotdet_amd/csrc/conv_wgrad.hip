@@ -316,16 +316,40 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_wgrad_kernel(WgradParams gp
   if (acc[0][0][0] != 12345.678f) return;
 #endif
   // ---- accumulate the partial tile into dW (fp32 atomics; rows = co, 16 consecutive ci per 16 lanes) ----
+  // Whole-tile fast path: the per-row FrozenBN scales are loaded up front and the 64 atomics of a wave follow in ONE
+  // basic block.  With a load or a bounds branch between two atomics hipcc puts `s_waitcnt vmcnt(0)` in front of every
+  // atomic (vmcnt counts the atomics too), which serialises them at ~300 ns each: a 20 us tail on EVERY workgroup and
+  // the whole duration of the small launches.
   float* __restrict__ dw = p.dw;
+  const int co_w = co0 + wm * WCOL_A + (lane >> 4) * 4;           // first co row of this lane (tile i adds 16 * i)
+  const int ci_w = ci0 + wn * WCOL_B + (lane & 15);               // first ci of this lane (tile j adds 16 * j)
+  if (co0 + TCO <= p.Cout && ci0 + TCI <= p.Cin) {
+    float scv[TA][4];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) scv[i][e] = p.scale ? p.scale[co_w + i * 16 + e] : 1.f;
+    float* base = dw + (size_t)co_w * p.Ktot + tap * p.Cin + ci_w;
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float* row = base + (size_t)(i * 16 + e) * p.Ktot;
+#pragma unroll
+        for (int j = 0; j < TB; ++j) atomicAdd(row + j * 16, acc[i][j][e] * scv[i][e]);
+      }
+    return;
+  }
+  // ragged tile (channel counts that are not multiples of the tile): per-element bounds checks
 #pragma unroll
   for (int i = 0; i < TA; ++i) {
 #pragma unroll
     for (int j = 0; j < TB; ++j) {
-      const int ci = ci0 + wn * WCOL_B + j * 16 + (lane & 15);
+      const int ci = ci_w + j * 16;
       if (ci >= p.Cin) continue;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int co = co0 + wm * WCOL_A + i * 16 + (lane >> 4) * 4 + e;
+        const int co = co_w + i * 16 + e;
         if (co < p.Cout) {
           const float sc = p.scale ? p.scale[co] : 1.f;
           atomicAdd(dw + (size_t)co * p.Ktot + tap * p.Cin + ci, acc[i][j][e] * sc);
