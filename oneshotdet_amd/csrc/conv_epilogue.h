@@ -50,8 +50,13 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
   constexpr int EPC = 16 / (int)sizeof(T);
   const int q_M = q.M, q_HoWo = q.HoWo, q_Wo = q.Wo;
   const void* q_y = q.y; const void* q_res = q.res; const void* q_mask = q.mask; const float* q_scale_dev = q.scale_dev;
-  T* __restrict__ yg = reinterpret_cast<T*>(const_cast<void*>(q_y));
-  const T* __restrict__ rg = reinterpret_cast<const T*>(q_res);
+  // explicit global address space: the per-segment pointers come out of the kernarg table as integers, so hipcc would
+  // otherwise treat them as generic and emit flat_load / flat_store (slower, and they tie up lgkmcnt as well)
+#define OSD_G __attribute__((address_space(1)))
+  OSD_G T* yg = (OSD_G T*)(const_cast<void*>(q_y));
+  const OSD_G T* rg = (const OSD_G T*)(q_res);
+  const OSD_G T* mkg = (const OSD_G T*)(q_mask);
+  const OSD_G float* biasg = (const OSD_G float*)(p.bias);
   constexpr int WC = TN * 16;                    // channels of a wave tile
   constexpr int CSW = WC * 4 + 16;               // staging row stride (bytes); +16 keeps ds_write_b128 conflict free
   constexpr int NPASS = TM >= 8 ? TM / 2 : (TM >= 2 ? 2 : 1);
@@ -100,19 +105,19 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
         }
         if constexpr (sizeof(T) == 2) {
           if (vec_ok && nval[it] == EPC) {
-            const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(rg + res_off);
+            const bf16x8 r8 = *(const OSD_G bf16x8*)(rg + res_off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[it][e] = (float)r8[e];
           } else {
             for (int e = 0; e < nval[it]; e += 4) {
-              const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rg + res_off + e);
+              const bf16x4 r4 = *(const OSD_G bf16x4*)(rg + res_off + e);
 #pragma unroll
               for (int k = 0; k < 4; ++k) v[it][e + k] = (float)r4[k];
             }
           }
         } else {
-          const float4 r4 = *reinterpret_cast<const float4*>(rg + res_off);
-          v[it][0] = r4.x; v[it][1] = r4.y; v[it][2] = r4.z; v[it][3] = r4.w;
+          const f32x4 r4 = *(const OSD_G f32x4*)(rg + res_off);
+          v[it][0] = r4[0]; v[it][1] = r4[1]; v[it][2] = r4[2]; v[it][3] = r4[3];
         }
       }
     }
@@ -127,26 +132,26 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
 #pragma unroll
       for (int e = 0; e < EPC; e += 4) {
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(src + e * 4);
-        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + c + e);
-        v[it][e] = (a4[0] + b4.x) + v[it][e];
-        v[it][e + 1] = (a4[1] + b4.y) + v[it][e + 1];
-        v[it][e + 2] = (a4[2] + b4.z) + v[it][e + 2];
-        v[it][e + 3] = (a4[3] + b4.w) + v[it][e + 3];
+        const f32x4 b4 = *(const OSD_G f32x4*)(biasg + c + e);
+        v[it][e] = (a4[0] + b4[0]) + v[it][e];
+        v[it][e + 1] = (a4[1] + b4[1]) + v[it][e + 1];
+        v[it][e + 2] = (a4[2] + b4[2]) + v[it][e + 2];
+        v[it][e + 3] = (a4[3] + b4[3]) + v[it][e + 3];
       }
       if (q_mask) {     // ReLU backward of the producer layer: zero where its forward output was not positive
-        const T* mk = reinterpret_cast<const T*>(q_mask) + ooff[it];
+        const OSD_G T* mk = mkg + ooff[it];
         if constexpr (sizeof(T) == 2) {
           if (vec_ok && nval[it] == EPC) {
-            const bf16x8 m8 = *reinterpret_cast<const bf16x8*>(mk);
+            const bf16x8 m8 = *(const OSD_G bf16x8*)(mk);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[it][e] = (float)m8[e] > 0.f ? v[it][e] : 0.f;
           } else {
             for (int e = 0; e < nval[it]; ++e) v[it][e] = (float)mk[e] > 0.f ? v[it][e] : 0.f;
           }
         } else {
-          const float4 m4 = *reinterpret_cast<const float4*>(mk);
-          v[it][0] = m4.x > 0.f ? v[it][0] : 0.f; v[it][1] = m4.y > 0.f ? v[it][1] : 0.f;
-          v[it][2] = m4.z > 0.f ? v[it][2] : 0.f; v[it][3] = m4.w > 0.f ? v[it][3] : 0.f;
+          const f32x4 m4 = *(const OSD_G f32x4*)(mk);
+          v[it][0] = m4[0] > 0.f ? v[it][0] : 0.f; v[it][1] = m4[1] > 0.f ? v[it][1] : 0.f;
+          v[it][2] = m4[2] > 0.f ? v[it][2] : 0.f; v[it][3] = m4[3] > 0.f ? v[it][3] : 0.f;
         }
       }
       if (p.act == OSD_ACT_RELU) {
@@ -154,28 +159,29 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
         for (int e = 0; e < EPC; ++e) v[it][e] = fmaxf(v[it][e], 0.f);
       } else if (p.act == OSD_ACT_EXP_SCALE) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[it][e] = expf(v[it][e] * (q_scale_dev ? *q_scale_dev : p.act_scale));
+        for (int e = 0; e < EPC; ++e) v[it][e] = expf(v[it][e] * (q_scale_dev ? *(const OSD_G float*)q_scale_dev : p.act_scale));
       }
-      T* dst = yg + ooff[it];
+      OSD_G T* dst = yg + ooff[it];
       if constexpr (sizeof(T) == 2) {
         if (vec_ok && nval[it] == EPC) {
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[it][e];
-          *reinterpret_cast<bf16x8*>(dst) = o;
+          *(OSD_G bf16x8*)(dst) = o;
         } else {
           for (int e = 0; e < nval[it]; e += 4) {
             bf16x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = (__bf16)v[it][e + k];
-            *reinterpret_cast<bf16x4*>(dst + e) = o;
+            *(OSD_G bf16x4*)(dst + e) = o;
           }
         }
       } else {
-        *reinterpret_cast<float4*>(dst) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+        *(OSD_G f32x4*)(dst) = f32x4{v[it][0], v[it][1], v[it][2], v[it][3]};
       }
     }
   }
 }
+#undef OSD_G
 
 }  // namespace
