@@ -4,6 +4,7 @@
 #include "osd_common.h"
 #include "conv_params.h"
 #include <cstddef>
+#include <type_traits>
 
 namespace {
 
@@ -68,6 +69,102 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
   char* stage = smem + wave * (ROWS * CSW);
   const bool vec_ok = (p.out_stride % EPC == 0) && (p.res_mode == OSD_RES_NONE || p.res_stride % EPC == 0);
   const int cbase = n0 + wn * WC;
+
+  // ---- fast path (wave-uniform): the wave's whole sub-tile is inside the output and every access is a full 16-byte
+  // chunk.  No per-lane bounds branches, so each phase is one basic block: all residual and mask loads of a pass are
+  // issued back to back (hipcc places `s_waitcnt vmcnt(0)` at every branch merge that follows a load, which made the
+  // general path below wait for each load — and, in pass 2, for the previous STORE — one at a time), then the arithmetic,
+  // then the stores with nothing to wait for between them.
+  if (vec_ok && m0 + (wm * TM + TM) * 16 <= q_M && cbase + WC <= p.Cout) {
+    typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type Vec;     // one 16-byte chunk
+    const int cc = lane % CPR;                 // 64 % CPR == 0: a lane keeps its channel chunk in every iteration
+    const int c = cbase + cc * EPC;
+    float bv[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; e += 4) {
+      const f32x4 b4 = *(const OSD_G f32x4*)(biasg + c + e);
+      bv[e] = b4[0]; bv[e + 1] = b4[1]; bv[e + 2] = b4[2]; bv[e + 3] = b4[3];
+    }
+    const float escale = p.act == OSD_ACT_EXP_SCALE ? (q_scale_dev ? *(const OSD_G float*)q_scale_dev : p.act_scale) : 1.f;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+      for (int jj = 0; jj < TMP; ++jj) {
+        const int j = ps * TMP + jj;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          *reinterpret_cast<f32x4*>(stage + (jj * 16 + (lane & 15)) * CSW + (i * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
+      }
+      const int mrow = m0 + (wm * TM + ps * TMP) * 16 + lane / CPR;     // iteration `it` adds it * (64 / CPR) rows
+      Vec rr[ITER], mm[ITER];
+      if (p.res_mode == OSD_RES_SAME) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+          rr[it] = *(const OSD_G Vec*)(rg + (size_t)(mrow + it * (64 / CPR)) * p.res_stride + c);
+      } else if (p.res_mode == OSD_RES_UP2X) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int m = mrow + it * (64 / CPR);
+          const int n_img = m / q_HoWo;
+          const int rem = m - n_img * q_HoWo;
+          const int ho = rem / q_Wo, wo = rem - (rem / q_Wo) * q_Wo;
+          rr[it] = *(const OSD_G Vec*)(rg + ((size_t)(n_img * p.res_h + (ho >> 1)) * p.res_w + (wo >> 1)) * p.res_stride + c);
+        }
+      }
+      if (q_mask) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+          mm[it] = *(const OSD_G Vec*)(mkg + (size_t)(mrow + it * (64 / CPR)) * p.out_stride + c);
+      }
+      float v[ITER][EPC];
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const char* src = stage + (it * (64 / CPR) + lane / CPR) * CSW + cc * EPC * 4;
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(src + e * 4);
+          v[it][e] = a4[0] + bv[e]; v[it][e + 1] = a4[1] + bv[e + 1];
+          v[it][e + 2] = a4[2] + bv[e + 2]; v[it][e + 3] = a4[3] + bv[e + 3];
+        }
+      }
+      if (p.res_mode != OSD_RES_NONE) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[it][e] += (float)rr[it][e];
+      }
+      if (q_mask) {     // ReLU backward of the producer layer: zero where its forward output was not positive
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[it][e] = (float)mm[it][e] > 0.f ? v[it][e] : 0.f;
+      }
+      if (p.act == OSD_ACT_RELU) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[it][e] = fmaxf(v[it][e], 0.f);
+      } else if (p.act == OSD_ACT_EXP_SCALE) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[it][e] = expf(v[it][e] * escale);
+      }
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        Vec o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          if constexpr (sizeof(T) == 2) o[e] = (__bf16)v[it][e];
+          else o[e] = v[it][e];
+        }
+        *(OSD_G Vec*)(yg + (size_t)(mrow + it * (64 / CPR)) * p.out_stride + c) = o;
+      }
+    }
+    return;
+  }
+
+  // ---- general path: ragged M / Cout tails, 8-byte granularity
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
