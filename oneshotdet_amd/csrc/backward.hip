@@ -271,18 +271,34 @@ __global__ void __launch_bounds__(256) correlate_bwd_q_kernel(const T* __restric
   float s[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) s[e] = 0.f;
-  if (pl < lanes)
-    for (int p = p0 + pl; p < p1; p += lanes) {
-      Chunk<T> a, b;
-      const size_t off = ((size_t)img * hw + p) * c + cc * E;
-      a.load(g + off);
-      b.load(feat + off);
+  if (pl < lanes && p0 < p1) {
+    constexpr int U = 4;            // 8 x 16-byte loads in flight per thread (unconditional, clamped: no branch merges)
+    for (int p = p0 + pl; p < p1; p += U * lanes) {
+      Chunk<T> a[U], b[U];
 #pragma unroll
-      for (int e = 0; e < E; ++e) s[e] += a.v[e] * b.v[e];
+      for (int k = 0; k < U; ++k) {
+        const size_t off = ((size_t)img * hw + min(p + k * lanes, p1 - 1)) * c + cc * E;
+        a[k].load(g + off);
+        b[k].load(feat + off);
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const float live = p + k * lanes < p1 ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[e] += live * a[k].v[e] * b[k].v[e];
+      }
     }
-  if (pl < lanes) {
+  }
+  // fold the pixel lanes of the workgroup in LDS, then ONE atomic per channel and workgroup (the 8 x 256 destinations are
+  // shared by every workgroup: fewer, block-reduced adds keep the contended-atomic cost negligible at 4x the workgroups)
+  __shared__ float red[256 * 8];
 #pragma unroll
-    for (int e = 0; e < E; ++e) atomicAdd(dq + (size_t)img * c + cc * E + e, s[e]);
+  for (int e = 0; e < E; ++e) red[(pl * cch + cc) * E + e] = (pl < lanes) ? s[e] : 0.f;
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += red[l * c + ch];
+    if (p0 < p1) atomicAdd(dq + (size_t)img * c + ch, t);
   }
 }
 
@@ -592,8 +608,8 @@ extern "C" int osd_correlate_bwd_query(const void* g, const void* feat, float* d
   hipError_t er = hipMemsetAsync(dq, 0, sizeof(float) * (size_t)n * c, OSD_STREAM(stream));
   if (er != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "correlate_bwd_query: memset failed");
   if (n == 0 || hw == 0) return OSD_OK;
-  int slabs = (hw + 255) / 256;
-  if (slabs > 128) slabs = 128;
+  int slabs = (hw + 63) / 64;        // 64 pixels per workgroup: enough workgroups to keep 8 loads x 256 threads in flight per CU
+  if (slabs > 512) slabs = 512;
   dim3 grid(slabs, n);
   OSD_DISPATCH_DTYPE(dtype,
       hipLaunchKernelGGL(correlate_bwd_q_kernel<float>, grid, dim3(256), 0, OSD_STREAM(stream), (const float*)g, (const float*)feat, dq, hw, c),
@@ -801,13 +817,11 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
     for (int p = p0 + pl; p < p1; p += U * lanes) {
       Chunk<T> uu[U], gg[U];
 #pragma unroll
-      for (int k = 0; k < U; ++k) {
-        const int pk = p + k * lanes;
-        if (pk < p1) {
-          const size_t off = ((size_t)img * hw + pk) * c + cc * E;
-          uu[k].load(u + off);
-          gg[k].load(dt + off);
-        }
+      for (int k = 0; k < U; ++k) {      // unconditional (clamped) loads: a branch around a load costs a vmcnt(0) at its merge
+        const int pk = min(p + k * lanes, p1 - 1);
+        const size_t off = ((size_t)img * hw + pk) * c + cc * E;
+        uu[k].load(u + off);
+        gg[k].load(dt + off);
       }
 #pragma unroll
       for (int k = 0; k < U; ++k) {
@@ -931,12 +945,11 @@ __global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const fl
   for (long long i = i0 + threadIdx.x; i < i1; i += (long long)U * blockDim.x) {
     Chunk<T> uu[U], gg[U];
 #pragma unroll
-    for (int k = 0; k < U; ++k) {
+    for (int k = 0; k < U; ++k) {        // unconditional loads; an out-of-range slot re-reads this thread's first chunk
       const long long ik = i + (long long)k * blockDim.x;
-      if (ik < i1) {
-        uu[k].load(u + base + ik * E);
-        gg[k].load(dt + base + ik * E);
-      }
+      const long long il = ik < i1 ? ik : i;
+      uu[k].load(u + base + il * E);
+      gg[k].load(dt + base + il * E);
     }
 #pragma unroll
     for (int k = 0; k < U; ++k) {
