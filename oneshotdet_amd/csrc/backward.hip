@@ -78,6 +78,39 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackEntry* __rest
   const float* w = src + e.src_off;
   const float* sc = e.scale_off >= 0 ? scales + e.scale_off : nullptr;
   T* out = dst + e.dst_off;
+  constexpr int EP = 16 / (int)sizeof(T);     // elements of one 16-byte output chunk
+  if (!dgrad && e.cin % EP == 0 && e.kpad % EP == 0 && (e.src_off & 3) == 0) {
+    // forward form, 16 bytes out per lane: a chunk lies entirely inside or entirely outside the real channels
+    const int kch = e.kpad / EP;
+    const int total = e.rows * e.R * e.S * kch;
+    const int stride = e.n_blocks * blockDim.x;
+    const int rs_c = e.R * e.S * kch;
+    for (int i = (blockIdx.x - e.first_block) * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const int row = i / rs_c, rem = i - row * rs_c;
+      const int tap = rem / kch, k = (rem - tap * kch) * EP;
+      float v[EP];
+#pragma unroll
+      for (int q = 0; q < EP; ++q) v[q] = 0.f;
+      if (row < e.cout && k < e.cin) {
+        const f32x4* sp = reinterpret_cast<const f32x4*>(w + ((size_t)row * e.R * e.S + tap) * e.cin + k);
+        const float f = sc ? sc[row] : 1.f;
+#pragma unroll
+        for (int q = 0; q < EP; q += 4) {
+          const f32x4 x = sp[q / 4];
+          v[q] = x[0] * f; v[q + 1] = x[1] * f; v[q + 2] = x[2] * f; v[q + 3] = x[3] * f;
+        }
+      }
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (__bf16)v[q];
+        *reinterpret_cast<bf16x8*>(out + (size_t)i * EP) = o;
+      } else {
+        *reinterpret_cast<f32x4*>(out + (size_t)i * EP) = f32x4{v[0], v[1], v[2], v[3]};
+      }
+    }
+    return;
+  }
   if (!dgrad) {              // forward form: same [row = co][r][s][k = ci] order as the master -> a scaled, padded copy
     const int total = e.rows * e.R * e.S * e.kpad;
     const int stride = e.n_blocks * blockDim.x;
@@ -94,8 +127,50 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackEntry* __rest
     }
     return;
   }
-  // data-gradient form [row = ci][r'][s'][k = co] with flipped taps: a transpose of the master per tap, done through
-  // LDS in 32 x 32 tiles so both the reads (along ci) and the writes (along co) are coalesced
+  // data-gradient form [row = ci][r'][s'][k = co] with flipped taps: a transpose of the master per tap through LDS.
+  // 64 x 64 tiles: 16-byte loads along ci, 16-byte stores along co
+  if (e.cin % 4 == 0 && e.kpad % 64 == 0 && (e.src_off & 3) == 0) {
+    __shared__ float big[64][65];
+    const int tci = (e.rows + 63) / 64, tco = e.kpad / 64;
+    const int ntiles = e.R * e.S * tci * tco;
+    for (int t = blockIdx.x - e.first_block; t < ntiles; t += e.n_blocks) {
+      const int cot = t % tco;
+      int u = t / tco;
+      const int cit = u % tci; u /= tci;
+      const int ss = u % e.S, rr = u / e.S;
+      const int co0 = cot * 64, ci0 = cit * 64;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int co = co0 + (threadIdx.x >> 4) + 16 * j, ci = ci0 + (threadIdx.x & 15) * 4;
+        f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (co < e.cout && ci < e.cin) {
+          x = *reinterpret_cast<const f32x4*>(w + (((size_t)co * e.R + (e.R - 1 - rr)) * e.S + (e.S - 1 - ss)) * e.cin + ci);
+          if (sc) { const float f = sc[co]; x[0] *= f; x[1] *= f; x[2] *= f; x[3] *= f; }
+        }
+        float* trow = &big[(threadIdx.x >> 4) + 16 * j][(threadIdx.x & 15) * 4];
+        trow[0] = x[0]; trow[1] = x[1]; trow[2] = x[2]; trow[3] = x[3];
+      }
+      __syncthreads();
+      constexpr int CPW = 64 / EP;                       // output chunks per ci row of the tile
+#pragma unroll
+      for (int j = 0; j < (64 * CPW) / 256; ++j) {
+        const int idx = threadIdx.x + 256 * j;
+        const int ci = ci0 + idx / CPW, cc = (idx % CPW) * EP;
+        if (ci >= e.rows) continue;
+        T* o = out + (((size_t)ci * e.R + rr) * e.S + ss) * e.kpad + co0 + cc;
+        if constexpr (sizeof(T) == 2) {
+          bf16x8 v;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = (__bf16)big[cc + q][idx / CPW];
+          *reinterpret_cast<bf16x8*>(o) = v;
+        } else {
+          *reinterpret_cast<f32x4*>(o) = f32x4{big[cc][idx / CPW], big[cc + 1][idx / CPW], big[cc + 2][idx / CPW], big[cc + 3][idx / CPW]};
+        }
+      }
+    }
+    return;
+  }
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int tci = (e.rows + 31) / 32, tco = (e.kpad + 31) / 32;
@@ -141,7 +216,30 @@ __global__ void __launch_bounds__(256) sgd_multi_kernel(const SgdEntry* __restri
   const SgdEntry e = table[block_entry[blockIdx.x]];
   const float step = lr * e.lr_mult;
   const long long stride = (long long)e.n_blocks * blockDim.x;
-  for (long long i = (long long)(blockIdx.x - e.first_block) * blockDim.x + threadIdx.x; i < e.numel; i += stride) {
+  const long long tid = (long long)(blockIdx.x - e.first_block) * blockDim.x + threadIdx.x;
+  // 16 bytes per lane (3 loads + 2 stores of 16 B per 4 parameters) when the tensor starts on a 16-byte boundary
+  const long long n4 = (e.off & 3) == 0 ? (e.numel >> 2) : 0;
+  f32x4* p4 = reinterpret_cast<f32x4*>(p + e.off);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g + e.off);
+  f32x4* b4 = reinterpret_cast<f32x4*>(buf + e.off);
+  for (long long i = tid; i < n4; i += stride) {
+    const f32x4 w = p4[i], gr = g4[i];
+    f32x4 m;
+    if (first) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = gr[k] + e.wd * w[k];
+    } else {
+      const f32x4 bb = b4[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = momentum * bb[k] + (gr[k] + e.wd * w[k]);
+    }
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = w[k] - step * m[k];
+    b4[i] = m;
+    p4[i] = o;
+  }
+  for (long long i = n4 * 4 + tid; i < e.numel; i += stride) {
     const long long k = e.off + i;
     const float w = p[k];
     const float d = g[k] + e.wd * w;
