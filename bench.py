@@ -265,12 +265,28 @@ class TrainTimer(ConvTimer):
             timer.flops += fl
             timer.launches += 1
         ops.conv2d_wgrad_batched = timed_batched
+        self._orig_m = ops.conv2d_wgrad_multi
+
+        def timed_multi(items, r, s, stride, pad, cout, algo=None):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            timer._orig_m(items, r, s, stride, pad, cout, algo=algo)
+            b.record()
+            timer.records.append((a, b))
+            m = sum(it[1].shape[0] * it[1].shape[1] * it[1].shape[2] for it in items)
+            kk = items[0][0].shape[-1] * r * s
+            fl = 2.0 * m * cout * kk
+            timer.labels.append(("wgrad%dx%d_multi%d" % (r, s, len(items)), m, cout, kk, fl))
+            timer.flops += fl
+            timer.launches += 1
+        ops.conv2d_wgrad_multi = timed_multi
 
     def uninstall(self, ops):
         ConvTimer.uninstall(self, ops)
         ops.conv2d_wgrad = self._orig_w
         ops.conv2d_wgrad_grouped = self._orig_g
         ops.conv2d_wgrad_batched = self._orig_b
+        ops.conv2d_wgrad_multi = self._orig_m
         ops.correlate = self._orig_c
 
     def correlation_roofline(self):

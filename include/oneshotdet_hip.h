@@ -211,18 +211,24 @@ int osd_pack_conv_weight_dgrad(const float* w, const float* scale, void* dst, in
  * 512, 256, 128, 64, 1024, 768, 384, 32 workgroups. */
 int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const void* dy, const float* scale, float* dw, float* db,
                      void* stream);
-/* the same over n_seg <= 8 (x, dy) pairs that share the weights (the FPN levels of the FCOS towers): d gives the conv
+/* the same over n_seg <= 24 (x, dy) pairs that share the weights (the FPN levels of the FCOS towers): d gives the conv
  * geometry, ns/hs/ws (HOST arrays) the batch and input size of each pair; one launch, the atomic traffic into dW is paid once */
 int osd_conv2d_wgrad_grouped(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
                              const int32_t* ns, const int32_t* hs, const int32_t* ws, const float* scale, float* dw,
                              float* db, void* stream);
-/* n_seg <= 8 convs of IDENTICAL geometry (d: the shared forward descriptor incl. n, h, w) but different tensors AND
+/* n_seg <= 24 convs of IDENTICAL geometry (d: the shared forward descriptor incl. n, h, w) but different tensors AND
  * different weights — the repeated bottleneck blocks of a ResNet stage (resnet.py:295-315) — in one launch; xs / dys /
  * scales / dws / dbs: HOST arrays of per-conv device pointers (scales, dbs nullable as a whole or per entry).  The output
  * tiles of all convs share the workgroup budget: each needs 1/n_seg of the pixel splits, and of the atomic traffic, that a
  * launch of its own would. */
 int osd_conv2d_wgrad_batched(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
                              const float* const* scales, float* const* dws, float* const* dbs, void* stream);
+/* The general form: n_seg <= 24 (x, dy) pairs, each with its own batch / height / width (ns, hs, ws) AND its own
+ * dW / scale / db (pairs that share a weight repeat its pointers): e.g. the four convs of an FCOS tower over the five
+ * FPN levels (20 pairs, 4 distinct dW) in one launch. */
+int osd_conv2d_wgrad_multi(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
+                           const int32_t* ns, const int32_t* hs, const int32_t* ws, const float* const* scales,
+                           float* const* dws, float* const* dbs, void* stream);
 /* packed fp32 dW [cout][r][s][cin] -> OIHW fp32 gradient, multiplied by the folded FrozenBN scale (nullable);
  * accumulate != 0 adds to grad_oihw (weights shared over FPN levels) */
 int osd_unpack_wgrad(const float* dw_packed, const float* scale, float* grad_oihw, int cout, int cin, int r, int s,

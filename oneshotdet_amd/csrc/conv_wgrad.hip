@@ -13,12 +13,13 @@
 // tens of output tiles); partial tiles are accumulated with fp32 atomics (no-return global_atomic_add_f32).
 // A 3-deep LDS ring with counted vmcnt and one raw barrier per stage, as in conv_igemm_dma.hip.
 #include "osd_common.h"
+#include <cstddef>
 
 namespace {
 
 __device__ __attribute__((aligned(256))) unsigned g_wzero[64];
 
-constexpr int kMaxSeg = 8;
+constexpr int kMaxSeg = 24;
 
 // One launch can reduce over several (x, dy) pairs that share the weights (the FPN levels of the FCOS towers): the
 // pixel splits are distributed over the segments, every workgroup works inside one segment, and all of them add into
@@ -110,15 +111,24 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_wgrad_kernel(WgradParams gp
     const void* x; const void* dy; float* dw; const float* scale; float* db;
     int H, W, Cin, Ho, Wo, Cout, HoWo, R, S, sh, sw, ph, pw, dy_stride, M, tilesCo, tilesCi, rows_per_split, Ktot;
   } p;
-  p.x = gp.seg[sidx].x; p.dy = gp.seg[sidx].dy;
-  p.dw = gp.seg[sidx].dw ? gp.seg[sidx].dw : gp.dw;
-  p.scale = gp.seg[sidx].dw ? gp.seg[sidx].scale : gp.scale;
-  p.db = gp.seg[sidx].dw ? gp.seg[sidx].db : gp.db;
-  p.H = gp.seg[sidx].H; p.W = gp.seg[sidx].W; p.Ho = gp.seg[sidx].Ho; p.Wo = gp.seg[sidx].Wo; p.HoWo = p.Ho * p.Wo;
-  p.M = gp.seg[sidx].M; p.rows_per_split = gp.seg[sidx].rows_per_split;
+  // the chosen entry is read straight from the kernarg segment (scalar loads at a dynamic offset): indexing the by-value
+  // struct with a runtime index would make hipcc copy the whole table to scratch
+  typedef const __attribute__((address_space(4))) char* kptr;
+  typedef unsigned long long u64;
+  kptr sb = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WgradParams, seg) + sidx * (int)sizeof(WgradSeg);
+#define OSD_WSEG(type, field) (*reinterpret_cast<const __attribute__((address_space(4))) type*>(sb + offsetof(WgradSeg, field)))
+  p.x = (const void*)OSD_WSEG(u64, x); p.dy = (const void*)OSD_WSEG(u64, dy);
+  float* seg_dw = (float*)OSD_WSEG(u64, dw);
+  p.dw = seg_dw ? seg_dw : gp.dw;
+  p.scale = seg_dw ? (const float*)OSD_WSEG(u64, scale) : gp.scale;
+  p.db = seg_dw ? (float*)OSD_WSEG(u64, db) : gp.db;
+  p.H = OSD_WSEG(int, H); p.W = OSD_WSEG(int, W); p.Ho = OSD_WSEG(int, Ho); p.Wo = OSD_WSEG(int, Wo); p.HoWo = p.Ho * p.Wo;
+  p.M = OSD_WSEG(int, M); p.rows_per_split = OSD_WSEG(int, rows_per_split);
+  const int seg_split_begin = OSD_WSEG(int, split_begin);
+#undef OSD_WSEG
   p.Cin = gp.Cin; p.Cout = gp.Cout; p.R = gp.R; p.S = gp.S; p.sh = gp.sh; p.sw = gp.sw; p.ph = gp.ph; p.pw = gp.pw;
   p.dy_stride = gp.dy_stride; p.tilesCo = gp.tilesCo; p.tilesCi = gp.tilesCi; p.Ktot = gp.Ktot;
-  split -= gp.seg[sidx].split_begin;
+  split -= seg_split_begin;
   const int tap = nt / p.tilesCi, ci_tile = nt % p.tilesCi;
   const int fr = tap / p.S, fs = tap % p.S;
   const int co0 = co_tile * TCO, ci0 = ci_tile * TCI;
@@ -562,6 +572,21 @@ extern "C" int osd_conv2d_wgrad_batched(const osd_conv_desc* d, int n_seg, const
     if (!dws[i]) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_batched: null dW %d", i);
     ns[i] = d->n; hs[i] = d->h; ws[i] = d->w;
   }
+  return wgrad_launch(d, n_seg, xs, dys, ns, hs, ws, nullptr, dws[0], nullptr, OSD_STREAM(stream), scales, dws, dbs);
+}
+
+// the general form: n_seg <= 24 (x, dy) pairs with their own batch / spatial size AND their own dW / scale / db — e.g. the
+// four convs of an FCOS tower x five FPN levels in one launch (pairs that share a dW simply repeat its pointer)
+extern "C" int osd_conv2d_wgrad_multi(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
+                                      const int32_t* ns, const int32_t* hs, const int32_t* ws, const float* const* scales,
+                                      float* const* dws, float* const* dbs, void* stream) {
+  if (!d || !xs || !dys || !ns || !hs || !ws || !dws || n_seg < 1 || n_seg > kMaxSeg)
+    return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_multi: bad arguments (1..%d segments)", kMaxSeg);
+  const int epc = d->dtype == OSD_BF16 ? 8 : 4;
+  if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad dtype");
+  if (d->cin % epc || d->out_stride % epc) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_multi: channel alignment");
+  for (int i = 0; i < n_seg; ++i)
+    if (!dws[i]) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_multi: null dW %d", i);
   return wgrad_launch(d, n_seg, xs, dys, ns, hs, ws, nullptr, dws[0], nullptr, OSD_STREAM(stream), scales, dws, dbs);
 }
 

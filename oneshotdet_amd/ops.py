@@ -524,6 +524,41 @@ def conv2d_wgrad_batched(items, r, s, stride, pad, cout, algo=None):
     launch([it[2] for it in items], [it[4] for it in items])
 
 
+def conv2d_wgrad_multi(items, r, s, stride, pad, cout, algo=None):
+    """items: [(x, dy, dw, scale or None, db or None)] with the same conv geometry (channels, kernel, stride, pad) but any
+    batch / spatial size per item; items may share a dw (FPN levels of one conv) or not (different convs): ONE launch."""
+    x0, dy0 = items[0][0], items[0][1]
+    d = _conv_desc(x0.shape, _dt(x0), cout, r, s, stride, pad, dy0.shape[-1])
+    k = len(items)
+    xs = (C.c_void_p * k)(*[it[0].data_ptr() for it in items])
+    dys = (C.c_void_p * k)(*[it[1].data_ptr() for it in items])
+    ns = (C.c_int32 * k)(*[it[0].shape[0] for it in items])
+    hs = (C.c_int32 * k)(*[it[0].shape[1] for it in items])
+    ws = (C.c_int32 * k)(*[it[0].shape[2] for it in items])
+    scales = (C.c_void_p * k)(*[(it[3].data_ptr() if it[3] is not None else 0) for it in items])
+    st = _stream()
+    real_dws, real_dbs = [it[2] for it in items], [it[4] for it in items]
+
+    def launch(dws, dbs):
+        dwp = (C.c_void_p * k)(*[t.data_ptr() for t in dws])
+        dbp = (C.c_void_p * k)(*[(t.data_ptr() if t is not None else 0) for t in dbs])
+        _lib.call("osd_conv2d_wgrad_multi", C.byref(d), k, xs, dys, ns, hs, ws, scales, dwp, dbp, st)
+    key = ("multi", d.dtype, tuple(tuple(it[0].shape) for it in items), tuple(id(it[2]) == id(items[0][2]) for it in items),
+           cout, r, s, stride, pad, dy0.shape[-1], any(b is not None for b in real_dbs))
+    if algo is None:
+        algo = WGRAD_ALGO_CACHE.get(key)
+    if algo is None:
+        if _TUNING[0]:
+            scratch = {}
+            sdw = [scratch.setdefault(id(t), torch.empty_like(t)) for t in real_dws]
+            sdb = [None if t is None else scratch.setdefault(id(t), torch.empty_like(t)) for t in real_dbs]
+            algo = _tune_wgrad(key, d, lambda a, b: launch(sdw, sdb), real_dws[0], None)
+        else:
+            algo = 0
+    d.algo = algo
+    launch(real_dws, real_dbs)
+
+
 def bias_grad(dy, db, c):
     n, h, w, stride = dy.shape
     _lib.call("osd_bias_grad", _ptr(dy), _ptr(db), n * h * w, c, stride, _dt(dy), _stream())

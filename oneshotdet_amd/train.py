@@ -463,13 +463,18 @@ class TrainEngine(object):
         dpred = [pred_grads[l][gi] for l in range(nl)]
         self._wgrad_grouped(pc, [(t_last[l], dpred[l]) for l in range(nl)])
         d_t = self._dgrad_levels(pc, dpred)
+        items = []
         for i in range(spec.NUM_CONVS - 1, -1, -1):
             (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
             c = cv["%s%s.%d" % (h, tower, 3 * i)]
             t_in, u, ab = layers[i]
             du = ops.groupnorm_relu_bwd_levels(u, d_t, ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
-            self._wgrad_grouped(c, [(t_in[l], du[l]) for l in range(nl)])
+            items += [(t_in[l], du[l], c.gw, c.bn_scale, c.gb if c.has_bias else None) for l in range(nl)]
             d_t = self._dgrad_levels(c, du)
+        # the four tower convs x five levels: ONE weight-gradient launch (20 pairs, 4 distinct dW) once the chain is done —
+        # each conv gets a quarter of the pixel splits / atomic traffic of a launch of its own
+        c0 = cv["%s%s.0" % (h, tower)]
+        self._on_wstream(lambda: ops.conv2d_wgrad_multi(items, c0.r, c0.s, 1, c0.r // 2, c0.cout), items)
         return d_t
 
     def backbone_backward(self, ctx, dP, need_input_grad=False):

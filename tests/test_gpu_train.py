@@ -389,3 +389,29 @@ def test_full_size_batch8_training_step_properties(dt):
         a, b = g8[lo:hi], g1[lo:hi]
         err = float((a - b).norm() / b.norm())
         assert err <= (2e-4 if dt == "f32" else 3e-2), (name, err)
+
+
+def test_conv_wgrad_multi_mixes_shared_and_own_weights():
+    """osd_conv2d_wgrad_multi: pairs of different spatial size, some sharing a dW (FPN levels of one conv), others with
+    their own (another conv of the tower), against one osd_conv2d_wgrad launch per pair."""
+    from oneshotdet_amd import ops
+    cin = cout = 256
+    sizes = [(2, 25, 32), (2, 13, 16), (2, 7, 8)]
+    dws = [torch.zeros(cout, 3, 3, cin, device="cuda") for _ in range(2)]
+    dbs = [torch.zeros(cout, device="cuda") for _ in range(2)]
+    refs = [torch.zeros_like(dws[0]) for _ in range(2)]
+    refb = [torch.zeros_like(dbs[0]) for _ in range(2)]
+    items = []
+    for conv in range(2):
+        for i, (n, h, w) in enumerate(sizes):
+            x = to_nhwc(rnd(n, cin, h, w, seed=100 * conv + i), torch.bfloat16)
+            dy = to_nhwc(rnd(n, cout, h, w, seed=100 * conv + 50 + i), torch.bfloat16)
+            items.append((x, dy, dws[conv], None, dbs[conv]))
+            ops.conv2d_wgrad(x, dy, refs[conv], 3, 3, 1, 1, cout, db=refb[conv])
+    for algo in (None, 1 + 0 + 8 * 2, 1 + 4 + 8 * 0):
+        for t in dws + dbs:
+            t.zero_()
+        ops.conv2d_wgrad_multi(items, 3, 3, 1, 1, cout, algo=algo)
+        for conv in range(2):
+            torch.testing.assert_close(dws[conv], refs[conv], rtol=1e-3, atol=1e-3 * float(refs[conv].abs().max()))
+            torch.testing.assert_close(dbs[conv], refb[conv], rtol=1e-3, atol=1e-3 * float(refb[conv].abs().max()))
