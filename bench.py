@@ -280,6 +280,23 @@ class TrainTimer(ConvTimer):
             timer.flops += fl
             timer.launches += 1
         ops.conv2d_wgrad_multi = timed_multi
+        self._orig_x = ops.conv2d_wgrad_mixed
+
+        def timed_mixed(items, algo=None):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            timer._orig_x(items, algo=algo)
+            b.record()
+            timer.records.append((a, b))
+            fl, mm = 0.0, 0
+            for x, dy, dw, sc, db, r, s, stride, pad, cout in items:
+                m = dy.shape[0] * dy.shape[1] * dy.shape[2]
+                fl += 2.0 * m * cout * x.shape[-1] * r * s
+                mm += m
+            timer.labels.append(("wgrad_mixed%d" % len(items), mm, 0, 0, fl))
+            timer.flops += fl
+            timer.launches += 1
+        ops.conv2d_wgrad_mixed = timed_mixed
 
     def uninstall(self, ops):
         ConvTimer.uninstall(self, ops)
@@ -287,6 +304,7 @@ class TrainTimer(ConvTimer):
         ops.conv2d_wgrad_grouped = self._orig_g
         ops.conv2d_wgrad_batched = self._orig_b
         ops.conv2d_wgrad_multi = self._orig_m
+        ops.conv2d_wgrad_mixed = self._orig_x
         ops.correlate = self._orig_c
 
     def correlation_roofline(self):

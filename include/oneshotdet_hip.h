@@ -229,6 +229,11 @@ int osd_conv2d_wgrad_batched(const osd_conv_desc* d, int n_seg, const void* cons
 int osd_conv2d_wgrad_multi(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
                            const int32_t* ns, const int32_t* hs, const int32_t* ws, const float* const* scales,
                            float* const* dws, float* const* dbs, void* stream);
+/* The most general form: every pair has its own conv descriptor (n, h, w, cin, cout, r, s, strides, pads, out_stride):
+ * all weight gradients of a ResNet stage (1x1 and 3x3, stride 1 and 2, FPN laterals) in one launch; dtype and algo are
+ * taken from descs[0]; descs is a HOST array of n_seg descriptors. */
+int osd_conv2d_wgrad_mixed(int n_seg, const osd_conv_desc* descs, const void* const* xs, const void* const* dys,
+                           const float* const* scales, float* const* dws, float* const* dbs, void* stream);
 /* packed fp32 dW [cout][r][s][cin] -> OIHW fp32 gradient, multiplied by the folded FrozenBN scale (nullable);
  * accumulate != 0 adds to grad_oihw (weights shared over FPN levels) */
 int osd_unpack_wgrad(const float* dw_packed, const float* scale, float* grad_oihw, int cout, int cin, int r, int s,

@@ -61,6 +61,7 @@ SIGNATURES = {
     "osd_conv2d_wgrad_grouped": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_wgrad_batched": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_wgrad_multi": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "osd_conv2d_wgrad_mixed": (_i, [_i, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
     "osd_unpack_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "osd_bias_grad": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "osd_conv2d_dgrad_naive": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),

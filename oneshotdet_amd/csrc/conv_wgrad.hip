@@ -27,22 +27,19 @@ constexpr int kMaxSeg = 24;
 struct WgradSeg {
   const void* x;
   const void* dy;
-  float* dw;            // per-segment outputs (batched launch over layers of identical geometry); null: the shared ones
-  const float* scale;
-  float* db;
-  int H, W, Ho, Wo, M, rows_per_split, split_begin;
-};
-
-struct WgradParams {
-  WgradSeg seg[kMaxSeg];
-  int n_seg;
   float* dw;
   const float* scale;   // optional per-Cout factor (folded FrozenBN scale: d/dw of conv(x, w*scale))
   float* db;            // optional bias gradient: db[co] += sum over pixels of dy (done by the tap-0 / ci-tile-0 blocks)
-  int Cin, Cout;
-  int R, S, sh, sw, ph, pw;
-  int dy_stride;
-  int tilesCo, tilesCi, splits, Ktot;
+  int H, W, Ho, Wo, M, rows_per_split;
+  int Cin, Cout, R, S, sh, sw, ph, pw, dy_stride, tilesCo, tilesCi, Ktot;
+  int block_begin;      // first (logical) workgroup of this segment; its workgroups: tilesCo x R*S*tilesCi x splits
+};
+
+// Every segment is a complete problem (its own tensors, geometry and outputs; segments that share a dW simply repeat the
+// pointer): the FPN levels of one conv, the repeated blocks of a stage, or all weight gradients of a stage at once.
+struct WgradParams {
+  WgradSeg seg[kMaxSeg];
+  int n_seg;
 };
 
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -97,38 +94,36 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_wgrad_kernel(WgradParams gp
     const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int co_tile = bid % gp.tilesCo;
-  bid /= gp.tilesCo;
-  const int ntile = gp.R * gp.S * gp.tilesCi;
-  const int nt = bid % ntile;
-  int split = bid / ntile;
   int sidx = 0;
 #pragma unroll
   for (int i = 1; i < kMaxSeg; ++i)
-    if (i < gp.n_seg && split >= gp.seg[i].split_begin) sidx = i;
-  // flatten the chosen segment into the single-problem view the rest of the kernel uses
+    if (i < gp.n_seg && bid >= gp.seg[i].block_begin) sidx = i;
+  // flatten the chosen segment into the single-problem view the rest of the kernel uses.  The entry is read straight
+  // from the kernarg segment (scalar loads at a dynamic offset): indexing the by-value struct with a runtime index would
+  // make hipcc copy the whole table to scratch
   struct {
     const void* x; const void* dy; float* dw; const float* scale; float* db;
     int H, W, Cin, Ho, Wo, Cout, HoWo, R, S, sh, sw, ph, pw, dy_stride, M, tilesCo, tilesCi, rows_per_split, Ktot;
   } p;
-  // the chosen entry is read straight from the kernarg segment (scalar loads at a dynamic offset): indexing the by-value
-  // struct with a runtime index would make hipcc copy the whole table to scratch
   typedef const __attribute__((address_space(4))) char* kptr;
   typedef unsigned long long u64;
   kptr sb = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WgradParams, seg) + sidx * (int)sizeof(WgradSeg);
 #define OSD_WSEG(type, field) (*reinterpret_cast<const __attribute__((address_space(4))) type*>(sb + offsetof(WgradSeg, field)))
   p.x = (const void*)OSD_WSEG(u64, x); p.dy = (const void*)OSD_WSEG(u64, dy);
-  float* seg_dw = (float*)OSD_WSEG(u64, dw);
-  p.dw = seg_dw ? seg_dw : gp.dw;
-  p.scale = seg_dw ? (const float*)OSD_WSEG(u64, scale) : gp.scale;
-  p.db = seg_dw ? (float*)OSD_WSEG(u64, db) : gp.db;
+  p.dw = (float*)OSD_WSEG(u64, dw); p.scale = (const float*)OSD_WSEG(u64, scale); p.db = (float*)OSD_WSEG(u64, db);
   p.H = OSD_WSEG(int, H); p.W = OSD_WSEG(int, W); p.Ho = OSD_WSEG(int, Ho); p.Wo = OSD_WSEG(int, Wo); p.HoWo = p.Ho * p.Wo;
   p.M = OSD_WSEG(int, M); p.rows_per_split = OSD_WSEG(int, rows_per_split);
-  const int seg_split_begin = OSD_WSEG(int, split_begin);
+  p.Cin = OSD_WSEG(int, Cin); p.Cout = OSD_WSEG(int, Cout); p.R = OSD_WSEG(int, R); p.S = OSD_WSEG(int, S);
+  p.sh = OSD_WSEG(int, sh); p.sw = OSD_WSEG(int, sw); p.ph = OSD_WSEG(int, ph); p.pw = OSD_WSEG(int, pw);
+  p.dy_stride = OSD_WSEG(int, dy_stride); p.tilesCo = OSD_WSEG(int, tilesCo); p.tilesCi = OSD_WSEG(int, tilesCi);
+  p.Ktot = OSD_WSEG(int, Ktot);
+  bid -= OSD_WSEG(int, block_begin);
 #undef OSD_WSEG
-  p.Cin = gp.Cin; p.Cout = gp.Cout; p.R = gp.R; p.S = gp.S; p.sh = gp.sh; p.sw = gp.sw; p.ph = gp.ph; p.pw = gp.pw;
-  p.dy_stride = gp.dy_stride; p.tilesCo = gp.tilesCo; p.tilesCi = gp.tilesCi; p.Ktot = gp.Ktot;
-  split -= seg_split_begin;
+  const int co_tile = bid % p.tilesCo;
+  bid /= p.tilesCo;
+  const int ntile = p.R * p.S * p.tilesCi;
+  const int nt = bid % ntile;
+  const int split = bid / ntile;
   const int tap = nt / p.tilesCi, ci_tile = nt % p.tilesCi;
   const int fr = tap / p.S, fs = tap % p.S;
   const int co0 = co_tile * TCO, ci0 = ci_tile * TCI;
@@ -427,66 +422,70 @@ __global__ void __launch_bounds__(256) bias_grad_kernel(const T* __restrict__ dy
 
 extern "C" int osd_bias_grad(const void* dy, float* db, int m, int c, int stride, int dtype, void* stream);
 
-static int wgrad_launch(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys, const int* ns,
-                        const int* hs, const int* ws, const float* scale, float* dw, float* db, hipStream_t s,
-                        const float* const* seg_scales = nullptr, float* const* seg_dws = nullptr,
-                        float* const* seg_dbs = nullptr) {
-  WgradParams p;
-  p.n_seg = n_seg; p.dw = dw; p.scale = scale; p.db = db;
-  p.Cin = d->cin; p.Cout = d->cout;
-  p.R = d->r; p.S = d->s; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
-  p.dy_stride = d->out_stride; p.Ktot = d->r * d->s * d->cin;
-  // d->algo (0 = default) = 1 + variant + 8 * target_code: per-shape choice made by the host-side tuner.
-  // variant 0..3: 128 x 128 channel tile on 4 waves, pixels per stage x ring depth = 32x3 / 64x2 / 32x4 / 64x3 (bf16;
-  // fp32 always 32x3); variant 4: 256 x 256 channel tile on 8 waves, 32 px x 3 stages (bf16)
+struct WgradProblem {      // host-side description of one segment
+  const osd_conv_desc* d;    // geometry: n, h, w, cin, cout, r, s, strides, pads, out_stride
+  int n, h, w;
+  const void* x; const void* dy; const float* scale; float* dw; float* db;
+};
+
+// dtype and algo (0 = default, else 1 + variant + 8 * target_code) come from the first problem's descriptor.
+// variant 0..3: 128 x 128 channel tile on 4 waves, pixels per stage x ring depth = 32x3 / 64x2 / 32x4 / 64x3 (bf16;
+// fp32 always 32x3); variant 4: 256 x 256 channel tile on 8 waves, 32 px x 3 stages (bf16)
+static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
+  if (n_seg < 1 || n_seg > kMaxSeg) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: 1..%d segments", kMaxSeg);
+  const osd_conv_desc* d0 = pr[0].d;
   static int env_target = -1, env_variant = -1;
   if (env_target < 0) { const char* e = getenv("OSD_WGRAD_BLOCKS"); env_target = e ? atoi(e) : 512; }
   if (env_variant < 0) { const char* e = getenv("OSD_WGRAD_VARIANT"); env_variant = e ? atoi(e) : 0; }
   static const int kTargets[8] = {512, 256, 128, 64, 1024, 768, 384, 32};
   int target = env_target, variant = env_variant;
-  if (d->algo > 0) {
-    const int a = d->algo - 1;
-    if (a >= 64 || (a & 7) > 4) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d->algo);
+  if (d0->algo > 0) {
+    const int a = d0->algo - 1;
+    if (a >= 64 || (a & 7) > 4) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d0->algo);
     variant = a & 7;
     target = kTargets[a >> 3];
   }
-  const bool big = variant == 4 && d->dtype == OSD_BF16;
-  const int tw = (d->dtype == OSD_BF16 ? 128 : 64) * (big ? 2 : 1);
-  p.tilesCo = cdiv(d->cout, tw);
-  p.tilesCi = cdiv(d->cin, tw);
-  const long long tiles = (long long)p.tilesCo * p.tilesCi * d->r * d->s;
-  long long Mtot = 0;
+  const bool big = variant == 4 && d0->dtype == OSD_BF16;
+  const int tw = (d0->dtype == OSD_BF16 ? 128 : 64) * (big ? 2 : 1);
+  const int epc = d0->dtype == OSD_BF16 ? 8 : 4;
+  WgradParams p;
+  p.n_seg = n_seg;
+  long long work = 0;        // sum over segments of pixels x output tiles
   for (int i = 0; i < n_seg; ++i) {
-    const int ho = (hs[i] + 2 * d->pad_h - d->r) / d->stride_h + 1, wo = (ws[i] + 2 * d->pad_w - d->s) / d->stride_w + 1;
-    const long long M = (long long)ns[i] * ho * wo;
-    if (M <= 0 || M > 0x7fffffffLL || !xs[i] || !dys[i]) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad segment %d", i);
-    if ((long long)ns[i] * hs[i] * ws[i] * d->cin > 0x7fffffffLL)
+    const osd_conv_desc* d = pr[i].d;
+    WgradSeg& g = p.seg[i];
+    if (d->dtype != d0->dtype) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: segments of different dtype");
+    if (d->cin % epc || d->out_stride % epc) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: channel counts must keep 16-byte alignment");
+    const int ho = (pr[i].h + 2 * d->pad_h - d->r) / d->stride_h + 1, wo = (pr[i].w + 2 * d->pad_w - d->s) / d->stride_w + 1;
+    const long long M = (long long)pr[i].n * ho * wo;
+    if (M <= 0 || M > 0x7fffffffLL || !pr[i].x || !pr[i].dy || !pr[i].dw) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad segment %d", i);
+    if ((long long)pr[i].n * pr[i].h * pr[i].w * d->cin > 0x7fffffffLL)
       return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: input of segment %d has more than 2^31 elements", i);
-    p.seg[i].x = xs[i]; p.seg[i].dy = dys[i]; p.seg[i].H = hs[i]; p.seg[i].W = ws[i]; p.seg[i].Ho = ho; p.seg[i].Wo = wo;
-    p.seg[i].dw = seg_dws ? seg_dws[i] : nullptr;
-    p.seg[i].scale = seg_scales ? seg_scales[i] : nullptr;
-    p.seg[i].db = seg_dbs ? seg_dbs[i] : nullptr;
-    p.seg[i].M = (int)M;
-    Mtot += M;
+    g.x = pr[i].x; g.dy = pr[i].dy; g.dw = pr[i].dw; g.scale = pr[i].scale; g.db = pr[i].db;
+    g.H = pr[i].h; g.W = pr[i].w; g.Ho = ho; g.Wo = wo; g.M = (int)M;
+    g.Cin = d->cin; g.Cout = d->cout; g.R = d->r; g.S = d->s;
+    g.sh = d->stride_h; g.sw = d->stride_w; g.ph = d->pad_h; g.pw = d->pad_w;
+    g.dy_stride = d->out_stride; g.Ktot = d->r * d->s * d->cin;
+    g.tilesCo = cdiv(d->cout, tw); g.tilesCi = cdiv(d->cin, tw);
+    work += M * g.tilesCo * g.tilesCi * d->r * d->s;
   }
-  // pixel splits: enough workgroups to fill the chip, at least 128 pixels each, shared out over the segments
-  long long want = (target + tiles - 1) / tiles;
-  const long long max_splits = (Mtot + 127) / 128;
-  if (want > max_splits) want = max_splits;
-  if (want < 1) want = 1;
-  const long long rows = ((Mtot + want - 1) / want + 31) / 32 * 32;
-  int total_splits = 0;
+  // pixel splits: enough workgroups to fill the chip, every workgroup about the same number of pixels (>= 128)
+  long long rows = (work + target - 1) / target;
+  rows = (rows + 31) / 32 * 32;
+  if (rows < 128) rows = 128;
+  long long nblocks = 0;
   for (int i = 0; i < n_seg; ++i) {
-    int sp = (int)((p.seg[i].M + rows - 1) / rows);
+    WgradSeg& g = p.seg[i];
+    int sp = (int)((g.M + rows - 1) / rows);
     if (sp < 1) sp = 1;
-    p.seg[i].rows_per_split = cdiv(cdiv(p.seg[i].M, sp), 32) * 32;
-    p.seg[i].split_begin = total_splits;
-    total_splits += cdiv(p.seg[i].M, p.seg[i].rows_per_split);
+    g.rows_per_split = cdiv(cdiv(g.M, sp), 32) * 32;
+    const int splits = cdiv(g.M, g.rows_per_split);
+    g.block_begin = (int)nblocks;
+    nblocks += (long long)g.tilesCo * g.tilesCi * g.R * g.S * splits;
+    if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
   }
   for (int i = n_seg; i < kMaxSeg; ++i) p.seg[i] = p.seg[0];
-  p.splits = total_splits;
-  const long long nblocks = tiles * total_splits;
-  if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
+  const osd_conv_desc* d = d0;
   // variant: 0 = 32 px x 3 stages, 1 = 64 px x 2, 2 = 32 px x 4, 3 = 64 px x 3 (bf16; fp32 always 32 x 3)
 #define OSD_WG_LAUNCH(TT, BK, NS, WC, WMM, WNN)                                                                     \
   do {                                                                                                               \
@@ -536,11 +535,8 @@ extern "C" int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const voi
     if (rc || !db) return rc;
     return osd_bias_grad(dy, db, (int)M, d->cout, d->out_stride, d->dtype, stream);
   }
-  if (d->cin % epc || d->out_stride % epc) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: channel counts must keep 16-byte alignment");
-  const void* xs[1] = {x};
-  const void* dys[1] = {dy};
-  const int hs[1] = {d->h}, ws[1] = {d->w}, ns[1] = {d->n};
-  return wgrad_launch(d, 1, xs, dys, ns, hs, ws, scale, dw, db, s);
+  const WgradProblem pr = {d, d->n, d->h, d->w, x, dy, scale, dw, db};
+  return wgrad_launch(1, &pr, s);
 }
 
 // several (x, dy) pairs with the same conv geometry except batch / spatial size, sharing dW (weights shared over FPN levels)
@@ -549,45 +545,58 @@ extern "C" int osd_conv2d_wgrad_grouped(const osd_conv_desc* d, int n_seg, const
                                         float* dw, float* db, void* stream) {
   if (!d || !xs || !dys || !ns || !hs || !ws || !dw || n_seg < 1 || n_seg > kMaxSeg)
     return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_grouped: bad arguments");
-  const int epc = d->dtype == OSD_BF16 ? 8 : 4;
   if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad dtype");
-  if (d->cin % epc || d->out_stride % epc) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_grouped: channel alignment");
-  return wgrad_launch(d, n_seg, xs, dys, ns, hs, ws, scale, dw, db, OSD_STREAM(stream));
+  WgradProblem pr[kMaxSeg];
+  for (int i = 0; i < n_seg; ++i) pr[i] = WgradProblem{d, ns[i], hs[i], ws[i], xs[i], dys[i], scale, dw, db};
+  return wgrad_launch(n_seg, pr, OSD_STREAM(stream));
 }
 
-// n_seg <= 8 convs of IDENTICAL geometry (same x / dy shapes, different tensors and different weights: the repeated
-// bottleneck blocks of a ResNet stage) in one launch, each with its own dW / scale / db: the output tiles of all of them
-// share the workgroup budget, so each needs 1/n_seg of the pixel splits — and of the atomic traffic — of a launch of its own
+// n_seg convs of IDENTICAL geometry (same x / dy shapes, different tensors and different weights: the repeated bottleneck
+// blocks of a ResNet stage) in one launch, each with its own dW / scale / db: the output tiles of all of them share the
+// workgroup budget, so each needs 1/n_seg of the pixel splits — and of the atomic traffic — of a launch of its own
 extern "C" int osd_conv2d_wgrad_batched(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
                                         const float* const* scales, float* const* dws, float* const* dbs, void* stream) {
   if (!d || !xs || !dys || !dws || n_seg < 1 || n_seg > kMaxSeg)
     return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_batched: bad arguments");
-  const int epc = d->dtype == OSD_BF16 ? 8 : 4;
   if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad dtype");
-  if (d->cin % epc || d->out_stride % epc) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_batched: channel alignment");
   if (d->in_stride_w != d->cin || d->in_stride_h != d->w * d->cin)
     return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad_batched: dense NHWC input required");
-  int ns[kMaxSeg], hs[kMaxSeg], ws[kMaxSeg];
-  for (int i = 0; i < n_seg; ++i) {
-    if (!dws[i]) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_batched: null dW %d", i);
-    ns[i] = d->n; hs[i] = d->h; ws[i] = d->w;
-  }
-  return wgrad_launch(d, n_seg, xs, dys, ns, hs, ws, nullptr, dws[0], nullptr, OSD_STREAM(stream), scales, dws, dbs);
+  WgradProblem pr[kMaxSeg];
+  for (int i = 0; i < n_seg; ++i)
+    pr[i] = WgradProblem{d, d->n, d->h, d->w, xs[i], dys[i], scales ? scales[i] : nullptr, dws[i], dbs ? dbs[i] : nullptr};
+  return wgrad_launch(n_seg, pr, OSD_STREAM(stream));
 }
 
-// the general form: n_seg <= 24 (x, dy) pairs with their own batch / spatial size AND their own dW / scale / db — e.g. the
-// four convs of an FCOS tower x five FPN levels in one launch (pairs that share a dW simply repeat its pointer)
+// (x, dy) pairs with their own batch / spatial size AND their own dW / scale / db, same conv geometry — e.g. the four
+// convs of an FCOS tower x five FPN levels in one launch (pairs that share a dW simply repeat its pointer)
 extern "C" int osd_conv2d_wgrad_multi(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
                                       const int32_t* ns, const int32_t* hs, const int32_t* ws, const float* const* scales,
                                       float* const* dws, float* const* dbs, void* stream) {
   if (!d || !xs || !dys || !ns || !hs || !ws || !dws || n_seg < 1 || n_seg > kMaxSeg)
     return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_multi: bad arguments (1..%d segments)", kMaxSeg);
-  const int epc = d->dtype == OSD_BF16 ? 8 : 4;
   if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad dtype");
-  if (d->cin % epc || d->out_stride % epc) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_multi: channel alignment");
+  WgradProblem pr[kMaxSeg];
   for (int i = 0; i < n_seg; ++i)
-    if (!dws[i]) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_multi: null dW %d", i);
-  return wgrad_launch(d, n_seg, xs, dys, ns, hs, ws, nullptr, dws[0], nullptr, OSD_STREAM(stream), scales, dws, dbs);
+    pr[i] = WgradProblem{d, ns[i], hs[i], ws[i], xs[i], dys[i], scales ? scales[i] : nullptr, dws[i], dbs ? dbs[i] : nullptr};
+  return wgrad_launch(n_seg, pr, OSD_STREAM(stream));
+}
+
+// the general form: every pair has its OWN conv descriptor (channels, kernel, stride, pad, n, h, w, out_stride): all weight
+// gradients of a ResNet stage — 1x1 and 3x3, stride 1 and 2, the FPN laterals — in one launch.  dtype and algo are taken
+// from descs[0].  The workgroup budget is shared out in proportion to pixels x output tiles.
+extern "C" int osd_conv2d_wgrad_mixed(int n_seg, const osd_conv_desc* descs, const void* const* xs, const void* const* dys,
+                                      const float* const* scales, float* const* dws, float* const* dbs, void* stream) {
+  if (!descs || !xs || !dys || !dws || n_seg < 1 || n_seg > kMaxSeg)
+    return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_mixed: bad arguments (1..%d segments)", kMaxSeg);
+  if (descs[0].dtype != OSD_F32 && descs[0].dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad dtype");
+  WgradProblem pr[kMaxSeg];
+  for (int i = 0; i < n_seg; ++i) {
+    const osd_conv_desc* d = descs + i;
+    if (d->in_stride_w != d->cin || d->in_stride_h != d->w * d->cin)
+      return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad_mixed: dense NHWC input required (segment %d)", i);
+    pr[i] = WgradProblem{d, d->n, d->h, d->w, xs[i], dys[i], scales ? scales[i] : nullptr, dws[i], dbs ? dbs[i] : nullptr};
+  }
+  return wgrad_launch(n_seg, pr, OSD_STREAM(stream));
 }
 
 extern "C" int osd_bias_grad(const void* dy, float* db, int m, int c, int stride, int dtype, void* stream) {

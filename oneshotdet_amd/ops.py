@@ -559,6 +559,55 @@ def conv2d_wgrad_multi(items, r, s, stride, pad, cout, algo=None):
     launch(real_dws, real_dbs)
 
 
+def conv2d_wgrad_mixed(items, algo=None):
+    """items: [(x, dy, dw, scale or None, db or None, r, s, stride, pad, cout)] — convs of ANY geometry (the weight
+    gradients of a whole ResNet stage): ONE launch, the workgroups shared out in proportion to pixels x output tiles."""
+    k = len(items)
+    descs = (ConvDesc * k)()
+    for i, (x, dy, dw, scale, db, r, s, stride, pad, cout) in enumerate(items):
+        d = _conv_desc(x.shape, _dt(x), cout, r, s, stride, pad, dy.shape[-1])
+        assert (dy.shape[1], dy.shape[2]) == (d.ho, d.wo), (x.shape, dy.shape)
+        descs[i] = d
+    xs = (C.c_void_p * k)(*[it[0].data_ptr() for it in items])
+    dys = (C.c_void_p * k)(*[it[1].data_ptr() for it in items])
+    scales = (C.c_void_p * k)(*[(it[3].data_ptr() if it[3] is not None else 0) for it in items])
+    st = _stream()
+    real_dws, real_dbs = [it[2] for it in items], [it[4] for it in items]
+
+    def launch(dws, dbs):
+        dwp = (C.c_void_p * k)(*[t.data_ptr() for t in dws])
+        dbp = (C.c_void_p * k)(*[(t.data_ptr() if t is not None else 0) for t in dbs])
+        _lib.call("osd_conv2d_wgrad_mixed", k, descs, xs, dys, scales, dwp, dbp, st)
+    key = ("mixed", descs[0].dtype, tuple((tuple(it[0].shape), tuple(it[1].shape)) + tuple(it[5:]) for it in items),
+           tuple([id(u) for u in real_dws].index(id(t)) for t in real_dws))
+    if algo is None:
+        algo = WGRAD_ALGO_CACHE.get(key)
+    if algo is None:
+        if _TUNING[0]:
+            scratch = {}
+            sdw = [scratch.setdefault(id(t), torch.empty_like(t)) for t in real_dws]
+            sdb = [None if t is None else scratch.setdefault(id(t), torch.empty_like(t)) for t in real_dbs]
+            best, best_t = 0, float("inf")
+            for cand in wgrad_algo_candidates(descs[0].dtype):
+                descs[0].algo = cand
+                launch(sdw, sdb)
+                torch.cuda.synchronize()
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                for _ in range(3):
+                    launch(sdw, sdb)
+                ev[1].record()
+                torch.cuda.synchronize()
+                t = ev[0].elapsed_time(ev[1])
+                if t < best_t:
+                    best, best_t = cand, t
+            WGRAD_ALGO_CACHE[key] = algo = best
+        else:
+            algo = 0
+    descs[0].algo = algo
+    launch(real_dws, real_dbs)
+
+
 def bias_grad(dy, db, c):
     n, h, w, stride = dy.shape
     _lib.call("osd_bias_grad", _ptr(dy), _ptr(db), n * h * w, c, stride, _dt(dy), _stream())

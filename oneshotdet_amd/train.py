@@ -402,28 +402,27 @@ class TrainEngine(object):
             self._update_bucket(name)
 
     def _wgrad(self, c, x, dy, stride=1, pad=0):
-        if self._wq is not None:       # inside a backbone: queued, launched per stage with the convs of identical geometry
-            key = (tuple(x.shape), tuple(dy.shape), c.r, c.s, stride, pad, c.cout, c.has_bias, c.bn_scale is not None)
-            self._wq.setdefault(key, []).append((c, x, dy))
+        if self._wq is not None:       # inside a backbone: queued, launched once per stage (all geometries together)
+            self._wq.append((c, x, dy, stride, pad))
             return
         self._on_wstream(lambda: ops.conv2d_wgrad(x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale,
                                                   db=c.gb if c.has_bias else None), (x, dy))
 
     def _flush_wgrads(self):
-        """Launch the queued weight gradients: convs of identical geometry (the repeated bottleneck blocks of a stage)
-        share ONE batched launch — their output tiles split the workgroup budget, so each conv pays 1/k of the pixel
-        splits and of the atomic traffic of a launch of its own, and the query branch's tiny launches become few."""
-        q, self._wq = self._wq, {}
-        for (xs, dys, r, s, stride, pad, cout, has_bias, has_scale), lst in q.items():
-            for i in range(0, len(lst), 8):
-                part = lst[i:i + 8]
-                if len(part) == 1:
-                    c, x, dy = part[0]
-                    self._on_wstream(lambda c=c, x=x, dy=dy: ops.conv2d_wgrad(
-                        x, dy, c.gw, r, s, stride, pad, cout, scale=c.bn_scale, db=c.gb if c.has_bias else None), (x, dy))
-                else:
-                    items = [(x, dy, c.gw, c.bn_scale, c.gb if c.has_bias else None) for c, x, dy in part]
-                    self._on_wstream(lambda items=items: ops.conv2d_wgrad_batched(items, r, s, stride, pad, cout), items)
+        """Launch the queued weight gradients of a stage as ONE mixed-geometry launch (<= 24 convs each): all output tiles
+        share the workgroup budget in proportion to their work, so every conv runs with few pixel splits — long inner
+        loops, little atomic traffic — and the query branch's latency-sized launches disappear into it."""
+        q, self._wq = self._wq, []
+        for i in range(0, len(q), 24):
+            part = q[i:i + 24]
+            if len(part) == 1:
+                c, x, dy, stride, pad = part[0]
+                self._on_wstream(lambda c=c, x=x, dy=dy, stride=stride, pad=pad: ops.conv2d_wgrad(
+                    x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale, db=c.gb if c.has_bias else None), (x, dy))
+            else:
+                items = [(x, dy, c.gw, c.bn_scale, c.gb if c.has_bias else None, c.r, c.s, stride, pad, c.cout)
+                         for c, x, dy, stride, pad in part]
+                self._on_wstream(lambda items=items: ops.conv2d_wgrad_mixed(items), items)
 
     def _wgrad_grouped(self, c, pairs):
         self._on_wstream(lambda: ops.conv2d_wgrad_grouped(pairs, c.gw, c.r, c.s, 1, c.r // 2, c.cout, scale=c.bn_scale,
@@ -479,7 +478,7 @@ class TrainEngine(object):
 
     def backbone_backward(self, ctx, dP, need_input_grad=False):
         cv, bb = self.convs, ctx["bb"]
-        self._wq = {}
+        self._wq = []
         f = bb + "fpn."
         dp3, dp4, dp5, dp6, dp7 = dP
         # P7 = conv(relu(P6)), P6 = conv(P5), both 3x3 stride 2 (fpn.py:95-99)

@@ -415,3 +415,35 @@ def test_conv_wgrad_multi_mixes_shared_and_own_weights():
         for conv in range(2):
             torch.testing.assert_close(dws[conv], refs[conv], rtol=1e-3, atol=1e-3 * float(refs[conv].abs().max()))
             torch.testing.assert_close(dbs[conv], refb[conv], rtol=1e-3, atol=1e-3 * float(refb[conv].abs().max()))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_wgrad_mixed_geometries_in_one_launch(dt):
+    """osd_conv2d_wgrad_mixed: 1x1 and 3x3, stride 1 and 2, different channel counts and map sizes, FrozenBN scales and
+    bias gradients — one launch vs one osd_conv2d_wgrad launch per conv."""
+    from oneshotdet_amd import ops
+    cases = [(2, 256, 14, 18, 128, 1, 1, 0), (2, 128, 14, 18, 128, 3, 1, 1), (2, 128, 14, 18, 512, 1, 1, 0),
+             (1, 512, 16, 12, 256, 1, 2, 0), (2, 256, 7, 9, 256, 3, 2, 1), (3, 64, 5, 4, 320, 3, 1, 1)]
+    items, refs = [], []
+    for i, (n, cin, h, w, cout, k, stride, pad) in enumerate(cases):
+        x = to_nhwc(rnd(n, cin, h, w, seed=10 + i), DT[dt])
+        ho, wo = ops.conv_out(h, k, stride, pad), ops.conv_out(w, k, stride, pad)
+        dy = to_nhwc(rnd(n, cout, ho, wo, seed=20 + i), DT[dt])
+        scale = (rnd(cout, seed=30 + i).abs() + 0.5).cuda() if i % 2 == 0 else None
+        dw = torch.zeros(cout, k, k, cin, device="cuda")
+        db = torch.zeros(cout, device="cuda") if i % 3 == 0 else None
+        rw, rb = torch.zeros_like(dw), (torch.zeros(cout, device="cuda") if db is not None else None)
+        ops.conv2d_wgrad(x, dy, rw, k, k, stride, pad, cout, scale=scale, db=rb)
+        items.append((x, dy, dw, scale, db, k, k, stride, pad, cout))
+        refs.append((rw, rb))
+    algos = (None, 1 + 0 + 8 * 3, 1 + 0 + 8 * 4) + ((1 + 1 + 8 * 0, 1 + 4 + 8 * 1) if dt == "bf16" else ())
+    for algo in algos:
+        for it in items:
+            it[2].zero_()
+            if it[4] is not None:
+                it[4].zero_()
+        ops.conv2d_wgrad_mixed(items, algo=algo)
+        for it, (rw, rb) in zip(items, refs):
+            torch.testing.assert_close(it[2], rw, rtol=1e-3, atol=1e-3 * float(rw.abs().max()))
+            if rb is not None:
+                torch.testing.assert_close(it[4], rb, rtol=1e-3, atol=1e-3 * float(rb.abs().max()))

@@ -57,14 +57,15 @@ run("full step")
 run_train_step("train_step (updates behind backward)")
 run("full step")
 run("no training proposals", with_proposals=False)
-orig = (ops.conv2d_wgrad, ops.conv2d_wgrad_grouped, ops.conv2d_wgrad_batched, ops.conv2d_wgrad_multi)
+orig = (ops.conv2d_wgrad, ops.conv2d_wgrad_grouped, ops.conv2d_wgrad_batched, ops.conv2d_wgrad_multi, ops.conv2d_wgrad_mixed)
 ops.conv2d_wgrad = lambda *a, **k: None
 ops.conv2d_wgrad_grouped = lambda *a, **k: None
 ops.conv2d_wgrad_batched = lambda *a, **k: None
 ops.conv2d_wgrad_multi = lambda *a, **k: None
+ops.conv2d_wgrad_mixed = lambda *a, **k: None
 run("no weight gradients")
 run("no weight gradients, no proposals", with_proposals=False)
-ops.conv2d_wgrad, ops.conv2d_wgrad_grouped, ops.conv2d_wgrad_batched, ops.conv2d_wgrad_multi = orig
+ops.conv2d_wgrad, ops.conv2d_wgrad_grouped, ops.conv2d_wgrad_batched, ops.conv2d_wgrad_multi, ops.conv2d_wgrad_mixed = orig
 g0 = (ops.groupnorm_relu_levels, ops.groupnorm_relu_bwd_levels)
 saved = eng.wstream, eng.wstream2, eng.s1
 eng.wstream = eng.wstream2 = eng.s1 = None
