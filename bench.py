@@ -57,6 +57,8 @@ class ConvTimer(object):
         self._orig_cg = ops.conv2d_grouped
 
         def timed_conv2d_grouped(xs, pc, *a, **kw):
+            if not (kw.get("_whole") or len(xs) < 3 or kw.get("algo") is not None):
+                return timer._orig_cg(xs, pc, *a, **kw)      # dispatcher call: the launches inside are bracketed
             s = torch.cuda.Event(enable_timing=True)
             e = torch.cuda.Event(enable_timing=True)
             s.record()

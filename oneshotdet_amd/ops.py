@@ -194,12 +194,49 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
     return out
 
 
-def conv2d_grouped(xs, pc, pad=0, act=ACT_NONE, residuals=None, masks=None, act_scale=1.0, act_scale_devs=None, algo=None):
+SPLIT_CACHE = {}
+
+
+def conv2d_grouped(xs, pc, pad=0, act=ACT_NONE, residuals=None, masks=None, act_scale=1.0, act_scale_devs=None, algo=None,
+                   _whole=False):
     """The same stride-1 convolution (shared packed weights pc) over several NHWC tensors of different size — the FPN
-    levels of an FCOS tower / prediction conv — in ONE launch.  residuals: same-size addends; masks: ReLU-backward
-    masks (data gradients); act_scale_devs: one device scalar per level (the learnable Scale).  Returns the outputs."""
+    levels of an FCOS tower / prediction conv — in ONE launch, or in TWO (large levels / small levels) where the tuner
+    measured that to be faster: 256-pixel tiles on 256 CUs quantise badly (P3..P7 at bs=8 are 534 tiles = 2 full rounds
+    plus a third with 22 tiles; P3+P4 alone are 500 = 2 rounds, and the small levels run on a small tile).
+    residuals: same-size addends; masks: ReLU-backward masks (data gradients); act_scale_devs: one device scalar per level
+    (the learnable Scale).  Returns the outputs."""
     _chk_dev(*xs)
     k = len(xs)
+    if k >= 3 and algo is None and not _whole:
+        skey = ("split", _dt(xs[0]), tuple(tuple(x.shape) for x in xs), pc.cout_store, pc.r, pad, act, residuals is not None,
+                masks is not None)
+        cut = SPLIT_CACHE.get(skey)
+
+        def run(c):
+            if c == 0:
+                return conv2d_grouped(xs, pc, pad, act, residuals, masks, act_scale, act_scale_devs, _whole=True)
+            sl = lambda t, a, b: None if t is None else t[a:b]          # noqa: E731
+            return (conv2d_grouped(xs[:c], pc, pad, act, sl(residuals, 0, c), sl(masks, 0, c), act_scale,
+                                   sl(act_scale_devs, 0, c), _whole=True) +
+                    conv2d_grouped(xs[c:], pc, pad, act, sl(residuals, c, k), sl(masks, c, k), act_scale,
+                                   sl(act_scale_devs, c, k), _whole=True))
+        if cut is None and _TUNING[0]:
+            best_t = float("inf")
+            for c in range(0, k - 1):
+                run(c)                                  # tunes the algorithms of the parts
+                torch.cuda.synchronize()
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                for _ in range(3):
+                    run(c)
+                ev[1].record()
+                torch.cuda.synchronize()
+                t = ev[0].elapsed_time(ev[1])
+                if t < best_t:
+                    cut, best_t = c, t
+            SPLIT_CACHE[skey] = cut
+        if cut:
+            return run(cut)
     c = xs[0].shape[-1]
     assert c == pc.cin_k and not pc.stem, "input channels %d != packed K per tap %d" % (c, pc.cin_k)
     d = ConvDesc()
