@@ -58,7 +58,7 @@ def main():
     convs = [r for r in trace if "conv_igemm" in r["Kernel_Name"] or "conv_dma" in r["Kernel_Name"] or
              (is_train and "conv_wgrad_kernel" in r["Kernel_Name"])]
     launches = workload.conv_launches(8, 800, 1024, 8, 127, 127)
-    per = len(launches)
+    per = (line.get("roofline") or {}).get("launches_per_step") or len(launches)   # the tuner may split grouped launches
     if is_train:
         return summarize_train(d, out, line, stats, convs)
     last = convs[-steps * per:]
@@ -87,6 +87,9 @@ def main():
                                                             float(s["AverageNs"]) / 1e3, s["Percentage"]))
         f.write("\n## conv_igemm per layer (one roofline-pass step)\n\n| layer | M | N | K | tile | us | TFLOP/s |\n"
                 "|---|---|---|---|---|---|---|\n")
+        if per != len(launches):
+            f.write("| (per-layer listing skipped: %d dispatches per step vs %d enumerated layers — the tuner split grouped launches) | | | | | | |\n" % (per, len(launches)))
+            launches = []
         for (name, m, n, k), r in zip(launches, last[-per:]):
             du = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             mt = re.search(r"Li(\d+)ELi(\d+)ELi(\d+)E", r["Kernel_Name"]) or \
