@@ -113,21 +113,36 @@ class ConvTimer(object):
         return ConvTimer._overhead
 
 
-def cpu_baseline(dtype_name, seconds_budget=25.0):
+def cpu_baseline(dtype_name, seconds_budget=25.0, train=False):
     """The oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores on a bounded sample of
-    the same workload: single 800x1024 + 127x127 pairs, forward incl. proposals."""
+    the same workload: single 800x1024 + 127x127 pairs — forward incl. proposals (forward mode), or forward + proposals +
+    FCOS loss + backward through autograd (train mode, the headline metric's step without the optimiser)."""
     import golden_utils as gu
     from oneshotdet_amd import spec, synth
     from oracle import hotpath_ref as orc
     sd = orc.to_torch_state_dict(synth.make_state_dict(spec.hot_path_shapes()))
+    if train:
+        for k, v in sd.items():
+            v.requires_grad_(not spec.is_frozen(k))
     img, q = gu.case_inputs("config1")
     img, q = torch.from_numpy(img), torch.from_numpy(q)
+    gts = synth.make_gt_boxes(1, 800, 1024, seed=1000, max_boxes=6)
     cores = torch.get_num_threads()
 
     def one():
+        if not train:
+            with torch.no_grad():
+                o = orc.hot_path_forward(img, q, sd)
+                orc.fcos_postprocess(o["logits"], o["bbox_reg"], o["centerness"], [(800, 1024)])
+            return
+        o = orc.hot_path_forward(img, q, sd)
         with torch.no_grad():
-            o = orc.hot_path_forward(img, q, sd)
-            orc.fcos_postprocess(o["logits"], o["bbox_reg"], o["centerness"], [(800, 1024)])
+            orc.fcos_postprocess(o["logits"], o["bbox_reg"], o["centerness"], [(800, 1024)], pre_nms_top_n=spec.PRE_NMS_TOP_N_TRAIN,
+                                 post_nms_top_n=spec.POST_NMS_TOP_N_TRAIN)
+        c, r, t, _ = orc.fcos_loss(o["logits"], o["bbox_reg"], o["centerness"], gts, focal="cuda")
+        (c + r + t).backward()
+        for v in sd.values():
+            v.grad = None
     one()                      # warm-up (oneDNN primitive creation)
     t0 = time.time()
     n = 0
@@ -137,9 +152,10 @@ def cpu_baseline(dtype_name, seconds_budget=25.0):
         if time.time() - t0 > seconds_budget * 0.6 or n >= 8:
             break
     dt = time.time() - t0
+    what = "forward + training proposals + FCOS loss + backward (autograd)" if train else "forward incl. proposals"
     return {"value": round(n / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d x (1x800x1024 target + 1x127x127 query) forward incl. proposals, oracle/hotpath_ref.py "
-                      "(torch CPU fp32, %d threads)" % (n, cores)}
+            "sample": "%d x (1x800x1024 target + 1x127x127 query) %s, oracle/hotpath_ref.py (torch CPU fp32, %d threads)"
+                      % (n, what, cores)}
 
 
 def dist_setup(backend):
@@ -391,7 +407,7 @@ def main_train(args, rank, world):
         workload = ("BASELINE.json configs[2]: bs=%d/GPU, 800x1024 target + 127x127 query, %s MFMA convs, forward "
                     "(two R-50-FPN backbones, query pooling, correlation, FCOS head, training proposals) + FCOS loss + "
                     "backward (stem/layer1 frozen) + gradient all-reduce + SGD(momentum) + weight repack" % (B, args.dtype))
-        cpu = cpu_baseline(args.dtype) if (world == 1 and not args.no_cpu_baseline) else None
+        cpu = cpu_baseline(args.dtype, train=True) if (world == 1 and not args.no_cpu_baseline) else None
         line = result_line(args, world, B, elapsed, workload, launch, roofline, cpu)
         if roofline is not None:
             line["roofline_correlation"] = corr_roofline
