@@ -275,7 +275,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default="small,nonsquare,shots5,tall,config1")
     ap.add_argument("--skip-train", action="store_true")
-    ap.add_argument("--train-cases", default="small,config1")
+    ap.add_argument("--train-cases", default="small,nonsquare,shots5,tall,config1")
     ap.add_argument("--only-train", action="store_true", help="regenerate only the training fixtures")
     args = ap.parse_args()
     torch.set_num_threads(8)
