@@ -94,10 +94,14 @@ def test_postprocess_config1_from_golden_head():
     assert gu.match_boxes(rb, rs, boxes.numpy(), scores.numpy()) >= 0.999
 
 
-def test_loss_and_gradients_match_reference(sd):
-    f = gu.load("train_small.npz")
-    B, H, W, S, qh, qw = gu.CASES["small"]
-    img, q = gu.case_inputs("small")
+@pytest.mark.parametrize("name", ["small", "nonsquare", "shots5", "tall"])
+def test_loss_and_gradients_match_reference(name, sd):
+    """The oracle's losses, targets and autograd gradients against the fixtures recorded from the REAL reference
+    (make_golden.py wrote them only after the two agreed on all 101 gradient tensors).  `config1` (800x1024) is checked
+    the same way on the GPU box, where the CPU has the cores for it (tests/test_gpu_train.py)."""
+    f = gu.load("train_%s.npz" % name)
+    B, H, W, S, qh, qw = gu.CASES[name]
+    img, q = gu.case_inputs(name)
     gts = synth.make_gt_boxes(B, H, W, seed=3, max_boxes=3)
     np.testing.assert_array_equal(np.concatenate(gts, 0), f["gt_boxes"][:, 1:])
     sd2 = {k: v.clone().requires_grad_(not spec.is_frozen(k)) for k, v in sd.items()}
