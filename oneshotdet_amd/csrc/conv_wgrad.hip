@@ -437,7 +437,7 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   static int env_target = -1, env_variant = -1;
   if (env_target < 0) { const char* e = getenv("OSD_WGRAD_BLOCKS"); env_target = e ? atoi(e) : 512; }
   if (env_variant < 0) { const char* e = getenv("OSD_WGRAD_VARIANT"); env_variant = e ? atoi(e) : 0; }
-  static const int kTargets[8] = {512, 256, 128, 64, 1024, 768, 384, 32};
+  static const int kTargets[8] = {512, 256, 128, 64, 1024, 768, 1536, 2048};
   int target = env_target, variant = env_variant;
   if (d0->algo > 0) {
     const int a = d0->algo - 1;

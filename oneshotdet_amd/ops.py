@@ -464,7 +464,7 @@ def wgrad_algo_candidates(dtype, cout=0, cin=0):
     variants = [0, 1, 2, 3] if dtype == OSD_BF16 else [0]
     if dtype == OSD_BF16 and cout >= 256 and cin >= 256:
         variants.append(4)
-    return [1 + v + 8 * t for t in (0, 1, 2, 3, 4) for v in variants]
+    return [1 + v + 8 * t for t in (0, 1, 2, 3, 4, 5, 6, 7) for v in variants]
 
 
 def _tune_wgrad(key, d, launch, dw, db):
