@@ -293,6 +293,14 @@ int osd_fcos_loss_level(int phase, const void* cls_ctr, const void* reg, const f
                         int max_gt, int n, int h, int w, int stride, float size_lo, float size_hi, float radius,
                         float gamma, float alpha, const float* scale_dev, float* sums, void* d_cls_ctr, void* d_reg,
                         int grad_stride, float* d_scale_raw, int dtype, void* stream);
+/* The same for ALL FPN levels in one launch per phase (the per-level launches sit on the critical path between forward
+ * and backward).  cls_ctrs / regs / scale_devs / d_cls_ctrs / d_regs / d_scale_raws: HOST arrays of n_levels (<= 6) device
+ * pointers; hs / ws / strides / size_lo / size_hi: HOST arrays. */
+int osd_fcos_loss_levels(int phase, int n_levels, const void* const* cls_ctrs, const void* const* regs,
+                         const float* gt_boxes, const int32_t* gt_count, int max_gt, int n, const int32_t* hs,
+                         const int32_t* ws, const int32_t* strides, const float* size_lo, const float* size_hi, float radius,
+                         float gamma, float alpha, const float* const* scale_devs, float* sums, void* const* d_cls_ctrs,
+                         void* const* d_regs, int grad_stride, float* const* d_scale_raws, int dtype, void* stream);
 /* losses[4] = {loss_cls, loss_reg, loss_centerness, num_pos} */
 int osd_fcos_loss_finalize(const float* sums, float* losses, int n, void* stream);
 

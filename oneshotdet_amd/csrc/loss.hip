@@ -96,12 +96,12 @@ __device__ __forceinline__ float giou_loss(const float pd[4], const Target& tg, 
 }
 
 template <typename T, int PHASE>
-__global__ void __launch_bounds__(256) fcos_loss_kernel(const T* __restrict__ cls_ctr, const T* __restrict__ reg,
+__device__ __forceinline__ void fcos_loss_body(const T* __restrict__ cls_ctr, const T* __restrict__ reg,
                                                         const float* __restrict__ gt, const int* __restrict__ gt_count,
                                                         int max_gt, LossLevel lv, int n_images, float gamma, float alpha,
                                                         const float* __restrict__ scale_dev, float* __restrict__ sums,
                                                         T* __restrict__ d_cls_ctr, T* __restrict__ d_reg, int gstride,
-                                                        float* __restrict__ d_scale_raw) {
+                                                        float* __restrict__ d_scale_raw, int bx, int nbx) {
   const float scale = scale_dev ? *scale_dev : 1.f;
   const int img = blockIdx.y;
   const int hw = lv.h * lv.w;
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) fcos_loss_kernel(const T* __restrict__ cl
     inv_w = sw > 0.f ? 1.f / sw : (npos > 0.f ? 1.f / npos : 0.f);   // iou_loss.py:46-49: weighted mean, else plain mean
     inv_pos = npos > 0.f ? 1.f / npos : 0.f;
   }
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+  for (int i = bx * blockDim.x + threadIdx.x; i < hw; i += nbx * blockDim.x) {
     const int yy = i / lv.w, xx = i - yy * lv.w;
     const float x = (float)(xx * lv.stride + lv.stride / 2), y = (float)(yy * lv.stride + lv.stride / 2);
     const Target tg = assign_target(x, y, g, ng, lv);
@@ -188,6 +188,43 @@ __global__ void __launch_bounds__(256) fcos_loss_kernel(const T* __restrict__ cl
   }
 }
 
+template <typename T, int PHASE>
+__global__ void __launch_bounds__(256) fcos_loss_kernel(const T* __restrict__ cls_ctr, const T* __restrict__ reg,
+                                                        const float* __restrict__ gt, const int* __restrict__ gt_count,
+                                                        int max_gt, LossLevel lv, int n_images, float gamma, float alpha,
+                                                        const float* __restrict__ scale_dev, float* __restrict__ sums,
+                                                        T* __restrict__ d_cls_ctr, T* __restrict__ d_reg, int gstride,
+                                                        float* __restrict__ d_scale_raw) {
+  fcos_loss_body<T, PHASE>(cls_ctr, reg, gt, gt_count, max_gt, lv, n_images, gamma, alpha, scale_dev, sums, d_cls_ctr, d_reg,
+                           gstride, d_scale_raw, blockIdx.x, gridDim.x);
+}
+
+// all FPN levels in one launch: blockIdx.z = level (the per-level launches sit on the critical path between forward and
+// backward, each a few microseconds of work behind a launch gap)
+constexpr int kLossLevels = 6;
+struct LossLevels {
+  const void* cc[kLossLevels]; const void* rg[kLossLevels]; void* dcc[kLossLevels]; void* drg[kLossLevels];
+  const float* scale_dev[kLossLevels]; float* d_scale_raw[kLossLevels];
+  LossLevel lv[kLossLevels];
+  int nbx[kLossLevels];
+};
+
+template <typename T, int PHASE>
+__global__ void __launch_bounds__(256) fcos_loss_levels_kernel(LossLevels L, const float* __restrict__ gt,
+                                                               const int* __restrict__ gt_count, int max_gt, int n_images,
+                                                               float gamma, float alpha, float* __restrict__ sums, int gstride) {
+  const T* cc = nullptr; const T* rg = nullptr; T* dcc = nullptr; T* drg = nullptr;
+  const float* sd = nullptr; float* dsr = nullptr; LossLevel lv = L.lv[0]; int nbx = 0;
+#pragma unroll
+  for (int i = 0; i < kLossLevels; ++i)
+    if (i == (int)blockIdx.z) {
+      cc = (const T*)L.cc[i]; rg = (const T*)L.rg[i]; dcc = (T*)L.dcc[i]; drg = (T*)L.drg[i];
+      sd = L.scale_dev[i]; dsr = L.d_scale_raw[i]; lv = L.lv[i]; nbx = L.nbx[i];
+    }
+  if ((int)blockIdx.x >= nbx) return;
+  fcos_loss_body<T, PHASE>(cc, rg, gt, gt_count, max_gt, lv, n_images, gamma, alpha, sd, sums, dcc, drg, gstride, dsr, blockIdx.x, nbx);
+}
+
 __global__ void fcos_loss_finalize_kernel(const float* __restrict__ sums, float* __restrict__ losses, int n_images) {
   const float npos = sums[0], sw = sums[1];
   losses[0] = sums[2] / (npos + (float)n_images);
@@ -231,4 +268,43 @@ extern "C" int osd_fcos_loss_finalize(const float* sums, float* losses, int n, v
   if (!sums || !losses) return osd_fail(OSD_ERR_INVALID_ARG, "fcos_loss_finalize: null argument");
   hipLaunchKernelGGL(fcos_loss_finalize_kernel, dim3(1), dim3(1), 0, OSD_STREAM(stream), sums, losses, n);
   return osd_check_launch("fcos_loss_finalize");
+}
+
+// every FPN level in one launch per phase (phase 0: sums; phase 1: gradients).  Host arrays of n_levels entries.
+extern "C" int osd_fcos_loss_levels(int phase, int n_levels, const void* const* cls_ctrs, const void* const* regs,
+                                    const float* gt_boxes, const int32_t* gt_count, int max_gt, int n, const int32_t* hs,
+                                    const int32_t* ws, const int32_t* strides, const float* size_lo, const float* size_hi,
+                                    float radius, float gamma, float alpha, const float* const* scale_devs, float* sums,
+                                    void* const* d_cls_ctrs, void* const* d_regs, int grad_stride,
+                                    float* const* d_scale_raws, int dtype, void* stream) {
+  if (!cls_ctrs || !regs || !gt_boxes || !gt_count || !sums || !hs || !ws || !strides || !size_lo || !size_hi ||
+      n_levels < 1 || n_levels > kLossLevels)
+    return osd_fail(OSD_ERR_INVALID_ARG, "fcos_loss_levels: bad arguments");
+  if (phase == 1 && (!d_cls_ctrs || !d_regs || !d_scale_raws || !scale_devs || grad_stride < 4))
+    return osd_fail(OSD_ERR_INVALID_ARG, "fcos_loss_levels: bad gradient output");
+  if (n == 0) return OSD_OK;
+  LossLevels L;
+  int bmax = 1;
+  for (int i = 0; i < kLossLevels; ++i) {
+    const int j = i < n_levels ? i : 0;
+    if (!cls_ctrs[j] || !regs[j]) return osd_fail(OSD_ERR_INVALID_ARG, "fcos_loss_levels: null level %d", j);
+    L.cc[i] = cls_ctrs[j]; L.rg[i] = regs[j];
+    L.dcc[i] = phase == 1 ? d_cls_ctrs[j] : nullptr; L.drg[i] = phase == 1 ? d_regs[j] : nullptr;
+    L.scale_dev[i] = scale_devs ? scale_devs[j] : nullptr; L.d_scale_raw[i] = phase == 1 ? d_scale_raws[j] : nullptr;
+    L.lv[i].h = hs[j]; L.lv[i].w = ws[j]; L.lv[i].stride = strides[j]; L.lv[i].lo = size_lo[j]; L.lv[i].hi = size_hi[j];
+    L.lv[i].radius_px = strides[j] * radius;
+    int bx = cdiv(hs[j] * ws[j], 256);
+    if (bx > 256) bx = 256;
+    L.nbx[i] = i < n_levels ? bx : 0;
+    if (i < n_levels && bx > bmax) bmax = bx;
+  }
+  dim3 grid(bmax, n, n_levels);
+#define OSD_LOSSL_LAUNCH(TT, PH)                                                                                       \
+  hipLaunchKernelGGL((fcos_loss_levels_kernel<TT, PH>), grid, dim3(256), 0, OSD_STREAM(stream), L, gt_boxes, gt_count, max_gt, n, \
+                     gamma, alpha, sums, grad_stride)
+  if (dtype == OSD_F32) { if (phase == 0) OSD_LOSSL_LAUNCH(float, 0); else OSD_LOSSL_LAUNCH(float, 1); }
+  else if (dtype == OSD_BF16) { if (phase == 0) OSD_LOSSL_LAUNCH(__bf16, 0); else OSD_LOSSL_LAUNCH(__bf16, 1); }
+  else return osd_fail(OSD_ERR_INVALID_ARG, "fcos_loss_levels: bad dtype");
+#undef OSD_LOSSL_LAUNCH
+  return osd_check_launch("fcos_loss_levels");
 }

@@ -743,6 +743,25 @@ def _ptr_array(tensors):
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+def fcos_loss_levels(phase, head_out, gt_boxes, gt_count, strides, size_ranges, radius, gamma, alpha, scale_devs, sums,
+                     d_cls_ctrs=None, d_regs=None, d_scale_raws=None):
+    """fcos_loss_level for every FPN level in ONE launch.  head_out: [(cls_ctr, reg)] per level."""
+    k = len(head_out)
+    n = head_out[0][0].shape[0]
+    gs = d_cls_ctrs[0].shape[-1] if d_cls_ctrs is not None else 4
+    hs = (C.c_int32 * k)(*[c.shape[1] for c, _ in head_out])
+    ws = (C.c_int32 * k)(*[c.shape[2] for c, _ in head_out])
+    st = (C.c_int32 * k)(*strides)
+    lo = (C.c_float * k)(*[float(a) for a, _ in size_ranges])
+    hi = (C.c_float * k)(*[float(b) for _, b in size_ranges])
+    none = C.c_void_p(0)
+    _lib.call("osd_fcos_loss_levels", phase, k, _ptr_array([c for c, _ in head_out]), _ptr_array([r for _, r in head_out]),
+              _ptr(gt_boxes), _ptr(gt_count), gt_boxes.shape[1], n, hs, ws, st, lo, hi, float(radius), float(gamma), float(alpha),
+              _ptr_array(scale_devs) if scale_devs is not None else none, _ptr(sums),
+              _ptr_array(d_cls_ctrs) if d_cls_ctrs is not None else none, _ptr_array(d_regs) if d_regs is not None else none,
+              gs, _ptr_array(d_scale_raws) if d_scale_raws is not None else none, _dt(head_out[0][0]), _stream())
+
+
 def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5):
     """relu(GroupNorm(x_l)) for the FPN levels of one tower layer in two launches.  Returns (ys, ab) with
     ab [L][2][N][C] fp32 (per-image scale/shift, kept for the backward pass)."""

@@ -67,6 +67,7 @@ class TrainEngine(object):
         self.ustream = torch.cuda.Stream(device=self.device)
         self._overlap, self._fuse_update, self._updated = True, False, set()
         self._wq = None
+        self._pred_grad_bufs = {}
         self.repack()
         self.zero_bias = torch.zeros(4096, device=self.device, dtype=torch.float32)
         # SGD with the reference's parameter groups (solver/build.py:8-26: bias lr x2, bias weight decay 0)
@@ -344,20 +345,24 @@ class TrainEngine(object):
         scales, gscales = self.extra[h + "scales"]
         n = head_out[0][0].shape[0]
         sums = torch.zeros(8, device=self.device, dtype=torch.float32)
-        for lvl, (cc, rg) in enumerate(head_out):
-            ops.fcos_loss_level(0, cc, rg, gt_boxes, gt_count, spec.FPN_STRIDES[lvl], SIZE_RANGES[lvl][0],
-                                SIZE_RANGES[lvl][1], spec.POS_RADIUS, spec.LOSS_GAMMA, spec.LOSS_ALPHA, None, sums)
+        nl = len(head_out)
+        ops.fcos_loss_levels(0, head_out, gt_boxes, gt_count, spec.FPN_STRIDES[:nl], SIZE_RANGES[:nl], spec.POS_RADIUS,
+                             spec.LOSS_GAMMA, spec.LOSS_ALPHA, None, sums)
         gstride = self.convs[h + "bbox_pred"].pd.cin_k
         grads = []
         raw = torch.zeros(5, device=self.device, dtype=torch.float32)
         for lvl, (cc, rg) in enumerate(head_out):
             shape = cc.shape[:3] + (gstride,)
-            dcc = torch.zeros(shape, device=self.device, dtype=self.dtype)
-            drg = torch.zeros(shape, device=self.device, dtype=self.dtype)
-            ops.fcos_loss_level(1, cc, rg, gt_boxes, gt_count, spec.FPN_STRIDES[lvl], SIZE_RANGES[lvl][0],
-                                SIZE_RANGES[lvl][1], spec.POS_RADIUS, spec.LOSS_GAMMA, spec.LOSS_ALPHA,
-                                scales[lvl:lvl + 1], sums, dcc, drg, raw[lvl:lvl + 1])
-            grads.append((dcc, drg))
+            # persistent gradient buffers: the kernel rewrites the real channels of EVERY location each step, the padding
+            # channels (K padding of the data-gradient convs) are zeroed once here instead of by 10 fill launches per step
+            key = (lvl, tuple(shape), self.dtype)
+            if key not in self._pred_grad_bufs:
+                self._pred_grad_bufs[key] = (torch.zeros(shape, device=self.device, dtype=self.dtype),
+                                             torch.zeros(shape, device=self.device, dtype=self.dtype))
+            grads.append(self._pred_grad_bufs[key])
+        ops.fcos_loss_levels(1, head_out, gt_boxes, gt_count, spec.FPN_STRIDES[:nl], SIZE_RANGES[:nl], spec.POS_RADIUS,
+                             spec.LOSS_GAMMA, spec.LOSS_ALPHA, [scales[l:l + 1] for l in range(nl)], sums,
+                             [g[0] for g in grads], [g[1] for g in grads], [raw[l:l + 1] for l in range(nl)])
         gscales.add_(raw / scales)      # d loss / d scale_l = sum ds * x, x = log(reg) / scale_l
         losses = torch.empty(4, device=self.device, dtype=torch.float32)
         ops._lib.call("osd_fcos_loss_finalize", ops._ptr(sums), ops._ptr(losses), n, ops._stream())
