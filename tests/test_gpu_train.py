@@ -449,3 +449,25 @@ def test_conv_wgrad_mixed_geometries_in_one_launch(dt):
             torch.testing.assert_close(it[2], rw, rtol=1e-3, atol=1e-3 * float(rw.abs().max()))
             if rb is not None:
                 torch.testing.assert_close(it[4], rb, rtol=1e-3, atol=1e-3 * float(rb.abs().max()))
+
+
+def test_two_ranks_on_one_gpu_average_gradients():
+    """World size 2 with BOTH ranks on this GPU (gloo moves the device tensors): the real TrainEngine with the
+    overlapped, bucketed gradient exchange must produce the average of the two ranks' gradients, and train_step must
+    apply the same update on both ranks.  (The RCCL flavour of the same path runs with one rank in
+    test_gradient_buckets_cover_the_flat_buffer_and_overlapped_exchange_runs; 8 GPUs are the driver's.)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root,
+                         env=dict(os.environ, OMP_NUM_THREADS="4"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "RANK 0 GPU_EXCHANGE=True" in out.stdout and "RANK 1 GPU_EXCHANGE=True" in out.stdout, out.stdout[-1500:]
