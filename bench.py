@@ -456,8 +456,11 @@ def main():
 
     rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), \
         int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dist_setup("nccl")
+    # OSD_BENCH_SHARE_GPU=1 (tests only): every rank on cuda:0 with the gloo backend, so the exact N > 1 code path
+    # (rank-seeded data, overlapped exchange, barrier-bracketed timing, MAX over ranks) runs on a one-GPU box
+    share = os.environ.get("OSD_BENCH_SHARE_GPU") == "1"
+    torch.cuda.set_device(0 if share else local_rank)
+    dist_setup("gloo" if share else "nccl")
     if not args.dtype:      # configs[2] (train) is bf16, configs[1] (forward parity config) is fp32
         args.dtype = "bf16" if args.mode == "train" else "f32"
     if args.mode == "train":

@@ -471,3 +471,31 @@ def test_two_ranks_on_one_gpu_average_gradients():
                          env=dict(os.environ, OMP_NUM_THREADS="4"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "RANK 0 GPU_EXCHANGE=True" in out.stdout and "RANK 1 GPU_EXCHANGE=True" in out.stdout, out.stdout[-1500:]
+
+
+def test_bench_two_ranks_sharing_the_gpu():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), with both ranks
+    placed on this GPU (OSD_BENCH_SHARE_GPU=1: gloo instead of RCCL): one JSON line from rank 0, whole-job value = 16
+    images per step / MAX-over-ranks time, the exchange in the parallelism string."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no-conv-timing"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root,
+                         env=dict(os.environ, OSD_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="4"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 16 and r["scaling"] == "weak"
+    assert abs(r["value"] - 16 * 1e3 / r["ms_per_step"]) / r["value"] < 0.01
+    assert "buckets" in r["config"]["parallelism"] and "cpu_baseline" not in r
