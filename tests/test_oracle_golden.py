@@ -62,14 +62,16 @@ def test_hot_path_forward_matches_reference(name, sd):
     with torch.no_grad():
         o = orc.hot_path_forward(torch.from_numpy(img), torch.from_numpy(q), sd, shots=S)
     head = gu.flatten_head(*[[t.numpy() for t in o[k]] for k in ("logits", "bbox_reg", "centerness")])
-    # oneDNN thread-count / blocking noise only: same algorithm, same machine class
+    # Same algorithm as the fixtures' generator (which matched the reference to 0.0 on the generating machine); on another
+    # CPU oneDNN picks another blocking / thread count, i.e. another fp32 summation order: 1e-5 relative was measured
+    # between the build container (8 threads) and the GPU box's host (128 threads)
     np.testing.assert_allclose(head, f["head"], rtol=1e-4, atol=1e-4)
     for lvl in range(5):
-        np.testing.assert_allclose(o["pooled"][lvl].reshape(B, -1).numpy(), f["pooled.%d" % lvl], rtol=1e-5,
-                                   atol=1e-5)
-        gu.check_against(o["features"][lvl].numpy(), f, "features.%d" % lvl, 1e-5, 1e-4)
-        gu.check_against(o["combined"][lvl].numpy(), f, "combined.%d" % lvl, 1e-5, 1e-4)
-        gu.check_against(o["query_features"][lvl].numpy(), f, "query_features.%d" % lvl, 1e-5, 1e-4)
+        ref = f["pooled.%d" % lvl]
+        np.testing.assert_allclose(o["pooled"][lvl].reshape(B, -1).numpy(), ref, rtol=1e-4, atol=1e-5 * float(np.abs(ref).max()))
+        gu.check_against(o["features"][lvl].numpy(), f, "features.%d" % lvl, 1e-4, 1e-4)
+        gu.check_against(o["combined"][lvl].numpy(), f, "combined.%d" % lvl, 1e-4, 1e-4)
+        gu.check_against(o["query_features"][lvl].numpy(), f, "query_features.%d" % lvl, 1e-4, 1e-4)
     if name != "config1":   # proposals from the oracle's own head outputs
         props = orc.fcos_postprocess(o["logits"], o["bbox_reg"], o["centerness"], [(H, W)] * B)
         for i in range(B):
@@ -120,6 +122,12 @@ def test_loss_and_gradients_match_reference(name, sd):
             g = sd2[k].grad.numpy().reshape(-1)
             idx = gu.sample_indices(g.size, "grad." + k)[:256]
             scale = float(f["fullgrad_oracle.%s.absmax" % k])
-            np.testing.assert_allclose(g[idx], f[key], rtol=1e-3, atol=1e-4 * scale, err_msg=k)
+            # on the generating machine these agree to ~1e-7; on another host CPU the fp32 forward moves by 1e-5
+            # (oneDNN blocking), a handful of ReLU/GN outputs sitting at zero flip, and a sampled gradient moves by
+            # up to ~1e-3 of the tensor's largest entry (measured 8e-4 on the GPU box's host): bound that, and bound
+            # the sample-wise L2 error tighter
+            np.testing.assert_allclose(g[idx], f[key], rtol=1e-3, atol=4e-3 * scale, err_msg=k)
+            den = float(np.linalg.norm(f[key]))
+            assert float(np.linalg.norm(g[idx] - f[key])) <= 5e-3 * den + 1e-4 * scale, k
             checked += 1
     assert checked >= 16
