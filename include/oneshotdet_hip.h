@@ -304,6 +304,42 @@ int osd_fcos_loss_levels(int phase, int n_levels, const void* const* cls_ctrs, c
 /* losses[4] = {loss_cls, loss_reg, loss_centerness, num_pos} */
 int osd_fcos_loss_finalize(const float* sums, float* losses, int n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Second-stage few-shot ROI box head (modeling/roi_heads/box_head/box_head.py:81-259).  Its
+ * convolutions and fully connected layers are osd_conv2d_fwd calls (a Linear is a 1x1 conv over [R][1][1][K]); the
+ * three entry points below are the rest.
+ * ---------------------------------------------------------------------------------------------------------------- */
+#define OSD_MAX_ROI_LEVELS 8
+/* Pooler.forward (modeling/poolers.py:93-124): every ROI is ROIAligned (pool x pool bins, `sampling_ratio` samples per
+ * bin side; _C.roi_align_forward, csrc/cuda/ROIAlign_cuda.cu:11-122) from the FPN level LevelMapper picks
+ * (poolers.py:11-42: floor(4 + log2(sqrt(area)/224 + 1e-6)) clamped to the levels, area with the "+1" of
+ * structures/bounding_box.py:226-236).  xs / hs / ws / scales: HOST arrays of n_levels (device pointer to the NHWC
+ * [n][h][w][c] map, its size, its spatial scale).  boxes [n][max_rois][4] fp32 xyxy, counts [n] (NULL: all max_rois are
+ * valid; the reference needs equal counts, poolers.py:80 - here ROIs past counts[image] give zero rows).
+ * y [n*max_rois][pool][pool][y_stride] `dtype` (channels 0..c-1 written).  level_out (optional) [n*max_rois] int32:
+ * the level each ROI used, -1 past the count. */
+int osd_roi_pool_levels(int n_levels, const void* const* xs, const int32_t* hs, const int32_t* ws, const float* scales,
+                        const float* boxes, const int32_t* counts, void* y, int n, int c, int max_rois, int pool,
+                        int sampling_ratio, int y_stride, int32_t* level_out, int dtype, void* stream);
+/* nn.GroupNorm(groups, c) + nn.LeakyReLU(slope) over [n_samples][hw][c] ROI maps, hw = 49 (box_head.py:43-66; slope 0
+ * = ReLU).  addend (optional, `dtype`, [..][hw][c]): added to x before the statistics; sample i reads addend map
+ * (i / rois_per_add) * add_stride + add_offset.  This is how the `concat` comparison runs: conv1x1(cat(x, q)) =
+ * conv1x1_x(x) + conv1x1_q(q) + bias, and the q half is one map per (image, shot) instead of one per ROI
+ * (box_head.py:126,146-148) - rois_per_add = max_rois, add_stride = shots, add_offset = shot. */
+int osd_groupnorm_act_rois(const void* x, const void* addend, const float* gamma, const float* beta, void* y,
+                           int n_samples, int hw, int c, int groups, float eps, float slope, int rois_per_add,
+                           int add_stride, int add_offset, int dtype, void* stream);
+/* Per-class arg-max over shots (box_head.py:239-252), softmax (box_head/inference.py:66), BoxCoder.decode of the class-1
+ * deltas (modeling/box_coder.py:50-95, weights reg_weights[4] on the HOST), clip_to_image (bounding_box.py:214-219).
+ * pred [shots][n*max_rois][pred_stride] `dtype`: columns 0..1 = cls_score, 2..9 = bbox_pred (roi_box_predictors.py:88-99).
+ * scores [n][max_rois] = class-1 probability, or -1 (dropped by osd_rank_sort_gather) for ROIs past counts[image] or
+ * probability <= score_thresh (inference.py:136); boxes [n][max_rois][4].  logits_out [n*max_rois][2] / reg_out
+ * [n*max_rois][8] (optional, fp32): the selected logits / deltas.  Follow with osd_rank_sort_gather + osd_nms_sorted
+ * (thresh ROI_HEADS.NMS, filter_results inference.py:120-166). */
+int osd_box_decode(const void* pred, const float* rois, const int32_t* counts, float* scores, float* boxes,
+                   float* logits_out, float* reg_out, int n, int max_rois, int shots, int pred_stride,
+                   const float* reg_weights, float img_h, float img_w, float score_thresh, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,12 +200,17 @@ class HotPathEngine(object):
         self.backbone = BackboneWeights(self.sd, "backbone.", self.dtype)
         self.supp_backbone = BackboneWeights(self.sd, "supp_backbone.", self.dtype)
         self.head = HeadWeights(self.sd, self.dtype)
+        # second stage: packed when the state_dict carries the reference's roi_heads.box.* entries
+        self.box_head = None
+        if all(k in self.sd for k in spec.box_head_shapes()):
+            from .box_head import BoxHeadWeights
+            self.box_head = BoxHeadWeights(self.sd, self.dtype)
 
-    def tune(self, images, queries):
+    def tune(self, images, queries, second_stage=False):
         """Pick, by measurement on this device, the conv algorithm (kernel generation, ring depth, tile) for every
         distinct conv shape of this input geometry (cached in ops.ALGO_CACHE; a few ms per shape, done once)."""
         with ops.tuning():
-            self.detect(images, queries, concurrent=False)
+            self.detect(images, queries, concurrent=False, second_stage=second_stage)
         torch.cuda.synchronize()
 
     def side_streams(self):
@@ -238,13 +243,28 @@ class HotPathEngine(object):
         head = run_head(self.head, combined, self.side_streams() if concurrent else None)
         return dict(features=feats, query_features=qfeats, pooled=pooled, combined=combined, head=head)
 
-    def detect(self, images, queries, training=False, cuda_nms=True, concurrent=True):
+    def detect(self, images, queries, training=False, cuda_nms=True, concurrent=True, second_stage=False):
+        """GeneralizedRCNN.forward in eval mode (generalized_rcnn.py:226-332): first stage -> out["proposals"] =
+        (boxes [N,P,4], scores [N,P], counts [N]); with second_stage also the few-shot ROI box head ->
+        out["detections"] = dict(boxes [N,K,4], scores [N,K] descending, counts [N])."""
         out = self.forward(images, queries, concurrent)
         h, w = images.shape[-2:]
         pre = spec.PRE_NMS_TOP_N_TRAIN if training else spec.PRE_NMS_TOP_N_TEST
         post = spec.POST_NMS_TOP_N_TRAIN if training else spec.POST_NMS_TOP_N_TEST
         out["proposals"] = run_proposals(out["head"], h, w, pre, post, spec.NMS_THRESH, cuda_nms)
+        if second_stage:
+            out["detections"] = self.box_detect(out["features"], out["query_features"], tuple(queries.shape[-2:]),
+                                                out["proposals"][0], out["proposals"][2], h, w,
+                                                shots=queries.shape[0] // images.shape[0], cuda_nms=cuda_nms)
         return out
+
+    def box_detect(self, feats, qfeats, q_size, boxes, counts, img_h, img_w, shots=1, cuda_nms=True, want_raw=False):
+        """roi_heads.box on given proposals (boxes [N,R,4] fp32, counts [N] int32 or None)."""
+        if self.box_head is None:
+            raise KeyError("state_dict has no roi_heads.box.* entries: the second stage was not packed")
+        from .box_head import run_box_head
+        return run_box_head(self.box_head, feats, qfeats, q_size, boxes, counts, img_h, img_w, shots=shots,
+                            cuda_nms=cuda_nms, want_raw=want_raw)
 
 
 class GraphedDetect(object):

@@ -787,3 +787,56 @@ def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32
     _lib.call("osd_groupnorm_relu_bwd_levels", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
               _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), _stream())
     return dus
+
+
+# ---- second-stage ROI box head ----
+def roi_pool_levels(feats, scales, boxes, counts, pool, sampling_ratio, out=None, want_levels=False):
+    """Pooler.forward (modeling/poolers.py:93-124): feats = NHWC level maps, boxes [N,R,4] fp32 xyxy, counts [N] int32 or
+    None -> [N*R, pool, pool, C] in the maps' dtype (zero rows past counts[image])."""
+    _chk_dev(boxes, counts, *feats)
+    n, r, _ = boxes.shape
+    c = feats[0].shape[-1]
+    k = len(feats)
+    if out is None:
+        out = torch.empty((n * r, pool, pool, c), device=boxes.device, dtype=feats[0].dtype)
+    lv = torch.empty((n * r,), device=boxes.device, dtype=torch.int32) if want_levels else None
+    xs = (C.c_void_p * k)(*[f.data_ptr() for f in feats])
+    hs = (C.c_int32 * k)(*[f.shape[1] for f in feats])
+    ws = (C.c_int32 * k)(*[f.shape[2] for f in feats])
+    sc = (C.c_float * k)(*[float(s) for s in scales])
+    assert all(f.shape[0] == n and f.shape[-1] == c and f.is_contiguous() for f in feats)
+    _lib.call("osd_roi_pool_levels", k, xs, hs, ws, sc, _ptr(boxes.contiguous()), _ptr(counts), _ptr(out), n, c, r, pool,
+              sampling_ratio, out.shape[-1], _ptr(lv), _dt(out), _stream())
+    return (out, lv) if want_levels else out
+
+
+def groupnorm_act_rois(x, gamma, beta, groups=32, eps=1e-5, slope=0.2, addend=None, rois_per_add=1, add_stride=1,
+                       add_offset=0, out=None):
+    """LeakyReLU(slope)(GroupNorm(groups, C)(x [+ addend map of the ROI's image / shot])) on [R,7,7,C] ROI maps."""
+    _chk_dev(x, gamma, beta, addend)
+    r, h, w, c = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    if addend is not None:
+        assert addend.dtype == x.dtype and addend.shape[1:] == x.shape[1:] and addend.is_contiguous()
+    _lib.call("osd_groupnorm_act_rois", _ptr(x), _ptr(addend), _ptr(gamma), _ptr(beta), _ptr(out), r, h * w, c, groups,
+              float(eps), float(slope), rois_per_add, add_stride, add_offset, _dt(x), _stream())
+    return out
+
+
+def box_decode(pred, rois, counts, reg_weights, img_h, img_w, score_thresh, want_raw=False):
+    """pred [S, N*R, P] (cols 0..1 logits, 2..9 deltas), rois [N,R,4] -> scores [N,R] (-1 = dropped), boxes [N,R,4]
+    (+ the selected logits [N*R,2] and deltas [N*R,8] in fp32 when want_raw)."""
+    _chk_dev(pred, rois, counts)
+    s, m, p = pred.shape
+    n, r, _ = rois.shape
+    assert m == n * r and pred.is_contiguous()
+    dev = pred.device
+    scores = torch.empty((n, r), device=dev, dtype=torch.float32)
+    boxes = torch.empty((n, r, 4), device=dev, dtype=torch.float32)
+    lo = torch.empty((m, 2), device=dev, dtype=torch.float32) if want_raw else None
+    ro = torch.empty((m, 8), device=dev, dtype=torch.float32) if want_raw else None
+    rw = (C.c_float * 4)(*[float(v) for v in reg_weights])
+    _lib.call("osd_box_decode", _ptr(pred), _ptr(rois.contiguous()), _ptr(counts), _ptr(scores), _ptr(boxes), _ptr(lo),
+              _ptr(ro), n, r, s, p, rw, float(img_h), float(img_w), float(score_thresh), _dt(pred), _stream())
+    return (scores, boxes, lo, ro) if want_raw else (scores, boxes)

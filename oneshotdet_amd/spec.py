@@ -31,6 +31,18 @@ LOSS_GAMMA = 2.0
 POS_RADIUS = 1.5
 SIZE_DIVISIBILITY = 32
 INF = 100000000
+# second stage: yaml ROI_BOX_HEAD + defaults.py:196-229,511
+BOX_POOL = 7                          # ROI_BOX_HEAD.POOLER_RESOLUTION
+BOX_MLP_DIM = 1024                    # ROI_BOX_HEAD.MLP_HEAD_DIM
+BOX_NUM_CLASSES = 2                   # ROI_BOX_HEAD.NUM_CLASSES (background, the query's class)
+BOX_REG_WEIGHTS = (10.0, 10.0, 5.0, 5.0)   # ROI_HEADS.BBOX_REG_WEIGHTS
+BOX_SCORE_THRESH = 0.0                # ROI_HEADS.SCORE_THRESH
+BOX_NMS_THRESH = 0.5                  # ROI_HEADS.NMS
+BOX_DETECTIONS_PER_IMG = 2000         # ROI_HEADS.DETECTIONS_PER_IMG
+BOX_LEAKY_SLOPE = 0.2                 # box_head.py:46,49,64
+LEVEL_MAP_SCALE = 224                 # poolers.py:16 LevelMapper canonical_scale / canonical_level / eps
+LEVEL_MAP_LEVEL = 4
+LEVEL_MAP_EPS = 1e-6
 
 
 def _bn(prefix, n, out):
@@ -99,12 +111,48 @@ def fcos_head_shapes(prefix="rpn.head."):
     return out
 
 
+def box_head_shapes(prefix="roi_heads.box."):
+    """Second-stage few-shot ROI box head keys (modeling/roi_heads/box_head/box_head.py:40-78: compress_dim_conv =
+    Sequential(conv1x1, GN, LeakyReLU, conv1x1, GN, LeakyReLU) -> indices 0,1,3,4; feature_aggreg = Sequential(conv3x3,
+    GN, LeakyReLU); fc6/fc7 make_fc; roi_box_predictors.py:37-99 FPNPredictor with 2 classes and 2x4 box deltas)."""
+    out = OrderedDict()
+    c2 = 2 * FPN_OUT
+    out[prefix + "compress_dim_conv.0.weight"] = (c2, c2, 1, 1)
+    out[prefix + "compress_dim_conv.0.bias"] = (c2,)
+    out[prefix + "compress_dim_conv.1.weight"] = (c2,)
+    out[prefix + "compress_dim_conv.1.bias"] = (c2,)
+    out[prefix + "compress_dim_conv.3.weight"] = (FPN_OUT, c2, 1, 1)
+    out[prefix + "compress_dim_conv.3.bias"] = (FPN_OUT,)
+    out[prefix + "compress_dim_conv.4.weight"] = (FPN_OUT,)
+    out[prefix + "compress_dim_conv.4.bias"] = (FPN_OUT,)
+    out[prefix + "feature_aggreg.0.weight"] = (FPN_OUT // 2, FPN_OUT, 3, 3)
+    out[prefix + "feature_aggreg.0.bias"] = (FPN_OUT // 2,)
+    out[prefix + "feature_aggreg.1.weight"] = (FPN_OUT // 2,)
+    out[prefix + "feature_aggreg.1.bias"] = (FPN_OUT // 2,)
+    out[prefix + "fc6.weight"] = (BOX_MLP_DIM, (FPN_OUT // 2) * BOX_POOL ** 2)
+    out[prefix + "fc6.bias"] = (BOX_MLP_DIM,)
+    out[prefix + "fc7.weight"] = (BOX_MLP_DIM, BOX_MLP_DIM)
+    out[prefix + "fc7.bias"] = (BOX_MLP_DIM,)
+    out[prefix + "predictor.cls_score.weight"] = (BOX_NUM_CLASSES, BOX_MLP_DIM)
+    out[prefix + "predictor.cls_score.bias"] = (BOX_NUM_CLASSES,)
+    out[prefix + "predictor.bbox_pred.weight"] = (BOX_NUM_CLASSES * 4, BOX_MLP_DIM)
+    out[prefix + "predictor.bbox_pred.bias"] = (BOX_NUM_CLASSES * 4,)
+    return out
+
+
 def hot_path_shapes():
     """All state_dict entries of the hot path: target backbone, query backbone (separate weights,
     generalized_rcnn.py:69-71), FCOS head."""
     out = backbone_shapes("backbone.")
     out.update(backbone_shapes("supp_backbone."))
     out.update(fcos_head_shapes())
+    return out
+
+
+def full_model_shapes():
+    """Hot path + second-stage box head = every state_dict entry of the reference model under the config of record."""
+    out = hot_path_shapes()
+    out.update(box_head_shapes())
     return out
 
 

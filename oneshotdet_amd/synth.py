@@ -45,8 +45,25 @@ def uniform(name, shape, lo, hi, seed=0):
     return (u * np.float32(hi - lo) + np.float32(lo)).astype(np.float32).reshape(shape)
 
 
+def _box_head_kind(key, shape):
+    """roi_heads.box.* (spec.box_head_shapes): Sequential index 1 / 4 = GroupNorm, 2-D weights = Linear."""
+    leaf = key.rsplit(".", 1)[-1]
+    if "predictor.cls_score" in key:
+        return "box_cls_w" if leaf == "weight" else "box_cls_b"
+    if "predictor.bbox_pred" in key:
+        return "box_reg_w" if leaf == "weight" else "box_reg_b"
+    if len(shape) in (2, 4):
+        return "conv_w"
+    parts = key.split(".")
+    if parts[-2].isdigit() and int(parts[-2]) in (1, 4):
+        return "gn_" + leaf
+    return "conv_b"
+
+
 def _kind(key, shape):
     leaf = key.rsplit(".", 1)[-1]
+    if key.startswith("roi_heads."):
+        return _box_head_kind(key, shape)
     if key.endswith(".scale"):
         return "scale"
     if len(shape) == 4:
@@ -68,8 +85,14 @@ def _kind(key, shape):
 
 def make_tensor(key, shape, seed=0):
     kind = _kind(key, shape)
+    if kind == "box_cls_w":     # class scores spread over a few units so NMS sees a real ranking
+        return uniform(key, shape, -0.08, 0.08, seed)
+    if kind == "box_reg_w":     # deltas / (10, 10, 5, 5): shifts of a few percent of the proposal size
+        return uniform(key, shape, -0.04, 0.04, seed)
+    if kind in ("box_cls_b", "box_reg_b"):
+        return uniform(key, shape, -0.1, 0.1, seed)
     if kind in ("conv_w", "pred_w"):
-        fan_in = shape[1] * shape[2] * shape[3]
+        fan_in = int(np.prod(shape[1:]))
         b = math.sqrt(3.0 / fan_in) * (2.0 if kind == "pred_w" else 1.0)
         return uniform(key, shape, -b, b, seed)
     if kind == "bn_weight":

@@ -26,6 +26,7 @@ import golden_utils as gu            # noqa: E402
 import ref_harness as rh             # noqa: E402
 from oneshotdet_amd import spec, synth  # noqa: E402
 from oracle import hotpath_ref as orc   # noqa: E402
+from oracle import box_head_ref as obh  # noqa: E402
 
 
 def t2n(t):
@@ -37,10 +38,12 @@ def load_synth_weights(model, seed=0):
     ref_sd = model.state_dict()
     hot = {k: v for k, v in ref_sd.items() if k.split(".")[0] in ("backbone", "supp_backbone", "rpn")}
     assert list(hot.keys()) == list(shapes.keys()), "spec.hot_path_shapes() key list/order differs from reference"
-    for k, v in hot.items():
-        assert tuple(v.shape) == tuple(shapes[k]), (k, v.shape, shapes[k])
-    np_sd = synth.make_state_dict(shapes, seed)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in np_sd.items()}, strict=False)
+    full = spec.full_model_shapes()
+    assert list(ref_sd.keys()) == list(full.keys()), "spec.full_model_shapes() key list/order differs from reference"
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(full[k]), (k, v.shape, full[k])
+    np_sd = synth.make_state_dict(full, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in np_sd.items()}, strict=True)
     return np_sd
 
 
@@ -123,6 +126,72 @@ def gen_case(model, np_sd, name):
         out["proposals.%d.scores" % i] = rs[order]
     out["ref_seconds"] = np.float64(cap["seconds"])
     np.savez_compressed(os.path.join(HERE, "case_%s.npz" % name), **out)
+
+
+def gen_box_case(model, np_sd, name):
+    """Second stage: `model.supproi_pooling` + `model.roi_heads` of the REAL reference on the
+    reference's own features and proposals.  The reference asserts an equal number of proposals per image
+    (modeling/poolers.py:80), so for B > 1 every image's proposal list is cut to the shortest one before the call."""
+    rh.load_reference()
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    B, H, W, S, qh, qw = gu.CASES[name]
+    img_np, q_np = gu.case_inputs(name)
+    images, queries = torch.from_numpy(img_np), torch.from_numpy(q_np)
+    cap = run_reference(model, images, queries, B)
+    feats, qfeats = list(cap["features"]), list(cap["query_features"])
+    rmin = min(len(bl) for bl in cap["proposals"])
+    props = [bl[:rmin] for bl in cap["proposals"]]
+    grabbed = {"logits": [], "reg": []}
+    def grab_pred(m, i, o):         # a hook that returns a value would replace the module's output
+        grabbed["logits"].append(o[0])
+        grabbed["reg"].append(o[1])
+
+    def grab_x(m, i, o):
+        grabbed["x"] = o
+    hooks = [model.roi_heads.box.predictor.register_forward_hook(grab_pred),
+             model.roi_heads.box.feature_extractor.register_forward_hook(grab_x)]
+    model.eval()
+    with torch.no_grad():
+        supp_boxes = [BoxList([[0, 0, qh, qw]], image_size=(qh, qw), mode="xyxy") for _ in range(B * S)]
+        supp_roi = model.supproi_pooling(qfeats, supp_boxes)                  # generalized_rcnn.py:257,290
+        _, result, _ = model.roi_heads(feats, props, None, supp_roi, target_ids=[1] * B)   # :317
+    for h in hooks:
+        h.remove()
+    # ---- oracle on the same inputs ----
+    sd = orc.to_torch_state_dict(np_sd)
+    with torch.no_grad():
+        o = obh.box_head_forward(feats, qfeats, [bl.bbox for bl in props], [(H, W)] * B, [(qh, qw)] * (B * S), sd)
+        o_supp = obh.query_roi_features(qfeats, [(qh, qw)] * (B * S))
+    err = {"supp_roi": (o_supp - supp_roi).abs().max().item() / max(supp_roi.abs().max().item(), 1e-6),
+           "pooled": (o["pooled"] - grabbed["x"]).abs().max().item() / max(grabbed["x"].abs().max().item(), 1e-6)}
+    if S == 1:
+        ref_logits, ref_reg = grabbed["logits"][0], grabbed["reg"][0]
+    else:   # the reference's own per-class arg-max over shots is internal to ROIBoxHead.forward: redo it on its outputs
+        tl, tr = torch.stack(grabbed["logits"], 0), torch.stack(grabbed["reg"], 0)
+        idx = torch.argmax(tl, dim=0)
+        ref_logits = torch.gather(tl, 0, idx.unsqueeze(0))[0]
+        ref_reg = torch.gather(tr, 0, idx[:, :, None].expand(-1, -1, 4).reshape(idx.shape[0], -1).unsqueeze(0))[0]
+    err["logits"] = (o["logits"] - ref_logits).abs().max().item()
+    err["reg"] = (o["box_regression"] - ref_reg).abs().max().item()
+    print(name, "box head: R=%d per image, oracle-vs-reference:" % rmin, {k: "%.2e" % v for k, v in err.items()})
+    assert err["supp_roi"] < 1e-5 and err["pooled"] < 1e-5 and err["logits"] < 2e-4 and err["reg"] < 2e-4, err
+    out = {"image_size": np.asarray([H, W], dtype=np.int64), "logits": t2n(ref_logits), "box_regression": t2n(ref_reg),
+           "n_shots_outputs": np.int64(len(grabbed["logits"]))}
+    out.update(gu.checksum(t2n(grabbed["x"]).reshape(B * rmin, -1, 7, 7), "pooled"))
+    out.update(gu.checksum(t2n(supp_roi).reshape(B * S, -1, 7, 7), "supp_roi"))
+    for i, bl in enumerate(result):
+        rb, rs = t2n(bl.bbox), t2n(bl.get_field("scores"))
+        ob, os_ = t2n(o["detections"][i][0]), t2n(o["detections"][i][1])
+        frac = gu.match_boxes(rb, rs, ob, os_)
+        print("  image %d: reference %d detections (labels %s), oracle %d, overlap %.4f"
+              % (i, len(rb), sorted(set(bl.get_field("labels").tolist())), len(ob), frac))
+        assert len(rb) == len(ob) and frac >= 0.999, (len(rb), len(ob), frac)
+        np.testing.assert_allclose(ob, rb, atol=2e-3)      # same order too (ascending proposal index)
+        order = np.argsort(-rs, kind="stable")
+        out["proposals.%d.boxes" % i] = t2n(props[i].bbox)
+        out["detections.%d.boxes" % i] = rb[order]
+        out["detections.%d.scores" % i] = rs[order]
+    np.savez_compressed(os.path.join(HERE, "box_%s.npz" % name), **out)
 
 
 def gen_train_case(model, np_sd, name="small"):
@@ -267,7 +336,8 @@ def gen_keys(model):
     sd = model.state_dict()
     hot = {k: list(v.shape) for k, v in sd.items() if k.split(".")[0] in ("backbone", "supp_backbone", "rpn")}
     frozen = sorted(n for n, p in model.named_parameters() if not p.requires_grad and n in hot)
-    json.dump({"shapes": hot, "frozen_params": frozen, "num_all_keys": len(sd)},
+    box = {k: list(v.shape) for k, v in sd.items() if k.startswith("roi_heads.")}
+    json.dump({"shapes": hot, "frozen_params": frozen, "num_all_keys": len(sd), "box_head_shapes": box},
               open(os.path.join(HERE, "state_dict_keys.json"), "w"), indent=0)
 
 
@@ -277,10 +347,19 @@ def main():
     ap.add_argument("--skip-train", action="store_true")
     ap.add_argument("--train-cases", default="small,nonsquare,shots5,tall,config1")
     ap.add_argument("--only-train", action="store_true", help="regenerate only the training fixtures")
+    ap.add_argument("--box-cases", default="small,nonsquare,shots5,tall,config1")
+    ap.add_argument("--only-box", action="store_true", help="regenerate only the second-stage fixtures (+ key list)")
     args = ap.parse_args()
     torch.set_num_threads(8)
     model, cfg = rh.build_reference_model()
     np_sd = load_synth_weights(model)
+    if args.only_box:
+        gen_keys(model)
+    if not args.only_train:
+        for name in [c for c in args.box_cases.split(",") if c]:
+            gen_box_case(model, np_sd, name)
+    if args.only_box:
+        return
     if not args.only_train:
         gen_keys(model)
         gen_nms_kat()

@@ -17,6 +17,11 @@ def sd():
     return orc.to_torch_state_dict(synth.make_state_dict(spec.hot_path_shapes()))
 
 
+@pytest.fixture(scope="module")
+def sd_full():
+    return orc.to_torch_state_dict(synth.make_state_dict(spec.full_model_shapes()))
+
+
 def test_state_dict_keys_match_reference():
     ref = json.load(open(os.path.join(gu.GOLDEN_DIR, "state_dict_keys.json")))
     mine = spec.hot_path_shapes()
@@ -131,3 +136,68 @@ def test_loss_and_gradients_match_reference(name, sd):
             assert float(np.linalg.norm(g[idx] - f[key])) <= 5e-3 * den + 1e-4 * scale, k
             checked += 1
     assert checked >= 16
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# second stage: oracle/box_head_ref.py against the fixtures recorded from the REAL reference's
+# model.roi_heads / model.supproi_pooling (make_golden.py gen_box_case: 0.0 difference on the generating machine)
+# ---------------------------------------------------------------------------------------------------------------------
+from oracle import box_head_ref as obh  # noqa: E402
+
+
+def test_box_head_keys_match_reference():
+    ref = json.load(open(os.path.join(gu.GOLDEN_DIR, "state_dict_keys.json")))
+    mine = spec.box_head_shapes()
+    assert list(mine.keys()) == list(ref["box_head_shapes"].keys())
+    for k, s in mine.items():
+        assert list(s) == ref["box_head_shapes"][k], k
+    assert len(spec.full_model_shapes()) == ref["num_all_keys"]
+
+
+def test_roi_align_vectorised_equals_per_roi_restatement():
+    """roi_align_vec (all ROIs at once) == hotpath_ref.roi_align (one ROI at a time, itself pinned by the reference
+    vectors above), incl. boxes that leave the map and degenerate boxes."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 8, 13, 17, generator=g)
+    rois = torch.tensor([[0, 1.5, 2.0, 60.0, 40.0], [1, -20.0, -8.0, 30.0, 20.0], [1, 100.0, 90.0, 100.0, 90.0],
+                         [0, 0.0, 0.0, 135.0, 103.0], [1, 50.0, 50.0, 49.0, 48.0], [0, 130.0, 100.0, 400.0, 300.0]])
+    for scale, p in ((0.125, 7), (0.0625, 3), (0.125, 1)):
+        a = obh.roi_align_vec(x, rois, scale, p, p, 2)
+        b = orc.roi_align(x, rois, scale, p, p, 2)
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=0, atol=2e-6)
+
+
+def test_level_mapper_boundaries():
+    """poolers.py:33-42: sqrt(area) = 224 -> level 4 (index 1); the '+1' of BoxList.area counts; clamped to P3..P7."""
+    b = torch.tensor([[0, 0, 223, 223], [0, 0, 222, 222], [0, 0, 10, 10], [0, 0, 447, 447], [0, 0, 5000, 5000],
+                      [0, 0, 111, 111], [0, 0, 110, 110]], dtype=torch.float32)
+    assert obh.map_levels(b).tolist() == [1, 0, 0, 2, 4, 0, 0]
+
+
+@pytest.mark.parametrize("name", ["small", "nonsquare", "shots5", "tall"])
+def test_box_head_matches_reference(name, sd_full):
+    f = gu.load("box_%s.npz" % name)
+    B, H, W, S, qh, qw = gu.CASES[name]
+    img, q = gu.case_inputs(name)
+    with torch.no_grad():
+        o = orc.hot_path_forward(torch.from_numpy(img), torch.from_numpy(q), sd_full, shots=S)
+        props = [torch.from_numpy(f["proposals.%d.boxes" % i]) for i in range(B)]
+        r = obh.box_head_forward(o["features"], o["query_features"], props, [(H, W)] * B, [(qh, qw)] * (B * S), sd_full)
+    R = len(props[0])
+    gu.check_against(r["pooled"].reshape(B * R, -1, 7, 7).numpy(), f, "pooled", 1e-4, 1e-4)
+    # other host CPU -> other oneDNN summation order in the backbone (see test_hot_path_forward_matches_reference)
+    np.testing.assert_allclose(r["logits"].numpy(), f["logits"], rtol=1e-3, atol=5e-4)
+    np.testing.assert_allclose(r["box_regression"].numpy(), f["box_regression"], rtol=1e-3, atol=5e-4)
+    for i in range(B):
+        db, ds = r["detections"][i]
+        assert abs(len(db) - len(f["detections.%d.boxes" % i])) <= 1
+        assert gu.match_boxes(f["detections.%d.boxes" % i], f["detections.%d.scores" % i], db.numpy(), ds.numpy()) >= 0.99
+
+
+def test_box_decode_known_values():
+    """BoxCoder.decode (box_coder.py:50-95): zero deltas give the proposal back ('+1' width, '-1' far edge); dw is
+    clamped at log(1000/16)."""
+    boxes = torch.tensor([[10.0, 20.0, 49.0, 99.0]])
+    np.testing.assert_allclose(obh.decode_boxes(torch.zeros(1, 4), boxes).numpy(), boxes.numpy(), atol=1e-5)
+    big = obh.decode_boxes(torch.tensor([[0.0, 0.0, 1000.0, 0.0]]), boxes)
+    assert abs((big[0, 2] - big[0, 0] + 1).item() - 40 * 1000.0 / 16) < 1e-2
