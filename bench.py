@@ -435,6 +435,9 @@ def main():
     ap.add_argument("--mode", default=os.environ.get("OSD_BENCH_MODE", "train"), choices=["train", "forward"],
                     help="train = forward + loss + backward + gradient all-reduce + SGD (the headline metric); "
                          "forward = BASELINE.json configs[1] (inference forward incl. proposals)")
+    ap.add_argument("--second-stage", action="store_true",
+                    help="forward mode: also run the few-shot ROI box head on the 2000 proposals per image "
+                         "(SURVEY.md 8f #1) = the reference's complete eval forward")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="exercise only the multi-process plumbing (gloo, no GPU work): used by tests/test_dist_cpu.py")
     args = ap.parse_args()
@@ -468,22 +471,24 @@ def main():
 
     from oneshotdet_amd import model, ops, spec, synth
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
-    eng = model.HotPathEngine(synth.make_state_dict(spec.hot_path_shapes()), dtype=dtype)
+    shapes = spec.full_model_shapes() if args.second_stage else spec.hot_path_shapes()
+    eng = model.HotPathEngine(synth.make_state_dict(shapes), dtype=dtype)
     B = args.batch
     images = torch.from_numpy(synth.make_images("bench.target", B, 800, 1024, seed=1000 + rank)).cuda()
     queries = torch.from_numpy(synth.make_images("bench.query", B, 127, 127, seed=1000 + rank)).cuda()
 
-    eng.tune(images, queries)      # per-shape conv algorithm selection by measurement (untimed, once)
+    two = bool(args.second_stage)
+    eng.tune(images, queries, second_stage=two)   # per-shape conv algorithm selection by measurement (untimed, once)
     use_graph = not args.no_graph
     if use_graph:
         # production path: the whole forward captured once into a hipGraph (multi-stream branches), then replayed
-        runner = model.GraphedDetect(eng, images, queries)
+        runner = model.GraphedDetect(eng, images, queries, second_stage=two)
 
         def step():
             return runner()
     else:
         def step():
-            return eng.detect(images, queries)
+            return eng.detect(images, queries, second_stage=two)
 
     elapsed = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, "cuda")
 
@@ -500,7 +505,7 @@ def main():
             # park the stream behind a spin kernel while the host enqueues the whole step, so every bracket measures
             # GPU time only (the host needs ~40 us per bracketed launch, more than the short kernels run)
             torch.cuda._sleep(int(60e6))
-            eng.detect(images, queries, concurrent=False)
+            eng.detect(images, queries, concurrent=False, second_stage=two)
             torch.cuda.synchronize()
         conv_ms = timer.total_ms()
         tflops = timer.flops / (conv_ms * 1e-3) / 1e12
@@ -519,7 +524,10 @@ def main():
     if rank == 0:
         workload = ("BASELINE.json configs[1] (forward-only parity/inference config; --mode train is the headline): bs=%d/GPU, 800x1024 target + "
                     "127x127 query, two R-50-FPN backbones + query pooling + correlation + FCOS head + proposals "
-                    "(top-k, NMS 0.8, top-2000), %s MFMA convs" % (B, args.dtype))
+                    "(top-k, NMS 0.8, top-2000)%s, %s MFMA convs"
+                    % (B, " + second-stage ROI box head on the proposals (7x7 level-routed ROIAlign, concat with the "
+                          "query ROI map, 3 conv+GN+LeakyReLU, fc6, fc7, predictor, decode, NMS 0.5)" if two else "",
+                       args.dtype))
         cpu = cpu_baseline(args.dtype) if (world == 1 and not args.no_cpu_baseline) else None
         line = result_line(args, world, B, elapsed, workload,
                            "hipGraph replay, 4 streams" if use_graph else "eager, 4 streams", roofline, cpu)

@@ -276,7 +276,7 @@ class GraphedDetect(object):
         self.engine = engine
         self.images = images.clone()
         self.queries = queries.clone()
-        engine.tune(self.images, self.queries)
+        engine.tune(self.images, self.queries, second_stage=bool(kw.get("second_stage")))
         side = torch.cuda.Stream(device=engine.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
