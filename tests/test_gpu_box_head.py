@@ -227,3 +227,25 @@ def test_full_size_batch8_second_stage_properties(engines):
     assert torch.all(s[:-1] >= s[1:]) and s.min() > 0 and s.max() <= 1
     assert b.min() >= 0 and b[:, 2].max() <= 1023 and b[:, 3].max() <= 799
     assert layers.nms(b, s, spec.BOX_NMS_THRESH).numel() == k
+
+
+def test_checkpoint_round_trip_through_the_engines(tmp_path, engines):
+    """TrainEngine.state_dict() -> reference-format .pth -> HotPathEngine: the reloaded engine reproduces the outputs
+    bit for bit (oneshotdet_amd/checkpoint.py; utils/checkpoint.py:33-103)."""
+    from oneshotdet_amd import checkpoint, model, train
+    np_sd = synth.make_state_dict(spec.full_model_shapes())
+    tr = train.TrainEngine({k: v for k, v in np_sd.items() if k in spec.hot_path_shapes()}, dtype=torch.float32)
+    sd = dict(tr.state_dict())
+    sd.update({k: torch.from_numpy(v) for k, v in np_sd.items() if k.startswith("roi_heads.")})
+    p = checkpoint.save_checkpoint(str(tmp_path / "model_0000001.pth"), {"module." + k: v for k, v in sd.items()},
+                                   iteration=1)
+    loaded, extras = checkpoint.load_checkpoint(p)
+    assert extras["iteration"] == 1 and list(loaded.keys()) == list(spec.full_model_shapes().keys())
+    eng = model.HotPathEngine(loaded, dtype=torch.float32)
+    img, q = gu.case_inputs("small")
+    a = eng.detect(torch.from_numpy(img).cuda(), torch.from_numpy(q).cuda(), second_stage=True)
+    b = engines["f32"].detect(torch.from_numpy(img).cuda(), torch.from_numpy(q).cuda(), second_stage=True)
+    k = int(b["detections"]["counts"][0])
+    assert int(a["detections"]["counts"][0]) == k and k > 0
+    assert torch.equal(a["detections"]["boxes"][0, :k], b["detections"]["boxes"][0, :k])
+    assert torch.equal(a["detections"]["scores"][0, :k], b["detections"]["scores"][0, :k])
