@@ -499,3 +499,34 @@ def test_bench_two_ranks_sharing_the_gpu():
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 16 and r["scaling"] == "weak"
     assert abs(r["value"] - 16 * 1e3 / r["ms_per_step"]) / r["value"] < 0.01
     assert "buckets" in r["config"]["parallelism"] and "cpu_baseline" not in r
+
+
+def test_config5_multiscale_five_shot_training_steps():
+    """BASELINE.json configs[4] at full size: bs=4, S=5 queries per image (20 x 127x127), the target's short edge cycling
+    through {640, 800, 1024} (640x832, 800x1024, 1024x1312) from step to step on ONE engine (buffers keyed by shape).
+    Properties: finite losses, positives found, every trainable bucket updated, and a repeat of the first shape after the
+    cycle still runs (no stale per-shape state); bf16 like configs[2]."""
+    from oneshotdet_amd import train
+    np_sd = synth.make_state_dict(spec.hot_path_shapes())
+    eng = train.TrainEngine(np_sd, dtype=torch.bfloat16, lr=0.002)
+    B, S = 4, 5
+    q = torch.from_numpy(synth.make_images("c5.query", B * S, 127, 127, seed=3)).cuda()
+    sizes = [(640, 832), (800, 1024), (1024, 1312), (640, 832)]
+    w0 = eng.flat_w.clone()
+    for step, (h, w) in enumerate(sizes):
+        img = torch.from_numpy(synth.make_images("c5.target.%d" % step, B, h, w, seed=step)).cuda()
+        gts = synth.make_gt_boxes(B, h, w, seed=20 + step, max_boxes=6)
+        G = max(len(g) for g in gts)
+        gtb = torch.zeros(B, G, 4)
+        for i, g in enumerate(gts):
+            gtb[i, :len(g)] = torch.from_numpy(g)
+        cnt = torch.tensor([len(g) for g in gts], dtype=torch.int32)
+        losses = eng.train_step(img, q, gtb.cuda(), cnt.cuda()).cpu()
+        assert torch.isfinite(losses).all(), (step, losses)
+        assert losses[3] > 0 and losses[:3].sum() > 0
+    torch.cuda.synchronize()
+    moved = (eng.flat_w != w0)
+    for name, (lo, hi) in eng.exchange.ranges.items():
+        assert moved[lo:hi].any(), name
+    assert moved.float().mean() > 0.5
+    assert torch.isfinite(eng.flat_w).all()
