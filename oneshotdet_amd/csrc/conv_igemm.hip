@@ -357,13 +357,17 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
     impl = a >> 5;                 // 0 = LDS-DMA kernel, 1 = register-staged kernel
     variant = (a >> 3) & 3;
     tile = a & 7;
-    if (variant == 3 || tile > 5 || (impl == 1 && (variant != 0 || tile > 3)) || (tile == 5 && variant != 0))
+    if (variant == 3 || tile > 6 || (impl == 1 && (variant != 0 || tile > 3)) || (tile >= 5 && variant != 0))
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv: algo %d not built", d->algo);
     if (p.Cout > 16 && tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: skinny tile on a wide conv");
   }
   if (impl == 0 && tile == 5) {
     if (d->dtype != OSD_BF16) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the ping-pong 256x256 kernel is bf16 only");
     return osd_conv_p8_launch(p, s);
+  }
+  if (impl == 0 && tile == 6) {
+    if (d->dtype != OSD_BF16) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the row-reuse 3x3 kernel is bf16 only");
+    return osd_conv_xr_launch(p, s);
   }
   if (impl == 0) return osd_conv_dma_dispatch(d->dtype, tile, variant, p, s);
   if (mask) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: mask epilogue only in the LDS-DMA kernel");
@@ -434,13 +438,17 @@ extern "C" int osd_conv2d_fwd_grouped(const osd_conv_desc* d, int n_seg, const v
     if (a >= 32) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d is not an LDS-DMA algorithm", d->algo);
     variant = (a >> 3) & 3;
     tile = a & 7;
-    if (variant == 3 || tile > 5 || (tile == 5 && variant != 0))
+    if (variant == 3 || tile > 6 || (tile >= 5 && variant != 0))
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d not built", d->algo);
     if (tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: skinny tile on a wide conv");
   }
   if (tile == 5) {
     if (d->dtype != OSD_BF16) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: the ping-pong 256x256 kernel is bf16 only");
     return osd_conv_p8_launch(p, reinterpret_cast<hipStream_t>(stream));
+  }
+  if (tile == 6) {
+    if (d->dtype != OSD_BF16) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: the row-reuse 3x3 kernel is bf16 only");
+    return osd_conv_xr_launch(p, reinterpret_cast<hipStream_t>(stream));
   }
   return osd_conv_dma_dispatch(d->dtype, tile, variant, p, reinterpret_cast<hipStream_t>(stream));
 }

@@ -39,3 +39,5 @@ struct ConvKParams {
 int osd_conv_dma_dispatch(int dtype, int tile, int variant, const ConvKParams& p, hipStream_t s);
 // conv_igemm_p8.hip: bf16, 256 x 256 tile, two wave groups one barrier apart (tile id 5)
 int osd_conv_p8_launch(const ConvKParams& p, hipStream_t s);
+// conv_igemm_xr.hip: bf16, 3x3 / stride 1 / pad 1, 256 x 256 tile, pixel rows fetched once per filter row (tile id 6)
+int osd_conv_xr_launch(const ConvKParams& p, hipStream_t s);

@@ -288,3 +288,51 @@ def test_conv2d_pingpong_kernel_is_bit_identical_to_the_dma_kernel():
         for _ in range(10):
             y = o.conv2d(x, pc, pad=pad, res=res, res_mode=o.RES_SAME, act=o.ACT_RELU, algo=P8)
             assert torch.equal(y, ref), (n, h, w, cin, cout, k)
+
+
+def test_conv2d_row_reuse_kernel_matches_the_dma_kernel():
+    """conv_igemm_xr.hip (tile id 6): 3x3 / stride 1 / pad 1, pixel rows fetched once per filter row into a zero-padded
+    LDS image.  It sums K in (r, c, s) order instead of (r, s, c), so it equals the LDS-DMA kernel to fp32 rounding
+    (bf16 outputs: at most one bf16 ulp apart) and itself bit for bit over repeats (race screen).  Shapes: every
+    supported width, tiles that straddle images (H*W not a multiple of 256), ragged M and Cout tails, residual + ReLU and
+    mask epilogues, a grouped launch over two levels; unsupported widths are refused."""
+    o = ops()
+    XR, DMA = 1 + 6, 1 + 8 + 4
+    for (n, h, w, cin, cout) in [(2, 50, 64, 256, 256), (3, 13, 128, 128, 256), (1, 5, 256, 64, 320), (8, 100, 128, 256, 256),
+                                 (2, 7, 64, 64, 260)]:
+        x = to_nhwc(rnd(n, cin, h, w, seed=1), torch.bfloat16)
+        wt = rnd(cout, cin, 3, 3, seed=2) / (cin * 9) ** 0.5
+        pc = o.pack_conv(wt.cuda(), bias=rnd(cout, seed=3).cuda(), dtype=torch.bfloat16)
+        res = to_nhwc(rnd(n, pc.cout_store, h, w, seed=4), torch.bfloat16)
+        ref = o.conv2d(x, pc, pad=1, res=res, res_mode=o.RES_SAME, act=o.ACT_RELU, algo=DMA)
+        y = o.conv2d(x, pc, pad=1, res=res, res_mode=o.RES_SAME, act=o.ACT_RELU, algo=XR)
+        d = (y.float() - ref.float()).abs()
+        tol = 2.0 ** -7 * ref.float().abs().clamp(min=1.0)
+        assert bool((d <= tol).all()), (n, h, w, cin, cout, d.max().item())
+        assert (d > 0).float().mean().item() < 0.05
+        for _ in range(5):
+            assert torch.equal(o.conv2d(x, pc, pad=1, res=res, res_mode=o.RES_SAME, act=o.ACT_RELU, algo=XR), y)
+        mask = to_nhwc(rnd(n, pc.cout_store, h, w, seed=5), torch.bfloat16)
+        ym = o.conv2d(x, pc, pad=1, mask=mask, algo=XR)
+        rm = o.conv2d(x, pc, pad=1, mask=mask, algo=DMA)
+        assert bool(((ym.float() - rm.float()).abs() <= 2.0 ** -7 * rm.float().abs().clamp(min=1.0)).all())
+        assert bool((ym[mask <= 0] == 0).all())
+    # fp32 reference of the op itself on one shape
+    n, h, w, cin, cout = 2, 20, 64, 64, 256
+    xf, wf, bf = rnd(n, cin, h, w, seed=7), rnd(cout, cin, 3, 3, seed=8) / (cin * 9) ** 0.5, rnd(cout, seed=9)
+    pc = o.pack_conv(wf.cuda(), bias=bf.cuda(), dtype=torch.bfloat16)
+    y = o.conv2d(to_nhwc(xf, torch.bfloat16), pc, pad=1, algo=XR)
+    ref = torch.nn.functional.conv2d(xf.bfloat16().float(), wf.bfloat16().float(), bf, padding=1)
+    np.testing.assert_allclose(y.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+    # grouped launch over two levels (128- and 64-wide)
+    xs = [to_nhwc(rnd(2, 256, 24, 128, seed=11), torch.bfloat16), to_nhwc(rnd(2, 256, 12, 64, seed=12), torch.bfloat16)]
+    wt = rnd(256, 256, 3, 3, seed=13) / (256 * 9) ** 0.5
+    pc = o.pack_conv(wt.cuda(), bias=rnd(256, seed=14).cuda(), dtype=torch.bfloat16)
+    ga = o.conv2d_grouped(xs, pc, pad=1, algo=XR)
+    for xa, ya in zip(xs, ga):
+        assert torch.equal(ya, o.conv2d(xa, pc, pad=1, algo=XR))
+    # refused: width 100, 1x1, stride 2
+    from oneshotdet_amd import _lib
+    with pytest.raises(_lib.OsdError):
+        o.conv2d(to_nhwc(rnd(1, 64, 8, 100, seed=1), torch.bfloat16), pc if pc.cin_k == 64 else o.pack_conv(
+            (rnd(256, 64, 3, 3, seed=2)).cuda(), dtype=torch.bfloat16), pad=1, algo=XR)

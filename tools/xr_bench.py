@@ -1,0 +1,49 @@
+"""GPU box: the row-reuse 3x3 kernel (tile id 6) against the LDS-DMA 256x256 kernel on the shapes it targets."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oneshotdet_amd import ops  # noqa: E402
+
+
+def bench(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(reps):
+        fn()
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / reps * 1e3
+
+
+def main():
+    g = torch.Generator(device="cuda").manual_seed(0)
+    algos = {"dma256/ring2": 1 + 8 + 4, "dma256/short": 1 + 16 + 4, "dma128": 1 + 0, "xr": 1 + 6}
+    for name, shapes, cin, cout in [("tower P3+P4 (grouped)", [(8, 100, 128), (8, 50, 64)], 256, 256),
+                                    ("tower all levels (grouped)", [(8, 100, 128), (8, 50, 64), (8, 25, 32), (8, 13, 16), (8, 7, 8)], 256, 256),
+                                    ("P3 only", [(8, 100, 128)], 256, 256), ("P4 only", [(8, 50, 64)], 256, 256),
+                                    ("layer2 3x3 128->128", [(8, 100, 128)], 128, 128)]:
+        xs = [torch.randn((n, h, w, cin), device="cuda", generator=g).bfloat16() for n, h, w in shapes]
+        wt = torch.randn((cout, cin, 3, 3), device="cuda", generator=g) / (cin * 9) ** 0.5
+        pc = ops.pack_conv(wt, bias=torch.zeros(cout, device="cuda"), dtype=torch.bfloat16)
+        flops = sum(2.0 * n * h * w * cout * cin * 9 for n, h, w in shapes)
+        out = []
+        for an, a in algos.items():
+            try:
+                if len(xs) == 1:
+                    t = bench(lambda: ops.conv2d(xs[0], pc, pad=1, algo=a))
+                else:
+                    t = bench(lambda: ops.conv2d_grouped(xs, pc, pad=1, algo=a))
+                out.append("%s %.1f us %.0f TF" % (an, t, flops / t / 1e6))
+            except Exception as e:      # noqa: BLE001
+                out.append("%s n/a" % an)
+        print("%-28s %s" % (name, " | ".join(out)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
