@@ -1,6 +1,7 @@
 """Thin torch-tensor wrappers over the C-ABI (include/oneshotdet_hip.h).  torch supplies device memory and the stream;
 all arithmetic happens in liboneshotdet_hip.so.  Activations are NHWC tensors [N, H, W, C] (float32 or bfloat16)."""
 import ctypes as C
+import os
 
 import torch
 
@@ -108,7 +109,8 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
         cands.append(1 + 0 * 32 + 1 * 8 + 4)          # 256x256 tile, shallow ring
         cands.append(1 + 0 * 32 + 2 * 8 + 4)          # 256x256 tile, short stages x 4
         cands.append(1 + 0 * 32 + 0 * 8 + 5)          # 256x256 tile, two wave groups one barrier apart (bf16 only)
-        cands.append(1 + 0 * 32 + 0 * 8 + 6)          # 3x3/1: pixel rows fetched once per filter row (bf16, W in 64/128/256)
+        if not os.environ.get("OSD_NO_XR"):           # (A/B switch for tools and benches)
+            cands.append(1 + 0 * 32 + 0 * 8 + 6)      # 3x3/1: pixel rows fetched once per filter row (bf16, W in 64/128/256)
     if not relu_in and not has_mask:
         cands += [1 + 1 * 32 + t for t in tiles]
     return cands

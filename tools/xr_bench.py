@@ -29,6 +29,8 @@ def main():
                                     ("P3 only", [(8, 100, 128)], 256, 256), ("P4 only", [(8, 50, 64)], 256, 256),
                                     ("layer2 3x3 128->128", [(8, 100, 128)], 128, 128)]:
         xs = [torch.randn((n, h, w, cin), device="cuda", generator=g).bfloat16() for n, h, w in shapes]
+        if os.environ.get("XR_RELU"):       # post-ReLU activations: half the operand is zero (what the tower convs see)
+            xs = [torch.relu(x) for x in xs]
         wt = torch.randn((cout, cin, 3, 3), device="cuda", generator=g) / (cin * 9) ** 0.5
         pc = ops.pack_conv(wt, bias=torch.zeros(cout, device="cuda"), dtype=torch.bfloat16)
         flops = sum(2.0 * n * h * w * cout * cin * 9 for n, h, w in shapes)
