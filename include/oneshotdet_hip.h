@@ -339,6 +339,13 @@ int osd_groupnorm_act_rois(const void* x, const void* addend, const float* gamma
 int osd_box_decode(const void* pred, const float* rois, const int32_t* counts, float* scores, float* boxes,
                    float* logits_out, float* reg_out, int n, int max_rois, int shots, int pred_stride,
                    const float* reg_weights, float img_h, float img_w, float score_thresh, int dtype, void* stream);
+/* add_gt_proposals of the TRAINING proposal path (modeling/rpn/fcos/inference.py:139-160,279): per image the kept
+ * proposals (boxes [n][cap][4], scores [n][cap], counts [n]) followed by its ground-truth boxes (gt_boxes [n][max_gt][4],
+ * gt_count [n]) with score 1 -> out_boxes [n][cap+max_gt][4], out_scores [n][cap+max_gt], out_counts [n]; rows past the
+ * new count are zero. */
+int osd_append_gt_boxes(const float* boxes, const float* scores, const int32_t* counts, const float* gt_boxes,
+                        const int32_t* gt_count, float* out_boxes, float* out_scores, int32_t* out_counts, int n, int cap,
+                        int max_gt, void* stream);
 
 #ifdef __cplusplus
 }

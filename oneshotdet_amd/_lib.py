@@ -79,6 +79,7 @@ SIGNATURES = {
     "osd_roi_pool_levels": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "osd_groupnorm_act_rois": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i, _p]),
     "osd_box_decode": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _f, _f, _f, _i, _p]),
+    "osd_append_gt_boxes": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 
 _lib = None

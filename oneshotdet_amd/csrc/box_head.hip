@@ -266,9 +266,47 @@ __global__ void box_decode_kernel(const T* __restrict__ pred, const float* __res
   o[0] = ox1; o[1] = oy1; o[2] = ox2; o[3] = oy2;
 }
 
+// add_gt_proposals (modeling/rpn/fcos/inference.py:139-160): per image the kept proposals followed by the ground-truth
+// boxes with score 1 (cat_boxlist((proposal, gt_box))); rows past the new count are zero.
+__global__ void append_gt_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                 const int32_t* __restrict__ counts, const float* __restrict__ gt, const int32_t* __restrict__ gt_count,
+                                 float* __restrict__ out_boxes, float* __restrict__ out_scores, int32_t* __restrict__ out_counts,
+                                 int n, int cap, int max_gt, int out_cap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * out_cap) return;
+  const int img = i / out_cap, r = i % out_cap;
+  const int c = min(counts[img], cap), g = min(gt_count[img], max_gt);
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, sc = 0.f;
+  if (r < c) {
+    const float* s = boxes + ((size_t)img * cap + r) * 4;
+    b0 = s[0]; b1 = s[1]; b2 = s[2]; b3 = s[3];
+    sc = scores[(size_t)img * cap + r];
+  } else if (r < c + g) {
+    const float* s = gt + ((size_t)img * max_gt + (r - c)) * 4;
+    b0 = s[0]; b1 = s[1]; b2 = s[2]; b3 = s[3];
+    sc = 1.f;
+  }
+  float* o = out_boxes + (size_t)i * 4;
+  o[0] = b0; o[1] = b1; o[2] = b2; o[3] = b3;
+  out_scores[i] = sc;
+  if (r == 0) out_counts[img] = c + g;
+}
+
 }  // namespace
 
 #define OSD_STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int osd_append_gt_boxes(const float* boxes, const float* scores, const int32_t* counts, const float* gt_boxes,
+                                   const int32_t* gt_count, float* out_boxes, float* out_scores, int32_t* out_counts, int n,
+                                   int cap, int max_gt, void* stream) {
+  if (!boxes || !scores || !counts || !gt_boxes || !gt_count || !out_boxes || !out_scores || !out_counts || cap < 0 || max_gt < 0)
+    return osd_fail(OSD_ERR_INVALID_ARG, "append_gt_boxes: bad args");
+  const int out_cap = cap + max_gt;
+  if (n == 0 || out_cap == 0) return OSD_OK;
+  hipLaunchKernelGGL(append_gt_kernel, dim3(grid_for((long long)n * out_cap, 256)), dim3(256), 0, OSD_STREAM(stream), boxes,
+                     scores, counts, gt_boxes, gt_count, out_boxes, out_scores, out_counts, n, cap, max_gt, out_cap);
+  return osd_check_launch("append_gt_boxes");
+}
 
 extern "C" int osd_roi_pool_levels(int n_levels, const void* const* xs, const int32_t* hs, const int32_t* ws,
                                    const float* scales, const float* boxes, const int32_t* counts, void* y, int n, int c,

@@ -843,3 +843,18 @@ def box_decode(pred, rois, counts, reg_weights, img_h, img_w, score_thresh, want
     _lib.call("osd_box_decode", _ptr(pred), _ptr(rois.contiguous()), _ptr(counts), _ptr(scores), _ptr(boxes), _ptr(lo),
               _ptr(ro), n, r, s, p, rw, float(img_h), float(img_w), float(score_thresh), _dt(pred), _stream())
     return (scores, boxes, lo, ro) if want_raw else (scores, boxes)
+
+
+def append_gt_boxes(boxes, scores, counts, gt_boxes, gt_count):
+    """add_gt_proposals (fcos/inference.py:139-160): boxes [N,P,4], scores [N,P], counts [N] + gt_boxes [N,G,4], gt_count [N]
+    -> boxes [N,P+G,4], scores [N,P+G], counts [N]."""
+    _chk_dev(boxes, scores, counts, gt_boxes, gt_count)
+    n, cap, _ = boxes.shape
+    g = gt_boxes.shape[1]
+    dev = boxes.device
+    ob = torch.empty((n, cap + g, 4), device=dev, dtype=torch.float32)
+    os_ = torch.empty((n, cap + g), device=dev, dtype=torch.float32)
+    oc = torch.empty((n,), device=dev, dtype=torch.int32)
+    _lib.call("osd_append_gt_boxes", _ptr(boxes.contiguous()), _ptr(scores.contiguous()), _ptr(counts),
+              _ptr(gt_boxes.contiguous().float()), _ptr(gt_count), _ptr(ob), _ptr(os_), _ptr(oc), n, cap, g, _stream())
+    return ob, os_, oc

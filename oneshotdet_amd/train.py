@@ -576,8 +576,10 @@ class TrainEngine(object):
             if ps is not main:
                 ps.wait_stream(main)
             with torch.cuda.stream(ps):
-                self.proposals = model.run_proposals(head_out, images.shape[-2], images.shape[-1],
-                                                     spec.PRE_NMS_TOP_N_TRAIN, spec.POST_NMS_TOP_N_TRAIN, spec.NMS_THRESH)
+                pb, ps_, pc = model.run_proposals(head_out, images.shape[-2], images.shape[-1],
+                                                  spec.PRE_NMS_TOP_N_TRAIN, spec.POST_NMS_TOP_N_TRAIN, spec.NMS_THRESH)
+                # add_gt_proposals (fcos/inference.py:139-160,279): the ground-truth boxes join the training proposals
+                self.proposals = ops.append_gt_boxes(pb, ps_, pc, gt_boxes, gt_count)
         # ---- loss + backward
         losses, pred_grads = self.loss_and_grads(head_out, gt_boxes, gt_count)
         d_comb = self.head_backward(combined, hctx, pred_grads)

@@ -314,6 +314,16 @@ def fcos_postprocess(logits, bbox_reg, centerness, image_sizes, pre_nms_top_n=60
     return results
 
 
+def add_gt_proposals(proposals, gt_boxes_per_image):
+    """modeling/rpn/fcos/inference.py:139-160 (training, non-RPN_ONLY, :276-279): cat_boxlist((proposal, gt_box)) with a
+    dummy score of 1 for the ground-truth boxes.  proposals: list of (boxes [K,4], scores [K])."""
+    out = []
+    for (b, s), g in zip(proposals, gt_boxes_per_image):
+        g = torch.as_tensor(g, dtype=b.dtype).reshape(-1, 4)
+        out.append((torch.cat([b, g], dim=0), torch.cat([s, torch.ones(len(g), dtype=s.dtype)], dim=0)))
+    return out
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # FCOS loss (training)
 # --------------------------------------------------------------------------------------------------------------------

@@ -331,6 +331,37 @@ def gen_roialign():
     np.savez_compressed(os.path.join(HERE, "roialign.npz"), **out)
 
 
+def gen_add_gt(model):
+    """add_gt_proposals of the REAL reference's training box selector (modeling/rpn/fcos/inference.py:139-160) on
+    hand-made proposals / targets, incl. an image without ground truth; the oracle restatement must agree exactly."""
+    rh.load_reference()
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    g = torch.Generator().manual_seed(21)
+    props, tgts, raw = [], [], []
+    for n_prop, n_gt in ((7, 2), (3, 0), (5, 4)):
+        xy = torch.rand(n_prop, 2, generator=g) * 100
+        pb = torch.cat([xy, xy + torch.rand(n_prop, 2, generator=g) * 60 + 1], 1)
+        ps = torch.rand(n_prop, generator=g)
+        gxy = torch.rand(n_gt, 2, generator=g) * 100
+        gb = torch.cat([gxy, gxy + torch.rand(n_gt, 2, generator=g) * 60 + 1], 1).reshape(-1, 4)
+        bl = BoxList(pb, (200, 160), mode="xyxy")
+        bl.add_field("scores", ps)
+        tg = BoxList(gb, (200, 160), mode="xyxy")
+        tg.add_field("labels", torch.ones(n_gt, dtype=torch.int64))
+        props.append(bl)
+        tgts.append(tg)
+        raw.append((pb, ps, gb))
+    res = model.rpn.box_selector_train.add_gt_proposals(props, tgts)
+    mine = orc.add_gt_proposals([(pb, ps) for pb, ps, _ in raw], [gb for _, _, gb in raw])
+    out = {"n": np.int64(len(raw))}
+    for i, (bl, (mb, ms)) in enumerate(zip(res, mine)):
+        assert torch.equal(bl.bbox, mb) and torch.equal(bl.get_field("scores"), ms)
+        out["props.%d" % i], out["scores.%d" % i], out["gt.%d" % i] = t2n(raw[i][0]), t2n(raw[i][1]), t2n(raw[i][2])
+        out["out_boxes.%d" % i], out["out_scores.%d" % i] = t2n(bl.bbox), t2n(bl.get_field("scores"))
+    print("add_gt_proposals: %d reference cases recorded, oracle agrees exactly" % len(raw))
+    np.savez_compressed(os.path.join(HERE, "add_gt.npz"), **out)
+
+
 def gen_keys(model):
     import json
     sd = model.state_dict()
@@ -355,6 +386,7 @@ def main():
     np_sd = load_synth_weights(model)
     if args.only_box:
         gen_keys(model)
+        gen_add_gt(model)
     if not args.only_train:
         for name in [c for c in args.box_cases.split(",") if c]:
             gen_box_case(model, np_sd, name)
@@ -364,6 +396,7 @@ def main():
         gen_keys(model)
         gen_nms_kat()
         gen_roialign()
+        gen_add_gt(model)
         for name in [c for c in args.cases.split(",") if c]:
             gen_case(model, np_sd, name)
     if not args.skip_train:

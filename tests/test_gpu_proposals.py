@@ -111,3 +111,52 @@ def test_proposals_from_golden_head(name):
         assert np.all(np.diff(sc) <= 0), "scores must be descending"
         assert gu.match_boxes(rb, rs, ob[i, :k].cpu().numpy(), sc) >= 0.999
         np.testing.assert_allclose(sc, rs, rtol=1e-5, atol=1e-7)
+
+
+def test_append_gt_boxes_matches_reference_vectors():
+    """osd_append_gt_boxes against the fixture recorded through the reference's add_gt_proposals (ragged proposal and
+    ground-truth counts, an image with no ground truth), bit-exact; and TrainEngine's training proposals end with the
+    ground-truth boxes at score 1."""
+    from oneshotdet_amd import ops
+    f = gu.load("add_gt.npz")
+    n = int(f["n"])
+    P = max(len(f["props.%d" % i]) for i in range(n)) + 2
+    G = max(len(f["gt.%d" % i]) for i in range(n)) + 1
+    boxes, scores, gt = torch.zeros(n, P, 4), torch.zeros(n, P), torch.zeros(n, G, 4)
+    cnt, gcnt = torch.zeros(n, dtype=torch.int32), torch.zeros(n, dtype=torch.int32)
+    for i in range(n):
+        p, g = f["props.%d" % i], f["gt.%d" % i].reshape(-1, 4)
+        boxes[i, :len(p)], scores[i, :len(p)], cnt[i] = torch.from_numpy(p), torch.from_numpy(f["scores.%d" % i]), len(p)
+        gt[i, :len(g)], gcnt[i] = torch.from_numpy(g), len(g)
+        boxes[i, len(p):] = 7.0            # stale rows past the count must not leak
+    ob, os_, oc = ops.append_gt_boxes(boxes.cuda(), scores.cuda(), cnt.cuda(), gt.cuda(), gcnt.cuda())
+    for i in range(n):
+        k = int(oc[i])
+        assert k == len(f["out_boxes.%d" % i])
+        np.testing.assert_array_equal(ob[i, :k].cpu().numpy(), f["out_boxes.%d" % i])
+        np.testing.assert_array_equal(os_[i, :k].cpu().numpy(), f["out_scores.%d" % i])
+        assert float(ob[i, k:].abs().sum()) == 0 and float(os_[i, k:].abs().sum()) == 0
+
+
+def test_training_proposals_end_with_ground_truth():
+    from oneshotdet_amd import spec, synth as sy, train
+    B, H, W = 2, 128, 160
+    eng = train.TrainEngine(sy.make_state_dict(spec.hot_path_shapes()), dtype=torch.float32)
+    img = torch.from_numpy(sy.make_images("t.img", B, H, W, seed=1)).cuda()
+    q = torch.from_numpy(sy.make_images("t.q", B, 63, 63, seed=1)).cuda()
+    gts = sy.make_gt_boxes(B, H, W, seed=9, max_boxes=3)
+    G = max(len(g) for g in gts)
+    gtb = torch.zeros(B, G, 4)
+    for i, g in enumerate(gts):
+        gtb[i, :len(g)] = torch.from_numpy(g)
+    cnt = torch.tensor([len(g) for g in gts], dtype=torch.int32)
+    eng.forward_backward(img, q, gtb.cuda(), cnt.cuda())
+    torch.cuda.synchronize()
+    pb, ps, pc = eng.proposals
+    for i, g in enumerate(gts):
+        k = int(pc[i])
+        assert k > len(g)
+        np.testing.assert_array_equal(pb[i, k - len(g):k].cpu().numpy(), g)
+        assert bool((ps[i, k - len(g):k] == 1).all())
+        s = ps[i, :k - len(g)]
+        assert bool((s[:-1] >= s[1:]).all())

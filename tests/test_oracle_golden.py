@@ -201,3 +201,14 @@ def test_box_decode_known_values():
     np.testing.assert_allclose(obh.decode_boxes(torch.zeros(1, 4), boxes).numpy(), boxes.numpy(), atol=1e-5)
     big = obh.decode_boxes(torch.tensor([[0.0, 0.0, 1000.0, 0.0]]), boxes)
     assert abs((big[0, 2] - big[0, 0] + 1).item() - 40 * 1000.0 / 16) < 1e-2
+
+
+def test_add_gt_proposals_reference_vectors():
+    """Training proposals (fcos/inference.py:139-160): fixture recorded through the reference's own add_gt_proposals."""
+    f = gu.load("add_gt.npz")
+    n = int(f["n"])
+    props = [(torch.from_numpy(f["props.%d" % i]), torch.from_numpy(f["scores.%d" % i])) for i in range(n)]
+    out = orc.add_gt_proposals(props, [f["gt.%d" % i] for i in range(n)])
+    for i, (b, s) in enumerate(out):
+        np.testing.assert_array_equal(b.numpy(), f["out_boxes.%d" % i])
+        np.testing.assert_array_equal(s.numpy(), f["out_scores.%d" % i])
