@@ -38,6 +38,14 @@ __device__ __forceinline__ void xr_dma16(const void* gsrc, unsigned lds_dst) {
       : "memory");
 }
 
+// XOR swizzle key of a padded pixel-image row (period 16).  The DMA kernel's key ((row >> 1) & 7) is conflict-free only for
+// fragments that start on a multiple of 16; the taps s = 0 / 2 read 16 consecutive rows starting at -1 / +1.  ds_read_b128
+// serves lanes in groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (16 lanes per LDS cycle: rows f..f+3, f+12..f+15 of
+// one k chunk with rows f+4..f+11 of the next chunk), so with a = key(even rows), b = key(odd rows) the three shifts need
+// {a0,a1,a6,a7, a2^1..a5^1}, the same with a2 <-> a6 exchanged, and likewise for b with b1 <-> b5: solved by a2 = a6,
+// b1 = b5 -> a = 2,3,0,4,7,6,0,4; b = 2,0,4,7,6,0,3,4 (checked exhaustively by tools/lds_swizzle_check.py --xr).
+__device__ __forceinline__ int xr_key(int row) { return (int)((0x4430066774400322ull >> ((row & 15) * 4)) & 7); }
+
 constexpr int XR_BM = 256, XR_BN = 256, XR_KB = 128 /* bytes per row per slab */, XR_BKE = 64, XR_EPC = 8;
 constexpr int XR_WM = 2, XR_WN = 4, XR_TM = 8, XR_TN = 4;
 constexpr int XR_AROWS = 336;                        // 256 + 16 * (256 / 64 + 1)
@@ -97,7 +105,7 @@ __global__ void __launch_bounds__(512) conv_xr_kernel(ConvKParams p) {
       const int rem = m - n_img * q_HoWo;
       const int ho = rem >> logw;
       const int wo = rem & (q_W - 1);
-      a_base[i] = xg + (size_t)n_img * q_sN + wo * p.sW + ((lpos ^ ((R >> 1) & 7)) * XR_EPC);
+      a_base[i] = xg + (size_t)n_img * q_sN + wo * p.sW + ((lpos ^ xr_key(R)) * XR_EPC);
       a_ho[i] = ho - 1;                                 // input line of filter row 0
     }
   }
@@ -148,7 +156,7 @@ __global__ void __launch_bounds__(512) conv_xr_kernel(ConvKParams p) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int e = frow + s - 1;                       // -1 .. 16: row relative to the fragment's first padded row
-      x_lane[s][kb] = e * KB + (((kb * 4 + fkq) ^ ((e >> 1) & 7)) << 4);
+      x_lane[s][kb] = e * KB + (((kb * 4 + fkq) ^ xr_key(e)) << 4);          // fragment bases are multiples of 16 rows
     }
   int x_frag[TM];                                       // wave-uniform: first padded row of fragment j (a multiple of 16)
 #pragma unroll

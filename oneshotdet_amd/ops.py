@@ -129,6 +129,16 @@ class tuning(object):
 def _tune(key, d, launch):
     """Time every candidate algorithm for this conv shape (launch() reads d.algo) and cache the fastest."""
     best, best_t = 0, float("inf")
+    forced = os.environ.get("OSD_FORCE_ALGO_3X3_256")     # experiments: pin the big 3x3 256-channel convs to one algorithm
+    if forced and d.cout == 256 and d.r == 3 and d.stride_h == 1:
+        d.algo = int(forced)
+        try:
+            launch()
+            torch.cuda.synchronize()
+            ALGO_CACHE[key] = int(forced)
+            return int(forced)
+        except _lib.OsdError:
+            pass
     for algo in conv_algo_candidates(d.cout, d.relu_in, has_mask=bool(key[-1])):
         d.algo = algo
         try:

@@ -41,3 +41,14 @@ for KB,g,nch in ((64,g64,4),(128,g128,8)):
     # no-swizzle baseline
     w=conflicts_read(lambda l: (l&15)*KB + (l>>4)*16)
     print("KB",KB,"unswizzled read ways",w)
+
+# ---- conv_igemm_xr.hip: fragments start at row 16k + s - 1 (s = 0, 1, 2) of the padded pixel image ----
+def xr_key(row): return (0x4430066774400322 >> ((row & 15) * 4)) & 7
+for name, key in (("dma key (row>>1)&7", g128), ("xr key", xr_key)):
+    for s in (0, 1, 2):
+        worst = 1
+        for kb in (0, 1):
+            for base in (16, 32, 160):
+                w = conflicts_read(lambda l: (base + (l & 15) + s - 1) * 128 + (((kb * 4 + (l >> 4)) ^ key(base + (l & 15) + s - 1)) * 16))
+                worst = max(worst, w)
+        print("xr image,", name, "tap", s, "read ways", worst)
