@@ -445,6 +445,10 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
     variant = a & 7;
     target = kTargets[a >> 3];
   }
+  // exact-fp32 MFMA runs at 1/16 of the bf16 rate and its channel tile is 64 wide (4x the output tiles): a workgroup's
+  // fixed costs and its atomic epilogue weigh 16x less, so the same codes mean 8x the workgroups (finer pixel splits
+  // also even out the FPN levels of a multi-segment launch: P3 has 228x the pixels of P7)
+  if (d0->dtype == OSD_F32) target *= 8;
   const bool big = variant == 4 && d0->dtype == OSD_BF16;
   const int tw = (d0->dtype == OSD_BF16 ? 128 : 64) * (big ? 2 : 1);
   const int epc = d0->dtype == OSD_BF16 ? 8 : 4;

@@ -24,7 +24,7 @@ def main():
         rows = last_step(list(csv.DictReader(open("%s/%s/run_counter_collection.csv" % (d, c)))))
         for r in rows:
             n = r["Kernel_Name"]
-            k = "conv_fwd_dgrad" if ("conv_dma" in n or "conv_igemm" in n) else (
+            k = "conv_fwd_dgrad" if ("conv_dma" in n or "conv_igemm" in n or "conv_xr_kernel" in n or "conv_p8_kernel" in n) else (
                 "conv_wgrad" if "conv_wgrad_kernel" in n else ("correlate" if "correlate_kernel" in n else None))
             if k is None:
                 continue

@@ -25,7 +25,7 @@ def summarize_train(d, out, line, stats, convs):
     flops = r["gflop_per_step"] * 1e9 * nst
     kinds = {}
     for x, du in zip(last, dur):
-        k = "conv_wgrad_kernel" if "wgrad" in x["Kernel_Name"] else "conv_dma/igemm (forward + data gradient)"
+        k = "conv_wgrad_kernel" if "wgrad" in x["Kernel_Name"] else "conv_dma/xr/igemm (forward + data gradient)"
         kinds.setdefault(k, [0, 0.0])
         kinds[k][0] += 1
         kinds[k][1] += du
@@ -55,7 +55,7 @@ def main():
     stats = list(csv.DictReader(open(os.path.join(d, "run_kernel_stats.csv"))))
     trace = [r for r in csv.DictReader(open(os.path.join(d, "run_kernel_trace.csv")))]
     is_train = "configs[2]" in line["config"]["workload"]
-    convs = [r for r in trace if "conv_igemm" in r["Kernel_Name"] or "conv_dma" in r["Kernel_Name"] or
+    convs = [r for r in trace if any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_dma", "conv_xr_kernel", "conv_p8_kernel")) or
              (is_train and "conv_wgrad_kernel" in r["Kernel_Name"])]
     launches = workload.conv_launches(8, 800, 1024, 8, 127, 127)
     per = (line.get("roofline") or {}).get("launches_per_step") or len(launches)   # the tuner may split grouped launches

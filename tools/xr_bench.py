@@ -12,6 +12,7 @@ def bench(fn, reps=20):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    torch.cuda._sleep(int(60e6))      # park the stream: the host needs ~100 us per grouped call, about what the kernel runs
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
     for _ in range(reps):
