@@ -208,7 +208,7 @@ int osd_pack_conv_weight_dgrad(const float* w, const float* scale, void* dst, in
  * receives the bias gradient sum_m dy[m][co] from the same pass over dy.
  * d->algo: 0 = default, else 1 + variant + 8 * split_target_code.  Variants 0..3: 128 x 128 channel tile, pixels per
  * stage x ring depth 32x3 / 64x2 / 32x4 / 64x3; variant 4: 256 x 256 channel tile on 8 waves (bf16).  Split targets
- * 512, 256, 128, 64, 1024, 768, 1536, 2048 workgroups. */
+ * 512, 256, 128, 64, 1024, 768, 1536, 2048 workgroups (x 8 for fp32). */
 int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const void* dy, const float* scale, float* dw, float* db,
                      void* stream);
 /* the same over n_seg <= 24 (x, dy) pairs that share the weights (the FPN levels of the FCOS towers): d gives the conv

@@ -437,6 +437,9 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   static int env_target = -1, env_variant = -1;
   if (env_target < 0) { const char* e = getenv("OSD_WGRAD_BLOCKS"); env_target = e ? atoi(e) : 512; }
   if (env_variant < 0) { const char* e = getenv("OSD_WGRAD_VARIANT"); env_variant = e ? atoi(e) : 0; }
+  // (3072 / 4096 were tried in place of 256 / 768: the big launches pick them and get 6-15 % faster in isolation —
+  // tower 857 -> 796 us — but the training step does not: 639.6 / 642.9 vs 638.3 / 634.9 images/s in one-box A/B, the
+  // extra workgroups compete with the main chain they run beside)
   static const int kTargets[8] = {512, 256, 128, 64, 1024, 768, 1536, 2048};
   int target = env_target, variant = env_variant;
   if (d0->algo > 0) {
