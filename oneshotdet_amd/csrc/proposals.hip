@@ -172,6 +172,8 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
   unsigned long long* remv = reinterpret_cast<unsigned long long*>(smem);   // [col_blocks]
   __shared__ unsigned long long s_keep;
   __shared__ int s_kept[2];   // double-buffered so the next block's writer cannot race this block's readers
+  __shared__ int s_rows[64];  // rows (within the 64-box block) of the boxes kept in this block, compacted
+  __shared__ int s_nrows;
   const int img = blockIdx.x;
   if (phase == 2 && !need_full[img]) return;
   const int n_all = counts[img];
@@ -212,26 +214,29 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
         out_scores[dst] = scores[src];
         out_pos[dst] = i;
       }
+      if ((keep >> lane) & 1ULL) s_rows[__popcll(keep & ((1ULL << lane) - 1ULL))] = lane;
       if (lane == 0) {
         s_keep = keep;
+        s_nrows = __popcll(keep);
         s_kept[(blk + 1) & 1] = kept_before + __popcll(keep);
       }
     }
     __syncthreads();
-    const unsigned long long keep = s_keep;
-    // every thread owns one 64-box column word and ORs in the rows of the boxes kept in this block.  The 64 row loads
-    // are issued unconditionally and independently (8 in flight at a time), then masked by the keep bits: a
-    // data-dependent `while (bits)` walk would serialise ~60 L2/MALL round trips per block.
-    const int rows_here = min(64, n - blk * 64);
-    for (int c = blk + 1 + threadIdx.x; c < nblk; c += blockDim.x) {
-      unsigned long long acc = 0ULL;
-      const unsigned long long* col = mk + (size_t)(blk * 64) * col_blocks + c;
-#pragma unroll 8
-      for (int l = 0; l < 64; ++l) {
-        const unsigned long long w = (l < rows_here) ? col[(size_t)l * col_blocks] : 0ULL;
-        acc |= ((keep >> l) & 1ULL) ? w : 0ULL;
+    // every thread owns one 64-box column word and ORs in the rows of the boxes KEPT in this block (typically a fifth to
+    // a third of the 64: only those rows are read).  The row list is compacted in LDS so the loads are unconditional and
+    // independent, 8 in flight at a time, the tail clamped to the last kept row (OR-ing a row twice is harmless): a
+    // data-dependent `while (bits)` walk, or a branch per row, would serialise an L2 / MALL round trip per row.
+    const int nrows = s_nrows;
+    if (nrows > 0) {
+      for (int c = blk + 1 + threadIdx.x; c < nblk; c += blockDim.x) {
+        unsigned long long acc = 0ULL;
+        const unsigned long long* col = mk + (size_t)(blk * 64) * col_blocks + c;
+        for (int k0 = 0; k0 < nrows; k0 += 8) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc |= col[(size_t)s_rows[min(k0 + k, nrows - 1)] * col_blocks];
+        }
+        remv[c] |= acc;
       }
-      remv[c] |= acc;
     }
     __syncthreads();
   }
