@@ -61,43 +61,67 @@ __global__ void __launch_bounds__(256) level_topk_kernel(const float* __restrict
 // For element i of level L let c_l = #elements of level l that come before i (score desc, index asc).  Then
 //   i survives the per-level top-k   <=>  c_L < topn            (inference.py:97-102)
 //   position of i among the survivors =  sum_l min(c_l, topn)   (the survivors of a level are a prefix of its order)
-// so ONE O(n^2) pass gives both, with a single 64-bit compare per pair: key64 = (score bits + 1) << 32 | ~index.
+// so ONE O(n^2) pass gives both.
 struct LevelTable {
   int n_levels;
   int lo[8];     // first location of each level
   int cnt[8];
 };
 
-__device__ __forceinline__ unsigned long long key64(float k, int idx) {
-  const unsigned hi = k >= 0.f ? __float_as_uint(k) + 1u : 0u;      // dropped candidates (-1) sort last
-  return ((unsigned long long)hi << 32) | (unsigned)(~idx);
-}
+__device__ __forceinline__ unsigned key32(float k) { return k >= 0.f ? __float_as_uint(k) + 1u : 0u; }   // dropped (-1) sort last
 
+// 32-bit compares: the order is (score desc, index asc) and a tile holds 1024 CONSECUTIVE indices, so for a tile that lies
+// entirely before the workgroup's own 256 indices a tie counts as "before" (>=), for a tile entirely after it does not
+// (>), and only the one or two tiles that overlap the workgroup's index range need the exact two-term test.  The choice
+// is uniform per tile; the padding value of the >= loop is chosen so that it never counts.  (One 64-bit compare per pair
+// took 350 us for 8 x 17,064 candidates; v_cmp_*_u64 runs at a fraction of the 32-bit rate and the tile was twice the
+// LDS bytes.)
 __global__ void __launch_bounds__(256) rank_sort_gather_kernel(const float* __restrict__ keys, const float* __restrict__ boxes,
                                                                int total, int max_count, int topn, LevelTable lt,
                                                                float* __restrict__ boxes_sorted,
                                                                float* __restrict__ scores_sorted, int* __restrict__ idx_sorted,
                                                                int* __restrict__ counts) {
-  __shared__ unsigned long long tile[1024];
+  __shared__ __attribute__((aligned(16))) unsigned tile[1024];
   const int img = blockIdx.y;
   const float* k = keys + (size_t)img * total;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i0 = blockIdx.x * blockDim.x;
+  const int i = i0 + threadIdx.x;
   const float ki = i < total ? k[i] : -1.f;
-  const unsigned long long mine = key64(ki, i);
+  const unsigned mine = key32(ki);
   int rank = 0, own_before = 0;
   for (int l = 0; l < lt.n_levels; ++l) {
     const int lo = lt.lo[l], cnt = lt.cnt[l];
     int c = 0;
     for (int j0 = 0; j0 < cnt; j0 += 1024) {
       const int m = min(1024, cnt - j0);
+      const int g0 = lo + j0;                                   // global index of tile element 0
+      const bool all_before = g0 + m <= i0;                     // every tile index < every index of this workgroup
+      const bool all_after = g0 >= i0 + (int)blockDim.x;
       __syncthreads();
-      for (int t = threadIdx.x; t < 1024; t += blockDim.x)
-        tile[t] = t < m ? key64(k[lo + j0 + t], lo + j0 + t) : 0ULL;      // 0 is never "before" anything
+      // padding: 0 is never > a key; for the >= loop a dropped candidate's own key is 0 too, but dropped candidates are
+      // not written out, so their counts do not matter
+      for (int t = threadIdx.x; t < 1024; t += blockDim.x) tile[t] = t < m ? key32(k[g0 + t]) : 0u;
       __syncthreads();
+      if (all_after) {
 #pragma unroll 8
-      for (int t = 0; t < 1024; t += 2) {       // whole tile: the zero padding keeps the loop branch free
-        const ulonglong2 two = *reinterpret_cast<const ulonglong2*>(&tile[t]);
-        c += (two.x > mine) + (two.y > mine);
+        for (int t = 0; t < 1024; t += 4) {
+          const uint4 q = *reinterpret_cast<const uint4*>(&tile[t]);
+          c += (q.x > mine) + (q.y > mine) + (q.z > mine) + (q.w > mine);
+        }
+      } else if (all_before) {
+        int ge = 0;
+#pragma unroll 8
+        for (int t = 0; t < 1024; t += 4) {
+          const uint4 q = *reinterpret_cast<const uint4*>(&tile[t]);
+          ge += (q.x >= mine) + (q.y >= mine) + (q.z >= mine) + (q.w >= mine);
+        }
+        // the 1024 - m padding zeros count as >= only for mine == 0 (a dropped candidate, never written)
+        c += ge;
+      } else {
+        for (int t = 0; t < m; ++t) {
+          const unsigned q = tile[t];
+          c += (q > mine) || (q == mine && g0 + t < i);
+        }
       }
     }
     if (i >= lo && i < lo + cnt) own_before = c;
