@@ -162,6 +162,12 @@ int osd_correlate_fwd(const void* x, const float* q, void* y, int n, int hw, int
 int osd_fcos_score_decode(const void* cls_ctr, const void* reg, float* scores, float* boxes, int n, int h, int w,
                           int cc_stride, int reg_stride, int stride, int loc_offset, int total_locs, float img_h,
                           float img_w, int dtype, void* stream);
+/* The same for a batch padded by to_image_list (structures/image_list.py:52-70; BatchCollator, data/collate_batch.py:15-20):
+ * img_hw [n][2] fp32 on the device = every image's true (height, width), which is what clip_to_image uses
+ * (fcos/inference.py:111-113); NULL = img_h / img_w for all images. */
+int osd_fcos_score_decode_sizes(const void* cls_ctr, const void* reg, float* scores, float* boxes, int n, int h, int w,
+                                int cc_stride, int reg_stride, int stride, int loc_offset, int total_locs, float img_h,
+                                float img_w, const float* img_hw, int dtype, void* stream);
 /* Per-level top-k of inference.py:97-102 (exact, by rank): within keys[img][lo .. lo+cnt) keep the `topn` largest
  * (ties: lower index first), write key -1 for the rest.  keys_in/keys_out: [n][total] fp32 (may alias). */
 int osd_level_topk(const float* keys_in, float* keys_out, int n, int total, int lo, int cnt, int topn, void* stream);
@@ -338,7 +344,8 @@ int osd_groupnorm_act_rois(const void* x, const void* addend, const float* gamma
  * (thresh ROI_HEADS.NMS, filter_results inference.py:120-166). */
 int osd_box_decode(const void* pred, const float* rois, const int32_t* counts, float* scores, float* boxes,
                    float* logits_out, float* reg_out, int n, int max_rois, int shots, int pred_stride,
-                   const float* reg_weights, float img_h, float img_w, float score_thresh, int dtype, void* stream);
+                   const float* reg_weights, float img_h, float img_w, const float* img_hw, float score_thresh, int dtype,
+                   void* stream);   /* img_hw: optional [n][2] device array of true (height, width) per image, as above */
 /* add_gt_proposals of the TRAINING proposal path (modeling/rpn/fcos/inference.py:139-160,279): per image the kept
  * proposals (boxes [n][cap][4], scores [n][cap], counts [n]) followed by its ground-truth boxes (gt_boxes [n][max_gt][4],
  * gt_count [n]) with score 1 -> out_boxes [n][cap+max_gt][4], out_scores [n][cap+max_gt], out_counts [n]; rows past the

@@ -45,6 +45,7 @@ SIGNATURES = {
     "osd_shot_mean": (_i, [_p, _p, _i, _i, _i, _p]),
     "osd_correlate_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "osd_fcos_score_decode": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "osd_fcos_score_decode_sizes": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p]),
     "osd_level_topk": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "osd_rank_sort_gather": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "osd_nms_sorted": (_i, [_p, _p, _p, _i, _i, _f, _i, _i, _p, _p, _p, _p, _p, _p]),
@@ -78,7 +79,7 @@ SIGNATURES = {
     "osd_fcos_loss_finalize": (_i, [_p, _p, _i, _p]),
     "osd_roi_pool_levels": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "osd_groupnorm_act_rois": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i, _p]),
-    "osd_box_decode": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _f, _f, _f, _i, _p]),
+    "osd_box_decode": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _f, _f, _p, _f, _i, _p]),
     "osd_append_gt_boxes": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 

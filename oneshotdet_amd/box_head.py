@@ -55,16 +55,21 @@ def query_level(qh, qw):
 
 
 def run_query_roi(qfeats, q_size, dtype):
-    """supproi_pooling: [B*S, 7, 7, C] in the activation dtype."""
+    """supproi_pooling: [B*S, 7, 7, C] in the activation dtype.  q_size: (h, w) shared by all queries, or one per query
+    (padded batch): each whole-image box goes through the level-routed Pooler like any other ROI."""
     from .model import whole_image_rois
     n = qfeats[0].shape[0]
-    lvl = query_level(*q_size)
-    rois = whole_image_rois([q_size] * n, qfeats[0].device)
-    v = ops.roi_align(qfeats[lvl], rois, spec.POOLER_SCALES[lvl], spec.BOX_POOL, spec.BOX_POOL, spec.POOLER_SAMPLING_RATIO)
-    return v if dtype == torch.float32 else ops.cast_f32(v, dtype)
+    sizes = [tuple(q_size)] * n if isinstance(q_size[0], int) else [tuple(s) for s in q_size]
+    if len(set(sizes)) == 1:
+        lvl = query_level(*sizes[0])
+        rois = whole_image_rois(sizes, qfeats[0].device)
+        v = ops.roi_align(qfeats[lvl], rois, spec.POOLER_SCALES[lvl], spec.BOX_POOL, spec.BOX_POOL, spec.POOLER_SAMPLING_RATIO)
+        return v if dtype == torch.float32 else ops.cast_f32(v, dtype)
+    boxes = whole_image_rois(sizes, qfeats[0].device)[:, 1:].reshape(n, 1, 4).contiguous()      # [0, 0, h, w] per query
+    return ops.roi_pool_levels(qfeats, spec.POOLER_SCALES, boxes, None, spec.BOX_POOL, spec.POOLER_SAMPLING_RATIO)
 
 
-def run_box_head(bw, feats, qfeats, q_size, boxes, counts, img_h, img_w, shots=1, cuda_nms=True, want_raw=False):
+def run_box_head(bw, feats, qfeats, q_size, boxes, counts, img_h, img_w, shots=1, cuda_nms=True, want_raw=False, img_hw=None):
     """feats / qfeats: NHWC P3..P7 of the target / query backbone; boxes [N,R,4], counts [N] = first-stage proposals.
     Returns dict(boxes [N,K,4], scores [N,K] descending, counts [N]) (+ raw logits / deltas / pooled maps)."""
     n, r, _ = boxes.shape
@@ -86,7 +91,8 @@ def run_box_head(bw, feats, qfeats, q_size, boxes, counts, img_h, img_w, shots=1
         t = ops.conv2d(t.view(n * r, 1, 1, -1), bw.fc6, act=ACT_RELU)
         t = ops.conv2d(t, bw.fc7, act=ACT_RELU)
         ops.conv2d(t, bw.pred, act=ACT_NONE, out=preds[s].view(n * r, 1, 1, -1))
-    dec = ops.box_decode(preds, boxes, counts, spec.BOX_REG_WEIGHTS, img_h, img_w, spec.BOX_SCORE_THRESH, want_raw=want_raw)
+    dec = ops.box_decode(preds, boxes, counts, spec.BOX_REG_WEIGHTS, img_h, img_w, spec.BOX_SCORE_THRESH, want_raw=want_raw,
+                         img_hw=img_hw)
     scores, dboxes = dec[0], dec[1]
     bs, ss, _, cnt = ops.rank_sort_gather(scores, dboxes, r)
     keep = min(spec.BOX_DETECTIONS_PER_IMG, r)

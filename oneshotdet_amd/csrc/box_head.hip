@@ -215,10 +215,15 @@ template <typename T>
 __global__ void box_decode_kernel(const T* __restrict__ pred, const float* __restrict__ rois, const int32_t* __restrict__ counts,
                                   float* __restrict__ scores, float* __restrict__ boxes, float* __restrict__ logits_out,
                                   float* __restrict__ reg_out, int n, int max_rois, int shots, int pstride, float wx,
-                                  float wy, float ww, float wh, float clip, float img_h, float img_w, float score_thresh) {
+                                  float wy, float ww, float wh, float clip, float img_h, float img_w, float score_thresh,
+                                  const float* __restrict__ img_hw) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * max_rois) return;
   const int img = i / max_rois, ri = i % max_rois;
+  if (img_hw) {      // per-image true sizes of a padded batch
+    img_h = img_hw[2 * img];
+    img_w = img_hw[2 * img + 1];
+  }
   const size_t shot_stride = (size_t)n * max_rois * pstride;
   const T* p0 = pred + (size_t)i * pstride;
   float l[2];
@@ -362,8 +367,8 @@ extern "C" int osd_groupnorm_act_rois(const void* x, const void* addend, const f
 
 extern "C" int osd_box_decode(const void* pred, const float* rois, const int32_t* counts, float* scores, float* boxes,
                               float* logits_out, float* reg_out, int n, int max_rois, int shots, int pred_stride,
-                              const float* reg_weights, float img_h, float img_w, float score_thresh, int dtype,
-                              void* stream) {
+                              const float* reg_weights, float img_h, float img_w, const float* img_hw, float score_thresh,
+                              int dtype, void* stream) {
   if (!pred || !rois || !scores || !boxes || !reg_weights || shots < 1 || pred_stride < 10)
     return osd_fail(OSD_ERR_INVALID_ARG, "box_decode: bad args");
   if (n * max_rois == 0) return OSD_OK;
@@ -372,11 +377,11 @@ extern "C" int osd_box_decode(const void* pred, const float* rois, const int32_t
   if (dtype == OSD_F32)
     hipLaunchKernelGGL(box_decode_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const float*)pred, rois, counts,
                        scores, boxes, logits_out, reg_out, n, max_rois, shots, pred_stride, reg_weights[0], reg_weights[1],
-                       reg_weights[2], reg_weights[3], clip, img_h, img_w, score_thresh);
+                       reg_weights[2], reg_weights[3], clip, img_h, img_w, score_thresh, img_hw);
   else if (dtype == OSD_BF16)
     hipLaunchKernelGGL(box_decode_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const __bf16*)pred, rois, counts,
                        scores, boxes, logits_out, reg_out, n, max_rois, shots, pred_stride, reg_weights[0], reg_weights[1],
-                       reg_weights[2], reg_weights[3], clip, img_h, img_w, score_thresh);
+                       reg_weights[2], reg_weights[3], clip, img_h, img_w, score_thresh, img_hw);
   else
     return osd_fail(OSD_ERR_INVALID_ARG, "bad dtype %d", dtype);
   return osd_check_launch("box_decode");

@@ -12,9 +12,14 @@ namespace {
 template <typename T>
 __global__ void fcos_score_decode_kernel(const T* __restrict__ cls_ctr, const T* __restrict__ reg, float* __restrict__ scores,
                                          float* __restrict__ boxes, int h, int w, int cc_stride, int reg_stride, int stride,
-                                         int loc_offset, int total_locs, float img_h, float img_w) {
+                                         int loc_offset, int total_locs, float img_h, float img_w,
+                                         const float* __restrict__ img_hw) {
   const int img = blockIdx.y;
   const int hw = h * w;
+  if (img_hw) {      // per-image true sizes of a padded batch (to_image_list, structures/image_list.py:52-70)
+    img_h = img_hw[2 * img];
+    img_w = img_hw[2 * img + 1];
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
     const size_t pix = (size_t)img * hw + i;
     const float lg = to_f32(cls_ctr[pix * cc_stride + 0]);
@@ -276,23 +281,30 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
 
 #define OSD_STREAM(s) reinterpret_cast<hipStream_t>(s)
 
-extern "C" int osd_fcos_score_decode(const void* cls_ctr, const void* reg, float* scores, float* boxes, int n, int h,
-                                     int w, int cc_stride, int reg_stride, int stride, int loc_offset, int total_locs,
-                                     float img_h, float img_w, int dtype, void* stream) {
+extern "C" int osd_fcos_score_decode_sizes(const void* cls_ctr, const void* reg, float* scores, float* boxes, int n, int h,
+                                           int w, int cc_stride, int reg_stride, int stride, int loc_offset, int total_locs,
+                                           float img_h, float img_w, const float* img_hw, int dtype, void* stream) {
   if (!cls_ctr || !reg || !scores || !boxes) return osd_fail(OSD_ERR_INVALID_ARG, "score_decode: null argument");
   if (n == 0 || h * w == 0) return OSD_OK;
   dim3 grid(cdiv(h * w, 256), n);
   if (dtype == OSD_F32)
     hipLaunchKernelGGL(fcos_score_decode_kernel<float>, grid, dim3(256), 0, OSD_STREAM(stream), (const float*)cls_ctr,
                        (const float*)reg, scores, boxes, h, w, cc_stride, reg_stride, stride, loc_offset, total_locs, img_h,
-                       img_w);
+                       img_w, img_hw);
   else if (dtype == OSD_BF16)
     hipLaunchKernelGGL(fcos_score_decode_kernel<__bf16>, grid, dim3(256), 0, OSD_STREAM(stream), (const __bf16*)cls_ctr,
                        (const __bf16*)reg, scores, boxes, h, w, cc_stride, reg_stride, stride, loc_offset, total_locs, img_h,
-                       img_w);
+                       img_w, img_hw);
   else
     return osd_fail(OSD_ERR_INVALID_ARG, "score_decode: bad dtype");
   return osd_check_launch("fcos_score_decode");
+}
+
+extern "C" int osd_fcos_score_decode(const void* cls_ctr, const void* reg, float* scores, float* boxes, int n, int h,
+                                     int w, int cc_stride, int reg_stride, int stride, int loc_offset, int total_locs,
+                                     float img_h, float img_w, int dtype, void* stream) {
+  return osd_fcos_score_decode_sizes(cls_ctr, reg, scores, boxes, n, h, w, cc_stride, reg_stride, stride, loc_offset,
+                                     total_locs, img_h, img_w, nullptr, dtype, stream);
 }
 
 extern "C" int osd_level_topk(const float* keys_in, float* keys_out, int n, int total, int lo, int cnt, int topn,

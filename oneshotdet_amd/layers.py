@@ -4,7 +4,10 @@ meaning and error behaviour, NCHW logical layout at this level, backed by libone
   nms(boxes, scores, thresh)                 layers/nms.py:5 -> _C.nms (csrc/nms.h:10-28)
   ROIAlign(output_size, spatial_scale, sampling_ratio)(input, rois)      layers/roi_align.py:50-68
   SigmoidFocalLoss(gamma, alpha)(logits, targets)                        layers/sigmoid_focal_loss.py:57-71
+  ImageList / to_image_list(tensors, size_divisible)                     structures/image_list.py:8-73
 """
+import math
+
 import torch
 from torch import nn
 
@@ -75,3 +78,42 @@ class SigmoidFocalLoss(nn.Module):
     def forward(self, logits, targets):
         _require_cuda(logits, "SigmoidFocalLoss")
         return _SigmoidFocalLoss.apply(logits.float(), targets.int(), self.gamma, self.alpha).sum()
+
+
+class ImageList(object):
+    """structures/image_list.py:8-27: a zero-padded batch [B,C,H,W] plus every image's true (height, width)."""
+
+    def __init__(self, tensors, image_sizes):
+        self.tensors = tensors
+        self.image_sizes = [tuple(int(v) for v in s) for s in image_sizes]
+
+    def to(self, *args, **kwargs):
+        return ImageList(self.tensors.to(*args, **kwargs), self.image_sizes)
+
+
+def to_image_list(tensors, size_divisible=0):
+    """structures/image_list.py:30-73 (R0 of SURVEY.md 8a).  An ImageList passes through; a 3-D / 4-D tensor is taken as
+    is (every image has the tensor's size); a list of CHW tensors is zero-padded at the bottom / right to the largest
+    height and width, rounded up to a multiple of `size_divisible` (BatchCollator, data/collate_batch.py:15-20, passes
+    DATALOADER.SIZE_DIVISIBILITY = 32), and the true sizes are kept for clip_to_image and the query ROI boxes.
+    Data movement only: torch slice copies on whatever device the tensors live on."""
+    if isinstance(tensors, torch.Tensor) and size_divisible > 0:
+        tensors = [tensors] if tensors.dim() == 3 else list(tensors)
+    if isinstance(tensors, ImageList):
+        return tensors
+    if isinstance(tensors, torch.Tensor):
+        if tensors.dim() == 3:
+            tensors = tensors[None]
+        if tensors.dim() != 4:
+            raise AssertionError("to_image_list: expected a 3-D or 4-D tensor")
+        return ImageList(tensors, [t.shape[-2:] for t in tensors])
+    if isinstance(tensors, (tuple, list)):
+        max_size = [max(s) for s in zip(*[img.shape for img in tensors])]
+        if size_divisible > 0:
+            max_size[1] = int(math.ceil(max_size[1] / size_divisible) * size_divisible)
+            max_size[2] = int(math.ceil(max_size[2] / size_divisible) * size_divisible)
+        batched = tensors[0].new_zeros((len(tensors),) + tuple(max_size))
+        for img, pad in zip(tensors, batched):
+            pad[:img.shape[0], :img.shape[1], :img.shape[2]].copy_(img)
+        return ImageList(batched, [im.shape[-2:] for im in tensors])
+    raise TypeError("Unsupported type for to_image_list: {}".format(type(tensors)))

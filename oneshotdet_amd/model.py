@@ -112,6 +112,17 @@ def whole_image_rois(q_sizes, device):
     return _ROI_CACHE[key]
 
 
+_SIZE_CACHE = {}
+
+
+def image_sizes_dev(image_sizes, device):
+    """[N,2] fp32 (height, width) per image on the device, cached like the ROI table (no copy in steady state)."""
+    key = (tuple(tuple(int(v) for v in s) for s in image_sizes), str(device))
+    if key not in _SIZE_CACHE:
+        _SIZE_CACHE[key] = torch.tensor([[float(h), float(w)] for h, w in key[0]], dtype=torch.float32, device=device)
+    return _SIZE_CACHE[key]
+
+
 def run_query_pool(qfeats, q_sizes, batch):
     """SuppAlignLayer (generalized_rcnn.py:20-52) + batch_pooling (:100-104) -> 5 x [B, C] fp32."""
     rois = whole_image_rois(q_sizes, qfeats[0].device)
@@ -156,10 +167,11 @@ def run_head(hw, feats, streams=None):
     return list(zip(cls_out, box_out))
 
 
-def run_proposals(head_out, img_h, img_w, pre_nms_top_n, post_nms_top_n, nms_thresh, cuda_nms=True, workspace=None):
-    """FCOSPostProcessor.forward (fcos/inference.py:251-323) for a batch whose images all have size (img_h, img_w)
-    (the 4-D tensor path of to_image_list, structures/image_list.py:44-50).  Everything stays on the device; returns
-    boxes [N, post, 4], scores [N, post] (descending), counts [N] int32."""
+def run_proposals(head_out, img_h, img_w, pre_nms_top_n, post_nms_top_n, nms_thresh, cuda_nms=True, workspace=None,
+                  image_sizes=None):
+    """FCOSPostProcessor.forward (fcos/inference.py:251-323).  Boxes are clipped to (img_h, img_w) (the 4-D tensor path of
+    to_image_list, structures/image_list.py:44-50) or, for a padded batch, to every image's own image_sizes[i] = (h, w)
+    (:52-70).  Everything stays on the device; returns boxes [N, post, 4], scores [N, post] (descending), counts [N]."""
     n = head_out[0][0].shape[0]
     dev = head_out[0][0].device
     sizes = [(c.shape[1], c.shape[2]) for c, _ in head_out]
@@ -168,8 +180,9 @@ def run_proposals(head_out, img_h, img_w, pre_nms_top_n, post_nms_top_n, nms_thr
     boxes = torch.empty((n, total, 4), device=dev, dtype=torch.float32)
     off = 0
     offs = []
+    hw_dev = None if image_sizes is None else image_sizes_dev(image_sizes, dev)
     for (cls_ctr, reg), stride in zip(head_out, spec.FPN_STRIDES):
-        ops.fcos_score_decode(cls_ctr, reg, scores, boxes, stride, off, img_h, img_w)
+        ops.fcos_score_decode(cls_ctr, reg, scores, boxes, stride, off, img_h, img_w, hw_dev)
         offs.append(off)
         off += cls_ctr.shape[1] * cls_ctr.shape[2]
     levels = [(lo, h * w) for (h, w), lo in zip(sizes, offs)]
@@ -218,10 +231,11 @@ class HotPathEngine(object):
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         return self._streams
 
-    def forward_features(self, images, queries, concurrent=True):
-        """Target backbone on the current stream; the (independent, tiny) query backbone + pooling on a side stream."""
+    def forward_features(self, images, queries, concurrent=True, query_sizes=None):
+        """Target backbone on the current stream; the (independent, tiny) query backbone + pooling on a side stream.
+        query_sizes: true (h, w) of every query of a padded batch (default: the tensor's size)."""
         batch = images.shape[0]
-        q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0]
+        q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0] if query_sizes is None else list(query_sizes)
         if concurrent:
             main, side = torch.cuda.current_stream(), self.side_streams()[0]
             side.wait_stream(main)
@@ -237,9 +251,9 @@ class HotPathEngine(object):
         combined = run_correlate(feats, pooled)
         return feats, qfeats, pooled, combined
 
-    def forward(self, images, queries, concurrent=True):
+    def forward(self, images, queries, concurrent=True, query_sizes=None):
         """images [B,3,H,W], queries [B*S,3,h,w] NCHW fp32 on the device -> dict of NHWC intermediates."""
-        feats, qfeats, pooled, combined = self.forward_features(images, queries, concurrent)
+        feats, qfeats, pooled, combined = self.forward_features(images, queries, concurrent, query_sizes)
         head = run_head(self.head, combined, self.side_streams() if concurrent else None)
         return dict(features=feats, query_features=qfeats, pooled=pooled, combined=combined, head=head)
 
@@ -247,24 +261,35 @@ class HotPathEngine(object):
         """GeneralizedRCNN.forward in eval mode (generalized_rcnn.py:226-332): first stage -> out["proposals"] =
         (boxes [N,P,4], scores [N,P], counts [N]); with second_stage also the few-shot ROI box head ->
         out["detections"] = dict(boxes [N,K,4], scores [N,K] descending, counts [N])."""
-        out = self.forward(images, queries, concurrent)
+        from .layers import ImageList
+        image_sizes = query_sizes = None
+        if isinstance(images, ImageList):       # padded batch (R0): clip to every image's own size
+            images, image_sizes = images.tensors, images.image_sizes
+        if isinstance(queries, ImageList):
+            queries, query_sizes = queries.tensors, queries.image_sizes
+        out = self.forward(images, queries, concurrent, query_sizes)
         h, w = images.shape[-2:]
         pre = spec.PRE_NMS_TOP_N_TRAIN if training else spec.PRE_NMS_TOP_N_TEST
         post = spec.POST_NMS_TOP_N_TRAIN if training else spec.POST_NMS_TOP_N_TEST
-        out["proposals"] = run_proposals(out["head"], h, w, pre, post, spec.NMS_THRESH, cuda_nms)
+        out["proposals"] = run_proposals(out["head"], h, w, pre, post, spec.NMS_THRESH, cuda_nms, image_sizes=image_sizes)
         if second_stage:
-            out["detections"] = self.box_detect(out["features"], out["query_features"], tuple(queries.shape[-2:]),
+            q_sizes = query_sizes if query_sizes is not None else tuple(queries.shape[-2:])
+            out["detections"] = self.box_detect(out["features"], out["query_features"], q_sizes,
                                                 out["proposals"][0], out["proposals"][2], h, w,
-                                                shots=queries.shape[0] // images.shape[0], cuda_nms=cuda_nms)
+                                                shots=queries.shape[0] // images.shape[0], cuda_nms=cuda_nms,
+                                                image_sizes=image_sizes)
         return out
 
-    def box_detect(self, feats, qfeats, q_size, boxes, counts, img_h, img_w, shots=1, cuda_nms=True, want_raw=False):
-        """roi_heads.box on given proposals (boxes [N,R,4] fp32, counts [N] int32 or None)."""
+    def box_detect(self, feats, qfeats, q_size, boxes, counts, img_h, img_w, shots=1, cuda_nms=True, want_raw=False,
+                   image_sizes=None):
+        """roi_heads.box on given proposals (boxes [N,R,4] fp32, counts [N] int32 or None).  q_size: (h, w) of all queries
+        or a list with every query's true size; image_sizes: true (h, w) per image of a padded batch."""
         if self.box_head is None:
             raise KeyError("state_dict has no roi_heads.box.* entries: the second stage was not packed")
         from .box_head import run_box_head
+        hw_dev = None if image_sizes is None else image_sizes_dev(image_sizes, boxes.device)
         return run_box_head(self.box_head, feats, qfeats, q_size, boxes, counts, img_h, img_w, shots=shots,
-                            cuda_nms=cuda_nms, want_raw=want_raw)
+                            cuda_nms=cuda_nms, want_raw=want_raw, img_hw=hw_dev)
 
 
 class GraphedDetect(object):

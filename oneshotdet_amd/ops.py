@@ -363,11 +363,13 @@ def nchw_f32_to_nhwc(x, dtype):
     return y
 
 
-def fcos_score_decode(cls_ctr, reg, scores, boxes, stride, loc_offset, img_h, img_w):
-    _chk_dev(cls_ctr, reg, scores, boxes)
+def fcos_score_decode(cls_ctr, reg, scores, boxes, stride, loc_offset, img_h, img_w, img_hw=None):
+    """img_hw: optional [N,2] fp32 device tensor of true (height, width) per image (padded batches)."""
+    _chk_dev(cls_ctr, reg, scores, boxes, img_hw)
     n, h, w, ccs = cls_ctr.shape
-    _lib.call("osd_fcos_score_decode", _ptr(cls_ctr), _ptr(reg), _ptr(scores), _ptr(boxes), n, h, w, ccs, reg.shape[-1],
-              stride, loc_offset, scores.shape[1], float(img_h), float(img_w), _dt(cls_ctr), _stream())
+    _lib.call("osd_fcos_score_decode_sizes", _ptr(cls_ctr), _ptr(reg), _ptr(scores), _ptr(boxes), n, h, w, ccs,
+              reg.shape[-1], stride, loc_offset, scores.shape[1], float(img_h), float(img_w), _ptr(img_hw), _dt(cls_ctr),
+              _stream())
 
 
 def level_topk(keys, lo, cnt, topn):
@@ -837,7 +839,7 @@ def groupnorm_act_rois(x, gamma, beta, groups=32, eps=1e-5, slope=0.2, addend=No
     return out
 
 
-def box_decode(pred, rois, counts, reg_weights, img_h, img_w, score_thresh, want_raw=False):
+def box_decode(pred, rois, counts, reg_weights, img_h, img_w, score_thresh, want_raw=False, img_hw=None):
     """pred [S, N*R, P] (cols 0..1 logits, 2..9 deltas), rois [N,R,4] -> scores [N,R] (-1 = dropped), boxes [N,R,4]
     (+ the selected logits [N*R,2] and deltas [N*R,8] in fp32 when want_raw)."""
     _chk_dev(pred, rois, counts)
@@ -851,7 +853,7 @@ def box_decode(pred, rois, counts, reg_weights, img_h, img_w, score_thresh, want
     ro = torch.empty((m, 8), device=dev, dtype=torch.float32) if want_raw else None
     rw = (C.c_float * 4)(*[float(v) for v in reg_weights])
     _lib.call("osd_box_decode", _ptr(pred), _ptr(rois.contiguous()), _ptr(counts), _ptr(scores), _ptr(boxes), _ptr(lo),
-              _ptr(ro), n, r, s, p, rw, float(img_h), float(img_w), float(score_thresh), _dt(pred), _stream())
+              _ptr(ro), n, r, s, p, rw, float(img_h), float(img_w), _ptr(img_hw), float(score_thresh), _dt(pred), _stream())
     return (scores, boxes, lo, ro) if want_raw else (scores, boxes)
 
 

@@ -544,7 +544,7 @@ class TrainEngine(object):
         return None
 
     # ------------------------------------------------------------------------------------------------ step
-    def forward_backward(self, images, queries, gt_boxes, gt_count, with_proposals=True):
+    def forward_backward(self, images, queries, gt_boxes, gt_count, with_proposals=True, image_sizes=None):
         """One training forward + backward.  images [B,3,H,W], queries [B*S,3,h,w] fp32 NCHW on the device;
         gt_boxes [B, G, 4] fp32 xyxy, gt_count [B] int32.  Returns losses [4] = (cls, reg, centerness, num_pos)."""
         from . import model
@@ -577,7 +577,8 @@ class TrainEngine(object):
                 ps.wait_stream(main)
             with torch.cuda.stream(ps):
                 pb, ps_, pc = model.run_proposals(head_out, images.shape[-2], images.shape[-1],
-                                                  spec.PRE_NMS_TOP_N_TRAIN, spec.POST_NMS_TOP_N_TRAIN, spec.NMS_THRESH)
+                                                  spec.PRE_NMS_TOP_N_TRAIN, spec.POST_NMS_TOP_N_TRAIN, spec.NMS_THRESH,
+                                                  image_sizes=image_sizes)   # padded batch: clip to each image's size
                 # add_gt_proposals (fcos/inference.py:139-160,279): the ground-truth boxes join the training proposals
                 self.proposals = ops.append_gt_boxes(pb, ps_, pc, gt_boxes, gt_count)
         # ---- loss + backward

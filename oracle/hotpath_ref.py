@@ -217,13 +217,28 @@ def compute_locations(level_hw):
     return locs
 
 
-def hot_path_forward(images, queries, sd, shots=1):
+def to_image_list(tensors, size_divisible=0):
+    """structures/image_list.py:30-73 for a list of CHW tensors: zero-pad bottom / right to the largest size rounded up to
+    a multiple of size_divisible; returns (batch [B,C,H,W], [(h, w) per image])."""
+    max_size = [max(s) for s in zip(*[t.shape for t in tensors])]
+    if size_divisible > 0:
+        max_size[1] = int(math.ceil(max_size[1] / size_divisible) * size_divisible)
+        max_size[2] = int(math.ceil(max_size[2] / size_divisible) * size_divisible)
+    out = tensors[0].new_zeros((len(tensors),) + tuple(max_size))
+    for t, o in zip(tensors, out):
+        o[:t.shape[0], :t.shape[1], :t.shape[2]].copy_(t)
+    return out, [tuple(t.shape[-2:]) for t in tensors]
+
+
+def hot_path_forward(images, queries, sd, shots=1, query_sizes=None):
     """generalized_rcnn.py:226-312 up to and including the FCOS head (eval or train; no BN/GN state differs).
-    images [B,3,H,W]; queries [B*shots,3,h,w].  Returns a dict of every intermediate."""
+    images [B,3,H,W]; queries [B*shots,3,h,w]; query_sizes: true (h, w) per query of a padded batch.
+    Returns a dict of every intermediate."""
     B = images.shape[0]
     feats = backbone(images, sd, "backbone.")
     qfeats = backbone(queries, sd, "supp_backbone.")
-    q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0]   # to_image_list on a 4-D tensor: image_list.py:44-50
+    # to_image_list on a 4-D tensor: image_list.py:44-50; on a list: the true sizes (:69)
+    q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0] if query_sizes is None else list(query_sizes)
     pooled = query_pool(qfeats, q_sizes, B)
     combined = correlate(feats, pooled)
     logits, bbox_reg, centerness = fcos_head(combined, sd)

@@ -194,6 +194,80 @@ def gen_box_case(model, np_sd, name):
     np.savez_compressed(os.path.join(HERE, "box_%s.npz" % name), **out)
 
 
+def gen_ragged(model, np_sd):
+    """R0: lists of different-size targets / queries through the REAL reference's to_image_list (zero padding to the largest
+    size rounded up to /32, true sizes kept) and model; first stage from hooks, second stage by calling
+    model.supproi_pooling / model.roi_heads with the proposal lists cut to the shorter one (poolers.py:80)."""
+    rh.load_reference()
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    t_np, q_np = gu.ragged_inputs()
+    div = gu.RAGGED["size_divisible"]
+    images = to_image_list([torch.from_numpy(a) for a in t_np], div)
+    queries = to_image_list([torch.from_numpy(a) for a in q_np], div)
+    B = len(t_np)
+    assert [tuple(s) for s in images.image_sizes] == gu.RAGGED["targets"]
+    cap = run_reference(model, images, queries, B)
+    sd = orc.to_torch_state_dict(np_sd)
+    # oracle on its own padding
+    o_img, o_sizes = orc.to_image_list([torch.from_numpy(a) for a in t_np], div)
+    o_q, o_qsizes = orc.to_image_list([torch.from_numpy(a) for a in q_np], div)
+    assert torch.equal(o_img, images.tensors) and torch.equal(o_q, queries.tensors)
+    assert o_sizes == [tuple(s) for s in images.image_sizes] and o_qsizes == [tuple(s) for s in queries.image_sizes]
+    with torch.no_grad():
+        o = orc.hot_path_forward(o_img, o_q, sd, shots=1, query_sizes=o_qsizes)
+    ref_head = gu.flatten_head(*[[t2n(t) for t in lst] for lst in cap["head_out"]])
+    orc_head = gu.flatten_head(*[[t2n(t) for t in o[k]] for k in ("logits", "bbox_reg", "centerness")])
+    err = float(np.abs(ref_head - orc_head).max())
+    print("ragged: padded to", tuple(images.tensors.shape), tuple(queries.tensors.shape), "head oracle-vs-reference %.2e" % err)
+    assert err < 2e-4
+    out = {"head": ref_head, "padded_target": np.asarray(images.tensors.shape, np.int64),
+           "padded_query": np.asarray(queries.tensors.shape, np.int64)}
+    for lvl in range(5):
+        pooled_ref = model.batch_pooling(cap["pooled_raw"][lvl], B)
+        assert (o["pooled"][lvl] - pooled_ref).abs().max().item() < 1e-5 * max(pooled_ref.abs().max().item(), 1e-6)
+        out["pooled.%d" % lvl] = t2n(pooled_ref).reshape(B, -1)
+        out.update(gu.checksum(t2n(cap["features"][lvl]), "features.%d" % lvl))
+    orc_props = orc.fcos_postprocess(*cap["head_out"], o_sizes)
+    for i, bl in enumerate(cap["proposals"]):
+        rb, rs = t2n(bl.bbox), t2n(bl.get_field("scores"))
+        assert bl.size == (o_sizes[i][1], o_sizes[i][0])
+        assert rb[:, 2].max() <= o_sizes[i][1] - 1 and rb[:, 3].max() <= o_sizes[i][0] - 1
+        frac = gu.match_boxes(rb, rs, t2n(orc_props[i][0]), t2n(orc_props[i][1]))
+        print("  image %d (%dx%d): reference %d proposals, oracle %d, overlap %.4f"
+              % (i, o_sizes[i][0], o_sizes[i][1], len(rb), len(orc_props[i][0]), frac))
+        assert len(rb) == len(orc_props[i][0]) and frac >= 0.999
+        order = np.argsort(-rs, kind="stable")
+        out["proposals.%d.boxes" % i], out["proposals.%d.scores" % i] = rb[order], rs[order]
+    # ---- second stage ----
+    rmin = min(len(bl) for bl in cap["proposals"])
+    props = [bl[:rmin] for bl in cap["proposals"]]
+    grabbed = {}
+
+    def grab_pred(m, i_, o_):
+        grabbed["logits"], grabbed["reg"] = o_[0], o_[1]
+    hook = model.roi_heads.box.predictor.register_forward_hook(grab_pred)
+    feats, qfeats = list(cap["features"]), list(cap["query_features"])
+    with torch.no_grad():
+        supp_boxes = [BoxList([[0, 0, h, w]], image_size=(h, w), mode="xyxy") for (h, w) in o_qsizes]
+        supp_roi = model.supproi_pooling(qfeats, supp_boxes)
+        _, result, _ = model.roi_heads(feats, props, None, supp_roi, target_ids=[1] * B)
+        r = obh.box_head_forward(feats, qfeats, [bl.bbox for bl in props], o_sizes, o_qsizes, sd)
+    hook.remove()
+    e2 = max((r["logits"] - grabbed["logits"]).abs().max().item(), (r["box_regression"] - grabbed["reg"]).abs().max().item())
+    print("  second stage R=%d: oracle-vs-reference logits/deltas %.2e" % (rmin, e2))
+    assert e2 < 2e-4
+    out["box.logits"], out["box.box_regression"] = t2n(grabbed["logits"]), t2n(grabbed["reg"])
+    for i, bl in enumerate(result):
+        rb, rs = t2n(bl.bbox), t2n(bl.get_field("scores"))
+        ob, os_ = t2n(r["detections"][i][0]), t2n(r["detections"][i][1])
+        assert len(rb) == len(ob) and gu.match_boxes(rb, rs, ob, os_) >= 0.999
+        order = np.argsort(-rs, kind="stable")
+        out["box.proposals.%d" % i] = t2n(props[i].bbox)
+        out["box.detections.%d.boxes" % i], out["box.detections.%d.scores" % i] = rb[order], rs[order]
+    np.savez_compressed(os.path.join(HERE, "case_ragged.npz"), **out)
+
+
 def gen_train_case(model, np_sd, name="small"):
     """R12 + gradients.  The reference's loss_evaluator (fcos/loss.py:213) is called directly on head outputs; parameter
     gradients come from the reference modules with the pooled query vector DETACHED (ROIAlign has no CPU backward in the
@@ -387,6 +461,7 @@ def main():
     if args.only_box:
         gen_keys(model)
         gen_add_gt(model)
+        gen_ragged(model, np_sd)
     if not args.only_train:
         for name in [c for c in args.box_cases.split(",") if c]:
             gen_box_case(model, np_sd, name)
@@ -397,6 +472,7 @@ def main():
         gen_nms_kat()
         gen_roialign()
         gen_add_gt(model)
+        gen_ragged(model, np_sd)
         for name in [c for c in args.cases.split(",") if c]:
             gen_case(model, np_sd, name)
     if not args.skip_train:

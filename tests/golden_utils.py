@@ -85,3 +85,15 @@ def case_inputs(name, seed=0):
     from oneshotdet_amd import synth
     B, H, W, S, qh, qw = CASES[name]
     return (synth.make_images("target." + name, B, H, W, seed), synth.make_images("query." + name, B * S, qh, qw, seed))
+
+
+# R0 (to_image_list on LISTS of different-size images, structures/image_list.py:52-70): target sizes, query sizes
+RAGGED = {"targets": [(96, 160), (128, 130)], "queries": [(63, 63), (96, 80)], "size_divisible": 32}
+
+
+def ragged_inputs(seed=0):
+    """lists of CHW float32 numpy arrays: (targets, queries) of the `ragged` case."""
+    from oneshotdet_amd import synth
+    t = [synth.make_images("target.ragged.%d" % i, 1, h, w, seed)[0] for i, (h, w) in enumerate(RAGGED["targets"])]
+    q = [synth.make_images("query.ragged.%d" % i, 1, h, w, seed)[0] for i, (h, w) in enumerate(RAGGED["queries"])]
+    return t, q

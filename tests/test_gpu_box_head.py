@@ -249,3 +249,50 @@ def test_checkpoint_round_trip_through_the_engines(tmp_path, engines):
     assert int(a["detections"]["counts"][0]) == k and k > 0
     assert torch.equal(a["detections"]["boxes"][0, :k], b["detections"]["boxes"][0, :k])
     assert torch.equal(a["detections"]["scores"][0, :k], b["detections"]["scores"][0, :k])
+
+
+def test_ragged_batch_of_lists_matches_reference_golden(engines):
+    """R0 (to_image_list on lists, structures/image_list.py:52-70): different-size targets and queries are zero-padded
+    to a common /32 size by layers.to_image_list; every image is clipped to ITS size, every query's whole-image ROI box
+    uses ITS size (pooling and second-stage level routing).  Fixture recorded through the real reference."""
+    from oneshotdet_amd import layers
+    f = gu.load("case_ragged.npz")
+    t_np, q_np = gu.ragged_inputs()
+    imgs = layers.to_image_list([torch.from_numpy(a).cuda() for a in t_np], gu.RAGGED["size_divisible"])
+    qs = layers.to_image_list([torch.from_numpy(a).cuda() for a in q_np], gu.RAGGED["size_divisible"])
+    assert tuple(imgs.tensors.shape) == tuple(f["padded_target"]) and imgs.image_sizes == gu.RAGGED["targets"]
+    assert tuple(qs.tensors.shape) == tuple(f["padded_query"]) and qs.image_sizes == gu.RAGGED["queries"]
+    eng = engines["f32"]
+    out = eng.detect(imgs, qs, cuda_nms=False, second_stage=True)
+    logits = [nchw(c)[:, 0:1].numpy() for c, _ in out["head"]]
+    ctr = [nchw(c)[:, 1:2].numpy() for c, _ in out["head"]]
+    reg = [nchw(r).numpy() for _, r in out["head"]]
+    np.testing.assert_allclose(gu.flatten_head(logits, reg, ctr), f["head"], rtol=1e-3, atol=1e-3)
+    for lvl in range(5):
+        np.testing.assert_allclose(out["pooled"][lvl].cpu().numpy(), f["pooled.%d" % lvl], rtol=1e-4, atol=1e-4)
+    ob, os_, oc = out["proposals"]
+    for i, (h, w) in enumerate(gu.RAGGED["targets"]):
+        k = int(oc[i])
+        b = ob[i, :k]
+        assert float(b[:, 2].max()) <= w - 1 and float(b[:, 3].max()) <= h - 1 and float(b.min()) >= 0
+        rb, rs = f["proposals.%d.boxes" % i], f["proposals.%d.scores" % i]
+        assert abs(k - len(rb)) <= 2
+        assert gu.match_boxes(rb, rs, b.cpu().numpy(), os_[i, :k].cpu().numpy()) >= 0.99
+    # second stage on the reference's own (equal-count) proposals
+    props = torch.stack([torch.from_numpy(f["box.proposals.%d" % i]) for i in range(2)], 0).cuda()
+    det = eng.box_detect(out["features"], out["query_features"], qs.image_sizes, props, None, 128, 160, cuda_nms=False,
+                         want_raw=True, image_sizes=imgs.image_sizes)
+    np.testing.assert_allclose(det["logits"].cpu().numpy(), f["box.logits"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(det["box_regression"].cpu().numpy(), f["box.box_regression"], rtol=1e-3, atol=1e-3)
+    for i, (h, w) in enumerate(gu.RAGGED["targets"]):
+        k = int(det["counts"][i])
+        b = det["boxes"][i, :k]
+        assert float(b[:, 2].max()) <= w - 1 and float(b[:, 3].max()) <= h - 1
+        rb, rs = f["box.detections.%d.boxes" % i], f["box.detections.%d.scores" % i]
+        assert abs(k - len(rb)) <= max(1, len(rb) // 100)
+        assert gu.match_boxes(rb, rs, b.cpu().numpy(), det["scores"][i, :k].cpu().numpy()) >= 0.99
+    # the end-to-end second stage (our proposals, ragged counts) is well formed
+    d2 = out["detections"]
+    for i, (h, w) in enumerate(gu.RAGGED["targets"]):
+        k = int(d2["counts"][i])
+        assert k > 0 and float(d2["boxes"][i, :k, 2].max()) <= w - 1 and float(d2["boxes"][i, :k, 3].max()) <= h - 1

@@ -212,3 +212,32 @@ def test_add_gt_proposals_reference_vectors():
     for i, (b, s) in enumerate(out):
         np.testing.assert_array_equal(b.numpy(), f["out_boxes.%d" % i])
         np.testing.assert_array_equal(s.numpy(), f["out_scores.%d" % i])
+
+
+def test_ragged_batch_matches_reference(sd_full):
+    """R0: lists of different-size targets / queries, padded by to_image_list (structures/image_list.py:52-70) with the
+    true sizes kept for clip_to_image and the query ROI boxes; fixture recorded through the REAL reference
+    (make_golden.py gen_ragged), first and second stage."""
+    f = gu.load("case_ragged.npz")
+    t_np, q_np = gu.ragged_inputs()
+    img, sizes = orc.to_image_list([torch.from_numpy(a) for a in t_np], gu.RAGGED["size_divisible"])
+    q, qsizes = orc.to_image_list([torch.from_numpy(a) for a in q_np], gu.RAGGED["size_divisible"])
+    assert tuple(img.shape) == tuple(f["padded_target"]) and tuple(q.shape) == tuple(f["padded_query"])
+    assert sizes == gu.RAGGED["targets"] and qsizes == gu.RAGGED["queries"]
+    assert float(img[0, :, 96:, :].abs().sum()) == 0 and float(img[1, :, :, 130:].abs().sum()) == 0    # zero padding
+    with torch.no_grad():
+        o = orc.hot_path_forward(img, q, sd_full, shots=1, query_sizes=qsizes)
+    head = gu.flatten_head(*[[t.numpy() for t in o[k]] for k in ("logits", "bbox_reg", "centerness")])
+    np.testing.assert_allclose(head, f["head"], rtol=1e-4, atol=1e-4)
+    props = orc.fcos_postprocess(o["logits"], o["bbox_reg"], o["centerness"], sizes)
+    for i, (b, s) in enumerate(props):
+        assert b[:, 2].max() <= sizes[i][1] - 1 and b[:, 3].max() <= sizes[i][0] - 1
+        assert gu.match_boxes(f["proposals.%d.boxes" % i], f["proposals.%d.scores" % i], b.numpy(), s.numpy()) >= 0.99
+    with torch.no_grad():
+        r = obh.box_head_forward(o["features"], o["query_features"],
+                                 [torch.from_numpy(f["box.proposals.%d" % i]) for i in range(2)], sizes, qsizes, sd_full)
+    np.testing.assert_allclose(r["logits"].numpy(), f["box.logits"], rtol=1e-3, atol=5e-4)
+    np.testing.assert_allclose(r["box_regression"].numpy(), f["box.box_regression"], rtol=1e-3, atol=5e-4)
+    for i in range(2):
+        db, ds = r["detections"][i]
+        assert gu.match_boxes(f["box.detections.%d.boxes" % i], f["box.detections.%d.scores" % i], db.numpy(), ds.numpy()) >= 0.99

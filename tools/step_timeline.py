@@ -97,6 +97,21 @@ def main():
     print("main stream %d: %d launches, busy %.2f ms, own gaps %.2f ms" % (main, len(ms), per[main] / 1e3, sum(g[0] for g in g2) / 1e3))
     for g, a, b, at in sorted(g2, reverse=True)[:15]:
         print("  gap %7.1f us at +%.2f ms between %s and %s" % (g, (at - t0) / 1e3, a, b))
+    by = collections.defaultdict(lambda: [0, 0.0])
+    for a, b, n in ms:
+        by[n][0] += 1
+        by[n][1] += b - a
+    print("  main stream by entry point (launches, ms):",
+          sorted(((n, c, round(t / 1e3, 2)) for n, (c, t) in by.items()), key=lambda x: -x[2]))
+    for st in sorted(per):
+        if st == main:
+            continue
+        by = collections.defaultdict(lambda: [0, 0.0])
+        for n, s_, a, b in step:
+            if streams[s_] == st:
+                by[n][0] += 1
+                by[n][1] += b - a
+        print("  stream %d:" % st, sorted(((n, c, round(t / 1e3, 2)) for n, (c, t) in by.items()), key=lambda x: -x[2])[:6])
     hist = collections.Counter(int(min(g[0], 99) // 5) * 5 for g in g2)
     print("  gap histogram (us bucket: count):", sorted(hist.items()))
 
