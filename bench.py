@@ -209,6 +209,23 @@ def result_line(args, world, batch, elapsed, workload, launch, roofline=None, cp
     return line
 
 
+def measured_peaks(dtype):
+    """Yardsticks measured on the box (profiles/r1_peak_probe.json: bare MFMA loop, streaming copy, vendor GEMM) reported
+    beside the datasheet peak the `frac` is taken against."""
+    path = os.path.join(ROOT, "profiles", "r1_peak_probe.json")
+    try:
+        j = json.load(open(path))
+    except Exception:
+        return None
+    if dtype == "bf16":
+        return {"mfma_loop_tflops": j["mfma_bf16_16x16x32_tflops"]["2_waves_per_simd"],
+                "vendor_gemm_same_shape_as_tower_conv_tflops": j["vendor_gemm_bf16_tflops"]["M128000_N256_K2304"],
+                "vendor_gemm_best_tflops": j["vendor_gemm_bf16_tflops"]["M16000_N1024_K6272"],
+                "copy_tb_per_s": j["copy_tb_per_s_read_plus_write"]["1024_workgroups"], "source": "profiles/r1_peak_probe.json"}
+    return {"mfma_loop_tflops": j["mfma_f32_16x16x4_tflops"]["2_waves_per_simd"],
+            "copy_tb_per_s": j["copy_tb_per_s_read_plus_write"]["1024_workgroups"], "source": "profiles/r1_peak_probe.json"}
+
+
 def measured_traffic(mode, dtype):
     """HBM bytes per conv-family launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections), collected
     offline by tools/prof_pmc.sh + tools/summarize_pmc.py in separate rocprofv3 --pmc passes and committed under
@@ -389,6 +406,7 @@ def main_train(args, rank, world):
         corr_roofline = timer.correlation_roofline()
         roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4), "traffic": measured_traffic("train", args.dtype),
+                    "peak_measured": measured_peaks(args.dtype),
                     "traffic_source": "profiles/r1_pmc_traffic_train_%s.json (rocprofv3 --pmc, bytes per launch)" % args.dtype,
                     "kernel": "conv_dma_kernel / conv_xr_kernel / conv_igemm_kernel (forward + data gradient) and conv_wgrad_kernel",
                     "avg_launch_us": round(conv_ms * 1e3 / max(timer.launches, 1), 2),
@@ -511,6 +529,7 @@ def main():
         tflops = timer.flops / (conv_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "peak_measured": measured_peaks(args.dtype),
                     "kernel": "conv_igemm_kernel (all instantiations)",
                     "avg_launch_us": round(conv_ms * 1e3 / max(timer.launches, 1), 2),
                     "launches_per_step": timer.launches // max(args.steps, 1),

@@ -1,0 +1,57 @@
+"""Summarise a `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace` pass of bench.py
+(tools/prof_pmc_generic.sh mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" bench.py ...) into profiles/<name>.md:
+per conv kernel the share of SIMD-cycles in which the matrix pipe was busy.
+  SQ_VALU_MFMA_BUSY_CYCLES  cycles, summed over all SIMDs (16 per v_mfma_f32_16x16x32_bf16: MI355X_MICROARCH.md, cycle constants)
+  GRBM_GUI_ACTIVE           active cycles summed over the 8 XCDs -> / 8 = the dispatch's cycles at the clock it ran at
+  MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs)
+usage: python tools/summarize_mfma.py gpurun_out/pmcg_mfma profiles/r1_pmc_mfma_busy_train_bf16.md"""
+import collections
+import csv
+import re
+import sys
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "")
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-zA-Z_0-9]+?)I(DF16b|f)(.*)", n)
+    if m:
+        t = re.findall(r"Li(\d+)E", m.group(3))
+        return m.group(1) + "<" + ("bf16" if m.group(2) == "DF16b" else "f32") + ("," + ",".join(t) if t else "") + ">"
+    return n.split("(")[0][:60]
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    per = collections.defaultdict(dict)
+    for r in csv.DictReader(open(d + "/run_counter_collection.csv")):
+        k = per[r["Dispatch_Id"]]
+        k["name"] = r["Kernel_Name"]
+        k[r["Counter_Name"]] = float(r["Counter_Value"])
+        k["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+    for k in per.values():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" not in k or "GRBM_GUI_ACTIVE" not in k:
+            continue
+        n = short(k["name"])
+        if not any(t in n for t in ("conv_", "mfma")):
+            continue
+        a = agg[n]
+        a[0] += 1
+        a[1] += k["SQ_VALU_MFMA_BUSY_CYCLES"]
+        a[2] += k["GRBM_GUI_ACTIVE"]
+        a[3] += k["ns"]
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][3])
+    tot = [sum(v[i] for _, v in rows) for i in range(4)]
+    with open(out, "w") as f:
+        f.write("# MFMA-busy counters of the conv kernels, `bench.py` training step (bf16), one rocprofv3 --pmc pass\n\n")
+        f.write("busy share = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); effective clock = GRBM_GUI_ACTIVE / 8 / "
+                "duration (reads high on dispatches shorter than ~0.3 ms).  Whole process: tuning + warm-up + timed steps.\n\n")
+        f.write("| kernel | dispatches | total ms | MFMA busy share | eff. clock GHz |\n|---|---|---|---|---|\n")
+        for n, (c, busy, gui, ns) in rows[:24]:
+            f.write("| `%s` | %d | %.2f | %.3f | %.2f |\n" % (n, c, ns / 1e6, busy / (gui / 8 * 1024), gui / 8 / ns))
+        f.write("| **all conv kernels** | %d | %.2f | **%.3f** | %.2f |\n" % (tot[0], tot[3] / 1e6, tot[1] / (tot[2] / 8 * 1024), tot[2] / 8 / tot[3]))
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    main()
