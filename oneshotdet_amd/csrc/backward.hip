@@ -805,13 +805,21 @@ __global__ void __launch_bounds__(256) gnl_stats_kernel(GnLevels L, float* __res
   const int per = (hw + kGnSplits - 1) / kGnSplits;
   const int p0 = split * per, p1 = min(hw, p0 + per);
   float s = 0.f, ss = 0.f;
-  if (pl < lanes)
-    for (int p = p0 + pl; p < p1; p += lanes) {
-      Chunk<T> v;
-      v.load(x + ((size_t)img * hw + p) * c + cc * E);
+  if (pl < lanes) {
+    constexpr int U = 4;        // pixels in flight per thread (one 16-byte load each): a P3 slab is 200 pixels on 2 workgroups per CU
+    for (int p = p0 + pl; p < p1; p += U * lanes) {
+      Chunk<T> v[U];
 #pragma unroll
-      for (int e = 0; e < E; ++e) { s += v.v[e]; ss += v.v[e] * v.v[e]; }
+      for (int k = 0; k < U; ++k)       // unconditional (clamped) loads, masked in the arithmetic
+        v[k].load(x + ((size_t)img * hw + min(p + k * lanes, p1 - 1)) * c + cc * E);
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const float m = (p + k * lanes < p1) ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const float t = v[k].v[e] * m; s += t; ss += t * t; }
+      }
     }
+  }
   __shared__ float red[2][256];
   red[0][threadIdx.x] = s;
   red[1][threadIdx.x] = ss;
@@ -874,13 +882,28 @@ __global__ void __launch_bounds__(256) gnl_apply_kernel(GnLevels L, const float*
   const long long chunks = (long long)hw * cch;
   const long long per = (chunks + gridDim.x - 1) / gridDim.x;
   const long long i0 = blockIdx.x * per, i1 = min(chunks, i0 + per);
-  for (long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-    const int cc = (int)(i % cch);
-    Chunk<T> v;
-    v.load(x + (size_t)img * hw * c + i * E);
+  // blockDim.x is a multiple of cch (checked by the launcher), so a thread's channel chunk never changes
+  const int cc = (int)((i0 + threadIdx.x) % cch);
+  float av[E], bv[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) v.v[e] = fmaxf(fmaf(v.v[e], sa[cc * E + e], sb[cc * E + e]), 0.f);
-    v.store(y + (size_t)img * hw * c + i * E);
+  for (int e = 0; e < E; ++e) { av[e] = sa[cc * E + e]; bv[e] = sb[cc * E + e]; }
+  constexpr int U = 4;
+  const size_t base = (size_t)img * hw * c;
+  for (long long i = i0 + threadIdx.x; i < i1; i += (long long)U * blockDim.x) {
+    Chunk<T> v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {        // unconditional loads; an out-of-range slot re-reads this thread's first chunk
+      const long long ik = i + (long long)k * blockDim.x;
+      v[k].load(x + base + (ik < i1 ? ik : i) * E);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const long long ik = i + (long long)k * blockDim.x;
+      if (ik >= i1) break;
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[k].v[e] = fmaxf(fmaf(v[k].v[e], av[e], bv[e]), 0.f);
+      v[k].store(y + base + ik * E);
+    }
   }
 }
 
@@ -1065,6 +1088,13 @@ __global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const fl
   }
 }
 
+// workgroups per (image, level) of the apply kernels (they split the chunks evenly, no workspace layout depends on it)
+int gn_apply_blocks() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("OSD_GN_APPLY_BLOCKS"); v = e ? atoi(e) : 32; if (v < 1) v = 32; }   // 32: measured best of 24..512 (tools/gn_bench.py: every workgroup re-reduces the slab partials)
+  return v;
+}
+
 int gn_levels_fill(GnLevels& L, int n_levels, const void* const* xs, const void* const* dys, void* const* ys, const int32_t* hws) {
   if (n_levels < 1 || n_levels > kGnL || !xs || !ys || !hws) return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_levels: bad arguments");
   L.n_levels = n_levels;
@@ -1088,7 +1118,7 @@ extern "C" int osd_groupnorm_relu_fwd_levels(int n_levels, const void* const* xs
   GnLevels L;
   int rc = gn_levels_fill(L, n_levels, xs, nullptr, ys, hws);
   if (rc) return rc;
-  dim3 g1(kGnSplits, n, n_levels), g2(64, n, n_levels);
+  dim3 g1(kGnSplits, n, n_levels), g2(gn_apply_blocks(), n, n_levels);
   OSD_DISPATCH_DTYPE(dtype,
       hipLaunchKernelGGL(gnl_stats_kernel<float>, g1, dim3(256), 0, OSD_STREAM(stream), L, ws, n, c, groups),
       hipLaunchKernelGGL(gnl_stats_kernel<__bf16>, g1, dim3(256), 0, OSD_STREAM(stream), L, ws, n, c, groups));
@@ -1111,7 +1141,7 @@ extern "C" int osd_groupnorm_relu_bwd_levels(int n_levels, const void* const* us
   GnLevels L;
   int rc = gn_levels_fill(L, n_levels, us, dts, dus, hws);
   if (rc) return rc;
-  dim3 g1(kGnSplits, n, n_levels), g2(64, n, n_levels);
+  dim3 g1(kGnSplits, n, n_levels), g2(gn_apply_blocks(), n, n_levels);
   OSD_DISPATCH_DTYPE(dtype,
       hipLaunchKernelGGL(gnl_bwd_stats_kernel<float>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups),
       hipLaunchKernelGGL(gnl_bwd_stats_kernel<__bf16>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups));
