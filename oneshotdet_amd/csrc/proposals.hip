@@ -80,7 +80,9 @@ __device__ __forceinline__ unsigned key32(float k) { return k >= 0.f ? __float_a
 // (>), and only the one or two tiles that overlap the workgroup's index range need the exact two-term test.  The choice
 // is uniform per tile; the padding value of the >= loop is chosen so that it never counts.  (One 64-bit compare per pair
 // took 350 us for 8 x 17,064 candidates; v_cmp_*_u64 runs at a fraction of the 32-bit rate and the tile was twice the
-// LDS bytes.)
+// LDS bytes.  Also tried: lanes holding 64 tile keys with the wave's own keys broadcast one at a time (v_readlane), so one
+// v_cmp + a scalar popcount covers 64 pairs - 441 us, slower than this form's 322: the scalar popcount / add chain sits in
+// the wave's in-order stream.)
 __global__ void __launch_bounds__(256) rank_sort_gather_kernel(const float* __restrict__ keys, const float* __restrict__ boxes,
                                                                int total, int max_count, int topn, LevelTable lt,
                                                                float* __restrict__ boxes_sorted,
