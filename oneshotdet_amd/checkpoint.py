@@ -4,10 +4,13 @@ Mirrors utils/checkpoint.py:33-103 (`{"model": state_dict, "optimizer": ..., "it
 `last_checkpoint` tag file) and utils/model_serialization.py:10-80 (strip a DataParallel `module.` prefix, then give every
 expected key the loaded key that is its LONGEST suffix), so a reference `model_XXXXXXX.pth` feeds
 `HotPathEngine` / `TrainEngine` unchanged and `TrainEngine.state_dict()` goes back out in the reference's format.
-Not built: the Caffe2 `.pkl` route (utils/c2_model_loading.py: Detectron key renaming) — it needs the Detectron model
-zoo, which is not reachable here.
+The Caffe2 / Detectron `.pkl` route (utils/c2_model_loading.py:12-175; `MODEL.WEIGHT: catalog://ImageNetPretrained/MSRA/R-50`)
+is `load_c2_resnet`: blob names are translated to the torchvision-style names the reference maps them to, and the same
+suffix alignment then fills BOTH backbones (every `*.body.layer1.0.conv1.weight` ends with `layer1.0.conv1.weight`).
 """
 import os
+import pickle
+import re
 from collections import OrderedDict
 
 import torch
@@ -83,3 +86,66 @@ def save_checkpoint(path, state_dict, tag_last=True, **extras):
         with open(os.path.join(d, "last_checkpoint"), "w") as f:       # checkpoint.py:95-98
             f.write(path)
     return path
+
+
+_C2_BRANCH = {"branch2a": ("conv1", "bn1"), "branch2b": ("conv2", "bn2"), "branch2c": ("conv3", "bn3"),
+              "branch1": ("downsample.0", "downsample.1")}
+_C2_BLOB = re.compile(r"^res(\d)_(\d+)_(branch2a|branch2b|branch2c|branch1)(_bn)?_(w|s|b)$")
+
+
+def translate_c2_resnet_name(name):
+    """One Caffe2 ResNet blob name -> the name the reference gives it (utils/c2_model_loading.py:12-60: `res2_0_branch2a_w`
+    -> `layer1.0.conv1.weight`, `res_conv1_bn_s` -> `bn1.weight`, `res3_0_branch1_bn_b` -> `layer2.0.downsample.1.bias`,
+    ...; AffineChannel scale / bias become the FrozenBN weight / bias).  None for blobs the loader skips (momentum)."""
+    if name.endswith("_momentum"):
+        return None
+    if name == "conv1_w":
+        return "conv1.weight"
+    if name == "conv1_b":
+        return "conv1.bias"
+    if name in ("res_conv1_bn_s", "conv1_bn_s"):
+        return "bn1.weight"
+    if name in ("res_conv1_bn_b", "conv1_bn_b"):
+        return "bn1.bias"
+    if name in ("fc1000_w", "pred_w"):
+        return "fc1000.weight"
+    if name in ("fc1000_b", "pred_b"):
+        return "fc1000.bias"
+    m = _C2_BLOB.match(name)
+    if m is None:
+        return name.replace("_", ".")          # anything else keeps the reference's basic `_` -> `.` renaming
+    stage, block, branch, bn, kind = int(m.group(1)), int(m.group(2)), m.group(3), m.group(4), m.group(5)
+    conv, norm = _C2_BRANCH[branch]
+    if bn:
+        leaf = {"s": "weight", "b": "bias"}.get(kind)
+        if leaf is None:
+            return None
+        return "layer%d.%d.%s.%s" % (stage - 1, block, norm, leaf)
+    leaf = {"w": "weight", "b": "bias"}.get(kind)
+    return None if leaf is None else "layer%d.%d.%s.%s" % (stage - 1, block, conv, leaf)
+
+
+def load_c2_resnet(path, defaults, second_stage=None):
+    """A Detectron ResNet `.pkl` (dict of numpy blobs, optionally under "blobs"; pickled by Python 2: latin1) -> a full
+    state_dict: the ResNet bodies of BOTH backbones come from the file, every other entry (FrozenBN running statistics —
+    AffineChannel has none —, FPN, FCOS head, second stage) from `defaults`, as `DetectronCheckpointer.load` leaves the
+    model's own initialisation for what the file lacks."""
+    with open(path, "rb") as f:
+        data = pickle.load(f, encoding="latin1")
+    blobs = data["blobs"] if isinstance(data, dict) and "blobs" in data else data
+    loaded = OrderedDict()
+    for k in sorted(blobs.keys()):
+        name = translate_c2_resnet_name(k)
+        if name is not None:
+            loaded[name] = torch.as_tensor(blobs[k])
+    shapes = spec.hot_path_shapes()
+    if second_stage or (second_stage is None and all(k in defaults for k in spec.box_head_shapes())):
+        shapes.update(spec.box_head_shapes())
+    body = OrderedDict((k, v) for k, v in shapes.items() if ".body." in k and not k.endswith(("running_mean", "running_var")))
+    sd, missing = align_state_dict(body, loaded)
+    if missing:
+        raise KeyError("%s lacks %d ResNet entries, e.g. %s" % (path, len(missing), missing[:3]))
+    out = OrderedDict()
+    for k in shapes:
+        out[k] = sd[k] if k in sd else torch.as_tensor(defaults[k]).to(torch.float32).cpu()
+    return out

@@ -56,3 +56,53 @@ def test_first_stage_only_file_and_errors(tmp_path):
     torch.save({"model": bad}, p)
     with pytest.raises(ValueError):
         checkpoint.load_checkpoint(p)
+
+
+def _fake_c2_r50(rng):
+    """Blob names of a Detectron R-50.pkl (conv1 + AffineChannel, res2..res5 bottlenecks, fc1000, momentum blobs)."""
+    blobs = {"conv1_w": rng.randn(64, 3, 7, 7).astype(np.float32), "res_conv1_bn_s": rng.rand(64).astype(np.float32),
+             "res_conv1_bn_b": rng.randn(64).astype(np.float32), "fc1000_w": rng.randn(1000, 2048).astype(np.float32),
+             "fc1000_b": rng.randn(1000).astype(np.float32), "conv1_w_momentum": np.zeros((64, 3, 7, 7), np.float32)}
+    cin = 64
+    for si, nblocks in enumerate(spec.STAGE_BLOCKS):
+        mid, cout = 64 * 2 ** si, 256 * 2 ** si
+        for b in range(nblocks):
+            p = "res%d_%d_" % (si + 2, b)
+            if b == 0:
+                blobs[p + "branch1_w"] = rng.randn(cout, cin, 1, 1).astype(np.float32)
+                blobs[p + "branch1_bn_s"], blobs[p + "branch1_bn_b"] = rng.rand(cout).astype(np.float32), rng.randn(cout).astype(np.float32)
+            for br, (ci, co, k) in (("branch2a", (cin, mid, 1)), ("branch2b", (mid, mid, 3)), ("branch2c", (mid, cout, 1))):
+                blobs[p + br + "_w"] = rng.randn(co, ci, k, k).astype(np.float32)
+                blobs[p + br + "_bn_s"], blobs[p + br + "_bn_b"] = rng.rand(co).astype(np.float32), rng.randn(co).astype(np.float32)
+            cin = cout
+    return blobs
+
+
+def test_caffe2_resnet_pickle_fills_both_backbones(tmp_path):
+    """utils/c2_model_loading.py:12-175 + the suffix alignment: `res4_5_branch2b_w` lands in layer3.5.conv2 of BOTH
+    backbones, AffineChannel scale / bias become FrozenBN weight / bias, running statistics / FPN / head keep the
+    defaults, momentum blobs and fc1000 are ignored."""
+    import pickle
+    blobs = _fake_c2_r50(np.random.RandomState(0))
+    p = str(tmp_path / "R-50.pkl")
+    with open(p, "wb") as f:
+        pickle.dump({"blobs": blobs}, f, protocol=2)
+    defaults = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec.hot_path_shapes()).items()}
+    sd = checkpoint.load_c2_resnet(p, defaults)
+    assert list(sd.keys()) == list(spec.hot_path_shapes().keys())
+    for bb in ("backbone.", "supp_backbone."):
+        assert np.array_equal(sd[bb + "body.layer3.5.conv2.weight"].numpy(), blobs["res4_5_branch2b_w"])
+        assert np.array_equal(sd[bb + "body.stem.conv1.weight"].numpy(), blobs["conv1_w"])
+        assert np.array_equal(sd[bb + "body.stem.bn1.weight"].numpy(), blobs["res_conv1_bn_s"])
+        assert np.array_equal(sd[bb + "body.layer2.0.downsample.1.bias"].numpy(), blobs["res3_0_branch1_bn_b"])
+        assert np.array_equal(sd[bb + "body.layer4.2.bn3.weight"].numpy(), blobs["res5_2_branch2c_bn_s"])
+        assert torch.equal(sd[bb + "body.layer1.0.bn1.running_var"], defaults[bb + "body.layer1.0.bn1.running_var"])
+        assert torch.equal(sd[bb + "fpn.fpn_inner2.weight"], defaults[bb + "fpn.fpn_inner2.weight"])
+    assert torch.equal(sd["rpn.head.cls_logits.bias"], defaults["rpn.head.cls_logits.bias"])
+    assert checkpoint.translate_c2_resnet_name("res2_0_branch2a_w_momentum") is None
+    assert checkpoint.translate_c2_resnet_name("res5_1_branch2c_bn_b") == "layer4.1.bn3.bias"
+    del blobs["res3_1_branch2b_w"]
+    with open(p, "wb") as f:
+        pickle.dump(blobs, f, protocol=2)                      # bare dict, one blob missing
+    with pytest.raises(KeyError):
+        checkpoint.load_c2_resnet(p, defaults)
