@@ -530,3 +530,38 @@ def test_config5_multiscale_five_shot_training_steps():
         assert moved[lo:hi].any(), name
     assert moved.float().mean() > 0.5
     assert torch.isfinite(eng.flat_w).all()
+
+
+def test_image_without_ground_truth_and_empty_second_stage_inputs():
+    """Edge cases the synthetic benchmark never hits: a training batch in which one image has NO ground-truth box (all of
+    its locations are negatives: finite losses and gradients, the positives of the other image still counted), and the
+    second stage on zero valid proposals for one image (zero detections for it, the other image unaffected)."""
+    from oneshotdet_amd import model, train
+    B, H, W = 2, 128, 160
+    np_sd = synth.make_state_dict(spec.full_model_shapes())
+    hot = {k: v for k, v in np_sd.items() if k in spec.hot_path_shapes()}
+    eng = train.TrainEngine(hot, dtype=torch.float32)
+    img = torch.from_numpy(synth.make_images("e.img", B, H, W, seed=4)).cuda()
+    q = torch.from_numpy(synth.make_images("e.q", B, 63, 63, seed=4)).cuda()
+    gtb = torch.zeros(B, 2, 4)
+    gtb[0, 0] = torch.tensor([20.0, 30.0, 90.0, 100.0])
+    cnt = torch.tensor([1, 0], dtype=torch.int32)
+    losses = eng.forward_backward(img, q, gtb.cuda(), cnt.cuda()).cpu()
+    assert torch.isfinite(losses).all() and losses[3] > 0
+    assert torch.isfinite(eng.flat_g).all() and float(eng.flat_g.abs().sum()) > 0
+    torch.cuda.synchronize()
+    pb, ps, pc = eng.proposals
+    assert int(pc[1]) > 0 and float(ps[1, int(pc[1]) - 1]) < 1.0          # no ground-truth row appended for image 1
+    assert float(ps[0, int(pc[0]) - 1]) == 1.0                            # image 0 ends with its ground-truth box
+    # the same image alone gives the same number of positives
+    one = eng.forward_backward(img[:1], q[:1], gtb[:1].cuda(), cnt[:1].cuda()).cpu()
+    assert int(one[3]) == int(losses[3])
+    inf = model.HotPathEngine(np_sd, dtype=torch.float32)
+    out = inf.detect(img, q, cuda_nms=False)
+    boxes, counts = out["proposals"][0], out["proposals"][2].clone()
+    counts[1] = 0
+    det = inf.box_detect(out["features"], out["query_features"], (63, 63), boxes, counts, H, W, cuda_nms=False)
+    ref = inf.box_detect(out["features"], out["query_features"], (63, 63), boxes, out["proposals"][2], H, W, cuda_nms=False)
+    assert int(det["counts"][1]) == 0 and int(det["counts"][0]) == int(ref["counts"][0]) > 0
+    k = int(ref["counts"][0])
+    assert torch.equal(det["boxes"][0, :k], ref["boxes"][0, :k])
