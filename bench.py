@@ -378,6 +378,9 @@ def main_train(args, rank, world):
                 f.write("conv %s -> %d\n" % (k, a))
 
     launch = "eager, 6 streams (main chain, query/bbox branch, 2 x weight gradients, proposals, exchange + update)"
+    # the step's tail (last weight gradients, exchange, update, repack) overlaps the next step's frozen layers; an
+    # explicit device synchronisation brackets the timed region as always (OSD_NO_DEFER_JOIN=1: A/B switch)
+    eng.defer_join = not os.environ.get("OSD_NO_DEFER_JOIN")
     step = lambda: eng.train_step(images, queries, gt_boxes, gt_count)     # noqa: E731
     if args.graph:
         try:

@@ -68,6 +68,8 @@ class TrainEngine(object):
         self._overlap, self._fuse_update, self._updated = True, False, set()
         self._wq = None
         self._pred_grad_bufs = {}
+        self.defer_join = False       # opt-in: train_step leaves its tail on the side streams (see train_step / join)
+        self._deferred, self._defer_now, self._joined_refs = None, False, None
         self.repack()
         self.zero_bias = torch.zeros(4096, device=self.device, dtype=torch.float32)
         # SGD with the reference's parameter groups (solver/build.py:8-26: bias lr x2, bias weight decay 0)
@@ -262,7 +264,9 @@ class TrainEngine(object):
         return self.extra[name + ".weight"], self.extra[name + ".bias"]
 
     # ------------------------------------------------------------------------------------------------ forward
-    def backbone_forward(self, bb, images):
+    def backbone_forward(self, bb, images, after_frozen=None):
+        """after_frozen: called once the stem and layer1 (frozen: resnet.py:127-136) have been enqueued, before the first
+        layer that reads trainable weights."""
         cv, dt = self.convs, self.dtype
         n, _, h, w = images.shape
         ho, wo = ops.conv_out(h, 7, 2, 3), ops.conv_out(w, 7, 2, 3)
@@ -286,6 +290,8 @@ class TrainEngine(object):
                     blocks.append(dict(p=p, s=s, ds=has_ds, x=x, o1=o1, o2=o2, y=y, first=(si == 1 and bi == 0)))
                 x = y
             stage_out.append(x)
+            if si == 0 and after_frozen is not None:
+                after_frozen()
         c3, c4, c5 = stage_out[1], stage_out[2], stage_out[3]
         f = bb + "fpn."
         inner4 = ops.conv2d(c5, cv[f + "fpn_inner4"].pc)
@@ -548,11 +554,24 @@ class TrainEngine(object):
         """One training forward + backward.  images [B,3,H,W], queries [B*S,3,h,w] fp32 NCHW on the device;
         gt_boxes [B, G, 4] fp32 xyxy, gt_count [B] int32.  Returns losses [4] = (cls, reg, centerness, num_pos)."""
         from . import model
-        self._keep = []
-        self.flat_g.zero_()
-        self.exchange.begin()
         main, s1 = torch.cuda.current_stream(), self.s1
         side = s1 if s1 is not None else main
+        # train_step(defer_join) left the previous step's tail (last weight gradients, exchange, update, repack, proposals)
+        # running on the side streams: the frozen prefix of this forward goes first, then the main stream joins them
+        deferred, self._deferred = self._deferred, None
+        prev_keep, self._keep = self._keep, []
+
+        def join_previous():
+            if deferred is not None:
+                for ev in deferred["events"]:       # events recorded when the previous step returned: NOT the streams'
+                    main.wait_event(ev)             # current tails, which already hold this step's query branch
+            self.flat_g.zero_()
+            self.exchange.begin()
+        if deferred is None:
+            join_previous()
+        elif s1 is not None:
+            for ev in deferred["events"]:           # the query branch is off the critical path: it simply waits
+                s1.wait_event(ev)
         batch = images.shape[0]
         shots = queries.shape[0] // batch
         q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0]
@@ -566,7 +585,8 @@ class TrainEngine(object):
             for feat, scale in zip(qfeats, spec.POOLER_SCALES):
                 v = ops.roi_align(feat, rois, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
                 pooled.append(ops.shot_mean(v.view(v.shape[0], -1), batch))
-        feats, tctx = self.backbone_forward("backbone.", images)
+        feats, tctx = self.backbone_forward("backbone.", images, after_frozen=join_previous if deferred is not None else None)
+        prev_keep = deferred = self._joined_refs = None   # what the previous step's side work reads is released only now
         if s1 is not None:
             main.wait_stream(s1)
         combined = [ops.correlate(f, q) for f, q in zip(feats, pooled)]
@@ -599,6 +619,17 @@ class TrainEngine(object):
                 dQ.append(ops.cast_f32(gx, self.dtype))
             self.backbone_backward(qctx, dQ)
         self.backbone_backward(tctx, dP)
+        self._keep.append((dq, dP, d_comb, pred_grads))
+        if self._defer_now:
+            # leave the tail on the side streams; the next forward_backward (or join()) orders the main stream after them
+            events = []
+            for st in (s1, self.wstream, self.wstream2, self.pstream, self.ustream, self.exchange.comm):
+                if st is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    events.append(ev)
+            self._deferred = dict(events=events, refs=(qctx, tctx, hctx, feats, qfeats, pooled, combined, head_out, dQ, rois))
+            return losses
         if s1 is not None:
             main.wait_stream(s1)
         if self.wstream is not None:
@@ -607,8 +638,17 @@ class TrainEngine(object):
             main.wait_stream(self.wstream2)
         if with_proposals and self.pstream is not None and s1 is not None:
             main.wait_stream(self.pstream)
-        self._keep.append((dq, dP, d_comb, pred_grads))
         return losses
+
+    def join(self):
+        """Order the current stream after everything a deferred train_step left on the side streams (weight gradients,
+        exchange, update, repack, proposals).  Call before reading weights, gradients or proposals on this stream."""
+        d, self._deferred = self._deferred, None
+        if d is not None:
+            cur = torch.cuda.current_stream()
+            for ev in d["events"]:
+                cur.wait_event(ev)
+            self._joined_refs = d["refs"]          # dropped at the next step: the waits above are enqueued, not finished
 
     def reduce_gradients(self):
         """DDP gradient averaging (tools/train_net.py:83-88).  The buckets of the flat fp32 buffer were handed to RCCL as
@@ -671,10 +711,20 @@ class TrainEngine(object):
         """forward + loss + backward + gradient averaging + SGD + repack.  With the fused optimiser each bucket's exchange,
         update and repack run on a side stream as soon as the bucket is final, beside the rest of the backward pass."""
         self._fuse_update = self.opt is None and self._overlap
+        # defer_join: do not make the main stream wait for the step's tail (the last stage's weight gradients, their
+        # exchange, update and repack): the next step's frozen layers (stem, layer1) run beside it.  Every bucket's update
+        # already sits on the update / communication stream in fused mode, so nothing is left to enqueue here
+        self._defer_now = bool(self.defer_join and self._fuse_update and self.s1 is not None and self.wstream is not None)
         try:
             losses = self.forward_backward(images, queries, gt_boxes, gt_count)
         finally:
             self._fuse_update = False
+            deferred_step, self._defer_now = self._defer_now, False
+        if deferred_step and all(name in self._updated for name in self.exchange.ranges):
+            self._updated = set()
+            self._sgd["steps"] += 1
+            return losses
+        self.join()
         self.reduce_gradients()
         self.optimizer_step()
         return losses
@@ -714,6 +764,7 @@ class TrainEngine(object):
         """The reference's state_dict (same names, OIHW shapes) with the current fp32 master weights: what
         `DetectronCheckpointer.save` (utils/checkpoint.py:35-52) would write for the hot-path modules.  Frozen tensors
         (stem, layer1, every FrozenBN buffer) are returned unchanged."""
+        self.join()
         out = {k: v.clone() for k, v in self._frozen_sd.items()}
         h = "rpn.head."
         for name, c in self.convs.items():

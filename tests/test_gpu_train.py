@@ -565,3 +565,42 @@ def test_image_without_ground_truth_and_empty_second_stage_inputs():
     assert int(det["counts"][1]) == 0 and int(det["counts"][0]) == int(ref["counts"][0]) > 0
     k = int(ref["counts"][0])
     assert torch.equal(det["boxes"][0, :k], ref["boxes"][0, :k])
+
+
+def test_deferred_join_matches_joined_steps():
+    """train_step(defer_join=True) leaves the step's tail (last weight gradients, update, repack, proposals) on the side
+    streams and lets the next step's frozen layers run beside it.  Same data, same steps: the losses of every step and the
+    weights after four steps equal those of the joined engine (fp32; the atomics' order is the only difference), the
+    state_dict() / join() accessors see finished work, and a changing input shape between steps is handled."""
+    from oneshotdet_amd import train
+    np_sd = synth.make_state_dict(spec.hot_path_shapes())
+    B = 2
+    q = torch.from_numpy(synth.make_images("dj.q", B, 63, 63, seed=1)).cuda()
+    sizes = [(128, 160), (128, 160), (96, 128), (128, 160)]
+    batches = []
+    for step, (h, w) in enumerate(sizes):
+        img = torch.from_numpy(synth.make_images("dj.img.%d" % step, B, h, w, seed=step)).cuda()
+        gts = synth.make_gt_boxes(B, h, w, seed=40 + step, max_boxes=3)
+        G = max(len(g) for g in gts)
+        gtb = torch.zeros(B, G, 4)
+        for i, g in enumerate(gts):
+            gtb[i, :len(g)] = torch.from_numpy(g)
+        batches.append((img, gtb.cuda(), torch.tensor([len(g) for g in gts], dtype=torch.int32).cuda()))
+    results = {}
+    for mode in (False, True):
+        eng = train.TrainEngine(np_sd, dtype=torch.float32, lr=0.002)
+        eng.defer_join = mode
+        losses = [eng.train_step(img, q, gtb, cnt) for img, gtb, cnt in batches]
+        if mode:
+            assert eng._deferred is not None              # the last step's tail is still un-joined on this stream
+        sd = eng.state_dict()                              # joins
+        assert eng._deferred is None
+        torch.cuda.synchronize()
+        results[mode] = (torch.stack(losses).cpu(), eng.flat_w.clone().cpu(), sd["rpn.head.cls_tower.0.weight"].cpu())
+        pb, ps, pc = eng.proposals
+        assert int(pc.min()) > 0
+    la, wa, _ = results[False]
+    lb, wb, ta = results[True]
+    np.testing.assert_allclose(lb.numpy(), la.numpy(), rtol=2e-3, atol=1e-6)      # run-to-run spread of one mode: ~5e-5
+    assert float((wb - wa).norm() / wa.norm()) < 1e-4
+    assert torch.isfinite(ta).all()
