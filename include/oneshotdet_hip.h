@@ -188,6 +188,17 @@ int osd_nms_sorted(const float* boxes_sorted, const float* scores_sorted, const 
                    float thresh, int cuda_semantics, int max_keep, uint64_t* mask_ws, float* out_boxes,
                    float* out_scores, int32_t* out_pos, int32_t* out_count, void* stream);
 int64_t osd_nms_workspace_bytes(int n, int max_count);
+/* osd_rank_sort_gather + osd_nms_sorted in one call that sorts only the HEAD of the order: greedy NMS stopping at max_keep
+ * survivors almost never reads past the first 1.25 * max_keep candidates, while ranking all `total` candidates against
+ * each other is O(total^2).  A per-image score threshold (two-level histogram) selects at least 1.25 * max_keep + 320
+ * candidates, only those are ranked (exactly: whatever precedes a selected candidate is selected too), NMS runs on them,
+ * and images that could not fill max_keep from the head are redone on the full order (launched unconditionally, exits at
+ * once otherwise: no host round trip).  Same outputs as the two separate calls: out_boxes [n][max_keep][4], out_scores
+ * [n][max_keep] (descending), out_count [n].  workspace: osd_proposals_workspace_bytes(n, total, max_count, max_keep). */
+int osd_proposals_sort_nms(const float* keys, const float* boxes, int n, int total, int max_count, const int32_t* level_lo,
+                           const int32_t* level_cnt, int n_levels, int topn, float thresh, int cuda_semantics, int max_keep,
+                           void* workspace, float* out_boxes, float* out_scores, int32_t* out_count, void* stream);
+int64_t osd_proposals_workspace_bytes(int n, int total, int max_count, int max_keep);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Sigmoid focal loss.  Replaces _C.sigmoid_focalloss_forward/backward (csrc/SigmoidFocalLoss.h;

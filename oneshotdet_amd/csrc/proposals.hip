@@ -87,9 +87,10 @@ __global__ void __launch_bounds__(256) rank_sort_gather_kernel(const float* __re
                                                                int total, int max_count, int topn, LevelTable lt,
                                                                float* __restrict__ boxes_sorted,
                                                                float* __restrict__ scores_sorted, int* __restrict__ idx_sorted,
-                                                               int* __restrict__ counts) {
+                                                               int* __restrict__ counts, const int* __restrict__ need = nullptr) {
   __shared__ __attribute__((aligned(16))) unsigned tile[1024];
   const int img = blockIdx.y;
+  if (need && !need[img]) return;        // second phase of osd_proposals_sort_nms: only images whose head of the order did not suffice
   const float* k = keys + (size_t)img * total;
   const int i0 = blockIdx.x * blockDim.x;
   const int i = i0 + threadIdx.x;
@@ -146,6 +147,209 @@ __global__ void __launch_bounds__(256) rank_sort_gather_kernel(const float* __re
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(counts + img, __popcll(b));
 }
 
+// ---- head of the order only ------------------------------------------------------------------------------------------
+// Greedy NMS that stops at max_keep survivors reads the candidates in score order and almost never gets past the first
+// 1.25 * max_keep of them, yet ranking all n candidates against each other is O(n^2) (n = 17,064: 2.3e9 compares per
+// batch of 8, the largest non-conv cost of a training step).  So: (1) a score threshold tau[img] is found by a two-level
+// histogram such that at least `want` live candidates have key >= tau; they are compacted in index order (so every FPN
+// level stays one contiguous run), (2) only those are ranked, against each other — every candidate that precedes a
+// selected one is selected too, so c_l, the per-level cut and the positions are EXACT for them, (3) NMS runs on that
+// head; if it cannot fill max_keep from it, the image is flagged and the full O(n^2) sort + the second NMS phase run for
+// it (launched unconditionally, exiting at once for unflagged images: no host round trip).
+struct SelMeta {            // per image, in device memory
+  int m;                    // selected candidates
+  int full_count;           // what osd_rank_sort_gather would report: min(sum_l min(live_l, topn), max_count)
+  int slot_lo[8];           // first slot of each level in the compacted list
+  int slot_cnt[8];
+};
+
+__global__ void __launch_bounds__(1024) select_head_kernel(const float* __restrict__ keys, int total, int max_count, int topn,
+                                                           LevelTable lt, int want, unsigned* __restrict__ keys_sel,
+                                                           int* __restrict__ idx_sel, SelMeta* __restrict__ meta) {
+  __shared__ int hist[2048];
+  __shared__ int s_scan[1024];
+  __shared__ int s_lvl_live[8], s_lvl_sel[8];
+  __shared__ unsigned s_tau;
+  __shared__ int s_b1, s_need2;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const float* k = keys + (size_t)img * total;
+  auto level_of = [&](int i) {
+    int l = 0;
+    for (int t = 1; t < lt.n_levels; ++t) l += (i >= lt.lo[t]);
+    return l;
+  };
+  // ---- level 1: 2048 buckets on the top bits of the key
+  for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+  if (tid < 8) { s_lvl_live[tid] = 0; s_lvl_sel[tid] = 0; }
+  __syncthreads();
+  for (int i = tid; i < total; i += 1024) {
+    const unsigned key = key32(k[i]);
+    if (key) {
+      atomicAdd(&hist[min(key >> 19, 2047u)], 1);
+      atomicAdd(&s_lvl_live[level_of(i)], 1);
+    }
+  }
+  __syncthreads();
+  // suffix counts: thread t owns buckets 2t, 2t+1; inclusive suffix sum over threads by a Hillis-Steele pass in LDS
+  const int h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+  s_scan[tid] = h0 + h1;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = tid + d < 1024 ? s_scan[tid + d] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  const int suf_pair = s_scan[tid];                 // live keys in buckets >= 2t
+  const int live = s_scan[0];
+  if (tid == 0) { s_b1 = -1; s_need2 = 0; s_tau = 1u; }
+  __syncthreads();
+  if (live > want) {
+    // the highest bucket b with suffix(b) >= want
+    const int suf1 = suf_pair - h0;                 // buckets >= 2t+1
+    const int above_pair = suf_pair - h0 - h1;      // buckets >= 2t+2
+    if (suf1 >= want && above_pair < want) { s_b1 = 2 * tid + 1; s_need2 = want - above_pair; }
+    else if (suf_pair >= want && suf1 < want) { s_b1 = 2 * tid; s_need2 = want - suf1; }
+  }
+  __syncthreads();
+  const int b1 = s_b1;
+  if (b1 >= 0) {
+    // ---- level 2: the next 11 bits inside bucket b1
+    for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < total; i += 1024) {
+      const unsigned key = key32(k[i]);
+      if (key && (int)min(key >> 19, 2047u) == b1) atomicAdd(&hist[(key >> 8) & 2047u], 1);
+    }
+    __syncthreads();
+    const int g0 = hist[2 * tid], g1 = hist[2 * tid + 1];
+    s_scan[tid] = g0 + g1;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const int v = tid + d < 1024 ? s_scan[tid + d] : 0;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    const int sp = s_scan[tid], need2 = s_need2;
+    const int sp1 = sp - g0, spa = sp - g0 - g1;
+    // keys clamped into bucket 2047 (scores above 1) are not resolved further: the whole bucket is taken
+    if (b1 == 2047) { if (tid == 0) s_tau = 2047u << 19; }
+    else if (sp1 >= need2 && spa < need2) s_tau = ((unsigned)b1 << 19) | ((unsigned)(2 * tid + 1) << 8);
+    else if (sp >= need2 && sp1 < need2) s_tau = ((unsigned)b1 << 19) | ((unsigned)(2 * tid) << 8);
+  }
+  __syncthreads();
+  const unsigned tau = s_tau;                       // selected <=> key >= tau (tau = 1: every live candidate)
+  // ---- compaction in index order: thread t owns a contiguous chunk
+  const int per = (total + 1023) / 1024;
+  const int c0 = min(total, tid * per), c1 = min(total, c0 + per);
+  int mine = 0;
+  for (int i = c0; i < c1; ++i) mine += key32(k[i]) >= tau ? 1 : 0;
+  s_scan[tid] = mine;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {              // inclusive prefix sum
+    const int v = tid >= d ? s_scan[tid - d] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  int slot = s_scan[tid] - mine;
+  const int m = s_scan[1023];
+  unsigned* ks = keys_sel + (size_t)img * total;
+  int* is = idx_sel + (size_t)img * total;
+  for (int i = c0; i < c1; ++i) {
+    const unsigned key = key32(k[i]);
+    if (key >= tau) {
+      ks[slot] = key;
+      is[slot] = i;
+      ++slot;
+      atomicAdd(&s_lvl_sel[level_of(i)], 1);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    SelMeta mt;
+    mt.m = m;
+    int full = 0, lo = 0;
+    for (int l = 0; l < 8; ++l) {
+      const bool on = l < lt.n_levels;
+      mt.slot_lo[l] = lo;
+      mt.slot_cnt[l] = on ? s_lvl_sel[l] : 0;
+      lo += mt.slot_cnt[l];
+      if (on) full += min(s_lvl_live[l], topn);
+    }
+    mt.full_count = min(full, max_count);
+    meta[img] = mt;
+  }
+}
+
+// rank_sort_gather_kernel on the compacted head: slots play the role of indices (same order), the level table and the
+// element count come from device memory.  valid[img] = number of positions written = length of the exactly sorted head.
+__global__ void __launch_bounds__(256) rank_head_kernel(const unsigned* __restrict__ keys_sel, const int* __restrict__ idx_sel,
+                                                        const SelMeta* __restrict__ meta, const float* __restrict__ keys,
+                                                        const float* __restrict__ boxes, int total, int max_count, int topn,
+                                                        int n_levels, float* __restrict__ boxes_sorted,
+                                                        float* __restrict__ scores_sorted, int* __restrict__ idx_sorted,
+                                                        int* __restrict__ valid) {
+  __shared__ __attribute__((aligned(16))) unsigned tile[1024];
+  const int img = blockIdx.y;
+  const int m = meta[img].m;
+  const int i0 = blockIdx.x * blockDim.x;
+  if (i0 >= m) return;
+  const unsigned* ks = keys_sel + (size_t)img * total;
+  const int i = i0 + threadIdx.x;
+  const unsigned mine = i < m ? ks[i] : 0u;
+  int rank = 0, own_before = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const int lo = meta[img].slot_lo[l], cnt = meta[img].slot_cnt[l];
+    int c = 0;
+    for (int j0 = 0; j0 < cnt; j0 += 1024) {
+      const int mm = min(1024, cnt - j0);
+      const int g0 = lo + j0;
+      const bool all_before = g0 + mm <= i0;
+      const bool all_after = g0 >= i0 + (int)blockDim.x;
+      __syncthreads();
+      for (int t = threadIdx.x; t < 1024; t += blockDim.x) tile[t] = t < mm ? ks[g0 + t] : 0u;
+      __syncthreads();
+      if (all_after) {
+#pragma unroll 8
+        for (int t = 0; t < 1024; t += 4) {
+          const uint4 q = *reinterpret_cast<const uint4*>(&tile[t]);
+          c += (q.x > mine) + (q.y > mine) + (q.z > mine) + (q.w > mine);
+        }
+      } else if (all_before) {
+#pragma unroll 8
+        for (int t = 0; t < 1024; t += 4) {
+          const uint4 q = *reinterpret_cast<const uint4*>(&tile[t]);
+          c += (q.x >= mine) + (q.y >= mine) + (q.z >= mine) + (q.w >= mine);
+        }
+      } else {
+        for (int t = 0; t < mm; ++t) {
+          const unsigned q = tile[t];
+          c += (q > mine) || (q == mine && g0 + t < i);
+        }
+      }
+    }
+    if (i >= lo && i < lo + cnt) own_before = c;
+    rank += min(c, topn);
+  }
+  const bool live = (i < m) && (own_before < topn) && (rank < max_count);
+  if (live) {
+    const int src = idx_sel[(size_t)img * total + i];
+    const size_t o = (size_t)img * max_count + rank;
+    *reinterpret_cast<float4*>(boxes_sorted + o * 4) = *reinterpret_cast<const float4*>(boxes + ((size_t)img * total + src) * 4);
+    scores_sorted[o] = keys[(size_t)img * total + src];
+    idx_sorted[o] = src;
+  }
+  const unsigned long long b = __ballot(live);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(valid + img, __popcll(b));
+}
+
+__global__ void meta_counts_kernel(const SelMeta* __restrict__ meta, int* __restrict__ counts, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) counts[i] = meta[i].full_count;
+}
+
 // ---- IoU bitmask, "+1" areas (csrc/cuda/nms.cu:13-21).  One wavefront = one 64-box row block x one column block ----
 __device__ __forceinline__ float iou_plus1(const float4 a, const float4 b) {
   const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
@@ -198,7 +402,8 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
                                                        int max_keep, const unsigned long long* __restrict__ mask,
                                                        float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                                        int* __restrict__ out_pos, int* __restrict__ out_count, int limit,
-                                                       int* __restrict__ need_full, int phase) {
+                                                       int* __restrict__ need_full, int phase,
+                                                       const int* __restrict__ counts_full = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* remv = reinterpret_cast<unsigned long long*>(smem);   // [col_blocks]
   __shared__ unsigned long long s_keep;
@@ -275,7 +480,8 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
     out_count[img] = s_kept[blk & 1];
     // phase 1 looked at the first `limit` candidates only: if that did not yield max_keep survivors and there are
     // more candidates, the full problem is redone by the (otherwise idle) phase-2 launches
-    if (phase == 1) need_full[img] = (s_kept[blk & 1] < max_keep && n_all > limit) ? 1 : 0;
+    // (counts_full: `counts` only covers the part of the order that has been sorted so far, the candidates go on)
+    if (phase == 1) need_full[img] = (s_kept[blk & 1] < max_keep && (counts_full ? counts_full[img] : n_all) > n) ? 1 : 0;
   }
 }
 
@@ -387,3 +593,98 @@ extern "C" int osd_nms_sorted(const float* boxes_sorted, const float* scores_sor
                      counts, max_count, col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, max_count, need_full, 2);
   return osd_check_launch("nms_scan(full)");
 }
+
+// ---- per-level top-k + order + NMS in one call, sorting only the head of the order (see select_head_kernel) ----
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" int64_t osd_proposals_workspace_bytes(int n, int total, int max_count, int max_keep) {
+  size_t b = 0;
+  b += align256((size_t)n * total * 4) * 2;                 // keys_sel, idx_sel
+  b += align256((size_t)n * max_count * 16);                // boxes_sorted
+  b += align256((size_t)n * max_count * 4) * 2;             // scores_sorted, idx_sorted
+  b += align256((size_t)n * sizeof(SelMeta));
+  b += align256((size_t)n * 4) * 3;                         // valid, counts, counts2
+  b += align256((size_t)n * (max_keep > 0 ? max_keep : 1) * 4);   // positions of the kept boxes in the order (scratch)
+  return (int64_t)b + osd_nms_workspace_bytes(n, max_count);
+}
+
+extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int n, int total, int max_count,
+                                      const int32_t* level_lo, const int32_t* level_cnt, int n_levels, int topn, float thresh,
+                                      int cuda_semantics, int max_keep, void* workspace, float* out_boxes, float* out_scores,
+                                      int32_t* out_count, void* stream) {
+  if (!keys || !boxes || !workspace || !out_boxes || !out_scores || !out_count)
+    return osd_fail(OSD_ERR_INVALID_ARG, "proposals_sort_nms: null argument");
+  if (n == 0) return OSD_OK;
+  if (total == 0 || max_count == 0) {
+    hipError_t e0 = hipMemsetAsync(out_count, 0, sizeof(int32_t) * n, OSD_STREAM(stream));
+    return e0 == hipSuccess ? OSD_OK : osd_fail(OSD_ERR_LAUNCH, "proposals_sort_nms: memset failed");
+  }
+  LevelTable lt;
+  if (n_levels <= 0 || !level_lo || !level_cnt) {
+    lt.n_levels = 1; lt.lo[0] = 0; lt.cnt[0] = total; topn = total;
+  } else {
+    if (n_levels > 8) return osd_fail(OSD_ERR_UNSUPPORTED, "proposals_sort_nms: at most 8 levels");
+    lt.n_levels = n_levels;
+    int expect = 0;
+    for (int l = 0; l < n_levels; ++l) {
+      lt.lo[l] = level_lo[l]; lt.cnt[l] = level_cnt[l];
+      if (level_lo[l] != expect) return osd_fail(OSD_ERR_INVALID_ARG, "proposals_sort_nms: levels must tile [0,total)");
+      expect += level_cnt[l];
+    }
+    if (expect != total) return osd_fail(OSD_ERR_INVALID_ARG, "proposals_sort_nms: levels must tile [0,total)");
+  }
+  for (int l = lt.n_levels; l < 8; ++l) { lt.lo[l] = total; lt.cnt[l] = 0; }
+  const int col_blocks = cdiv(max_count, 64);
+  if ((size_t)col_blocks * 8 > 60000) return osd_fail(OSD_ERR_UNSUPPORTED, "proposals_sort_nms: max_count %d too large", max_count);
+  char* w = reinterpret_cast<char*>(workspace);
+  unsigned* keys_sel = reinterpret_cast<unsigned*>(w); w += align256((size_t)n * total * 4);
+  int* idx_sel = reinterpret_cast<int*>(w); w += align256((size_t)n * total * 4);
+  float* boxes_sorted = reinterpret_cast<float*>(w); w += align256((size_t)n * max_count * 16);
+  float* scores_sorted = reinterpret_cast<float*>(w); w += align256((size_t)n * max_count * 4);
+  int* idx_sorted = reinterpret_cast<int*>(w); w += align256((size_t)n * max_count * 4);
+  SelMeta* meta = reinterpret_cast<SelMeta*>(w); w += align256((size_t)n * sizeof(SelMeta));
+  int* valid = reinterpret_cast<int*>(w); w += align256((size_t)n * 4);
+  int* counts = reinterpret_cast<int*>(w); w += align256((size_t)n * 4);
+  int* counts2 = reinterpret_cast<int*>(w); w += align256((size_t)n * 4);
+  int* out_pos = reinterpret_cast<int*>(w); w += align256((size_t)n * (max_keep > 0 ? max_keep : 1) * 4);
+  uint64_t* mask_ws = reinterpret_cast<uint64_t*>(w);
+  hipStream_t st = OSD_STREAM(stream);
+  if (hipMemsetAsync(valid, 0, align256((size_t)n * 4) * 3, st) != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "proposals_sort_nms: memset failed");
+  int limit = cdiv(max_keep * 5 / 4 + 64, 64) * 64;
+  if (limit > max_count) limit = max_count;
+  const int want = limit + 256;
+  hipLaunchKernelGGL(select_head_kernel, dim3(n), dim3(1024), 0, st, keys, total, max_count, topn, lt, want, keys_sel, idx_sel, meta);
+  int rc = osd_check_launch("select_head");
+  if (rc) return rc;
+  hipLaunchKernelGGL(rank_head_kernel, dim3(cdiv(total, 256), n), dim3(256), 0, st, keys_sel, idx_sel, meta, keys, boxes, total,
+                     max_count, topn, lt.n_levels, boxes_sorted, scores_sorted, idx_sorted, valid);
+  rc = osd_check_launch("rank_head");
+  if (rc) return rc;
+  hipLaunchKernelGGL(meta_counts_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, meta, counts, n);
+  int* need_full = reinterpret_cast<int*>(mask_ws);
+  unsigned long long* mk = reinterpret_cast<unsigned long long*>(mask_ws) + cdiv(n, 2) + 8;
+  const int lim_blocks = cdiv(limit, 64);
+  // phase 1: the exactly sorted head (valid[img] candidates), at most `limit` of them
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(min(lim_blocks * lim_blocks, 4096), n), dim3(64), 0, st, boxes_sorted, valid, max_count,
+                     col_blocks, thresh, cuda_semantics, mk, limit, (const int*)nullptr);
+  rc = osd_check_launch("nms_mask");
+  if (rc) return rc;
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8, st, boxes_sorted, scores_sorted, valid, max_count,
+                     col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, limit, need_full, 1, (const int*)counts);
+  rc = osd_check_launch("nms_scan");
+  if (rc || limit >= max_count) return rc;
+  // phase 2, flagged images only: the whole order, then NMS over all of it
+  hipLaunchKernelGGL(rank_sort_gather_kernel, dim3(cdiv(total, 256), n), dim3(256), 0, st, keys, boxes, total, max_count, topn, lt,
+                     boxes_sorted, scores_sorted, idx_sorted, counts2, (const int*)need_full);
+  rc = osd_check_launch("rank_sort_gather(full)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(min(col_blocks * col_blocks, 4096), n), dim3(64), 0, st, boxes_sorted, counts, max_count,
+                     col_blocks, thresh, cuda_semantics, mk, max_count, (const int*)need_full);
+  rc = osd_check_launch("nms_mask(full)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8, st, boxes_sorted, scores_sorted, counts, max_count,
+                     col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, max_count, need_full, 2,
+                     (const int*)nullptr);
+  return osd_check_launch("nms_scan(full)");
+}
+

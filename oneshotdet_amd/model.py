@@ -7,6 +7,8 @@ Mirrors, function for function, the reference call stack of SURVEY.md §3.1:
     rpn = FCOSModule: FCOSHead + FCOSPostProcessor               (modeling/rpn/fcos/fcos.py, inference.py)
 All tensors between kernels are NHWC; state_dict names and OIHW shapes are the reference's (oneshotdet_amd/spec.py).
 """
+import os
+
 import torch
 
 from . import ops, spec
@@ -187,10 +189,13 @@ def run_proposals(head_out, img_h, img_w, pre_nms_top_n, post_nms_top_n, nms_thr
         off += cls_ctr.shape[1] * cls_ctr.shape[2]
     levels = [(lo, h * w) for (h, w), lo in zip(sizes, offs)]
     max_count = sum(min(c, pre_nms_top_n) for _, c in levels)
-    bs, ss, idx, cnt = ops.rank_sort_gather(scores, boxes, max_count, levels, pre_nms_top_n)
-    ob, os_, op, oc = ops.nms_sorted(bs, ss, cnt, nms_thresh, post_nms_top_n, cuda_semantics=cuda_nms,
-                                     workspace=workspace)
-    return ob, os_, oc
+    if os.environ.get("OSD_PROPOSALS_FULL_SORT"):      # A/B: rank all candidates (two separate calls)
+        bs, ss, idx, cnt = ops.rank_sort_gather(scores, boxes, max_count, levels, pre_nms_top_n)
+        ob, os_, op, oc = ops.nms_sorted(bs, ss, cnt, nms_thresh, post_nms_top_n, cuda_semantics=cuda_nms,
+                                         workspace=workspace)
+        return ob, os_, oc
+    return ops.proposals_sort_nms(scores, boxes, max_count, levels, pre_nms_top_n, nms_thresh, post_nms_top_n,
+                                  cuda_semantics=cuda_nms)
 
 
 class HotPathEngine(object):

@@ -870,3 +870,26 @@ def append_gt_boxes(boxes, scores, counts, gt_boxes, gt_count):
     _lib.call("osd_append_gt_boxes", _ptr(boxes.contiguous()), _ptr(scores.contiguous()), _ptr(counts),
               _ptr(gt_boxes.contiguous().float()), _ptr(gt_count), _ptr(ob), _ptr(os_), _ptr(oc), n, cap, g, _stream())
     return ob, os_, oc
+
+
+def proposals_sort_nms(keys, boxes, max_count, levels, topn, thresh, max_keep, cuda_semantics=False, workspace=None):
+    """rank_sort_gather + nms_sorted in one call that ranks only the head of the score order (osd_proposals_sort_nms).
+    keys [N,T] fp32 (dropped = -1), boxes [N,T,4] -> boxes [N,max_keep,4], scores [N,max_keep] (descending), counts [N]."""
+    _chk_dev(keys, boxes)
+    n, total = keys.shape
+    dev = keys.device
+    need = _lib.load().osd_proposals_workspace_bytes(n, total, max_count, max_keep)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((max(need, 8) // 8 + 1,), device=dev, dtype=torch.int64)
+    ob = torch.zeros((n, max_keep, 4), device=dev, dtype=torch.float32)
+    os_ = torch.zeros((n, max_keep), device=dev, dtype=torch.float32)
+    oc = torch.empty((n,), device=dev, dtype=torch.int32)
+    if levels:
+        lo = (C.c_int32 * len(levels))(*[l for l, _ in levels])
+        lc = (C.c_int32 * len(levels))(*[c for _, c in levels])
+        nl = len(levels)
+    else:
+        lo, lc, nl = None, None, 0
+    _lib.call("osd_proposals_sort_nms", _ptr(keys), _ptr(boxes), n, total, max_count, lo, lc, nl, int(topn), float(thresh),
+              int(cuda_semantics), max_keep, _ptr(workspace), _ptr(ob), _ptr(os_), _ptr(oc), _stream())
+    return ob, os_, oc

@@ -206,3 +206,48 @@ def test_rank_sort_gather_against_a_plain_sort(case):
         np.testing.assert_array_equal(idx[i, :k].cpu().numpy(), want)
         np.testing.assert_array_equal(ss[i, :k].cpu().numpy(), scores[i, want])
         np.testing.assert_array_equal(bs[i, :k].cpu().numpy(), boxes[i, want])
+
+
+@pytest.mark.parametrize("case", ["fcos_test", "fcos_train", "needs_full_order", "tiny", "ties"])
+def test_proposals_sort_nms_equals_the_two_call_pipeline(case):
+    """osd_proposals_sort_nms (ranks only the head of the score order, falls back to the full order per image when NMS
+    cannot fill max_keep from it) against osd_rank_sort_gather + osd_nms_sorted: identical boxes, scores and counts.
+    `needs_full_order`: boxes that nearly all overlap, so NMS exhausts the head and the second phase must run; `ties`:
+    quantised scores (the threshold falls inside a run of equal keys); `tiny`: fewer candidates than the head."""
+    from oneshotdet_amd import ops
+    rng = np.random.RandomState(3)
+    if case in ("fcos_test", "fcos_train", "needs_full_order", "ties"):
+        levels = [(0, 12800), (12800, 3200), (16000, 800), (16800, 208), (17008, 56)]
+        topn, max_keep = (12000, 4000) if case == "fcos_train" else (6000, 2000)
+        n_img = 2
+    else:
+        levels, topn, max_keep, n_img = [(0, 300), (300, 100)], 250, 200, 3
+    total = levels[-1][0] + levels[-1][1]
+    scores = (rng.rand(n_img, total).astype(np.float32) ** 4) * 0.9 + 1e-4
+    if case == "ties":
+        scores = np.round(scores * 200) / 200
+    scores[:, ::23] = -1.0
+    ctr = rng.rand(n_img, total, 2).astype(np.float32) * np.array([1000.0, 780.0], np.float32)
+    wh = rng.rand(n_img, total, 2).astype(np.float32) * 90 + 10
+    if case == "needs_full_order":      # a few heavily overlapping clusters: NMS keeps very few boxes of the head
+        ctr = (ctr // 250) * 250 + rng.rand(n_img, total, 2).astype(np.float32) * 6
+        wh = np.full_like(wh, 200.0) + rng.rand(n_img, total, 2).astype(np.float32) * 4
+        ctr[:, -3000:] = rng.rand(n_img, 3000, 2).astype(np.float32) * np.array([1000.0, 780.0], np.float32)   # low-score loners
+        wh[:, -3000:] = 12.0
+        scores[:, -3000:] = np.abs(scores[:, -3000:]) * 1e-3 + 1e-6
+    boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], -1).astype(np.float32)
+    max_count = sum(min(c, topn) for _, c in levels)
+    k, b = torch.from_numpy(scores).cuda(), torch.from_numpy(boxes).cuda()
+    for rule in (False, True):
+        bs, ss, idx, cnt = ops.rank_sort_gather(k, b, max_count, levels, topn)
+        rb, rs, _, rc = ops.nms_sorted(bs, ss, cnt, 0.8 if case != "needs_full_order" else 0.5, max_keep, cuda_semantics=rule)
+        ob, os_, oc = ops.proposals_sort_nms(k, b, max_count, levels, topn, 0.8 if case != "needs_full_order" else 0.5,
+                                             max_keep, cuda_semantics=rule)
+        assert torch.equal(oc, rc), (case, oc.tolist(), rc.tolist())
+        for i in range(n_img):
+            c = int(rc[i])
+            assert torch.equal(ob[i, :c], rb[i, :c]) and torch.equal(os_[i, :c], rs[i, :c]), (case, i)
+    if case == "needs_full_order":      # the head (2564 candidates) did not fill max_keep: the second phase really ran
+        hb, hs, _, hc = ops.nms_sorted(bs[:, :2564].contiguous(), ss[:, :2564].contiguous(), cnt.clamp(max=2564), 0.5, max_keep,
+                                       cuda_semantics=True)
+        assert int(hc.max()) < int(rc.min())
