@@ -253,6 +253,17 @@ def test_gradient_buckets_cover_the_flat_buffer_and_overlapped_exchange_runs():
             torch.cuda.synchronize()
             assert torch.equal(losses, ref_losses)
             torch.testing.assert_close(eng.flat_g, ref_grads, rtol=1e-3, atol=1e-5)   # atomics: order-dependent last bits
+        # full steps over RCCL with the tail left un-joined (bench.py's mode): exchange, update and repack of every bucket
+        # ride the communication stream, the next step joins on the events; weights stay finite and keep moving
+        eng.defer_join = True
+        w0 = eng.flat_w.clone()
+        for _ in range(3):
+            out = eng.train_step(img, q, gtb, cnt)
+        assert eng._deferred is not None
+        eng.join()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all() and torch.isfinite(eng.flat_w).all() and not torch.equal(eng.flat_w, w0)
+        assert eng._sgd["steps"] == 3
     finally:
         dist.destroy_process_group()
 
