@@ -10,6 +10,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 B = 8
 sd = synth.make_state_dict(spec.hot_path_shapes())
 eng = train.TrainEngine(sd, dtype=torch.bfloat16, lr=0.0005)
+eng.defer_join = not os.environ.get("OSD_NO_DEFER_JOIN")        # bench.py's mode: the step's tail is joined by the next step
 ref = train.TrainEngine(sd, dtype=torch.bfloat16, lr=0.0005)
 images = torch.from_numpy(synth.make_images("bench.target", B, 800, 1024, seed=1000)).cuda()
 queries = torch.from_numpy(synth.make_images("bench.query", B, 127, 127, seed=1000)).cuda()
@@ -30,6 +31,7 @@ for it in range(steps):
         l = losses.cpu().numpy()
         assert np.isfinite(l).all(), (it, l)
         first = l[:3].sum() if first is None else first
+        eng.join()                                                # the update / repack of the last buckets may still be in flight
         ref.flat_w.copy_(eng.flat_w)
         ref.repack()
         ga = eng.forward_backward(images, queries, gt_boxes, gt_count)
