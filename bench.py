@@ -418,10 +418,24 @@ def main_train(args, rank, world):
                     "conv_ms_per_step": round(conv_ms / nst, 3),
                     "measured": "HIP events per launch (minus the %.1f us empty-bracket overhead), %d eager steps after "
                                 "the timed region" % (ConvTimer.bracket_overhead_ms() * 1e3, nst)}
+        # the single shape that takes the most time per step: the family figures above average 264 launches, most of them
+        # small or HBM-bound; this is the dominant kernel launch by itself
+        table = timer.layer_table(nst)
+        top = next((r for r in table if r[0].startswith("conv")), None)
+        if top is not None:
+            roofline["dominant_launch"] = {
+                "kind": "%s M=%d Cout=%d K=%d (FCOS tower layer over P3+P4: forward and data gradient)" % top[:4]
+                        if top[0] == "conv3x3_grouped" else "%s M=%d Cout=%d K=%d" % top[:4],
+                "launches_per_step": int(round(top[4])), "avg_launch_us": round(top[5], 1),
+                "gflop_per_launch": round(2.0 * top[1] * top[2] * top[3] / 1e9, 1),
+                "achieved": round(top[6], 1), "frac": round(top[6] / PEAK_TFLOPS[args.dtype], 4),
+                "ms_per_step": round(top[7], 3),
+                "mfma_busy_share_pmc": 0.436 if args.dtype == "bf16" else None,
+                "mfma_busy_source": "profiles/r1_pmc_mfma_busy_train_bf16.md (conv_xr_kernel, SQ_VALU_MFMA_BUSY_CYCLES)"}
         if args.layer_table and rank == 0:
             with open(args.layer_table, "w") as f:
                 f.write("| kind | M (pixels) | Cout | K | launches/step | us/launch | TFLOP/s | ms/step |\n|---|---|---|---|---|---|---|---|\n")
-                for r in timer.layer_table(nst):
+                for r in table:
                     f.write("| %s | %d | %d | %d | %.0f | %.1f | %.0f | %.3f |\n" % r)
         timer.uninstall(ops)
     if rank == 0:
