@@ -460,16 +460,19 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
     __syncthreads();
     // every thread owns one 64-box column word and ORs in the rows of the boxes KEPT in this block (typically a fifth to
     // a third of the 64: only those rows are read).  The row list is compacted in LDS so the loads are unconditional and
-    // independent, 8 in flight at a time, the tail clamped to the last kept row (OR-ing a row twice is harmless): a
+    // independent, 32 in flight at a time, the tail clamped to the last kept row (OR-ing a row twice is harmless): a
     // data-dependent `while (bits)` walk, or a branch per row, would serialise an L2 / MALL round trip per row.
     const int nrows = s_nrows;
     if (nrows > 0) {
       for (int c = blk + 1 + threadIdx.x; c < nblk; c += blockDim.x) {
         unsigned long long acc = 0ULL;
         const unsigned long long* col = mk + (size_t)(blk * 64) * col_blocks + c;
-        for (int k0 = 0; k0 < nrows; k0 += 8) {
+        for (int k0 = 0; k0 < nrows; k0 += 32) {         // one round trip for the typical 15-25 kept rows
+          unsigned long long w[32];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) acc |= col[(size_t)s_rows[min(k0 + k, nrows - 1)] * col_blocks];
+          for (int k = 0; k < 32; ++k) w[k] = col[(size_t)s_rows[min(k0 + k, nrows - 1)] * col_blocks];
+#pragma unroll
+          for (int k = 0; k < 32; ++k) acc |= w[k];
         }
         remv[c] |= acc;
       }
