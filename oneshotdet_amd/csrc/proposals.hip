@@ -428,10 +428,18 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
       const int i = blk * 64 + lane;
       const unsigned long long diag = (i < n) ? mk[(size_t)i * col_blocks + blk] : 0ULL;
       const int valid = min(64, n - blk * 64);
-      unsigned long long alive = ~remv[blk];
-      if (valid < 64) alive &= (1ULL << valid) - 1ULL;
+      unsigned long long alive_v = ~remv[blk];
+      if (valid < 64) alive_v &= (1ULL << valid) - 1ULL;
+      // the 64-step greedy chain on the SCALAR unit: every operand is wave-uniform (v_readlane / v_readfirstlane results),
+      // so the chain is ~4 scalar instructions per step instead of two ds_bpermute round trips (64-bit __shfl) per step
+      // (the builtins return int: go through unsigned, or the low half sign-extends into the high one)
+      unsigned long long alive = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(alive_v >> 32)) << 32) |
+                                 (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)alive_v);
+      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+#pragma unroll
       for (int l = 0; l < 64; ++l) {
-        const unsigned long long d = __shfl(diag, l);
+        const unsigned long long d = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, l) << 32) |
+                                     (unsigned long long)(unsigned)__builtin_amdgcn_readlane(dlo, l);
         if ((alive >> l) & 1ULL) alive &= ~d;
       }
       // cap at max_keep: keep only the first (max_keep - kept_before) survivors
