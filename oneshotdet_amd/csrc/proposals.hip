@@ -406,6 +406,7 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
                                                        const int* __restrict__ counts_full = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* remv = reinterpret_cast<unsigned long long*>(smem);   // [col_blocks]
+  int* kept_list = reinterpret_cast<int*>(remv + col_blocks);                // [max_keep] positions of the survivors
   __shared__ unsigned long long s_keep;
   __shared__ int s_kept[2];   // double-buffered so the next block's writer cannot race this block's readers
   __shared__ int s_rows[64];  // rows (within the 64-box block) of the boxes kept in this block, compacted
@@ -451,13 +452,9 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
           if ((keep >> l) & 1ULL) { trimmed |= 1ULL << l; --room; }
         keep = trimmed;
       }
-      if ((keep >> lane) & 1ULL) {
-        const int o = kept_before + __popcll(keep & ((1ULL << lane) - 1ULL));
-        const size_t src = (size_t)img * max_count + i, dst = (size_t)img * max_keep + o;
-        *reinterpret_cast<float4*>(out_boxes + dst * 4) = *reinterpret_cast<const float4*>(boxes + src * 4);
-        out_scores[dst] = scores[src];
-        out_pos[dst] = i;
-      }
+        // the survivors' positions go to an LDS list; boxes and scores are gathered by the whole workgroup after the walk
+      // (a global load + store per block here put an L2 round trip on the serial chain in front of every barrier)
+      if ((keep >> lane) & 1ULL) kept_list[kept_before + __popcll(keep & ((1ULL << lane) - 1ULL))] = i;
       if ((keep >> lane) & 1ULL) s_rows[__popcll(keep & ((1ULL << lane) - 1ULL))] = lane;
       if (lane == 0) {
         s_keep = keep;
@@ -486,6 +483,16 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
       }
     }
     __syncthreads();
+  }
+  {
+    const int kept = s_kept[blk & 1];
+    for (int o = threadIdx.x; o < kept; o += blockDim.x) {
+      const int i = kept_list[o];
+      const size_t src = (size_t)img * max_count + i, dst = (size_t)img * max_keep + o;
+      *reinterpret_cast<float4*>(out_boxes + dst * 4) = *reinterpret_cast<const float4*>(boxes + src * 4);
+      out_scores[dst] = scores[src];
+      out_pos[dst] = i;
+    }
   }
   if (threadIdx.x == 0) {
     out_count[img] = s_kept[blk & 1];
@@ -564,6 +571,15 @@ extern "C" int osd_rank_sort_gather(const float* keys, const float* boxes, int n
   return osd_check_launch("rank_sort_gather");
 }
 
+// nms_scan_kernel keeps the removal bitmap and the survivors' positions in dynamic LDS (beyond the 64 KB default)
+static void scan_lds_attr() {
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    done = true;
+  }
+}
+
 extern "C" int64_t osd_nms_workspace_bytes(int n, int max_count) {
   return (int64_t)n * max_count * cdiv(max_count, 64) * 8 + ((int64_t)cdiv(n, 2) + 8) * 8;   // mask + per-image flags
 }
@@ -579,7 +595,9 @@ extern "C" int osd_nms_sorted(const float* boxes_sorted, const float* scores_sor
     return e == hipSuccess ? OSD_OK : osd_fail(OSD_ERR_LAUNCH, "nms_sorted: memset failed");
   }
   const int col_blocks = cdiv(max_count, 64);
-  if ((size_t)col_blocks * 8 > 60000) return osd_fail(OSD_ERR_UNSUPPORTED, "nms_sorted: max_count %d too large", max_count);
+  if ((size_t)col_blocks * 8 + (size_t)max_keep * 4 > 150 * 1024)
+    return osd_fail(OSD_ERR_UNSUPPORTED, "nms_sorted: max_count %d / max_keep %d too large for the scan's LDS", max_count, max_keep);
+  scan_lds_attr();
   // Phase 1: only the first `limit` candidates (in score order) — greedy NMS needs no more than that whenever they yield
   // max_keep survivors, the common case: IoU tiles drop from (n/64)^2/2 to (limit/64)^2/2.  Phase 2 (full problem)
   // is launched unconditionally but exits at once unless phase 1 flagged the image: no host round trip.
@@ -592,7 +610,7 @@ extern "C" int osd_nms_sorted(const float* boxes_sorted, const float* scores_sor
                      boxes_sorted, counts, max_count, col_blocks, thresh, cuda_semantics, mk, limit, (const int*)nullptr);
   int rc = osd_check_launch("nms_mask");
   if (rc) return rc;
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8, OSD_STREAM(stream), boxes_sorted, scores_sorted,
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8 + max_keep * 4, OSD_STREAM(stream), boxes_sorted, scores_sorted,
                      counts, max_count, col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, limit, need_full, 1);
   rc = osd_check_launch("nms_scan");
   if (rc || limit >= max_count) return rc;
@@ -600,7 +618,7 @@ extern "C" int osd_nms_sorted(const float* boxes_sorted, const float* scores_sor
                      boxes_sorted, counts, max_count, col_blocks, thresh, cuda_semantics, mk, max_count, (const int*)need_full);
   rc = osd_check_launch("nms_mask(full)");
   if (rc) return rc;
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8, OSD_STREAM(stream), boxes_sorted, scores_sorted,
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8 + max_keep * 4, OSD_STREAM(stream), boxes_sorted, scores_sorted,
                      counts, max_count, col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, max_count, need_full, 2);
   return osd_check_launch("nms_scan(full)");
 }
@@ -646,7 +664,9 @@ extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int
   }
   for (int l = lt.n_levels; l < 8; ++l) { lt.lo[l] = total; lt.cnt[l] = 0; }
   const int col_blocks = cdiv(max_count, 64);
-  if ((size_t)col_blocks * 8 > 60000) return osd_fail(OSD_ERR_UNSUPPORTED, "proposals_sort_nms: max_count %d too large", max_count);
+  if ((size_t)col_blocks * 8 + (size_t)max_keep * 4 > 150 * 1024)
+    return osd_fail(OSD_ERR_UNSUPPORTED, "proposals_sort_nms: max_count %d / max_keep %d too large for the scan's LDS", max_count, max_keep);
+  scan_lds_attr();
   char* w = reinterpret_cast<char*>(workspace);
   unsigned* keys_sel = reinterpret_cast<unsigned*>(w); w += align256((size_t)n * total * 4);
   int* idx_sel = reinterpret_cast<int*>(w); w += align256((size_t)n * total * 4);
@@ -680,7 +700,7 @@ extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int
                      col_blocks, thresh, cuda_semantics, mk, limit, (const int*)nullptr);
   rc = osd_check_launch("nms_mask");
   if (rc) return rc;
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8, st, boxes_sorted, scores_sorted, valid, max_count,
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8 + max_keep * 4, st, boxes_sorted, scores_sorted, valid, max_count,
                      col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, limit, need_full, 1, (const int*)counts);
   rc = osd_check_launch("nms_scan");
   if (rc || limit >= max_count) return rc;
@@ -693,7 +713,7 @@ extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int
                      col_blocks, thresh, cuda_semantics, mk, max_count, (const int*)need_full);
   rc = osd_check_launch("nms_mask(full)");
   if (rc) return rc;
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8, st, boxes_sorted, scores_sorted, counts, max_count,
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8 + max_keep * 4, st, boxes_sorted, scores_sorted, counts, max_count,
                      col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, max_count, need_full, 2,
                      (const int*)nullptr);
   return osd_check_launch("nms_scan(full)");
