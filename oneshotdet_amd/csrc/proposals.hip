@@ -396,6 +396,10 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ 
   }
 }
 
+// workgroup barrier that waits for LDS traffic only: __syncthreads() also drains vmcnt, i.e. would wait for the global loads
+// that nms_scan_kernel deliberately keeps in flight from one block of its walk to the next (no global stores in that loop)
+__device__ __forceinline__ void scan_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- greedy scan: one workgroup per image walks the 64-box blocks in score order ----
 __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                        const int* __restrict__ counts, int max_count, int col_blocks,
@@ -420,14 +424,41 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
   for (int c = threadIdx.x; c < col_blocks; c += blockDim.x) remv[c] = 0ULL;
   if (threadIdx.x == 0) s_kept[0] = 0;
   __syncthreads();
+  // Register prefetch (walks of at most 256 blocks: one column word per thread).  The words block b+1 will OR in — its 64
+  // rows x this thread's column of that block — are known one block early; only WHICH rows survive is not.  So every
+  // thread loads all 64 of them while block b is being resolved and keeps them in registers (one wave per SIMD: 512
+  // registers), and after the barrier the OR is a register pass masked by the keep bits: no L2 / MALL round trip between
+  // resolving a block and updating the removal bitmap.  Same for wave 0's diagonal word.
+  const bool fast = nblk <= (int)blockDim.x - 64;      // columns belong to waves 1-3: wave 0 only runs the serial chain
+  unsigned long long w_next[64], d_next = 0ULL;
+  auto prefetch = [&](int b) {           // rows of block b, column b + 1 + tid; wave 0 also its diagonal word
+    const int c = b + 1 + (int)threadIdx.x - 64;
+    if (threadIdx.x < 64) {
+      const int i = b * 64 + (int)threadIdx.x;
+      d_next = (b < nblk && i < n) ? mk[(size_t)i * col_blocks + b] : 0ULL;
+    }
+    if (threadIdx.x >= 64 && b < nblk && c < nblk) {
+      const unsigned long long* col = mk + (size_t)(b * 64) * col_blocks + c;
+      const int rows = min(64, n - b * 64);
+#pragma unroll
+      for (int l = 0; l < 64; ++l) w_next[l] = col[(size_t)min(l, rows - 1) * col_blocks];     // clamped: rows past n are never kept
+    }
+  };
+  if (fast) prefetch(0);
   int blk = 0;
   for (; blk < nblk; ++blk) {
     const int kept_before = s_kept[blk & 1];
     if (kept_before >= max_keep) break;
+    unsigned long long w_cur[64], d_cur = d_next;
+    if (fast) {
+#pragma unroll
+      for (int l = 0; l < 64; ++l) w_cur[l] = w_next[l];
+      prefetch(blk + 1);
+    }
     if (threadIdx.x < 64) {
       const int lane = threadIdx.x;
       const int i = blk * 64 + lane;
-      const unsigned long long diag = (i < n) ? mk[(size_t)i * col_blocks + blk] : 0ULL;
+      const unsigned long long diag = fast ? d_cur : ((i < n) ? mk[(size_t)i * col_blocks + blk] : 0ULL);
       const int valid = min(64, n - blk * 64);
       unsigned long long alive_v = ~remv[blk];
       if (valid < 64) alive_v &= (1ULL << valid) - 1ULL;
@@ -462,13 +493,22 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
         s_kept[(blk + 1) & 1] = kept_before + __popcll(keep);
       }
     }
-    __syncthreads();
+    scan_barrier();       // LDS visibility only: the prefetch loads stay in flight across it
     // every thread owns one 64-box column word and ORs in the rows of the boxes KEPT in this block (typically a fifth to
     // a third of the 64: only those rows are read).  The row list is compacted in LDS so the loads are unconditional and
     // independent, 32 in flight at a time, the tail clamped to the last kept row (OR-ing a row twice is harmless): a
     // data-dependent `while (bits)` walk, or a branch per row, would serialise an L2 / MALL round trip per row.
     const int nrows = s_nrows;
-    if (nrows > 0) {
+    if (fast) {
+      const int c = blk + 1 + (int)threadIdx.x - 64;
+      if (threadIdx.x >= 64 && nrows > 0 && c < nblk) {
+        const unsigned long long keep = s_keep;
+        unsigned long long acc = 0ULL;
+#pragma unroll
+        for (int l = 0; l < 64; ++l) acc |= ((keep >> l) & 1ULL) ? w_cur[l] : 0ULL;
+        remv[c] |= acc;
+      }
+    } else if (nrows > 0) {
       for (int c = blk + 1 + threadIdx.x; c < nblk; c += blockDim.x) {
         unsigned long long acc = 0ULL;
         const unsigned long long* col = mk + (size_t)(blk * 64) * col_blocks + c;
@@ -482,7 +522,7 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
         remv[c] |= acc;
       }
     }
-    __syncthreads();
+    scan_barrier();       // LDS visibility only: the prefetch loads stay in flight across it
   }
   {
     const int kept = s_kept[blk & 1];
