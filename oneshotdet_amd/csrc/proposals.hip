@@ -350,6 +350,14 @@ __global__ void meta_counts_kernel(const SelMeta* __restrict__ meta, int* __rest
   if (i < n) counts[i] = meta[i].full_count;
 }
 
+// Layout of the IoU bitmask: [image][row block][column block][64 rows] 64-bit words — for a fixed (row block, column block)
+// the 64 rows' words are contiguous: the mask kernel's wave writes 512 contiguous bytes, and the scan reads a block's 64
+// words of one column as four full cache lines (row-major [row][column block] made every one of those 64 words its own
+// line: 16x the line traffic, which is what bounded the scan on its single CU).
+__device__ __forceinline__ size_t mask_at(int col_blocks, int row, int col_b) {
+  return (((size_t)(row >> 6) * col_blocks + col_b) << 6) + (row & 63);
+}
+
 // ---- IoU bitmask, "+1" areas (csrc/cuda/nms.cu:13-21).  One wavefront = one 64-box row block x one column block ----
 __device__ __forceinline__ float iou_plus1(const float4 a, const float4 b) {
   const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
@@ -391,7 +399,7 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ 
         const bool hit = gt_rule ? (v > thresh) : (v >= thresh);
         if (hit) bits |= 1ULL << j;
       }
-      mask[((size_t)img * max_count + i) * col_blocks + col_b] = bits;
+      mask[(size_t)img * col_blocks * col_blocks * 64 + mask_at(col_blocks, i, col_b)] = bits;
     }
   }
 }
@@ -420,7 +428,7 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
   const int n_all = counts[img];
   const int n = min(n_all, limit);
   const int nblk = (n + 63) / 64;
-  const unsigned long long* mk = mask + (size_t)img * max_count * col_blocks;
+  const unsigned long long* mk = mask + (size_t)img * col_blocks * col_blocks * 64;
   for (int c = threadIdx.x; c < col_blocks; c += blockDim.x) remv[c] = 0ULL;
   if (threadIdx.x == 0) s_kept[0] = 0;
   __syncthreads();
@@ -435,13 +443,13 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
     const int c = b + 1 + (int)threadIdx.x - 64;
     if (threadIdx.x < 64) {
       const int i = b * 64 + (int)threadIdx.x;
-      d_next = (b < nblk && i < n) ? mk[(size_t)i * col_blocks + b] : 0ULL;
+      d_next = (b < nblk && i < n) ? mk[mask_at(col_blocks, i, b)] : 0ULL;
     }
     if (threadIdx.x >= 64 && b < nblk && c < nblk) {
-      const unsigned long long* col = mk + (size_t)(b * 64) * col_blocks + c;
+      const unsigned long long* col = mk + mask_at(col_blocks, b * 64, c);      // 64 consecutive words
       const int rows = min(64, n - b * 64);
 #pragma unroll
-      for (int l = 0; l < 64; ++l) w_next[l] = col[(size_t)min(l, rows - 1) * col_blocks];     // clamped: rows past n are never kept
+      for (int l = 0; l < 64; ++l) w_next[l] = col[min(l, rows - 1)];     // clamped: rows past n are never kept (nor written)
     }
   };
   if (fast) prefetch(0);
@@ -458,7 +466,7 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
     if (threadIdx.x < 64) {
       const int lane = threadIdx.x;
       const int i = blk * 64 + lane;
-      const unsigned long long diag = fast ? d_cur : ((i < n) ? mk[(size_t)i * col_blocks + blk] : 0ULL);
+      const unsigned long long diag = fast ? d_cur : ((i < n) ? mk[mask_at(col_blocks, i, blk)] : 0ULL);
       const int valid = min(64, n - blk * 64);
       unsigned long long alive_v = ~remv[blk];
       if (valid < 64) alive_v &= (1ULL << valid) - 1ULL;
@@ -511,11 +519,11 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
     } else if (nrows > 0) {
       for (int c = blk + 1 + threadIdx.x; c < nblk; c += blockDim.x) {
         unsigned long long acc = 0ULL;
-        const unsigned long long* col = mk + (size_t)(blk * 64) * col_blocks + c;
+        const unsigned long long* col = mk + mask_at(col_blocks, blk * 64, c);
         for (int k0 = 0; k0 < nrows; k0 += 32) {         // one round trip for the typical 15-25 kept rows
           unsigned long long w[32];
 #pragma unroll
-          for (int k = 0; k < 32; ++k) w[k] = col[(size_t)s_rows[min(k0 + k, nrows - 1)] * col_blocks];
+          for (int k = 0; k < 32; ++k) w[k] = col[s_rows[min(k0 + k, nrows - 1)]];
 #pragma unroll
           for (int k = 0; k < 32; ++k) acc |= w[k];
         }
@@ -621,7 +629,7 @@ static void scan_lds_attr() {
 }
 
 extern "C" int64_t osd_nms_workspace_bytes(int n, int max_count) {
-  return (int64_t)n * max_count * cdiv(max_count, 64) * 8 + ((int64_t)cdiv(n, 2) + 8) * 8;   // mask + per-image flags
+  return (int64_t)n * cdiv(max_count, 64) * 64 * cdiv(max_count, 64) * 8 + ((int64_t)cdiv(n, 2) + 8) * 8;   // mask (rows padded to 64) + per-image flags
 }
 
 extern "C" int osd_nms_sorted(const float* boxes_sorted, const float* scores_sorted, const int32_t* counts, int n,

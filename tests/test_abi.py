@@ -58,4 +58,4 @@ def test_invalid_arguments_return_error_codes(lib_path):
     rc = lib.osd_correlate_fwd(None, None, None, 1, 1, 8, 0, None)
     assert rc == -1
     assert lib.osd_correlate_fwd(None, None, None, 0, 1, 8, 0, None) == 0     # empty batch: no-op
-    assert lib.osd_nms_workspace_bytes(2, 130) == 2 * 130 * 3 * 8 + (1 + 8) * 8
+    assert lib.osd_nms_workspace_bytes(2, 130) == 2 * 192 * 3 * 8 + (1 + 8) * 8      # mask rows padded to 64 + per-image flags
