@@ -358,49 +358,67 @@ __device__ __forceinline__ size_t mask_at(int col_blocks, int row, int col_b) {
   return (((size_t)(row >> 6) * col_blocks + col_b) << 6) + (row & 63);
 }
 
+static inline int mask_grid(int blocks) { return max(1, min((blocks * (blocks + 1) / 2 + 3) / 4, 1024)); }
+
 // ---- IoU bitmask, "+1" areas (csrc/cuda/nms.cu:13-21).  One wavefront = one 64-box row block x one column block ----
-__device__ __forceinline__ float iou_plus1(const float4 a, const float4 b) {
+__device__ __forceinline__ float area_plus1(const float4 a) {
+#pragma clang fp contract(off)
+  return (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
+}
+__device__ __forceinline__ float iou_plus1(const float4 a, const float sa, const float4 b, const float sb) {
+#pragma clang fp contract(off)      // separately rounded mul / add / sub like the reference's CPU kernel (nms_cpu.cpp): no FMA
   const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
   const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
   const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
   const float inter = width * height;
-  const float sa = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
-  const float sb = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
   return inter / (sa + sb - inter);
 }
 
-__global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
-                                                      int max_count, int col_blocks, float thresh, int gt_rule,
-                                                      unsigned long long* __restrict__ mask, int limit,
-                                                      const int* __restrict__ need_full) {
+// Four wavefronts per workgroup, each on its own tile of the UPPER triangle (the scan never reads below the diagonal), so a
+// launch is (nb+1)*nb/8 workgroups per image instead of nb*nb one-wave workgroups of which half returned at once: the
+// training step runs this beside the 255-register conv workgroups, and what it costs them is dispatches, not math.
+// The column block's 64 boxes live one per lane; the j loop reads them through `v_readlane` (wave-uniform j), so there
+// is no LDS staging and no barrier.
+__device__ __forceinline__ float lane_f(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+
+__global__ void __launch_bounds__(256) nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
+                                                       int max_count, int col_blocks, float thresh, int gt_rule,
+                                                       unsigned long long* __restrict__ mask, int limit,
+                                                       const int* __restrict__ need_full) {
   const int img = blockIdx.y;
   if (need_full && !need_full[img]) return;      // phase 2 runs only for images phase 1 could not finish
   const int n = min(counts[img], limit);
   const int nb = (n + 63) / 64;
-  __shared__ float4 cb[64];
+  const int ntri = nb * (nb + 1) / 2;
   const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)img * max_count;
-  const int lane = threadIdx.x;
-  // grid-stride over the tiles of the upper triangle (a fixed, small grid: an idle phase costs a few hundred
-  // workgroups, not (n/64)^2 of them)
-  for (int tile = blockIdx.x; tile < nb * nb; tile += gridDim.x) {
-    const int row_b = tile / nb, col_b = tile - row_b * nb;
-    if (col_b < row_b) continue;                 // lower triangle is never read by the scan
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned long long* mk = mask + (size_t)img * col_blocks * col_blocks * 64;
+  // grid-stride over the tiles of the upper triangle, row block r holding the nb - r tiles (r, r..nb-1)
+  for (int t = blockIdx.x * 4 + wave; t < ntri; t += gridDim.x * 4) {
+    // first(r) = r*nb - r*(r-1)/2 tiles precede row block r: estimate r from the quadratic, then settle it exactly
+    const float e = (float)(2 * nb + 1);
+    int row_b = (int)((e - sqrtf(fmaxf(e * e - 8.f * (float)t, 0.f))) * 0.5f);
+    row_b = max(0, min(row_b, nb - 1));
+    while (row_b > 0 && row_b * nb - row_b * (row_b - 1) / 2 > t) --row_b;
+    while (row_b + 1 < nb && (row_b + 1) * nb - (row_b + 1) * row_b / 2 <= t) ++row_b;
+    const int col_b = row_b + (t - (row_b * nb - row_b * (row_b - 1) / 2));
     const int col_size = min(64, n - col_b * 64);
-    __syncthreads();
-    if (lane < col_size) cb[lane] = bx[col_b * 64 + lane];
-    __syncthreads();
     const int i = row_b * 64 + lane;
-    if (i < n) {
-      const float4 me = bx[i];
-      unsigned long long bits = 0;
-      const int start = (row_b == col_b) ? lane + 1 : 0;
-      for (int j = start; j < col_size; ++j) {
-        const float v = iou_plus1(me, cb[j]);
-        const bool hit = gt_rule ? (v > thresh) : (v >= thresh);
-        if (hit) bits |= 1ULL << j;
-      }
-      mask[(size_t)img * col_blocks * col_blocks * 64 + mask_at(col_blocks, i, col_b)] = bits;
+    const float4 me = bx[min(i, n - 1)];
+    const float4 cb = bx[min(col_b * 64 + lane, n - 1)];
+    const float my_area = area_plus1(me), cb_area = area_plus1(cb);
+    unsigned long long bits = 0;
+    const int start = (row_b == col_b) ? lane + 1 : 0;
+    for (int j = 0; j < col_size; ++j) {
+      const float4 o = make_float4(lane_f(cb.x, j), lane_f(cb.y, j), lane_f(cb.z, j), lane_f(cb.w, j));
+      const float v = iou_plus1(me, my_area, o, lane_f(cb_area, j));
+      const bool hit = (gt_rule ? (v > thresh) : (v >= thresh)) && j >= start;
+      if (hit) bits |= 1ULL << j;
     }
+    if (i < n) mk[mask_at(col_blocks, i, col_b)] = bits;
   }
 }
 
@@ -654,7 +672,7 @@ extern "C" int osd_nms_sorted(const float* boxes_sorted, const float* scores_sor
   int* need_full = reinterpret_cast<int*>(mask_ws);                 // n ints at the head of the workspace
   unsigned long long* mk = reinterpret_cast<unsigned long long*>(mask_ws) + cdiv(n, 2) + 8;
   const int lim_blocks = cdiv(limit, 64);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(min(lim_blocks * lim_blocks, 4096), n), dim3(64), 0, OSD_STREAM(stream),
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_grid(lim_blocks), n), dim3(256), 0, OSD_STREAM(stream),
                      boxes_sorted, counts, max_count, col_blocks, thresh, cuda_semantics, mk, limit, (const int*)nullptr);
   int rc = osd_check_launch("nms_mask");
   if (rc) return rc;
@@ -662,7 +680,7 @@ extern "C" int osd_nms_sorted(const float* boxes_sorted, const float* scores_sor
                      counts, max_count, col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, limit, need_full, 1);
   rc = osd_check_launch("nms_scan");
   if (rc || limit >= max_count) return rc;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(min(col_blocks * col_blocks, 4096), n), dim3(64), 0, OSD_STREAM(stream),
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_grid(col_blocks), n), dim3(256), 0, OSD_STREAM(stream),
                      boxes_sorted, counts, max_count, col_blocks, thresh, cuda_semantics, mk, max_count, (const int*)need_full);
   rc = osd_check_launch("nms_mask(full)");
   if (rc) return rc;
@@ -744,7 +762,7 @@ extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int
   unsigned long long* mk = reinterpret_cast<unsigned long long*>(mask_ws) + cdiv(n, 2) + 8;
   const int lim_blocks = cdiv(limit, 64);
   // phase 1: the exactly sorted head (valid[img] candidates), at most `limit` of them
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(min(lim_blocks * lim_blocks, 4096), n), dim3(64), 0, st, boxes_sorted, valid, max_count,
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_grid(lim_blocks), n), dim3(256), 0, st, boxes_sorted, valid, max_count,
                      col_blocks, thresh, cuda_semantics, mk, limit, (const int*)nullptr);
   rc = osd_check_launch("nms_mask");
   if (rc) return rc;
@@ -757,7 +775,7 @@ extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int
                      boxes_sorted, scores_sorted, idx_sorted, counts2, (const int*)need_full);
   rc = osd_check_launch("rank_sort_gather(full)");
   if (rc) return rc;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(min(col_blocks * col_blocks, 4096), n), dim3(64), 0, st, boxes_sorted, counts, max_count,
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_grid(col_blocks), n), dim3(256), 0, st, boxes_sorted, counts, max_count,
                      col_blocks, thresh, cuda_semantics, mk, max_count, (const int*)need_full);
   rc = osd_check_launch("nms_mask(full)");
   if (rc) return rc;
