@@ -358,7 +358,10 @@ __device__ __forceinline__ size_t mask_at(int col_blocks, int row, int col_b) {
   return (((size_t)(row >> 6) * col_blocks + col_b) << 6) + (row & 63);
 }
 
-static inline int mask_grid(int blocks) { return max(1, min((blocks * (blocks + 1) / 2 + 3) / 4, 1024)); }
+// `cap`: phase 1 takes one workgroup per four tiles; phase 2 (which exits at once unless an image was flagged, i.e. never
+// in the measured workloads) gets a small grid-stride grid, because even workgroups that return immediately take
+// dispatch slots from the convolutions running beside them.
+static inline int mask_grid(int blocks, int cap = 1024) { return max(1, min((blocks * (blocks + 1) / 2 + 3) / 4, cap)); }
 
 // ---- IoU bitmask, "+1" areas (csrc/cuda/nms.cu:13-21).  One wavefront = one 64-box row block x one column block ----
 __device__ __forceinline__ float area_plus1(const float4 a) {
@@ -680,7 +683,7 @@ extern "C" int osd_nms_sorted(const float* boxes_sorted, const float* scores_sor
                      counts, max_count, col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, limit, need_full, 1);
   rc = osd_check_launch("nms_scan");
   if (rc || limit >= max_count) return rc;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_grid(col_blocks), n), dim3(256), 0, OSD_STREAM(stream),
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_grid(col_blocks, 96), n), dim3(256), 0, OSD_STREAM(stream),
                      boxes_sorted, counts, max_count, col_blocks, thresh, cuda_semantics, mk, max_count, (const int*)need_full);
   rc = osd_check_launch("nms_mask(full)");
   if (rc) return rc;
@@ -775,7 +778,7 @@ extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int
                      boxes_sorted, scores_sorted, idx_sorted, counts2, (const int*)need_full);
   rc = osd_check_launch("rank_sort_gather(full)");
   if (rc) return rc;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_grid(col_blocks), n), dim3(256), 0, st, boxes_sorted, counts, max_count,
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_grid(col_blocks, 96), n), dim3(256), 0, st, boxes_sorted, counts, max_count,
                      col_blocks, thresh, cuda_semantics, mk, max_count, (const int*)need_full);
   rc = osd_check_launch("nms_mask(full)");
   if (rc) return rc;

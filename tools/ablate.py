@@ -52,6 +52,27 @@ def run_train_step(label):
     print("%-40s %.2f ms/step" % (label, (time.perf_counter() - t0) / steps * 1e3), flush=True)
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "props":
+    # interleaved A/B of the training proposals (single runs differ by +-2 %): medians of 6 alternating rounds
+    def timed(**kw):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.forward_backward(images, queries, gt_boxes, gt_count, **kw)
+            eng.optimizer_step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    timed(); timed(with_proposals=False)
+    a, b = [], []
+    for _ in range(6):
+        a.append(timed())
+        b.append(timed(with_proposals=False))
+    a.sort(); b.sort()
+    ma, mb = (a[2] + a[3]) / 2, (b[2] + b[3]) / 2
+    print("with proposals    median %.3f ms/step  (%s)" % (ma, " ".join("%.2f" % v for v in a)))
+    print("without proposals median %.3f ms/step  (%s)" % (mb, " ".join("%.2f" % v for v in b)))
+    print("training proposals cost %.2f %% of the step" % (100.0 * (ma - mb) / ma))
+    sys.exit(0)
 run_train_step("train_step (updates behind backward)")
 run("full step")
 run_train_step("train_step (updates behind backward)")
