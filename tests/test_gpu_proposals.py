@@ -50,6 +50,39 @@ def test_nms_random_vs_oracle(n):
     assert again.numel() == keep.numel()
 
 
+def test_nms_iou_rounding_matches_the_cpu_kernel():
+    """The threshold is set to the fp32 IoU of one pair, computed like nms_cpu.cpp:40-60 (separately rounded mul / add / sub /
+    div): under the CPU rule '>=' that pair is suppressed only if the kernel rounds its IoU identically (an FMA-contracted
+    union differs in the last bit for about one pair in three)."""
+    from oneshotdet_amd import layers
+    rng = np.random.RandomState(7)
+    n = 384
+    ctr = rng.uniform(40, 160, (n, 2)).astype(np.float32)
+    wh = rng.uniform(30, 90, (n, 2)).astype(np.float32)
+    boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+    scores = rng.permutation(n).astype(np.float32) / n
+    one = np.float32(1)
+    area = (boxes[:, 2] - boxes[:, 0] + one) * (boxes[:, 3] - boxes[:, 1] + one)
+    b_dev, s_dev = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    tried = 0
+    for _ in range(400):
+        i, j = rng.randint(0, n, 2)
+        w = np.maximum(np.float32(0), np.minimum(boxes[i, 2], boxes[j, 2]) - np.maximum(boxes[i, 0], boxes[j, 0]) + one)
+        h = np.maximum(np.float32(0), np.minimum(boxes[i, 3], boxes[j, 3]) - np.maximum(boxes[i, 1], boxes[j, 1]) + one)
+        inter = np.float32(w * h)
+        thr = np.float32(inter / np.float32(np.float32(area[i] + area[j]) - inter))
+        if i == j or not (0.2 < thr < 0.9):
+            continue
+        tried += 1
+        for cuda in (False, True):
+            ref = orc.nms(boxes, scores, float(thr), cuda_semantics=cuda)
+            got = layers.nms(b_dev, s_dev, float(thr), cuda_semantics=cuda)
+            np.testing.assert_array_equal(got.cpu().numpy(), ref, err_msg="pair (%d, %d) thr %r" % (i, j, thr))
+        if tried == 48:
+            break
+    assert tried == 48
+
+
 def test_nms_second_phase_when_first_candidates_do_not_suffice():
     """Heavy overlap among the best-scoring boxes: the first `limit` candidates yield fewer than max_keep survivors, so
     the device-side fallback (full mask + full scan) must produce the answer; an image of the same batch that needs no
