@@ -3,6 +3,9 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|f32] [--batch 8] [--no-cpu-baseline]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
               bench.py --gpus N --steps K --warmup W
+          or simply `python bench.py --gpus N`: with no WORLD_SIZE in the environment the process starts N ranks of itself
+          (one per GPU, rendezvous on 127.0.0.1) BEFORE touching the GPU and exits with their worst return code.
+  A WORLD_SIZE that disagrees with --gpus is an error (exit 2): the line's n_gpus is always the world size that ran.
 
 One "step" = one pass of the hot path over one batch of synthetic (target, query) pairs already resident in HBM:
 two ResNet-50-FPN backbones, query pooling, correlation, FCOS towers + predictions, score/decode/top-k/NMS proposals.
@@ -158,6 +161,55 @@ def cpu_baseline(dtype_name, seconds_budget=25.0, train=False):
                       % (n, what, cores)}
 
 
+def self_launch(argv, n):
+    """`python bench.py --gpus N` without a launcher (tools/train_net.py:224-226 reads WORLD_SIZE the same way): start N
+    ranks of this script as child processes, one per GPU, and return the worst exit code.  The parent never initialises
+    the GPU (no HIP call, no exec of a GPU process: children are ordinary subprocesses)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OSD_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        try:
+            p.wait()
+        except KeyboardInterrupt:
+            for q in procs:
+                q.terminate()
+            raise
+        rc = rc or p.returncode
+    return rc
+
+
+def check_world(args):
+    """--gpus N is the contract: N ranks run, or nothing does.  Returns (rank, local_rank, world) from the environment;
+    launches the ranks itself when there is no launcher; exits 2 when the launcher's WORLD_SIZE disagrees with --gpus."""
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            if not (args.dry_run_cpu or os.environ.get("OSD_BENCH_SHARE_GPU") == "1"):
+                have = torch.cuda.device_count()          # counting devices does not initialise the GPU on this image
+                if have < args.gpus:
+                    print("bench.py: --gpus %d but %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
+                    sys.exit(2)
+            sys.exit(self_launch(sys.argv[1:], args.gpus))
+        return 0, 0, 1
+    world = int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; pass --gpus %d or launch %d ranks"
+              % (args.gpus, world, world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world
+
+
 def dist_setup(backend):
     """One process per GPU, launched by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env)."""
     rank = int(os.environ.get("RANK", "0"))
@@ -194,14 +246,20 @@ def timed_steps(step, steps, warmup, world, device_sync, reduce_device):
 
 
 def result_line(args, world, batch, elapsed, workload, launch, roofline=None, cpu=None):
+    pg_world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    assert pg_world == world == args.gpus, (pg_world, world, args.gpus)
+    if world == 1:
+        par = "dp1: one rank, no collective anywhere in the step"
+    else:
+        par = "dp%d: batch sharded over ranks (weak scaling), process-group world size %d, backend %s" % (
+            world, pg_world, dist.get_backend())
     line = {
         "metric": METRIC, "value": round(batch * world * args.steps / elapsed, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": workload, "global_batch": batch * world,
-                   "parallelism": "dp%d (batch sharded over ranks, no collective in forward)" % world,
-                   "launch": launch},
+                   "parallelism": par, "world_size": pg_world, "launch": launch},
         "roofline": roofline,
     }
     if cpu is not None:
@@ -227,15 +285,23 @@ def measured_peaks(dtype):
 
 
 def measured_traffic(mode, dtype):
-    """HBM bytes per conv-family launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections), collected
-    offline by tools/prof_pmc.sh + tools/summarize_pmc.py in separate rocprofv3 --pmc passes and committed under
-    profiles/ (counters cannot be read from inside the process).  None when no profile exists for this mode."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic_%s_%s.json" % (mode, dtype))
+    """HBM bytes per conv-family launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections).  Counters
+    cannot be read from inside the process: they are collected OFFLINE by tools/prof_pmc.sh + tools/summarize_pmc.py in
+    separate rocprofv3 --pmc passes of this same command and committed under profiles/ with the commit they were taken
+    at.  Returns (bytes per launch or None, provenance string): the newest round's file for this mode is used."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s_%s.json" % (mode, dtype))),
+                   key=lambda f: int(os.path.basename(f)[1:].split("_", 1)[0]))
+    if not files:
+        return None, "no PMC profile committed for this mode"
     try:
-        with open(path) as f:
-            return round(json.load(f)["conv_family"]["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+        with open(files[-1]) as f:
+            j = json.load(f)
+        src = "OFFLINE, not measured by this run: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, at commit %s)" % (
+            os.path.basename(files[-1]), j.get("commit", "c80270d (round 1)"))
+        return round(j["conv_family"]["hbm_bytes_per_launch"]), src
+    except Exception as e:
+        return None, "unreadable PMC profile: %r" % (e,)
 
 
 class TrainTimer(ConvTimer):
@@ -407,10 +473,10 @@ def main_train(args, rank, world):
         conv_ms = timer.total_ms()
         tflops = timer.flops / (conv_ms * 1e-3) / 1e12
         corr_roofline = timer.correlation_roofline()
+        traffic, traffic_src = measured_traffic("train", args.dtype)
         roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                    "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4), "traffic": measured_traffic("train", args.dtype),
-                    "peak_measured": measured_peaks(args.dtype),
-                    "traffic_source": "profiles/r1_pmc_traffic_train_%s.json (rocprofv3 --pmc, bytes per launch)" % args.dtype,
+                    "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
+                    "peak_measured": measured_peaks(args.dtype), "traffic_source": traffic_src,
                     "kernel": "conv_dma_kernel / conv_xr_kernel / conv_igemm_kernel (forward + data gradient) and conv_wgrad_kernel",
                     "avg_launch_us": round(conv_ms * 1e3 / max(timer.launches, 1), 2),
                     "launches_per_step": timer.launches // nst,
@@ -429,9 +495,7 @@ def main_train(args, rank, world):
                 "launches_per_step": int(round(top[4])), "avg_launch_us": round(top[5], 1),
                 "gflop_per_launch": round(2.0 * top[1] * top[2] * top[3] / 1e9, 1),
                 "achieved": round(top[6], 1), "frac": round(top[6] / PEAK_TFLOPS[args.dtype], 4),
-                "ms_per_step": round(top[7], 3),
-                "mfma_busy_share_pmc": 0.436 if args.dtype == "bf16" else None,
-                "mfma_busy_source": "profiles/r1_pmc_mfma_busy_train_bf16.md (conv_xr_kernel, SQ_VALU_MFMA_BUSY_CYCLES)"}
+                "ms_per_step": round(top[7], 3)}
         if args.layer_table and rank == 0:
             with open(args.layer_table, "w") as f:
                 f.write("| kind | M (pixels) | Cout | K | launches/step | us/launch | TFLOP/s | ms/step |\n|---|---|---|---|---|---|---|---|\n")
@@ -446,8 +510,13 @@ def main_train(args, rank, world):
         line = result_line(args, world, B, elapsed, workload, launch, roofline, cpu)
         if roofline is not None:
             line["roofline_correlation"] = corr_roofline
-        line["config"]["parallelism"] = ("dp%d, fp32 gradient averaging over RCCL: %d buckets of the flat buffer, each "
-                                         "all-reduced behind backward as soon as it is final" % (world, len(eng.exchange.ranges)))
+        if world > 1:
+            assert eng.exchange.active and eng.exchange.world == world
+            line["config"]["parallelism"] += ("; fp32 gradient averaging (%s all-reduce): %d buckets of the flat buffer, each "
+                                              "exchanged behind backward as soon as it is final"
+                                              % (dist.get_backend(), len(eng.exchange.ranges)))
+        else:
+            assert not eng.exchange.active
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -477,8 +546,9 @@ def main():
                     help="exercise only the multi-process plumbing (gloo, no GPU work): used by tests/test_dist_cpu.py")
     args = ap.parse_args()
 
+    rank, local_rank, world = check_world(args)      # may start the ranks and exit; never touches the GPU
     if args.dry_run_cpu:
-        rank, local_rank, world = dist_setup("gloo")
+        dist_setup("gloo")
         work = torch.zeros(1)
 
         def fake_step():
@@ -492,8 +562,6 @@ def main():
             dist.destroy_process_group()
         return
 
-    rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), \
-        int(os.environ.get("WORLD_SIZE", "1"))
     # OSD_BENCH_SHARE_GPU=1 (tests only): every rank on cuda:0 with the gloo backend, so the exact N > 1 code path
     # (rank-seeded data, overlapped exchange, barrier-bracketed timing, MAX over ranks) runs on a one-GPU box
     share = os.environ.get("OSD_BENCH_SHARE_GPU") == "1"

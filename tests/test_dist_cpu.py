@@ -34,12 +34,37 @@ def test_bench_two_ranks_gloo():
     assert abs(r["value"] - 16 * 1e3 / r["ms_per_step"]) / r["value"] < 0.01
 
 
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the process starts two ranks of itself (gloo here)
+    and the line says n_gpus 2 with the process group's own world size in it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                          "--dry-run-cpu"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["world_size"] == 2 and r["config"]["global_batch"] == 16
+    assert "world size 2" in r["config"]["parallelism"] and r["ms_per_step"] >= 3.9
+
+
+def test_bench_rejects_a_world_size_that_is_not_gpus():
+    """--gpus is the contract: a launcher that started a different number of ranks is an error, not a silent n_gpus."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                          "--dry-run-cpu"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert out.returncode == 2 and "WORLD_SIZE=1" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_single_process_dry_run():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--dry-run-cpu"],
                          capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert r["n_gpus"] == 1 and r["metric"].startswith("images/sec/GPU")
+    assert "no collective" in r["config"]["parallelism"]
 
 
 def test_gradient_average_two_ranks():

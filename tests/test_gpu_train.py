@@ -512,6 +512,33 @@ def test_bench_two_ranks_sharing_the_gpu():
     assert "buckets" in r["config"]["parallelism"] and "cpu_baseline" not in r
 
 
+def test_bench_self_launches_two_ranks_sharing_the_gpu():
+    """`python3 bench.py --gpus 2` with NO launcher (no WORLD_SIZE): bench.py starts its own two ranks before touching
+    the GPU; both share this GPU (OSD_BENCH_SHARE_GPU=1, gloo).  The line reports n_gpus 2 and the process group's own
+    world size; a single-rank run says there is no collective."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OSD_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="4")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--no-conv-timing"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["world_size"] == 2 and r["config"]["global_batch"] == 16
+    assert "buckets" in r["config"]["parallelism"] and "gloo" in r["config"]["parallelism"]
+    # --gpus 2 on a box with one GPU and no sharing switch: refused before any rank starts
+    env.pop("OSD_BENCH_SHARE_GPU")
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                             capture_output=True, text=True, timeout=300, cwd=root, env=env)
+        assert out.returncode == 2 and "GPU(s) visible" in out.stderr
+
+
 def test_config5_multiscale_five_shot_training_steps():
     """BASELINE.json configs[4] at full size: bs=4, S=5 queries per image (20 x 127x127), the target's short edge cycling
     through {640, 800, 1024} (640x832, 800x1024, 1024x1312) from step to step on ONE engine (buffers keyed by shape).

@@ -48,6 +48,11 @@ def main():
                           "measured_read_bytes": res["correlate"]["hbm_read_bytes"],
                           "measured_write_bytes": res["correlate"]["hbm_write_bytes"],
                           "launches": res["correlate"]["launches"]}
+    import subprocess
+    try:
+        res["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        res["commit"] = "unknown"
     json.dump(res, open(out + ".json", "w"), indent=1)
     with open(out + ".md", "w") as f:
         f.write("# HBM traffic from PMC counters (rocprofv3 --pmc, separate passes), one training step, bf16, bs=8\n\n")
