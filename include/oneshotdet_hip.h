@@ -188,6 +188,15 @@ int osd_nms_sorted(const float* boxes_sorted, const float* scores_sorted, const 
                    float thresh, int cuda_semantics, int max_keep, uint64_t* mask_ws, float* out_boxes,
                    float* out_scores, int32_t* out_pos, int32_t* out_count, void* stream);
 int64_t osd_nms_workspace_bytes(int n, int max_count);
+/* _C.nms as one entry point (csrc/vision.cpp:8, csrc/nms.h:10-28; layers/nms.py:5): dets [num_boxes][4] fp32 xyxy, scores
+ * [num_boxes] fp32 (any finite values, ties broken by lower index) -> keep_out [num_boxes] int64 = the ORIGINAL indices of
+ * the kept boxes in ascending order (csrc/cuda/nms.cu:127-130, csrc/cpu/nms_cpu.cpp:64), the first *count_out of them
+ * valid; count_out is a DEVICE int32 (the reference returns a tensor sized on the host after a blocking copy,
+ * nms.cu:94-100; here the caller reads the count when it needs it).  Rule as osd_nms_sorted.  num_boxes == 0 -> count 0.
+ * workspace: osd_nms_single_workspace_bytes(num_boxes) bytes. */
+int osd_nms(const float* dets, const float* scores, int num_boxes, float thresh, int cuda_semantics, void* workspace,
+            int64_t* keep_out, int32_t* count_out, void* stream);
+int64_t osd_nms_single_workspace_bytes(int num_boxes);
 /* osd_rank_sort_gather + osd_nms_sorted in one call that sorts only the HEAD of the order: greedy NMS stopping at max_keep
  * survivors almost never reads past the first 1.25 * max_keep candidates, while ranking all `total` candidates against
  * each other is O(total^2).  A per-image score threshold (two-level histogram) selects at least 1.25 * max_keep + 320

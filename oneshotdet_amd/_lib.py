@@ -50,6 +50,8 @@ SIGNATURES = {
     "osd_rank_sort_gather": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "osd_nms_sorted": (_i, [_p, _p, _p, _i, _i, _f, _i, _i, _p, _p, _p, _p, _p, _p]),
     "osd_nms_workspace_bytes": (_i64, [_i, _i]),
+    "osd_nms": (_i, [_p, _p, _i, _f, _i, _p, _p, _p, _p]),
+    "osd_nms_single_workspace_bytes": (_i64, [_i]),
     "osd_sigmoid_focal_fwd": (_i, [_p, _p, _p, _i, _i, _f, _f, _p]),
     "osd_sigmoid_focal_bwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _f, _p]),
     "osd_pack_conv_weight_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

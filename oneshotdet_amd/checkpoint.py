@@ -88,6 +88,23 @@ def save_checkpoint(path, state_dict, tag_last=True, **extras):
     return path
 
 
+def save_training_checkpoint(path, engine, iteration, tag_last=True):
+    """utils/checkpoint.py:33-50 as the trainer calls it (engine/trainer.py:111-119): model + optimizer + iteration.
+    `optimizer` holds TrainEngine.optimizer_state_dict() (momentum buffers under reference names, steps taken, lr)."""
+    return save_checkpoint(path, engine.state_dict(), tag_last=tag_last, optimizer=engine.optimizer_state_dict(),
+                           iteration=int(iteration))
+
+
+def resume_training(path, make_engine):
+    """Load a checkpoint written by save_training_checkpoint: make_engine(state_dict) -> TrainEngine; its momentum and
+    step count are restored.  Returns (engine, iteration)."""
+    sd, extras = load_checkpoint(path)
+    eng = make_engine(sd)
+    if "optimizer" in extras and isinstance(extras["optimizer"], dict) and "momentum_buffer" in extras["optimizer"]:
+        eng.load_optimizer_state_dict(extras["optimizer"])
+    return eng, int(extras.get("iteration", 0))
+
+
 _C2_BRANCH = {"branch2a": ("conv1", "bn1"), "branch2b": ("conv2", "bn2"), "branch2c": ("conv3", "bn3"),
               "branch1": ("downsample.0", "downsample.1")}
 _C2_BLOB = re.compile(r"^res(\d)_(\d+)_(branch2a|branch2b|branch2c|branch1)(_bn)?_(w|s|b)$")

@@ -74,6 +74,12 @@ struct LevelTable {
 };
 
 __device__ __forceinline__ unsigned key32(float k) { return k >= 0.f ? __float_as_uint(k) + 1u : 0u; }   // dropped (-1) sort last
+// any finite float, order preserving (osd_nms: _C.nms sorts whatever scores it is given); -0 and +0 compare equal
+__device__ __forceinline__ unsigned key32_signed(float k) {
+  const unsigned u = __float_as_uint(k + 0.f);
+  return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+template <bool kSigned> __device__ __forceinline__ unsigned key32_of(float k) { return kSigned ? key32_signed(k) : key32(k); }
 
 // 32-bit compares: the order is (score desc, index asc) and a tile holds 1024 CONSECUTIVE indices, so for a tile that lies
 // entirely before the workgroup's own 256 indices a tie counts as "before" (>=), for a tile entirely after it does not
@@ -83,6 +89,7 @@ __device__ __forceinline__ unsigned key32(float k) { return k >= 0.f ? __float_a
 // LDS bytes.  Also tried: lanes holding 64 tile keys with the wave's own keys broadcast one at a time (v_readlane), so one
 // v_cmp + a scalar popcount covers 64 pairs - 441 us, slower than this form's 322: the scalar popcount / add chain sits in
 // the wave's in-order stream.)
+template <bool kSigned>
 __global__ void __launch_bounds__(256) rank_sort_gather_kernel(const float* __restrict__ keys, const float* __restrict__ boxes,
                                                                int total, int max_count, int topn, LevelTable lt,
                                                                float* __restrict__ boxes_sorted,
@@ -95,7 +102,7 @@ __global__ void __launch_bounds__(256) rank_sort_gather_kernel(const float* __re
   const int i0 = blockIdx.x * blockDim.x;
   const int i = i0 + threadIdx.x;
   const float ki = i < total ? k[i] : -1.f;
-  const unsigned mine = key32(ki);
+  const unsigned mine = key32_of<kSigned>(ki);
   int rank = 0, own_before = 0;
   for (int l = 0; l < lt.n_levels; ++l) {
     const int lo = lt.lo[l], cnt = lt.cnt[l];
@@ -108,7 +115,7 @@ __global__ void __launch_bounds__(256) rank_sort_gather_kernel(const float* __re
       __syncthreads();
       // padding: 0 is never > a key; for the >= loop a dropped candidate's own key is 0 too, but dropped candidates are
       // not written out, so their counts do not matter
-      for (int t = threadIdx.x; t < 1024; t += blockDim.x) tile[t] = t < m ? key32(k[g0 + t]) : 0u;
+      for (int t = threadIdx.x; t < 1024; t += blockDim.x) tile[t] = t < m ? key32_of<kSigned>(k[g0 + t]) : 0u;
       __syncthreads();
       if (all_after) {
 #pragma unroll 8
@@ -135,7 +142,7 @@ __global__ void __launch_bounds__(256) rank_sort_gather_kernel(const float* __re
     if (i >= lo && i < lo + cnt) own_before = c;
     rank += min(c, topn);
   }
-  const bool live = (i < total) && (ki >= 0.f) && (own_before < topn) && (rank < max_count);
+  const bool live = (i < total) && (kSigned || ki >= 0.f) && (own_before < topn) && (rank < max_count);
   if (live) {
     const size_t o = (size_t)img * max_count + rank;
     *reinterpret_cast<float4*>(boxes_sorted + o * 4) =
@@ -635,8 +642,8 @@ extern "C" int osd_rank_sort_gather(const float* keys, const float* boxes, int n
   hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * n, OSD_STREAM(stream));
   if (e != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "rank_sort_gather: memset: %s", hipGetErrorString(e));
   if (total == 0) return OSD_OK;
-  hipLaunchKernelGGL(rank_sort_gather_kernel, dim3(cdiv(total, 256), n), dim3(256), 0, OSD_STREAM(stream), keys, boxes,
-                     total, max_count, topn, lt, boxes_sorted, scores_sorted, idx_sorted, counts);
+  hipLaunchKernelGGL(rank_sort_gather_kernel<false>, dim3(cdiv(total, 256), n), dim3(256), 0, OSD_STREAM(stream), keys, boxes,
+                     total, max_count, topn, lt, boxes_sorted, scores_sorted, idx_sorted, counts, (const int*)nullptr);
   return osd_check_launch("rank_sort_gather");
 }
 
@@ -690,6 +697,81 @@ extern "C" int osd_nms_sorted(const float* boxes_sorted, const float* scores_sor
   hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8 + max_keep * 4, OSD_STREAM(stream), boxes_sorted, scores_sorted,
                      counts, max_count, col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, max_count, need_full, 2);
   return osd_check_launch("nms_scan(full)");
+}
+
+// ---- _C.nms as ONE entry point (csrc/nms.h:10-28): any scores, kept ORIGINAL indices in ascending order ----
+namespace {
+// one workgroup: flags[idx_sorted[pos[p]]] = 1 for the p < count survivors, then an ordered compaction of the flags
+__global__ void __launch_bounds__(1024) nms_keep_indices_kernel(const int* __restrict__ idx_sorted, const int* __restrict__ pos,
+                                                                const int* __restrict__ count, int num, int* __restrict__ flags,
+                                                                long long* __restrict__ keep_out, int* __restrict__ count_out) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  for (int i = t; i < num; i += 1024) flags[i] = 0;
+  __syncthreads();
+  const int kept = min(count[0], num);
+  for (int p = t; p < kept; p += 1024) flags[idx_sorted[pos[p]]] = 1;
+  __syncthreads();
+  const int per = (num + 1023) / 1024;
+  const int lo = min(t * per, num), hi = min(lo + per, num);
+  int c = 0;
+  for (int i = lo; i < hi; ++i) c += flags[i];
+  part[t] = c;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {            // inclusive scan
+    const int v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int o = part[t] - c;
+  for (int i = lo; i < hi; ++i)
+    if (flags[i]) keep_out[o++] = i;
+  if (t == 1023) count_out[0] = part[1023];
+}
+}  // namespace
+
+static size_t nms_align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" int64_t osd_nms_single_workspace_bytes(int num_boxes) {
+  const size_t n = (size_t)(num_boxes > 0 ? num_boxes : 1);
+  // boxes_sorted, scores_sorted, idx_sorted, out_boxes, out_scores, out_pos, flags, 2 counters, the IoU bitmask
+  return (int64_t)(nms_align256(n * 16) * 2 + nms_align256(n * 4) * 5 + 256 + nms_align256((size_t)osd_nms_workspace_bytes(1, (int)n)));
+}
+
+extern "C" int osd_nms(const float* dets, const float* scores, int num_boxes, float thresh, int cuda_semantics,
+                       void* workspace, int64_t* keep_out, int32_t* count_out, void* stream) {
+  if (!count_out) return osd_fail(OSD_ERR_INVALID_ARG, "nms: null count_out");
+  hipStream_t st = OSD_STREAM(stream);
+  if (num_boxes <= 0) {                                   // csrc/cpu/nms_cpu.cpp:12-14: empty in, empty out
+    hipError_t e = hipMemsetAsync(count_out, 0, sizeof(int32_t), st);
+    return e == hipSuccess ? OSD_OK : osd_fail(OSD_ERR_LAUNCH, "nms: memset failed");
+  }
+  if (!dets || !scores || !workspace || !keep_out) return osd_fail(OSD_ERR_INVALID_ARG, "nms: null argument");
+  const size_t n = (size_t)num_boxes;
+  char* p = static_cast<char*>(workspace);
+  float* bs = reinterpret_cast<float*>(p); p += nms_align256(n * 16);
+  float* ob = reinterpret_cast<float*>(p); p += nms_align256(n * 16);
+  float* ss = reinterpret_cast<float*>(p); p += nms_align256(n * 4);
+  int* idx = reinterpret_cast<int*>(p); p += nms_align256(n * 4);
+  float* os = reinterpret_cast<float*>(p); p += nms_align256(n * 4);
+  int* op = reinterpret_cast<int*>(p); p += nms_align256(n * 4);
+  int* flags = reinterpret_cast<int*>(p); p += nms_align256(n * 4);
+  int* cnt = reinterpret_cast<int*>(p); p += 256;         // cnt[0] sorted count, cnt[1] kept count
+  uint64_t* mask = reinterpret_cast<uint64_t*>(p);
+  hipError_t e = hipMemsetAsync(cnt, 0, 2 * sizeof(int), st);
+  if (e != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "nms: memset failed");
+  LevelTable lt;
+  lt.n_levels = 1; lt.lo[0] = 0; lt.cnt[0] = num_boxes;
+  hipLaunchKernelGGL(rank_sort_gather_kernel<true>, dim3(cdiv(num_boxes, 256), 1), dim3(256), 0, st, scores, dets, num_boxes,
+                     num_boxes, num_boxes, lt, bs, ss, idx, cnt, (const int*)nullptr);
+  int rc = osd_check_launch("nms: sort");
+  if (rc) return rc;
+  rc = osd_nms_sorted(bs, ss, cnt, 1, num_boxes, thresh, cuda_semantics, num_boxes, mask, ob, os, op, cnt + 1, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(nms_keep_indices_kernel, dim3(1), dim3(1024), 0, st, idx, op, cnt + 1, num_boxes, flags,
+                     reinterpret_cast<long long*>(keep_out), count_out);
+  return osd_check_launch("nms: keep indices");
 }
 
 // ---- per-level top-k + order + NMS in one call, sorting only the head of the order (see select_head_kernel) ----
@@ -774,7 +856,7 @@ extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int
   rc = osd_check_launch("nms_scan");
   if (rc || limit >= max_count) return rc;
   // phase 2, flagged images only: the whole order, then NMS over all of it
-  hipLaunchKernelGGL(rank_sort_gather_kernel, dim3(cdiv(total, 256), n), dim3(256), 0, st, keys, boxes, total, max_count, topn, lt,
+  hipLaunchKernelGGL(rank_sort_gather_kernel<false>, dim3(cdiv(total, 256), n), dim3(256), 0, st, keys, boxes, total, max_count, topn, lt,
                      boxes_sorted, scores_sorted, idx_sorted, counts2, (const int*)need_full);
   rc = osd_check_launch("rank_sort_gather(full)");
   if (rc) return rc;

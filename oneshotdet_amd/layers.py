@@ -22,20 +22,46 @@ def _require_cuda(t, what):
 
 def nms(boxes, scores, nms_thresh, cuda_semantics=True, max_keep=None):
     """boxes [N,4] fp32 xyxy, scores [N] -> int64 indices of kept boxes, ascending in the original order (what
-    csrc/cuda/nms.cu:127-130 returns).  Suppression when IoU > thresh (CUDA rule) or >= thresh (CPU rule)."""
+    csrc/cuda/nms.cu:127-130 returns).  Suppression when IoU > thresh (CUDA rule) or >= thresh (CPU rule).  One C-ABI
+    call (osd_nms); max_keep (not in the reference): stop after that many survivors in score order."""
     _require_cuda(boxes, "nms")
     n = boxes.shape[0]
     if n == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     if boxes.dim() != 2 or boxes.shape[1] != 4 or scores.shape[0] != n:
         raise RuntimeError("nms: boxes must be [N,4] and scores [N]")
-    keys = scores.float().reshape(1, n).contiguous()
-    bs, ss, idx, cnt = ops.rank_sort_gather(keys, boxes.float().reshape(1, n, 4).contiguous(), n)
-    max_keep = n if max_keep is None else max_keep
-    ob, os_, op, oc = ops.nms_sorted(bs, ss, cnt, nms_thresh, max_keep, cuda_semantics=cuda_semantics)
-    k = int(oc[0].item())           # the reference API returns a dynamically sized tensor: one host read
-    kept_sorted_pos = op[0, :k].long()
-    return idx[0].long()[kept_sorted_pos].sort()[0]
+    if max_keep is not None and max_keep < n:
+        keys = scores.float().reshape(1, n).contiguous()
+        bs, ss, idx, cnt = ops.rank_sort_gather(keys, boxes.float().reshape(1, n, 4).contiguous(), n)
+        ob, os_, op, oc = ops.nms_sorted(bs, ss, cnt, nms_thresh, max_keep, cuda_semantics=cuda_semantics)
+        k = int(oc[0].item())
+        return idx[0].long()[op[0, :k].long()].sort()[0]
+    keep, count = ops.nms(boxes.float().contiguous(), scores.float().contiguous(), nms_thresh, cuda_semantics)
+    return keep[:int(count.item())]     # the reference API returns a dynamically sized tensor: one host read
+
+
+class _ROIAlign(torch.autograd.Function):
+    """layers/roi_align.py:11-44: forward = _C.roi_align_forward, backward = _C.roi_align_backward (gradient w.r.t. the
+    input only; the ROIs get None there too).  Logical NCHW in and out; the kernels work on NHWC."""
+
+    @staticmethod
+    def forward(ctx, input, rois, output_size, spatial_scale, sampling_ratio):
+        rois = rois.contiguous().float()
+        ctx.save_for_backward(rois)
+        ctx.output_size, ctx.spatial_scale, ctx.sampling_ratio = output_size, spatial_scale, sampling_ratio
+        ctx.input_shape, ctx.input_dtype = input.shape, input.dtype
+        x = input.permute(0, 2, 3, 1).contiguous()       # no copy when input is channels_last
+        y = ops.roi_align(x, rois, spatial_scale, output_size[0], output_size[1], sampling_ratio)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        rois, = ctx.saved_tensors
+        b, c, h, w = ctx.input_shape
+        gy = grad_output.float().permute(0, 2, 3, 1).contiguous()      # [R, ph, pw, C]
+        gx = ops.roi_align_bwd(gy, rois, (b, h, w, c), ctx.spatial_scale, ctx.output_size[0], ctx.output_size[1],
+                               ctx.sampling_ratio)
+        return gx.permute(0, 3, 1, 2).to(ctx.input_dtype), None, None, None, None
 
 
 class ROIAlign(nn.Module):
@@ -46,11 +72,9 @@ class ROIAlign(nn.Module):
         self.sampling_ratio = sampling_ratio
 
     def forward(self, input, rois):
-        """input [B,C,H,W] (any memory format), rois [R,5] -> [R,C,ph,pw] fp32."""
+        """input [B,C,H,W] (any memory format; fp32 or bf16), rois [R,5] -> [R,C,ph,pw] fp32, differentiable w.r.t. input."""
         _require_cuda(input, "ROIAlign")
-        x = input.permute(0, 2, 3, 1).contiguous()       # no copy when input is channels_last
-        y = ops.roi_align(x, rois, self.spatial_scale, self.output_size[0], self.output_size[1], self.sampling_ratio)
-        return y.permute(0, 3, 1, 2)
+        return _ROIAlign.apply(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio)
 
     def __repr__(self):
         return "ROIAlign(output_size=%s, spatial_scale=%s, sampling_ratio=%s)" % (

@@ -197,7 +197,9 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
         assert mask.shape == out.shape and mask.dtype == out.dtype
     args = (_ptr(x), _ptr(pc.w), _ptr(pc.bias), _ptr(res), _ptr(mask), _ptr(act_scale_dev), None, _ptr(out), _stream())
     if algo is None:
-        key = (d.dtype, n * ho * wo, d.cout, d.cin, d.r, d.s, d.stride_h, d.pad_h, res_mode, act, int(relu_in),
+        # full geometry in the key: some algorithms only exist for some map widths (the row-reuse kernel: W in 64/128/256),
+        # and a transposed batch (1024x800 after 800x1024) has the same n*ho*wo
+        key = (d.dtype, n, ho, wo, d.cout, d.cin, d.r, d.s, d.stride_h, d.pad_h, res_mode, act, int(relu_in),
                mask is not None)
         algo = ALGO_CACHE.get(key)
         if algo is None:
@@ -412,6 +414,21 @@ def nms_sorted(boxes_sorted, scores_sorted, counts, thresh, max_keep, cuda_seman
     _lib.call("osd_nms_sorted", _ptr(boxes_sorted), _ptr(scores_sorted), _ptr(counts), n, max_count, float(thresh),
               int(cuda_semantics), max_keep, _ptr(workspace), _ptr(ob), _ptr(os_), _ptr(op), _ptr(oc), _stream())
     return ob, os_, op, oc
+
+
+def nms(dets, scores, thresh, cuda_semantics=True):
+    """_C.nms in one call: dets [N,4] fp32, scores [N] fp32 -> (keep [N] int64 ascending original indices, count [1] int32
+    on the device; keep[:count] is the result)."""
+    _chk_dev(dets, scores)
+    n = dets.shape[0]
+    dev = dets.device
+    keep = torch.empty((n,), device=dev, dtype=torch.int64)
+    count = torch.empty((1,), device=dev, dtype=torch.int32)
+    need = int(_lib.load().osd_nms_single_workspace_bytes(n))
+    ws = torch.empty((need // 8 + 1,), device=dev, dtype=torch.int64)
+    _lib.call("osd_nms", _ptr(dets), _ptr(scores), n, float(thresh), int(cuda_semantics), _ptr(ws), _ptr(keep), _ptr(count),
+              _stream())
+    return keep, count
 
 
 def sigmoid_focal_loss_fwd(logits, targets, gamma, alpha):

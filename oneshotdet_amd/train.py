@@ -72,11 +72,13 @@ class TrainEngine(object):
         self._deferred, self._defer_now, self._joined_refs = None, False, None
         self.repack()
         self.zero_bias = torch.zeros(4096, device=self.device, dtype=torch.float32)
-        # SGD with the reference's parameter groups (solver/build.py:8-26: bias lr x2, bias weight decay 0)
+        # SGD with the reference's parameter groups (solver/build.py:8-26): a parameter whose reference KEY contains "bias"
+        # gets lr x BIAS_LR_FACTOR (2) and WEIGHT_DECAY_BIAS (0); every other one — conv / GroupNorm weights AND the Scale
+        # scalars `rpn.head.scales.N.scale` — gets BASE_LR and WEIGHT_DECAY
         weights = [c.w for c in self.convs.values() if c.trainable] + \
-                  [p for n, (p, _) in self.extra.items() if n.endswith(".weight")]
+                  [p for n, (p, _) in self.extra.items() if "bias" not in n]
         biases = [c.b for c in self.convs.values() if c.trainable and c.has_bias] + \
-                 [p for n, (p, _) in self.extra.items() if not n.endswith(".weight")]
+                 [p for n, (p, _) in self.extra.items() if "bias" in n]
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.opt = None
         if optimizer == "torch":     # the reference's optimiser object, kept for A/B tests of the fused kernel
@@ -808,3 +810,80 @@ class TrainEngine(object):
             else:
                 out[name] = g
         return out
+
+    # ------------------------------------------------------------------------------------------------ optimiser state
+    def _named_views(self, flat):
+        """Reference-named OIHW copies of a flat buffer laid out like the masters (momentum, gradients...)."""
+        out = {}
+        h = "rpn.head."
+        base = self.flat_w.data_ptr()
+
+        def view(t):
+            off = (t.data_ptr() - base) // 4
+            return flat[off:off + t.numel()].view(t.shape)
+        for name, c in self.convs.items():
+            if not c.trainable:
+                continue
+            w = view(c.w).permute(0, 3, 1, 2).clone(memory_format=torch.contiguous_format)
+            if name == h + "cls_ctr":
+                b = view(c.b)
+                out[h + "cls_logits.weight"], out[h + "centerness.weight"] = w[0:1].clone(), w[1:2].clone()
+                out[h + "cls_logits.bias"], out[h + "centerness.bias"] = b[0:1].clone(), b[1:2].clone()
+                continue
+            out[name + ".weight"] = w
+            if c.has_bias:
+                out[name + ".bias"] = view(c.b).clone()
+        for name, (p, _) in self.extra.items():
+            v = view(p)
+            if name == h + "scales":
+                for i in range(5):
+                    out["%sscales.%d.scale" % (h, i)] = v[i:i + 1].clone()
+            else:
+                out[name] = v.clone()
+        return out
+
+    def optimizer_state_dict(self):
+        """What the reference checkpoint stores under 'optimizer' (utils/checkpoint.py:42-46: torch.optim.SGD.state_dict()),
+        keyed by reference parameter NAME instead of torch's positional ids: momentum buffers (OIHW, reference names), the
+        number of steps taken (the first step initialises the buffer with the gradient, torch.optim.SGD semantics) and
+        the hyper-parameters.  load_optimizer_state_dict() restores it, so a resumed run continues with its momentum."""
+        self.join()
+        if self.opt is not None:
+            raise NotImplementedError("optimizer='torch' (A/B mode): use self.opt.state_dict()")
+        return {"momentum_buffer": self._named_views(self._sgd["buf"]), "steps": int(self._sgd["steps"]),
+                "lr": float(self.lr), "momentum": float(self.momentum), "weight_decay": float(self.weight_decay)}
+
+    def load_optimizer_state_dict(self, state):
+        self.join()
+        if self.opt is not None:
+            raise NotImplementedError("optimizer='torch' (A/B mode): use self.opt.load_state_dict()")
+        h = "rpn.head."
+        mb = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state["momentum_buffer"].items()}
+        base = self.flat_w.data_ptr()
+        buf = self._sgd["buf"]
+
+        def view(t):
+            off = (t.data_ptr() - base) // 4
+            return buf[off:off + t.numel()].view(t.shape)
+        for name, c in self.convs.items():
+            if not c.trainable:
+                continue
+            if name == h + "cls_ctr":
+                w = torch.cat([mb[h + "cls_logits.weight"], mb[h + "centerness.weight"]], 0)
+                view(c.w).copy_(w.permute(0, 2, 3, 1))
+                view(c.b).copy_(torch.cat([mb[h + "cls_logits.bias"], mb[h + "centerness.bias"]], 0))
+                continue
+            view(c.w).copy_(mb[name + ".weight"].permute(0, 2, 3, 1))
+            if c.has_bias:
+                view(c.b).copy_(mb[name + ".bias"])
+        for name, (p, _) in self.extra.items():
+            if name == h + "scales":
+                view(p).copy_(torch.cat([mb["%sscales.%d.scale" % (h, i)].reshape(1) for i in range(5)]))
+            else:
+                view(p).copy_(mb[name])
+        self._sgd["steps"] = int(state["steps"])
+        self.lr = float(state.get("lr", self.lr))
+        self.momentum = float(state.get("momentum", self.momentum))
+        if float(state.get("weight_decay", self.weight_decay)) != self.weight_decay:
+            raise ValueError("weight decay is baked into the update tables: construct the engine with weight_decay=%r"
+                             % state["weight_decay"])

@@ -43,3 +43,35 @@ def test_documented_focal_loss_stub_matches_the_oracle():
     out = ns["sigmoid_focalloss_forward"](logits.cuda(), targets.cuda(), 1, 2.0, 0.25).cpu()
     ref = orc.sigmoid_focal_loss_cuda_formula(logits, targets, 2.0, 0.25)
     torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_documented_nms_stub_matches_the_oracle():
+    ns = _stub_namespace()
+    rng = np.random.RandomState(3)
+    xy = rng.rand(900, 2).astype(np.float32) * 200
+    boxes = np.concatenate([xy, xy + rng.rand(900, 2).astype(np.float32) * 90 + 2], 1)
+    scores = rng.rand(900).astype(np.float32)
+    keep = ns["nms"](torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 0.6).cpu().numpy()
+    assert np.array_equal(keep, orc.nms(boxes, scores, 0.6, cuda_semantics=True))
+
+
+def test_documented_roi_align_backward_stub_matches_oracle_autograd():
+    ns = _stub_namespace()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 8, 12, 10, generator=g, requires_grad=True)
+    rois = torch.tensor([[0, 1.0, 2.0, 17.0, 15.5], [1, 0.0, 0.0, 19.0, 23.0]])
+    ref = orc.roi_align(x, rois, 0.5, 2, 2, 2)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    gx = ns["roi_align_backward"](w.cuda(), rois.cuda(), 0.5, 2, 2, 2, 8, 12, 10, 2).cpu()
+    torch.testing.assert_close(gx, x.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_documented_conv_argument_order_is_the_headers():
+    """INTEGRATION.md section 4 quotes osd_conv2d_fwd's parameter list: it must be the header's."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    hdr = open(os.path.join(ROOT, "include", "oneshotdet_hip.h")).read()
+    m = re.search(r"int osd_conv2d_fwd\((.*?)\);", hdr, re.S)
+    names = [a.strip().split()[-1].lstrip("*") for a in m.group(1).replace("\n", " ").split(",")]
+    doc = re.search(r"`osd_conv2d_fwd\((.*?)\)`", text).group(1)
+    assert [a.strip() for a in doc.split(",")] == ["desc" if n == "d" else n for n in names]

@@ -336,3 +336,45 @@ def test_conv2d_row_reuse_kernel_matches_the_dma_kernel():
     with pytest.raises(_lib.OsdError):
         o.conv2d(to_nhwc(rnd(1, 64, 8, 100, seed=1), torch.bfloat16), pc if pc.cin_k == 64 else o.pack_conv(
             (rnd(256, 64, 3, 3, seed=2)).cuda(), dtype=torch.bfloat16), pad=1, algo=XR)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_roi_align_module_backward_matches_oracle_autograd(dt):
+    """layers.ROIAlign is differentiable like the reference's (layers/roi_align.py:27-44 -> _C.roi_align_backward): the
+    gradient w.r.t. the input equals autograd through the oracle's ROIAlign (tap weights are constants)."""
+    from oneshotdet_amd import layers
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 16, 13, 11, generator=g)
+    rois = torch.tensor([[0, 1.5, 2.0, 30.0, 40.0], [1, 0.0, 0.0, 43.0, 51.0], [1, 10.0, 5.0, 12.0, 9.0],
+                         [0, -8.0, -4.0, 20.0, 18.0]], dtype=torch.float32)
+    for (ph, pw, sr, scale) in ((1, 1, 2, 0.25), (7, 7, 2, 0.25), (3, 2, 0, 0.125)):
+        xr = x.clone().requires_grad_(True)
+        ref = orc.roi_align(xr, rois, scale, ph, pw, sr)
+        w = torch.randn(ref.shape, generator=g)
+        (ref * w).sum().backward()
+        xd = x.to(DT[dt]).cuda().to(memory_format=torch.channels_last).requires_grad_(True)
+        mod = layers.ROIAlign((ph, pw), scale, sr)
+        y = mod(xd, rois.cuda())
+        assert y.shape == ref.shape and y.requires_grad
+        (y * w.cuda()).sum().backward()
+        tol = dict(rtol=1e-4, atol=1e-5) if dt == "f32" else dict(rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(y.detach().float().cpu(), ref.detach() if dt == "f32" else
+                                   orc.roi_align(x.to(DT[dt]).float(), rois, scale, ph, pw, sr), **tol)
+        assert xd.grad.dtype == xd.dtype and xd.grad.shape == xd.shape
+        torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, **tol)
+
+
+def test_conv_algorithm_cache_is_keyed_on_the_full_geometry():
+    """A tuned 3x3 conv on a [*, 16, 128] map (row-reuse kernel allowed: W = 128) must not hand its algorithm to the
+    transposed [*, 128, 16] map, which has the same number of output pixels but a width that kernel does not support."""
+    o = ops()
+    w = rnd(256, 256, 3, 3, seed=1, scale=0.05)
+    pc = o.pack_conv(w.cuda(), bias=torch.zeros(256).cuda(), dtype=torch.bfloat16)
+    for shape in ((2, 256, 16, 128), (2, 256, 128, 16)):
+        x = rnd(*shape, seed=2)
+        with o.tuning():
+            y = o.conv2d(to_nhwc(x, torch.bfloat16), pc, pad=1)
+        ref = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), padding=1)
+        torch.testing.assert_close(y.float().permute(0, 3, 1, 2).cpu(), ref, rtol=2e-2, atol=2e-1)
+    keys = [k for k in o.ALGO_CACHE if k[0] == o.OSD_BF16 and k[4:8] == (256, 256, 3, 3)]
+    assert len({k[1:4] for k in keys}) >= 2

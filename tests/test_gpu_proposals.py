@@ -284,3 +284,24 @@ def test_proposals_sort_nms_equals_the_two_call_pipeline(case):
         hb, hs, _, hc = ops.nms_sorted(bs[:, :2564].contiguous(), ss[:, :2564].contiguous(), cnt.clamp(max=2564), 0.5, max_keep,
                                        cuda_semantics=True)
         assert int(hc.max()) < int(rc.min())
+
+
+def test_osd_nms_single_entry_matches_the_oracle_for_any_scores():
+    """osd_nms = _C.nms (csrc/nms.h:10) in ONE C-ABI call: ascending original indices + a device-side count; scores of
+    either sign (the reference sorts whatever it is given), ties broken by the lower index."""
+    from oneshotdet_amd import ops
+    rng = np.random.RandomState(11)
+    for n in (1, 63, 64, 65, 700, 5000):
+        xy = rng.rand(n, 2).astype(np.float32) * 300
+        wh = rng.rand(n, 2).astype(np.float32) * 120 + 1
+        boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        scores = (rng.randn(n) * 3).astype(np.float32)              # negative scores included
+        scores[rng.randint(0, n, max(1, n // 10))] = scores[0]      # ties
+        for cuda in (True, False):
+            keep, count = ops.nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 0.5, cuda_semantics=cuda)
+            assert keep.dtype == torch.int64 and count.dtype == torch.int32 and keep.shape == (n,)
+            got = keep[:int(count.item())].cpu().numpy()
+            ref = orc.nms(boxes, scores, 0.5, cuda_semantics=cuda)      # stable argsort: ties -> lower index first
+            assert np.array_equal(got, ref), (n, cuda)
+    keep, count = ops.nms(torch.zeros(0, 4, device="cuda"), torch.zeros(0, device="cuda"), 0.5)
+    assert int(count.item()) == 0 and keep.shape == (0,)

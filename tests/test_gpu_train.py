@@ -195,6 +195,62 @@ def test_fused_sgd_matches_torch_optim():
     torch.testing.assert_close(a.flat_w, b.flat_w, rtol=1e-6, atol=1e-7)
 
 
+def test_sgd_step_uses_the_reference_parameter_groups():
+    """One optimiser step vs torch.optim.SGD built the way solver/build.py:8-26 builds it — one group per parameter, keyed
+    on the REFERENCE key name: "bias" in the key -> lr x 2 and weight decay 0, everything else (conv and GroupNorm weights
+    and the Scale scalars rpn.head.scales.N.scale) BASE_LR and WEIGHT_DECAY.  Built here from state_dict() names, not from
+    the engine's own lists."""
+    from oneshotdet_amd import train
+    np_sd = synth.make_state_dict(spec.hot_path_shapes())
+    lr, wd, mom = 0.05, 0.01, 0.9
+    eng = train.TrainEngine(np_sd, dtype=torch.bfloat16, lr=lr, weight_decay=wd, momentum=mom)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    sd0 = {k: v.clone() for k, v in eng.state_dict().items() if not spec.is_frozen(k)}
+    params = {k: torch.nn.Parameter(v.clone()) for k, v in sd0.items()}
+    groups = [{"params": [p], "lr": lr * (2 if "bias" in k else 1), "weight_decay": 0.0 if "bias" in k else wd}
+              for k, p in params.items()]
+    ref = torch.optim.SGD(groups, lr, momentum=mom)
+    for _ in range(2):
+        eng.flat_g.copy_(torch.randn(eng.flat_g.shape, device="cuda", generator=g) * 0.01)
+        for k, gr in eng.named_grads().items():
+            params[k].grad = gr.detach().clone().reshape(params[k].shape)
+        eng.optimizer_step()
+        ref.step()
+    sd1 = eng.state_dict()
+    scales = [k for k in params if ".scales." in k]
+    assert len(scales) == 5
+    for k, p in params.items():
+        torch.testing.assert_close(sd1[k], p.detach(), rtol=1e-6, atol=1e-7, msg=lambda m, k=k: "%s: %s" % (k, m))
+    # the Scale scalars decay (weights group): with a zero gradient they shrink by lr * wd
+    assert all((sd1[k] != sd0[k]).all() for k in scales)
+
+
+def test_optimizer_state_survives_a_checkpoint(tmp_path):
+    """utils/checkpoint.py:33-50 stores model + optimizer + iteration: a run resumed from save_training_checkpoint continues
+    with its momentum (weights after one more step are identical to the uninterrupted run's)."""
+    from oneshotdet_amd import checkpoint, train
+    eng, img, q, gtb, cnt = _engine_and_inputs("f32")
+    for _ in range(2):
+        eng.train_step(img, q, gtb, cnt)
+    path = checkpoint.save_training_checkpoint(str(tmp_path / "model_0000002.pth"), eng, 2)
+    st = eng.optimizer_state_dict()
+    assert st["steps"] == 2 and any(v.abs().max() > 0 for v in st["momentum_buffer"].values())
+    assert set(st["momentum_buffer"]) == {k for k in eng.state_dict() if not spec.is_frozen(k)}
+    eng2, it = checkpoint.resume_training(path, lambda sd: train.TrainEngine(sd, dtype=torch.float32))
+    assert it == 2 and eng2._sgd["steps"] == 2
+    torch.testing.assert_close(eng2._sgd["buf"], eng._sgd["buf"], rtol=0, atol=0)
+    eng.train_step(img, q, gtb, cnt)
+    eng2.train_step(img, q, gtb, cnt)
+    eng.join(), eng2.join()
+    torch.cuda.synchronize()
+    a, b = eng.state_dict(), eng2.state_dict()
+    # same kernels, same inputs; the weight-gradient atomics make the two runs differ in the last bits only
+    for k in a:
+        torch.testing.assert_close(a[k], b[k], rtol=1e-4, atol=1e-6, msg=lambda m, k=k: "%s: %s" % (k, m))
+    fresh = train.TrainEngine(a, dtype=torch.float32)          # without the momentum the next step differs visibly
+    assert fresh._sgd["steps"] == 0
+
+
 def test_state_dict_round_trip_and_update():
     """TrainEngine.state_dict() returns the reference's names/shapes (tests/golden/state_dict_keys.json); untouched it
     equals the input bit for bit; after an SGD step exactly the trainable tensors have moved."""
