@@ -374,6 +374,8 @@ class TrainEngine(object):
         gscales.add_(raw / scales)      # d loss / d scale_l = sum ds * x, x = log(reg) / scale_l
         losses = torch.empty(4, device=self.device, dtype=torch.float32)
         ops._lib.call("osd_fcos_loss_finalize", ops._ptr(sums), ops._ptr(losses), n, ops._stream())
+        # {num_pos, sum_w, sum_focal, sum_w*(1-giou), sum_bce}: the un-normalised sums are additive over images (tests)
+        self.last_loss_sums = sums
         return losses, grads
 
     # ------------------------------------------------------------------------------------------------ backward

@@ -77,6 +77,9 @@ CASES = {
     "nonsquare": (2, 96, 160, 1, 96, 160),      # pins the (h, w)-as-(x2, y2) query-box quirk
     "shots5": (2, 128, 128, 5, 127, 127),       # S=5 mean-pooled queries (configs[4])
     "tall": (1, 160, 96, 1, 64, 96),
+    # two DISTINCT full-size (target, query, boxes) triples: the bs=8 benchmark batch built from them is checked per image
+    # against this (cross-image aliasing at the benchmark's grid sizes)
+    "config1x2": (2, 800, 1024, 1, 127, 127),
 }
 
 

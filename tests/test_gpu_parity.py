@@ -37,7 +37,7 @@ def head_of(out):
     return gu.flatten_head(logits, reg, ctr)
 
 
-@pytest.mark.parametrize("name", ["small", "nonsquare", "shots5", "tall", "config1"])
+@pytest.mark.parametrize("name", ["small", "nonsquare", "shots5", "tall", "config1", "config1x2"])
 def test_fp32_forward_matches_reference_golden(name, engines):
     B, H, W, S, qh, qw = gu.CASES[name]
     img, q = gu.case_inputs(name)
@@ -99,3 +99,40 @@ def test_full_size_batch8_properties(dt, engines):
     b = ob[0, :k]
     assert b.min() >= 0 and b[:, 2].max() <= 1023 and b[:, 3].max() <= 799
     assert layers.nms(b, os_[0, :k], spec.NMS_THRESH).numel() == k
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_full_size_batch8_of_distinct_images_equals_the_single_image_runs(dt, engines):
+    """The MEASURED configuration (bench.py: 8 DISTINCT 800x1024 targets, 8 distinct 127x127 queries): every image's
+    pooled query vector, head outputs and proposals in the batch equal its own single-image run bit for bit — any
+    cross-image aliasing at the benchmark's grid sizes (a tile of image 3 reading image 2, a wrong image index in a tail
+    tile, proposals written into a neighbour's slot) breaks it.  Images 0 and 1 are the `config1x2` inputs, whose fp32
+    outputs are pinned to the REAL reference by tests/golden/case_config1x2.npz (recorded at batch 2)."""
+    eng = engines[dt]
+    a_img, a_q = gu.case_inputs("config1x2")
+    images = np.concatenate([a_img, synth.make_images("target.distinct8", 6, 800, 1024, seed=11)], 0)
+    queries = np.concatenate([a_q, synth.make_images("query.distinct8", 6, 127, 127, seed=11)], 0)
+    images, queries = torch.from_numpy(images).cuda(), torch.from_numpy(queries).cuda()
+    assert not torch.equal(images[0], images[1]) and not torch.equal(images[2], images[7])
+    out8 = eng.detect(images, queries)
+    ob8, os8, oc8 = out8["proposals"]
+    for i in range(8):
+        out1 = eng.detect(images[i:i + 1].contiguous(), queries[i:i + 1].contiguous())
+        for lvl in range(5):
+            assert torch.equal(out8["pooled"][lvl][i], out1["pooled"][lvl][0]), (i, lvl)
+            for a, b in zip(out8["head"][lvl], out1["head"][lvl]):
+                assert torch.equal(a[i], b[0]), "image %d of the batch differs from its single-image run (level %d)" % (i, lvl)
+        ob1, os1, oc1 = out1["proposals"]
+        k = int(oc1[0])
+        assert int(oc8[i]) == k and k > 0
+        assert torch.equal(ob8[i, :k], ob1[0, :k]) and torch.equal(os8[i, :k], os1[0, :k])
+    # different images must not give the same answer (a batch that broadcast image 0 would pass the loop above otherwise)
+    assert not torch.equal(out8["head"][0][0][0], out8["head"][0][0][1])
+    if dt == "f32":
+        f = gu.load("case_config1x2.npz")
+        np.testing.assert_allclose(head_of(out8)[:2], f["head"], rtol=1e-3, atol=1e-3)
+        for i in range(2):
+            k = int(oc8[i])
+            rb, rs = f["proposals.%d.boxes" % i], f["proposals.%d.scores" % i]
+            assert abs(k - len(rb)) <= max(1, len(rb) // 200)
+            assert gu.match_boxes(rb, rs, ob8[i, :k].cpu().numpy(), os8[i, :k].cpu().numpy()) >= 0.99

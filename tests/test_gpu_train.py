@@ -100,7 +100,7 @@ def _engine_and_inputs(dt, name="small"):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["small", "nonsquare", "shots5", "tall", "config1"])
+@pytest.mark.parametrize("name", ["small", "nonsquare", "shots5", "tall", "config1", "config1x2"])
 def test_forward_backward_matches_oracle_autograd(name, dt):
     """Losses (R12) and parameter gradients of the whole training forward+backward vs the oracle's autograd (stored in
     train_<case>.npz; the oracle itself is pinned bit-exact to the reference's losses and gradients there).  `config1` is
@@ -113,7 +113,10 @@ def test_forward_backward_matches_oracle_autograd(name, dt):
     losses = eng.forward_backward(img, q, gtb, cnt).cpu().numpy()
     assert int(losses[3]) == int(f["num_pos"])
     np.testing.assert_allclose(losses[:3], f["losses_cuda_formula"], rtol=1e-4 if dt == "f32" else 3e-2)
-    grads = eng.named_grads()
+    _check_grads_against_fixture(eng.named_grads(), f, dt)
+
+
+def _check_grads_against_fixture(grads, f, dt):
     tol = 2e-2 if dt == "f32" else 0.25
     checked = 0
     for key in f.files:
@@ -458,6 +461,75 @@ def test_full_size_batch8_training_step_properties(dt):
         a, b = g8[lo:hi], g1[lo:hi]
         err = float((a - b).norm() / b.norm())
         assert err <= (2e-4 if dt == "f32" else 3e-2), (name, err)
+
+
+def _batch_of(name, order, dt):
+    """A batch assembled from the images of fixture case `name` in the given order (indices into the case's batch)."""
+    from oneshotdet_amd import train
+    B, H, W, S, qh, qw = gu.CASES[name]
+    img, q = gu.case_inputs(name)
+    gts = synth.make_gt_boxes(B, H, W, seed=3, max_boxes=3)
+    G = max(len(g) for g in gts)
+    gtb = torch.zeros(len(order), G, 4)
+    for j, i in enumerate(order):
+        gtb[j, :len(gts[i])] = torch.from_numpy(gts[i])
+    cnt = torch.tensor([len(gts[i]) for i in order], dtype=torch.int32)
+    eng = train.TrainEngine(synth.make_state_dict(spec.hot_path_shapes()), dtype=DT[dt])
+    idx = torch.tensor(order)
+    return eng, torch.from_numpy(img)[idx].cuda(), torch.from_numpy(q)[idx].cuda(), gtb.cuda(), cnt.cuda()
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_full_size_batch8_of_two_distinct_images_matches_the_reference_fixture(dt):
+    """bs=8 at 800x1024 built from the two DISTINCT (image, query, boxes) triples of train_config1x2.npz (recorded through
+    the reference at batch 2) in an irregular order [A,B,B,A,B,A,A,B].  The FCOS losses are normalised over the whole
+    batch (fcos/loss.py:251-271), so a batch with every triple four times has the fixture's losses and parameter gradients:
+    image-index mistakes in any forward / loss / data-gradient / weight-gradient kernel at the benchmark's grid sizes show
+    as a difference between A-slots and B-slots.  The training proposals of every slot equal those of the other slots
+    with the same image, and differ between A and B."""
+    f = gu.load("train_config1x2.npz")
+    order = [0, 1, 1, 0, 1, 0, 0, 1]
+    eng, img, q, gtb, cnt = _batch_of("config1x2", order, dt)
+    losses = eng.forward_backward(img, q, gtb, cnt).cpu().numpy()
+    assert int(losses[3]) == 4 * int(f["num_pos"])
+    np.testing.assert_allclose(losses[:3], f["losses_cuda_formula"], rtol=1e-4 if dt == "f32" else 3e-2)
+    _check_grads_against_fixture(eng.named_grads(), f, dt)
+    torch.cuda.synchronize()
+    pb, ps, pc = eng.proposals
+    for j in range(2, 8):
+        k = order.index(order[j])
+        assert int(pc[j]) == int(pc[k]) and torch.equal(pb[j], pb[k]) and torch.equal(ps[j], ps[k]), (j, k)
+    assert not torch.equal(pb[0], pb[1])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_full_size_batch8_of_eight_distinct_images_has_additive_loss_sums(dt):
+    """bench.py's batch: 8 DISTINCT images, queries and box sets.  The un-normalised loss sums {num_pos, sum_w, sum_focal,
+    sum_w*(1-GIoU), sum_bce} of the batch are the sums of the eight single-image runs (per-image target assignment and
+    loss terms do not see the other images), and the batch losses follow from them by fcos/loss.py:251-271."""
+    from oneshotdet_amd import train
+    B = 8
+    images = torch.from_numpy(synth.make_images("bench.target", B, 800, 1024, seed=1000)).cuda()
+    queries = torch.from_numpy(synth.make_images("bench.query", B, 127, 127, seed=1000)).cuda()
+    gts = synth.make_gt_boxes(B, 800, 1024, seed=1000, max_boxes=6)
+    gtb = torch.zeros(B, 6, 4)
+    for i, g in enumerate(gts):
+        gtb[i, :len(g)] = torch.from_numpy(g)
+    gtb = gtb.cuda()
+    cnt = torch.tensor([len(g) for g in gts], dtype=torch.int32).cuda()
+    eng = train.TrainEngine(synth.make_state_dict(spec.hot_path_shapes()), dtype=DT[dt])
+    l8 = eng.forward_backward(images, queries, gtb, cnt, with_proposals=False).cpu().double()
+    s8 = eng.last_loss_sums[:5].cpu().double()
+    tot = torch.zeros(5, dtype=torch.float64)
+    for i in range(B):
+        eng.forward_backward(images[i:i + 1].contiguous(), queries[i:i + 1].contiguous(), gtb[i:i + 1].contiguous(),
+                             cnt[i:i + 1].contiguous(), with_proposals=False)
+        tot += eng.last_loss_sums[:5].cpu().double()
+    assert int(s8[0]) == int(tot[0]) and int(tot[0]) > 8
+    # the forward is batch-invariant bit for bit (test_gpu_parity); the sums differ only by the order of the atomics
+    torch.testing.assert_close(s8, tot, rtol=1e-5, atol=1e-6)
+    expect = torch.stack([tot[2] / (tot[0] + B), tot[3] / tot[1], tot[4] / tot[0]])
+    torch.testing.assert_close(l8[:3], expect, rtol=1e-5, atol=1e-7)
 
 
 def test_conv_wgrad_multi_mixes_shared_and_own_weights():
