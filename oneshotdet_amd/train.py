@@ -607,6 +607,7 @@ class TrainEngine(object):
                 self.proposals = ops.append_gt_boxes(pb, ps_, pc, gt_boxes, gt_count)
         # ---- loss + backward
         losses, pred_grads = self.loss_and_grads(head_out, gt_boxes, gt_count)
+        self.last_head_out, self.last_pred_grads = head_out, pred_grads      # (tests: conditioning of the Scale gradients)
         d_comb = self.head_backward(combined, hctx, pred_grads)
         self._bucket_ready("head", [st for st in (main, s1, self.wstream, self.wstream2) if st is not None])
         # correlation backward (generalized_rcnn.py:307-311): d feat = g * q, d q = sum_hw g * feat

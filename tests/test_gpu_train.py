@@ -1,8 +1,11 @@
 """GPU (-m gpu): training path — weight-gradient / GroupNorm-backward / loss kernels against PyTorch autograd on CPU,
 and the whole forward+backward against the oracle's autograd gradients stored in tests/golden/train_small.npz.
 
-Tolerances: gradients are sums over 1e3..1e5 locations with ReLU / min / max kinks, so they are compared relative to the
-tensor's absmax: fp32 path 2e-2 (measured ~1e-3 median), bf16 path 0.25; losses fp32 rtol 1e-4, bf16 rtol 3e-2."""
+Tolerances (set from tools/grad_stats.py on MI355X): gradients are compared relative to the tensor's absmax on 256 sampled
+elements per tensor.  fp32: every element within 5e-4 (measured <= 2.5e-4), cosine >= 0.9995, relative L2 <= 2e-2; the one
+case with a documented ReLU-mask flip (MASK_FLIP_CASES) allows 2 elements above 5e-3, none above 2e-2.  bf16: relative L2
+<= 0.35 and cosine >= 0.96 per tensor (measured 0.26 / 0.9715 at worst), Scale gradients against their conditioning sum.
+Losses: fp32 rtol 1e-4, bf16 rtol 3e-2."""
 import numpy as np
 import pytest
 import torch
@@ -113,31 +116,80 @@ def test_forward_backward_matches_oracle_autograd(name, dt):
     losses = eng.forward_backward(img, q, gtb, cnt).cpu().numpy()
     assert int(losses[3]) == int(f["num_pos"])
     np.testing.assert_allclose(losses[:3], f["losses_cuda_formula"], rtol=1e-4 if dt == "f32" else 3e-2)
-    _check_grads_against_fixture(eng.named_grads(), f, dt)
+    _check_grads_against_fixture(eng.named_grads(), f, dt, case=name)
 
 
-def _check_grads_against_fixture(grads, f, dt):
-    tol = 2e-2 if dt == "f32" else 0.25
+# fp32 cases in which ONE GroupNorm output per level lies within ~1e-8 of zero, so the fp32 rounding of x*scale+shift
+# decides its ReLU mask differently here and in ATen (tools/tower_trace.py prints the element): the reference is
+# discontinuous there.  The flipped element changes one row of the cls tower's weight gradient by 1-2 % of the tensor's
+# largest entry and everything upstream of it by ~1e-3 (tools/grad_stats.py: config1 cls_tower.0 errors 1.6e-2, 9.4e-4,
+# 5.6e-4, 1.3e-4, ...; backbone tensors up to 2.9e-3).  Every other case has no such element: max error <= 2.5e-4.
+MASK_FLIP_CASES = {"config1": dict(tier1=5e-3, outliers=2)}
+
+
+def _check_grads_against_fixture(grads, f, dt, case=None):
+    """Two-tier element bound + whole-tensor bounds on the 256 sampled elements of every fixture tensor.
+    fp32: every element within 5e-4 x absmax (measured <= 2.5e-4), except in MASK_FLIP_CASES where at most `outliers`
+    elements may exceed `tier1` x absmax and none 2e-2; cosine >= 0.9995 and relative L2 <= 2e-2 in all cases.
+    bf16 (activations and gradients rounded to 8 bits at every layer): relative L2 <= 0.35 and cosine >= 0.96 per tensor
+    (measured over the six cases: L2 <= 0.26, cosine >= 0.9715); the Scale gradients are checked by
+    test_bf16_scale_gradients_within_their_conditioning."""
     checked = 0
     for key in f.files:
         if key.startswith("fullgrad_oracle.") and key.endswith(".samples"):
             k = key[len("fullgrad_oracle."):-len(".samples")]
             if dt == "bf16" and k.endswith(".scale"):
-                continue   # d/d scale = sum of signed terms that nearly cancel: ill-conditioned under bf16 activations
+                continue
             g = grads[k].float().cpu().numpy().reshape(-1)
             idx = gu.sample_indices(g.size, "grad." + k)[:256]
             scale = float(f["fullgrad_oracle.%s.absmax" % k])
+            ref = f[key]
+            if scale == 0.0:
+                assert np.abs(g[idx]).max() == 0.0, k
+                continue
+            err = np.abs(g[idx] - ref) / scale
+            l2 = np.linalg.norm(g[idx] - ref) / max(np.linalg.norm(ref), 1e-30)
+            cos = float(np.dot(g[idx], ref) / max(np.linalg.norm(g[idx]) * np.linalg.norm(ref), 1e-30))
             if dt == "bf16":
-                # bf16 activations: sums over many pixels of signed terms (GroupNorm affine and bias gradients, the end of
-                # the backward chain) carry element-wise noise of tens of percent of the largest entry; the tensor as a
-                # whole must still agree.  Measured worst cases: 0.21 (config1, backbone.layer2.0.conv1), 0.2x on the tiny
-                # (3e-6) FPN bias gradients of the small cases
-                err = np.linalg.norm(g[idx] - f[key]) / max(np.linalg.norm(f[key]), 1e-12)
-                assert err <= 0.35, (k, err)
+                assert l2 <= 0.35 and cos >= 0.96, (k, l2, cos)
             else:
-                assert np.abs(g[idx] - f[key]).max() <= tol * scale, (k, np.abs(g[idx] - f[key]).max(), scale)
+                flip = MASK_FLIP_CASES.get(case)
+                tier1 = flip["tier1"] if flip else 5e-4
+                n_out = int((err > tier1).sum())
+                assert n_out <= (flip["outliers"] if flip else 0), (k, n_out, np.sort(err)[::-1][:4])
+                assert err.max() <= 2e-2, (k, err.max())
+                assert l2 <= 2e-2 and cos >= 0.9995, (k, l2, cos)
             checked += 1
     assert checked >= 14
+
+
+@pytest.mark.parametrize("name", ["small", "nonsquare", "shots5", "tall"])
+def test_bf16_scale_gradients_within_their_conditioning(name):
+    """d loss / d scale_l = sum over locations of signed terms t_p = (d loss / d conv_p) * x_p / scale_l that nearly cancel,
+    so under bf16 activations its RELATIVE error is unbounded; what the rounding of 8-bit operands bounds is the error
+    against sum |t_p|.  The fp32 engine first validates the formula (its own Scale gradient = sum t_p to 1e-3), then the
+    bf16 engine's Scale gradients must lie within 2^-6 * sum |t_p| of the reference's (fixture: the oracle's autograd)."""
+    f = gu.load("train_%s.npz" % name)
+    for dt in ("f32", "bf16"):
+        eng, img, q, gtb, cnt = _engine_and_inputs(dt, name)
+        eng.forward_backward(img, q, gtb, cnt)
+        torch.cuda.synchronize()
+        scales, gscales = eng.extra["rpn.head.scales"]
+        for lvl in (0, 4):
+            key = "fullgrad_oracle.rpn.head.scales.%d.scale.samples" % lvl
+            if key not in f.files:
+                continue
+            ref = float(f[key][0])
+            reg = eng.last_head_out[lvl][1].float()[..., :4]                   # exp(scale * x)
+            x = reg.log() / scales[lvl]
+            d = eng.last_pred_grads[lvl][1].float()[..., :4]
+            terms = d * x / scales[lvl]
+            got = float(gscales[lvl])
+            if dt == "f32":
+                assert abs(float(terms.sum()) - got) <= 1e-3 * float(terms.abs().sum()) + 1e-7, (lvl, float(terms.sum()), got)
+                assert abs(got - ref) <= 1e-4 * float(terms.abs().sum()) + 1e-7, (lvl, got, ref)
+            else:
+                assert abs(got - ref) <= 2.0 ** -6 * float(terms.abs().sum()) + 1e-7, (lvl, got, ref, float(terms.abs().sum()))
 
 
 def test_sgd_steps_reduce_the_loss():
