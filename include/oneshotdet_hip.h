@@ -81,16 +81,27 @@ int osd_conv_algo_count(void);
 int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void* w, const float* bias, const void* res,
                    const void* mask, const float* act_scale_dev, const void* reserved, void* y, void* stream);
 
-/* The same convolution applied to n_seg <= 6 dense NHWC tensors of different batch / spatial size in ONE launch: the
- * FPN levels that share an FCOS tower or prediction conv (fcos.py:83-99 loops `for l, feature in enumerate(x)` over
- * the same modules).  d gives dtype, cin, cout, r, s, strides, pads, w_rows, out_stride, res_mode (NONE or SAME),
- * res_stride, act, act_scale, algo (LDS-DMA algorithms 1..32 only); xs / ys / residuals / masks / act_scale_devs are
- * HOST arrays of n_seg device pointers (the last three nullable as a whole; act_scale_devs[l] = the level's Scale),
- * ns / hs / ws HOST arrays with each tensor's batch, height and width. */
+/* The same convolution applied to n_seg <= OSD_CONV_MAX_SEG dense NHWC tensors of different batch / spatial size in ONE
+ * launch: the FPN levels that share an FCOS tower or prediction conv (fcos.py:83-99 loops `for l, feature in enumerate(x)`
+ * over the same modules).  d gives dtype, cin, cout, r, s, strides, pads, w_rows, out_stride, res_mode (NONE, SAME, or UP2X
+ * with an addend of exactly half the output size), res_stride, act, act_scale, algo (LDS-DMA algorithms 1..32 only);
+ * xs / ys / residuals / masks / act_scale_devs are HOST arrays of n_seg device pointers (the last three nullable as a
+ * whole; act_scale_devs[l] = the level's Scale), ns / hs / ws HOST arrays with each tensor's batch, height and width. */
+#define OSD_CONV_MAX_SEG 12
 int osd_conv2d_fwd_grouped(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys,
                            const void* const* residuals, const void* const* masks, const float* const* act_scale_devs,
                            const int32_t* ns, const int32_t* hs, const int32_t* ws, const void* w, const float* bias,
                            void* stream);
+
+/* The general form: every pair also has its OWN packed weights and bias (wts / biases: HOST arrays of n_seg device
+ * pointers; all of geometry d).  Convs that walk the same graph with different parameters go out as one launch: the cls
+ * and the bbox tower of FCOSHead (fcos.py:27-49, 2 x 5 levels), and every layer of the query backbone beside the same layer
+ * of the target backbone (generalized_rcnn.py:69-71,270-272: SIAMESE_BACKBONE = two separately parameterised R-50-FPN),
+ * whose latency-sized launches (M = 8..8192 pixels) thereby disappear into the target's. */
+int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys,
+                         const void* const* residuals, const void* const* masks, const float* const* act_scale_devs,
+                         const int32_t* ns, const int32_t* hs, const int32_t* ws, const void* const* wts,
+                         const float* const* biases, void* stream);
 
 /* OIHW fp32 conv weight (+ optional per-Cout scale = FrozenBN weight*rsqrt(var), layers/batch_norm.py:20) ->
  * packed [w_rows][r][s][cin_pad] rows of `dtype`, zero padded. */

@@ -32,6 +32,7 @@ SIGNATURES = {
     "osd_conv_algo_count": (_i, []),
     "osd_conv2d_fwd": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_fwd_grouped": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "osd_conv2d_fwd_multi": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_pack_conv_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "osd_pack_stem_weight": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "osd_pack_image": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

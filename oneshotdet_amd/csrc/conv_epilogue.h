@@ -10,15 +10,16 @@ namespace {
 
 // everything that differs between the (x, y) pairs of a grouped launch; uniform per workgroup (SGPRs)
 struct ConvView {
-  const void* x; void* y; const void* res; const void* mask; const float* scale_dev;
-  int H, W, Ho, Wo, M, sN, sH, HoWo;
+  const void* x; void* y; const void* res; const void* mask; const float* scale_dev; const void* w; const float* bias;
+  int H, W, Ho, Wo, M, sN, sH, HoWo, res_h, res_w;
 };
 
 // tile_m: global pixel-tile index of this workgroup; on return it is the index inside the selected segment
 __device__ __forceinline__ ConvView conv_select_view(const ConvKParams& p, int& tile_m) {
   ConvView q;
-  q.x = p.x; q.y = p.y; q.res = p.res; q.mask = p.mask; q.scale_dev = p.act_scale_dev;
+  q.x = p.x; q.y = p.y; q.res = p.res; q.mask = p.mask; q.scale_dev = p.act_scale_dev; q.w = p.w; q.bias = p.bias;
   q.H = p.H; q.W = p.W; q.Ho = p.Ho; q.Wo = p.Wo; q.M = p.M; q.sN = p.sN; q.sH = p.sH;
+  q.res_h = p.res_h; q.res_w = p.res_w;
   if (p.n_seg > 0) {
     int si = 0;
 #pragma unroll
@@ -32,10 +33,12 @@ __device__ __forceinline__ ConvView conv_select_view(const ConvKParams& p, int& 
 #define OSD_KSEG(type, field) (*reinterpret_cast<const __attribute__((address_space(4))) type*>(base + offsetof(ConvSeg, field)))
     q.x = (const void*)OSD_KSEG(u64, x); q.y = (void*)OSD_KSEG(u64, y); q.res = (const void*)OSD_KSEG(u64, res);
     q.mask = (const void*)OSD_KSEG(u64, mask); q.scale_dev = (const float*)OSD_KSEG(u64, act_scale_dev);
+    q.w = (const void*)OSD_KSEG(u64, w); q.bias = (const float*)OSD_KSEG(u64, bias);
     q.H = OSD_KSEG(int, H); q.W = OSD_KSEG(int, W); q.Ho = OSD_KSEG(int, Ho); q.Wo = OSD_KSEG(int, Wo);
     q.M = OSD_KSEG(int, M); q.sN = OSD_KSEG(int, sN); q.sH = OSD_KSEG(int, sH);
     tile_m -= OSD_KSEG(int, tile_begin);
 #undef OSD_KSEG
+    q.res_h = q.Ho >> 1; q.res_w = q.Wo >> 1;     // nearest-2x top-down add: the addend is exactly half size (checked by the host)
   }
   q.HoWo = q.Ho * q.Wo;
   return q;
@@ -57,7 +60,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
   OSD_G T* yg = (OSD_G T*)(const_cast<void*>(q_y));
   const OSD_G T* rg = (const OSD_G T*)(q_res);
   const OSD_G T* mkg = (const OSD_G T*)(q_mask);
-  const OSD_G float* biasg = (const OSD_G float*)(p.bias);
+  const OSD_G float* biasg = (const OSD_G float*)(q.bias);
   constexpr int WC = TN * 16;                    // channels of a wave tile
   constexpr int CSW = WC * 4 + 16;               // staging row stride (bytes); +16 keeps ds_write_b128 conflict free
   constexpr int NPASS = TM >= 8 ? TM / 2 : (TM >= 2 ? 2 : 1);
@@ -108,7 +111,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
           const int n_img = m / q_HoWo;
           const int rem = m - n_img * q_HoWo;
           const int ho = rem / q_Wo, wo = rem - (rem / q_Wo) * q_Wo;
-          rr[it] = *(const OSD_G Vec*)(rg + ((size_t)(n_img * p.res_h + (ho >> 1)) * p.res_w + (wo >> 1)) * p.res_stride + c);
+          rr[it] = *(const OSD_G Vec*)(rg + ((size_t)(n_img * q.res_h + (ho >> 1)) * q.res_w + (wo >> 1)) * p.res_stride + c);
         }
       }
       if (q_mask) {
@@ -198,7 +201,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
           const int n_img = m / q_HoWo;
           const int rem = m - n_img * q_HoWo;
           const int ho = rem / q_Wo, wo = rem - (rem / q_Wo) * q_Wo;
-          res_off = ((size_t)(n_img * p.res_h + (ho >> 1)) * p.res_w + (wo >> 1)) * p.res_stride + c;
+          res_off = ((size_t)(n_img * q.res_h + (ho >> 1)) * q.res_w + (wo >> 1)) * p.res_stride + c;
         }
         if constexpr (sizeof(T) == 2) {
           if (vec_ok && nval[it] == EPC) {

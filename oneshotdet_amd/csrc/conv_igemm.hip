@@ -380,27 +380,29 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
   return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad dtype %d", d->dtype);
 }
 
-// One launch over n_seg (x, y) pairs that share weights, bias and conv geometry but differ in batch / spatial size: the
-// five FPN levels of an FCOS tower conv (fcos.py:83-99 applies the same modules to every level).  LDS-DMA kernel only.
-extern "C" int osd_conv2d_fwd_grouped(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys,
-                                      const void* const* residuals, const void* const* masks,
-                                      const float* const* act_scale_devs, const int32_t* ns, const int32_t* hs,
-                                      const int32_t* ws, const void* w, const float* bias, void* stream) {
-  if (!d || !xs || !ys || !ns || !hs || !ws || !w || !bias || n_seg < 1 || n_seg > kConvMaxSeg)
+// One launch over n_seg (x, y) pairs with the same conv geometry (channels, taps, stride, pad) but their own batch / spatial
+// size AND their own weights / bias: the five FPN levels of an FCOS tower conv (fcos.py:83-99 applies the same modules to
+// every level: they repeat one weight pointer), both towers at once, or the same layer of the target and the query backbone
+// (generalized_rcnn.py:270-272: two R-50-FPN with separate parameters walk the same graph).  LDS-DMA kernels only.
+extern "C" int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys,
+                                    const void* const* residuals, const void* const* masks,
+                                    const float* const* act_scale_devs, const int32_t* ns, const int32_t* hs,
+                                    const int32_t* ws, const void* const* wts, const float* const* biases, void* stream) {
+  if (!d || !xs || !ys || !ns || !hs || !ws || !wts || !biases || n_seg < 1 || n_seg > kConvMaxSeg)
     return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad arguments (1..%d segments)", kConvMaxSeg);
   if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad dtype %d", d->dtype);
   if (d->gn_in || d->relu_in) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: input prologues not supported");
   if (d->cout % 4 != 0 || d->out_stride % 4 != 0)
     return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: cout/out_stride must be multiples of 4");
-  if (d->res_mode != OSD_RES_NONE && d->res_mode != OSD_RES_SAME)
-    return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: only the same-size residual is supported");
-  if (d->res_mode == OSD_RES_SAME && (!residuals || d->res_stride % 4 != 0))
+  if (d->res_mode != OSD_RES_NONE && d->res_mode != OSD_RES_SAME && d->res_mode != OSD_RES_UP2X)
+    return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad res_mode %d", d->res_mode);
+  if (d->res_mode != OSD_RES_NONE && (!residuals || d->res_stride % 4 != 0))
     return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: residual requested without residual tensors");
   if (d->w_rows < d->cout) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: w_rows < cout");
   const int epc = d->dtype == OSD_BF16 ? 8 : 4;
   if (d->cin % epc) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: cin must keep 16-byte alignment");
   ConvKParams p;
-  p.w = w; p.bias = bias;
+  p.w = wts[0]; p.bias = biases[0];
   p.Cin = d->cin; p.sW = d->cin; p.Cout = d->cout;
   p.R = d->r; p.S = d->s; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
   p.w_rows = d->w_rows; p.Ktot = d->r * d->s * d->cin; p.out_stride = d->out_stride;
@@ -412,11 +414,11 @@ extern "C" int osd_conv2d_fwd_grouped(const osd_conv_desc* d, int n_seg, const v
   for (int i = 0; i < kConvMaxSeg; ++i) {
     const int j = i < n_seg ? i : 0;
     ConvSeg& sg = p.seg[i];
-    if (!xs[j] || !ys[j] || ns[j] <= 0 || hs[j] <= 0 || ws[j] <= 0)
+    if (!xs[j] || !ys[j] || !wts[j] || !biases[j] || ns[j] <= 0 || hs[j] <= 0 || ws[j] <= 0)
       return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad segment %d", j);
-    sg.x = xs[j]; sg.y = ys[j];
-    sg.res = d->res_mode == OSD_RES_SAME ? residuals[j] : nullptr;
-    if (d->res_mode == OSD_RES_SAME && !sg.res) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: null residual %d", j);
+    sg.x = xs[j]; sg.y = ys[j]; sg.w = wts[j]; sg.bias = biases[j];
+    sg.res = d->res_mode != OSD_RES_NONE ? residuals[j] : nullptr;
+    if (d->res_mode != OSD_RES_NONE && !sg.res) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: null residual %d", j);
     sg.mask = masks ? masks[j] : nullptr;
     sg.act_scale_dev = act_scale_devs ? act_scale_devs[j] : nullptr;
     sg.H = hs[j]; sg.W = ws[j];
@@ -424,6 +426,8 @@ extern "C" int osd_conv2d_fwd_grouped(const osd_conv_desc* d, int n_seg, const v
     sg.Wo = (ws[j] + 2 * d->pad_w - d->s) / d->stride_w + 1;
     const long long M = (long long)ns[j] * sg.Ho * sg.Wo;
     if (sg.Ho <= 0 || sg.Wo <= 0 || M > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad M in segment %d", j);
+    if (d->res_mode == OSD_RES_UP2X && ((sg.Ho | sg.Wo) & 1))
+      return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: the nearest-2x addend needs an even output size (segment %d: %d x %d)", j, sg.Ho, sg.Wo);
     sg.M = (int)M; sg.sH = ws[j] * d->cin; sg.sN = hs[j] * ws[j] * d->cin; sg.tile_begin = 0;
     if (i < n_seg) mtot += M;
   }
@@ -451,4 +455,17 @@ extern "C" int osd_conv2d_fwd_grouped(const osd_conv_desc* d, int n_seg, const v
     return osd_conv_xr_launch(p, reinterpret_cast<hipStream_t>(stream));
   }
   return osd_conv_dma_dispatch(d->dtype, tile, variant, p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// the same with ONE weight / bias pointer for all pairs (the FPN levels of one conv)
+extern "C" int osd_conv2d_fwd_grouped(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys,
+                                      const void* const* residuals, const void* const* masks,
+                                      const float* const* act_scale_devs, const int32_t* ns, const int32_t* hs,
+                                      const int32_t* ws, const void* w, const float* bias, void* stream) {
+  if (n_seg < 1 || n_seg > kConvMaxSeg || !w || !bias)
+    return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad arguments (1..%d segments)", kConvMaxSeg);
+  const void* wts[kConvMaxSeg];
+  const float* bs[kConvMaxSeg];
+  for (int i = 0; i < n_seg; ++i) { wts[i] = w; bs[i] = bias; }
+  return osd_conv2d_fwd_multi(d, n_seg, xs, ys, residuals, masks, act_scale_devs, ns, hs, ws, wts, bs, stream);
 }

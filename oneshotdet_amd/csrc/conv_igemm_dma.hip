@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const T* __restrict__ xg = reinterpret_cast<const T*>(q_x);
-  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(q.w);
   const T* zero = reinterpret_cast<const T*>(g_zero_page) + (lane & 15) * EPC;
 
   // ---- per-lane DMA source coordinates ----

@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(512) conv_p8_kernel(ConvKParams p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const T* __restrict__ xg = reinterpret_cast<const T*>(q.x);
-  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(q.w);
   const T* zero = reinterpret_cast<const T*>(g_zero_page_p8) + (lane & 7) * EPC;
 
   // ---- per-lane DMA coordinates.  A wave moves pieces 2*wave, 2*wave+1 (8 rows x 128 B each) of every half tile.

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(512) conv_xr_kernel(ConvKParams p) {
   const int logw = __builtin_ctz((unsigned)q_W);       // W is a power of two in {64, 128, 256} (checked by the launcher)
 
   const T* __restrict__ xg = reinterpret_cast<const T*>(q.x);
-  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(q.w);
   const T* zero = reinterpret_cast<const T*>(g_xr_zero_page) + (lane & 15) * XR_EPC;
 
   // ---- zero both pixel images once: the pad rows stay zero for the whole K loop ----

@@ -2,14 +2,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-// one (input, output) pair of a grouped launch: the FPN levels of a tower conv share weights, geometry differs
-constexpr int kConvMaxSeg = 6;
+// one (input, output) pair of a grouped launch: same conv geometry (channels, taps, stride, pad), its own tensors, batch and
+// spatial size, and its own weights / bias pointer (the FPN levels of a tower conv repeat one pointer; the two towers, or
+// the target and the query backbone, bring their own)
+constexpr int kConvMaxSeg = 12;
 struct ConvSeg {
   const void* x;
   void* y;
   const void* res;
   const void* mask;
   const float* act_scale_dev;
+  const void* w;
+  const float* bias;
   int H, W, Ho, Wo, M, sN, sH;
   int tile_begin;     // first pixel tile of this segment (filled by the launcher: depends on the tile height)
 };

@@ -444,7 +444,7 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   int target = env_target, variant = env_variant;
   if (d0->algo > 0) {
     const int a = d0->algo - 1;
-    if (a >= 64 || (a & 7) > 4) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d0->algo);
+    if (a >= 64) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d0->algo);
     variant = a & 7;
     target = kTargets[a >> 3];
   }
@@ -452,8 +452,12 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   // fixed costs and its atomic epilogue weigh 16x less, so the same codes mean 8x the workgroups (finer pixel splits
   // also even out the FPN levels of a multi-segment launch: P3 has 228x the pixels of P7)
   if (d0->dtype == OSD_F32) target *= 8;
-  const bool big = variant == 4 && d0->dtype == OSD_BF16;
-  const int tw = (d0->dtype == OSD_BF16 ? 128 : 64) * (big ? 2 : 1);
+  // channel tile (co x ci) in 256-byte sub-tiles: variants 4 / 5 = 2 x 2, 6 = 1 x 2, 7 = 2 x 1 (bf16, 8 waves); else 1 x 1
+  const bool bf = d0->dtype == OSD_BF16;
+  if (!bf && variant != 0) variant = 0;
+  const int sub_co = bf && (variant == 4 || variant == 5 || variant == 7) ? 2 : 1;
+  const int sub_ci = bf && (variant == 4 || variant == 5 || variant == 6) ? 2 : 1;
+  const int tw = bf ? 128 : 64;
   const int epc = d0->dtype == OSD_BF16 ? 8 : 4;
   WgradParams p;
   p.n_seg = n_seg;
@@ -473,7 +477,7 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
     g.Cin = d->cin; g.Cout = d->cout; g.R = d->r; g.S = d->s;
     g.sh = d->stride_h; g.sw = d->stride_w; g.ph = d->pad_h; g.pw = d->pad_w;
     g.dy_stride = d->out_stride; g.Ktot = d->r * d->s * d->cin;
-    g.tilesCo = cdiv(d->cout, tw); g.tilesCi = cdiv(d->cin, tw);
+    g.tilesCo = cdiv(d->cout, tw * sub_co); g.tilesCi = cdiv(d->cin, tw * sub_ci);
     work += M * g.tilesCo * g.tilesCi * d->r * d->s;
   }
   // pixel splits: enough workgroups to fill the chip, every workgroup about the same number of pixels (>= 128)
@@ -494,10 +498,11 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   for (int i = n_seg; i < kMaxSeg; ++i) p.seg[i] = p.seg[0];
   const osd_conv_desc* d = d0;
   // variant: 0 = 32 px x 3 stages, 1 = 64 px x 2, 2 = 32 px x 4, 3 = 64 px x 3 (bf16; fp32 always 32 x 3)
-#define OSD_WG_LAUNCH(TT, BK, NS, WC, WMM, WNN)                                                                     \
+#define OSD_WG_LAUNCH(TT, BK, NS, WC, WMM, WNN) OSD_WG_LAUNCH2(TT, BK, NS, WC, WC, WMM, WNN)
+#define OSD_WG_LAUNCH2(TT, BK, NS, WCOO, WCII, WMM, WNN)                                                            \
   do {                                                                                                               \
-    auto kern = conv_wgrad_kernel<TT, BK, NS, WC, WC, WMM, WNN>;                                                     \
-    constexpr int lds = NS * 2 * WC * BK * 256;                                                                      \
+    auto kern = conv_wgrad_kernel<TT, BK, NS, WCOO, WCII, WMM, WNN>;                                                 \
+    constexpr int lds = NS * (WCOO + WCII) * BK * 256;                                                               \
     static bool attr = false;                                                                                        \
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; } \
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * WMM * WNN), lds, s, p);                             \
@@ -510,10 +515,15 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
       case 2: OSD_WG_LAUNCH(__bf16, 32, 4, 1, 2, 2); break;
       case 3: OSD_WG_LAUNCH(__bf16, 64, 3, 1, 2, 2); break;
       case 4: OSD_WG_LAUNCH(__bf16, 32, 3, 2, 2, 4); break;
+      // long stages on 8 waves (64 MFMAs per wave between barriers, as the forward kernel's 256 x 256 tile): 2-deep ring
+      case 5: OSD_WG_LAUNCH(__bf16, 64, 2, 2, 2, 4); break;          // 256 co x 256 ci
+      case 6: OSD_WG_LAUNCH2(__bf16, 64, 2, 1, 2, 2, 4); break;      // 128 co x 256 ci
+      case 7: OSD_WG_LAUNCH2(__bf16, 64, 2, 2, 1, 4, 2); break;      // 256 co x 128 ci
       default: OSD_WG_LAUNCH(__bf16, 32, 3, 1, 2, 2); break;
     }
   }
 #undef OSD_WG_LAUNCH
+#undef OSD_WG_LAUNCH2
   return osd_check_launch("conv_wgrad");
 }
 

@@ -495,7 +495,11 @@ def wgrad_algo_candidates(dtype, cout=0, cin=0):
     different stage shapes (bf16; fp32 has one); variant 4: 256 x 256 channel tile on 8 waves (bf16, wide layers)."""
     variants = [0, 1, 2, 3] if dtype == OSD_BF16 else [0]
     if dtype == OSD_BF16 and cout >= 256 and cin >= 256:
-        variants.append(4)
+        variants += [4, 5]
+    if dtype == OSD_BF16 and cin >= 256:
+        variants.append(6)          # 128 co x 256 ci
+    if dtype == OSD_BF16 and cout >= 256:
+        variants.append(7)          # 256 co x 128 ci
     return [1 + v + 8 * t for t in (0, 1, 2, 3, 4, 5, 6, 7) for v in variants]
 
 
@@ -657,7 +661,7 @@ def conv2d_wgrad_mixed(items, algo=None):
             sdw = [scratch.setdefault(id(t), torch.empty_like(t)) for t in real_dws]
             sdb = [None if t is None else scratch.setdefault(id(t), torch.empty_like(t)) for t in real_dbs]
             best, best_t = 0, float("inf")
-            for cand in wgrad_algo_candidates(descs[0].dtype):
+            for cand in wgrad_algo_candidates(descs[0].dtype, max(d.cout for d in descs), max(d.cin for d in descs)):
                 descs[0].algo = cand
                 launch(sdw, sdb)
                 torch.cuda.synchronize()
