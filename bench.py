@@ -57,16 +57,17 @@ class ConvTimer(object):
             timer.launches += 1
             return y
         ops.conv2d = timed_conv2d
-        self._orig_cg = ops.conv2d_grouped
+        self._orig_cg = ops.conv2d_multi
 
-        def timed_conv2d_grouped(xs, pc, *a, **kw):
+        def timed_conv2d_multi(xs, pcs, *a, **kw):
             if not (kw.get("_whole") or len(xs) < 3 or kw.get("algo") is not None):
-                return timer._orig_cg(xs, pc, *a, **kw)      # dispatcher call: the launches inside are bracketed
+                return timer._orig_cg(xs, pcs, *a, **kw)     # dispatcher call: the launches inside are bracketed
             s = torch.cuda.Event(enable_timing=True)
             e = torch.cuda.Event(enable_timing=True)
             s.record()
-            ys = timer._orig_cg(xs, pc, *a, **kw)
+            ys = timer._orig_cg(xs, pcs, *a, **kw)
             e.record()
+            pc = pcs[0]
             m = sum(y.shape[0] * y.shape[1] * y.shape[2] for y in ys)
             k_real = pc.r * pc.s * getattr(pc, "cin_real", pc.cin_k)
             timer.records.append((s, e))
@@ -74,11 +75,11 @@ class ConvTimer(object):
             timer.flops += 2.0 * m * pc.cout * k_real
             timer.launches += 1
             return ys
-        ops.conv2d_grouped = timed_conv2d_grouped
+        ops.conv2d_multi = timed_conv2d_multi
 
     def uninstall(self, ops):
         ops.conv2d = self._orig
-        ops.conv2d_grouped = self._orig_cg
+        ops.conv2d_multi = self._orig_cg
 
     def reset(self):
         self.records, self.flops, self.launches, self.labels = [], 0.0, 0, []
@@ -311,18 +312,18 @@ class TrainTimer(ConvTimer):
     def install(self, ops):
         ConvTimer.install(self, ops)
         self.corr, self.corr_bytes = [], 0.0
-        self._orig_c = ops.correlate
+        self._orig_c = ops.correlate_levels
         tm = self
 
-        def timed_correlate(x, q, out=None):
+        def timed_correlate(xs, qs):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            y = tm._orig_c(x, q, out=out)
+            ys = tm._orig_c(xs, qs)
             b.record()
             tm.corr.append((a, b))
-            tm.corr_bytes += 2.0 * x.numel() * x.element_size() + q.numel() * 4
-            return y
-        ops.correlate = timed_correlate
+            tm.corr_bytes += sum(2.0 * x.numel() * x.element_size() for x in xs) + sum(q.numel() * 4 for q in qs)
+            return ys
+        ops.correlate_levels = timed_correlate
         self._orig_w = ops.conv2d_wgrad
         timer = self
 
@@ -406,13 +407,13 @@ class TrainTimer(ConvTimer):
         ops.conv2d_wgrad_batched = self._orig_b
         ops.conv2d_wgrad_multi = self._orig_m
         ops.conv2d_wgrad_mixed = self._orig_x
-        ops.correlate = self._orig_c
+        ops.correlate_levels = self._orig_c
 
     def correlation_roofline(self):
         ms = sum(a.elapsed_time(b) for a, b in self.corr) - self.bracket_overhead_ms() * len(self.corr)
         gbs = self.corr_bytes / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
-                "kernel": "correlate_kernel (forward y = x*q and backward d_feat = g*q, 5 FPN levels each)",
+                "kernel": "correlate_levels_kernel (forward y = x*q and backward d_feat = g*q; one launch covers all 5 FPN levels)",
                 "avg_launch_us": round(ms * 1e3 / max(len(self.corr), 1), 2), "launches": len(self.corr),
                 "bytes_per_launch": round(self.corr_bytes / max(len(self.corr), 1))}
 
@@ -443,7 +444,8 @@ def main_train(args, rank, world):
             for k, a in ops.ALGO_CACHE.items():
                 f.write("conv %s -> %d\n" % (k, a))
 
-    launch = "eager, 6 streams (main chain, query/bbox branch, 2 x weight gradients, proposals, exchange + update)"
+    launch = ("eager, 6 streams (main chain: both backbones in lockstep + both towers per launch; 2 x weight gradients; "
+              "proposals; pooled-query gradient chain; exchange + update)")
     # the step's tail (last weight gradients, exchange, update, repack) overlaps the next step's frozen layers; an
     # explicit device synchronisation brackets the timed region as always (OSD_NO_DEFER_JOIN=1: A/B switch)
     eng.defer_join = not os.environ.get("OSD_NO_DEFER_JOIN")

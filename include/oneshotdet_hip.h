@@ -162,6 +162,11 @@ int osd_shot_mean(const float* x, float* y, int b, int shots, int c, void* strea
  * generalized_rcnn.py:307-311.  x, y NHWC `dtype`; q [n][c] fp32.
  * ---------------------------------------------------------------------------------------------------------------- */
 int osd_correlate_fwd(const void* x, const float* q, void* y, int n, int hw, int c, int dtype, void* stream);
+/* The same for all FPN levels in ONE launch (the reference's list comprehension over levels, generalized_rcnn.py:307-311;
+ * also the backward d_feat_l = g_l * q_l): xs / qs / ys HOST arrays of n_levels <= 6 device pointers ([n][hw_l][c], [n][c],
+ * [n][hw_l][c]), hws HOST array. */
+int osd_correlate_levels(int n_levels, const void* const* xs, const float* const* qs, void* const* ys, const int32_t* hws,
+                         int n, int c, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Proposal pipeline (FCOSPostProcessor, modeling/rpn/fcos/inference.py:46-137,251-323) and NMS (_C.nms,
@@ -291,6 +296,9 @@ int osd_add_mask(const void* a, const void* b, const void* mask, void* out, int6
 int osd_upsample2x_bwd(const void* inner, const void* prev, void* top, int n, int h, int w, int c, int dtype, void* stream);
 /* dq[n][c] = sum_p g[n,p,c] * feat[n,p,c] (correlation backward w.r.t. the pooled query; d_feat = osd_correlate_fwd(g, q)) */
 int osd_correlate_bwd_query(const void* g, const void* feat, float* dq, int n, int hw, int c, int dtype, void* stream);
+/* all FPN levels in one launch: dqs[l] [n][c] fp32 (zeroed by the call) */
+int osd_correlate_bwd_query_levels(int n_levels, const void* const* gs, const void* const* feats, float* const* dqs,
+                                   const int32_t* hws, int n, int c, int dtype, void* stream);
 /* _C.roi_align_backward on NHWC fp32: gx [b][h][w][c] (zeroed by the call) += taps of gy [r][ph][pw][c] */
 int osd_roialign_bwd(const float* gy, const float* rois, float* gx, int b, int h, int w, int c, int num_rois,
                      float spatial_scale, int ph, int pw, int sampling_ratio, void* stream);

@@ -45,6 +45,8 @@ SIGNATURES = {
     "osd_roialign_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _p]),
     "osd_shot_mean": (_i, [_p, _p, _i, _i, _i, _p]),
     "osd_correlate_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "osd_correlate_levels": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "osd_correlate_bwd_query_levels": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "osd_fcos_score_decode": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "osd_fcos_score_decode_sizes": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p]),
     "osd_level_topk": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

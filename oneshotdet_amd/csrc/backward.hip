@@ -715,6 +715,99 @@ extern "C" int osd_correlate_bwd_query(const void* g, const void* feat, float* d
   return osd_check_launch("correlate_bwd_query");
 }
 
+// every FPN level in one launch: the same kernel per (level, image, slab) through a table of static-index selects
+constexpr int kCorrQLevels = 6;
+struct CorrQLevels {
+  const void* g[kCorrQLevels]; const void* feat[kCorrQLevels]; float* dq[kCorrQLevels];
+  int hw[kCorrQLevels], slabs[kCorrQLevels], begin[kCorrQLevels];
+  int n_levels;
+};
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256) correlate_bwd_q_levels_kernel(CorrQLevels L, int c) {
+  constexpr int E = Chunk<T>::N;
+  const int b = blockIdx.x;
+  int lvl = 0;
+#pragma unroll
+  for (int i = 1; i < kCorrQLevels; ++i)
+    if (i < L.n_levels && b >= L.begin[i]) lvl = i;
+  const void* gv = L.g[0]; const void* fv = L.feat[0]; float* dq = L.dq[0];
+  int hw = L.hw[0], slabs = L.slabs[0], beg = L.begin[0];
+#pragma unroll
+  for (int i = 1; i < kCorrQLevels; ++i)
+    if (lvl == i) { gv = L.g[i]; fv = L.feat[i]; dq = L.dq[i]; hw = L.hw[i]; slabs = L.slabs[i]; beg = L.begin[i]; }
+  const T* g = reinterpret_cast<const T*>(gv);
+  const T* feat = reinterpret_cast<const T*>(fv);
+  const int local = b - beg;
+  const int img = local / slabs, slab = local - img * slabs;
+  const int cch = c / E;
+  const int lanes = 256 / cch;
+  const int cc = threadIdx.x % cch, pl = threadIdx.x / cch;
+  const int per = (hw + slabs - 1) / slabs;
+  const int p0 = slab * per, p1 = min(hw, p0 + per);
+  float s[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s[e] = 0.f;
+  if (pl < lanes && p0 < p1) {
+    constexpr int U = 4;
+    for (int p = p0 + pl; p < p1; p += U * lanes) {
+      Chunk<T> a[U], bb[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const size_t off = ((size_t)img * hw + min(p + k * lanes, p1 - 1)) * c + cc * E;
+        a[k].load(g + off);
+        bb[k].load(feat + off);
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const float live = p + k * lanes < p1 ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[e] += live * a[k].v[e] * bb[k].v[e];
+      }
+    }
+  }
+  __shared__ float red[256 * 8];
+#pragma unroll
+  for (int e = 0; e < E; ++e) red[(pl * cch + cc) * E + e] = (pl < lanes) ? s[e] : 0.f;
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += red[l * c + ch];
+    if (p0 < p1) atomicAdd(dq + (size_t)img * c + ch, t);
+  }
+}
+}  // namespace
+
+extern "C" int osd_correlate_bwd_query_levels(int n_levels, const void* const* gs, const void* const* feats,
+                                              float* const* dqs, const int32_t* hws, int n, int c, int dtype, void* stream) {
+  const int e = dtype == OSD_BF16 ? 8 : 4;
+  if (n_levels < 1 || n_levels > kCorrQLevels || !gs || !feats || !dqs || !hws || c % e || 256 % (c / e) || c > 2048)
+    return osd_fail(OSD_ERR_INVALID_ARG, "correlate_bwd_query_levels: bad args");
+  if (dtype != OSD_F32 && dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "correlate_bwd_query_levels: bad dtype");
+  if (n == 0) return OSD_OK;
+  CorrQLevels L;
+  L.n_levels = 0;
+  int blocks = 0;
+  for (int i = 0; i < n_levels; ++i) {
+    if (!dqs[i]) return osd_fail(OSD_ERR_INVALID_ARG, "correlate_bwd_query_levels: null dq at level %d", i);
+    hipError_t er = hipMemsetAsync(dqs[i], 0, sizeof(float) * (size_t)n * c, OSD_STREAM(stream));
+    if (er != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "correlate_bwd_query_levels: memset failed");
+    if (hws[i] <= 0) continue;
+    if (!gs[i] || !feats[i]) return osd_fail(OSD_ERR_INVALID_ARG, "correlate_bwd_query_levels: null tensor at level %d", i);
+    int slabs = (hws[i] + 63) / 64;
+    if (slabs > 512) slabs = 512;
+    const int k = L.n_levels++;
+    L.g[k] = gs[i]; L.feat[k] = feats[i]; L.dq[k] = dqs[i]; L.hw[k] = hws[i]; L.slabs[k] = slabs; L.begin[k] = blocks;
+    blocks += slabs * n;
+  }
+  if (L.n_levels == 0) return OSD_OK;
+  for (int k = L.n_levels; k < kCorrQLevels; ++k) { L.g[k] = L.g[0]; L.feat[k] = L.feat[0]; L.dq[k] = L.dq[0]; L.hw[k] = 0; L.slabs[k] = 1; L.begin[k] = 0x7fffffff; }
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(correlate_bwd_q_levels_kernel<float>, dim3(blocks), dim3(256), 0, OSD_STREAM(stream), L, c),
+      hipLaunchKernelGGL(correlate_bwd_q_levels_kernel<__bf16>, dim3(blocks), dim3(256), 0, OSD_STREAM(stream), L, c));
+  return osd_check_launch("correlate_bwd_query_levels");
+}
+
 extern "C" int osd_roialign_bwd(const float* gy, const float* rois, float* gx, int b, int h, int w, int c, int num_rois,
                                 float spatial_scale, int ph, int pw, int sampling_ratio, void* stream) {
   if (!gy || !rois || !gx) return osd_fail(OSD_ERR_INVALID_ARG, "roialign_bwd: null argument");

@@ -404,6 +404,128 @@ __global__ void __launch_bounds__(256) conv_wgrad_skinny_kernel(const T* __restr
   }
 }
 
+// ---- read-once weight gradient of the FCOS prediction convs (3x3 / stride 1 / pad 1, Cout <= 4: cls_logits + centerness
+// fused, bbox_pred; fcos.py:50-61) over all FPN levels in one launch ----
+// The MFMA kernel above spends a 128-channel output tile on 2 or 4 channels (11-19 TFLOP/s, 0.25 ms per step).  Here a wave
+// owns an INPUT pixel q: it reads x[q][256 channels] once (4 channels per lane) and adds dy[q - tap][co] * x[q][c] into
+// acc[co][tap][c] for the nine output pixels whose 3x3 window covers q (lanes 0..8 fetch those nine dy vectors, broadcast
+// with v_readlane).  A workgroup reduces its four waves through LDS and adds its 36 x 256 partial with one atomic per value.
+constexpr int kPredLevels = 6;
+struct PredWgradLevels {
+  const void* x[kPredLevels]; const void* dy[kPredLevels];
+  int H[kPredLevels], W[kPredLevels], npix[kPredLevels], begin[kPredLevels];   // npix = n * H * W; begin = first workgroup
+  int n_levels;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) pred_wgrad_kernel(PredWgradLevels L, float* __restrict__ dw, float* __restrict__ db,
+                                                         int C, int cout, int dy_stride, int pix_per_block) {
+  __shared__ float red[64 * 144];
+  const int b = blockIdx.x, cg = blockIdx.y;          // cg: group of 256 input channels
+  int lvl = 0;
+#pragma unroll
+  for (int i = 1; i < kPredLevels; ++i)
+    if (i < L.n_levels && b >= L.begin[i]) lvl = i;
+  const void* xv = L.x[0]; const void* dyv = L.dy[0];
+  int H = L.H[0], W = L.W[0], npix = L.npix[0], beg = L.begin[0];
+#pragma unroll
+  for (int i = 1; i < kPredLevels; ++i)
+    if (lvl == i) { xv = L.x[i]; dyv = L.dy[i]; H = L.H[i]; W = L.W[i]; npix = L.npix[i]; beg = L.begin[i]; }
+  const T* __restrict__ x = reinterpret_cast<const T*>(xv);
+  const T* __restrict__ dy = reinterpret_cast<const T*>(dyv);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q0 = (b - beg) * pix_per_block, q1 = min(npix, q0 + pix_per_block);
+  const int c0 = cg * 256 + lane * 4;
+  const int HW = H * W;
+  float acc[4][9][4];
+#pragma unroll
+  for (int co = 0; co < 4; ++co)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[co][t][k] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const int tr = lane / 3, ts = lane - tr * 3;         // the tap this lane fetches dy for (lanes 0..8)
+  for (int q = q0 + wave; q < q1; q += 4) {
+    const int img = q / HW, rem = q - img * HW, qy = rem / W, qx = rem - qy * W;
+    float xk[4];
+    if constexpr (sizeof(T) == 2) {
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>(x + (size_t)q * C + c0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xk[k] = (float)v[k];
+    } else {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)q * C + c0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xk[k] = v[k];
+    }
+    // output pixel whose tap (tr, ts) reads input pixel q: (qy - tr + 1, qx - ts + 1)
+    const int py = qy - tr + 1, px = qx - ts + 1;
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    if (lane < 9 && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
+      const T* dp = dy + ((size_t)(img * H + py) * W + px) * dy_stride;
+      if constexpr (sizeof(T) == 2) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(dp);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = (float)v[k];
+      } else {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dp);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = v[k];
+      }
+    }
+    if (lane == 4) {                                   // the centre tap is the pixel itself: bias gradient (cg 0 only)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bsum[k] += d[k];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int co = 0; co < 4; ++co) {
+        const float dv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d[co]), t));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[co][t][k] += dv * xk[k];
+      }
+    }
+  }
+  // fold the four waves: waves 1..3 hand their accumulators to wave 0 through LDS, one after the other
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int co = 0; co < 4; ++co)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) red[((co * 9 + t) * 4 + k) * 64 + lane] = acc[co][t][k];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int co = 0; co < 4; ++co)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[co][t][k] += red[((co * 9 + t) * 4 + k) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (wave == 0 && q0 < q1) {
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      if (co < cout) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) atomicAdd(dw + ((size_t)co * 9 + t) * C + c0 + k, acc[co][t][k]);
+      }
+    }
+  }
+  if (db != nullptr && cg == 0 && lane == 4 && q0 < q1) {
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+      if (co < cout) atomicAdd(db + co, bsum[co]);
+  }
+}
+
 // ---- bias gradient: db[c] += sum over pixels of dy[m][c] ----
 template <typename T>
 __global__ void __launch_bounds__(256) bias_grad_kernel(const T* __restrict__ dy, float* __restrict__ db, int M, int C,
@@ -563,6 +685,31 @@ extern "C" int osd_conv2d_wgrad_grouped(const osd_conv_desc* d, int n_seg, const
   if (!d || !xs || !dys || !ns || !hs || !ws || !dw || n_seg < 1 || n_seg > kMaxSeg)
     return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_grouped: bad arguments");
   if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad dtype");
+  static int no_pred = -1;
+  if (no_pred < 0) { const char* e = getenv("OSD_NO_PRED_WGRAD"); no_pred = e ? atoi(e) : 0; }     // A/B switch
+  if (!no_pred && d->cout <= 4 && d->r == 3 && d->s == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 &&
+      d->pad_w == 1 && d->cin % 256 == 0 && !scale && n_seg <= kPredLevels && d->out_stride % 4 == 0) {
+    // prediction convs (Cout 2 / 4): the read-once kernel instead of a 128-channel MFMA tile for 2-4 channels
+    PredWgradLevels L;
+    L.n_levels = 0;
+    const int ppb = 256;
+    int blocks = 0;
+    for (int i = 0; i < n_seg; ++i) {
+      const long long npix = (long long)ns[i] * hs[i] * ws[i];
+      if (npix <= 0 || npix > 0x7fffffffLL / d->cin || !xs[i] || !dys[i])
+        return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_grouped: bad segment %d", i);
+      const int k = L.n_levels++;
+      L.x[k] = xs[i]; L.dy[k] = dys[i]; L.H[k] = hs[i]; L.W[k] = ws[i]; L.npix[k] = (int)npix; L.begin[k] = blocks;
+      blocks += cdiv((int)npix, ppb);
+    }
+    for (int k = L.n_levels; k < kPredLevels; ++k) { L.x[k] = L.x[0]; L.dy[k] = L.dy[0]; L.H[k] = 1; L.W[k] = 1; L.npix[k] = 0; L.begin[k] = 0x7fffffff; }
+    dim3 grid(blocks, d->cin / 256);
+    if (d->dtype == OSD_F32)
+      hipLaunchKernelGGL(pred_wgrad_kernel<float>, grid, dim3(256), 0, OSD_STREAM(stream), L, dw, db, d->cin, d->cout, d->out_stride, ppb);
+    else
+      hipLaunchKernelGGL(pred_wgrad_kernel<__bf16>, grid, dim3(256), 0, OSD_STREAM(stream), L, dw, db, d->cin, d->cout, d->out_stride, ppb);
+    return osd_check_launch("pred_wgrad");
+  }
   WgradProblem pr[kMaxSeg];
   for (int i = 0; i < n_seg; ++i) pr[i] = WgradProblem{d, ns[i], hs[i], ws[i], xs[i], dys[i], scale, dw, db};
   return wgrad_launch(n_seg, pr, OSD_STREAM(stream));

@@ -338,6 +338,69 @@ __global__ void __launch_bounds__(256) correlate_kernel(const T* __restrict__ x,
   }
 }
 
+// All FPN levels in ONE launch (forward y_l = x_l * q_l and backward d_feat_l = g_l * q_l of generalized_rcnn.py:307-311):
+// a workgroup finds its (level, image, slab) from a table in the kernel arguments (static indices only: scalar selects,
+// no scratch copy of the table), stages that image's query vector of that level in LDS and streams its slab with two
+// independent 16-byte loads in flight per thread.
+constexpr int kCorrLevels = 6;
+struct CorrLevels {
+  const void* x[kCorrLevels];
+  const float* q[kCorrLevels];
+  void* y[kCorrLevels];
+  int hw[kCorrLevels];
+  int bx[kCorrLevels];        // workgroups per image at this level
+  int begin[kCorrLevels];     // first workgroup of this level
+  int n_levels;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) correlate_levels_kernel(CorrLevels L, int c) {
+  constexpr int E = Chunk<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* qs = reinterpret_cast<float*>(smem);
+  const int b = blockIdx.x;
+  int lvl = 0;
+#pragma unroll
+  for (int i = 1; i < kCorrLevels; ++i)
+    if (i < L.n_levels && b >= L.begin[i]) lvl = i;
+  const void* xv = L.x[0]; const float* q = L.q[0]; void* yv = L.y[0];
+  int hw = L.hw[0], bx = L.bx[0], beg = L.begin[0];
+#pragma unroll
+  for (int i = 1; i < kCorrLevels; ++i)
+    if (lvl == i) { xv = L.x[i]; q = L.q[i]; yv = L.y[i]; hw = L.hw[i]; bx = L.bx[i]; beg = L.begin[i]; }
+  const int local = b - beg;
+  const int img = local / bx, slab = local - img * bx;
+  for (int i = threadIdx.x; i < c; i += blockDim.x) qs[i] = q[(size_t)img * c + i];
+  __syncthreads();
+  const int cch = c / E;
+  const long long total = (long long)hw * cch;
+  const T* xi = reinterpret_cast<const T*>(xv) + (size_t)img * hw * c;
+  T* yi = reinterpret_cast<T*>(yv) + (size_t)img * hw * c;
+  const long long stride = (long long)bx * blockDim.x;
+  long long i = slab * (long long)blockDim.x + threadIdx.x;
+  // the host makes bx * 256 a multiple of the chunks per pixel: a thread's channel chunk is loop invariant
+  const int cc = (int)(i % cch);
+  float qv[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) qv[e] = qs[cc * E + e];
+  for (; i + stride < total; i += 2 * stride) {
+    Chunk<T> v0, v1;
+    v0.load(xi + i * E);
+    v1.load(xi + (i + stride) * E);
+#pragma unroll
+    for (int e = 0; e < E; ++e) { v0.v[e] *= qv[e]; v1.v[e] *= qv[e]; }
+    v0.store(yi + i * E);
+    v1.store(yi + (i + stride) * E);
+  }
+  if (i < total) {
+    Chunk<T> v;
+    v.load(xi + i * E);
+#pragma unroll
+    for (int e = 0; e < E; ++e) v.v[e] *= qv[e];
+    v.store(yi + i * E);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ sigmoid focal loss
 // csrc/cuda/SigmoidFocalLoss_cuda.cu:21-58 / :62-101
 __global__ void sigmoid_focal_fwd_kernel(const float* __restrict__ logits, const int* __restrict__ targets,
@@ -512,6 +575,36 @@ extern "C" int osd_correlate_fwd(const void* x, const float* q, void* y, int n, 
       hipLaunchKernelGGL(correlate_kernel<float>, grid, dim3(256), c * sizeof(float), OSD_STREAM(stream), (const float*)x, q, (float*)y, hw, c),
       hipLaunchKernelGGL(correlate_kernel<__bf16>, grid, dim3(256), c * sizeof(float), OSD_STREAM(stream), (const __bf16*)x, q, (__bf16*)y, hw, c));
   return osd_check_launch("correlate");
+}
+
+extern "C" int osd_correlate_levels(int n_levels, const void* const* xs, const float* const* qs, void* const* ys,
+                                    const int32_t* hws, int n, int c, int dtype, void* stream) {
+  const int e = dtype == OSD_BF16 ? 8 : 4;
+  if (n_levels < 1 || n_levels > kCorrLevels || !xs || !qs || !ys || !hws)
+    return osd_fail(OSD_ERR_INVALID_ARG, "correlate_levels: 1..%d levels", kCorrLevels);
+  if (c % e != 0 || c > 8192 || 256 % (c / e) != 0) return osd_fail(OSD_ERR_INVALID_ARG, "correlate_levels: bad channel count %d", c);
+  if (dtype != OSD_F32 && dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "correlate_levels: bad dtype");
+  if (n == 0) return OSD_OK;
+  CorrLevels L;
+  L.n_levels = 0;
+  int blocks = 0;
+  for (int i = 0; i < n_levels; ++i) {
+    if (hws[i] <= 0) continue;
+    if (!xs[i] || !qs[i] || !ys[i]) return osd_fail(OSD_ERR_INVALID_ARG, "correlate_levels: null tensor at level %d", i);
+    const long long chunks = (long long)hws[i] * (c / e);
+    int bx = (int)((chunks + 256LL * 8 - 1) / (256LL * 8));     // >= 8 chunks (128 B) per thread where the level is large enough
+    if (bx < 1) bx = 1;
+    if (bx > 1024) bx = 1024;
+    const int k = L.n_levels++;
+    L.x[k] = xs[i]; L.q[k] = qs[i]; L.y[k] = ys[i]; L.hw[k] = hws[i]; L.bx[k] = bx; L.begin[k] = blocks;
+    blocks += bx * n;
+  }
+  if (L.n_levels == 0) return OSD_OK;
+  for (int k = L.n_levels; k < kCorrLevels; ++k) { L.x[k] = L.x[0]; L.q[k] = L.q[0]; L.y[k] = L.y[0]; L.hw[k] = 0; L.bx[k] = 1; L.begin[k] = 0x7fffffff; }
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(correlate_levels_kernel<float>, dim3(blocks), dim3(256), c * sizeof(float), OSD_STREAM(stream), L, c),
+      hipLaunchKernelGGL(correlate_levels_kernel<__bf16>, dim3(blocks), dim3(256), c * sizeof(float), OSD_STREAM(stream), L, c));
+  return osd_check_launch("correlate_levels");
 }
 
 extern "C" int osd_sigmoid_focal_fwd(const float* logits, const int32_t* targets, float* losses, int m, int classes,

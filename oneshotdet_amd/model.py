@@ -100,6 +100,43 @@ def run_backbone(wts, images, dtype, return_body=False):
     return (out, feats) if return_body else out
 
 
+def run_backbones(wt, wq, images, queries, dtype):
+    """Target and query backbone (BackboneWeights wt / wq: generalized_rcnn.py:270-272, separately parameterised, same
+    graph) in LOCKSTEP: every layer is one osd_conv2d_fwd_multi launch over (target, query), so the query branch's
+    latency-sized launches ride in the tail of the target's.  -> ([P3..P7] target, [P3..P7] query), NHWC."""
+    xs = []
+    for wts, im in ((wt, images), (wq, queries)):
+        n, _, h, w = im.shape
+        ho, wo = ops.conv_out(h, 7, 2, 3), ops.conv_out(w, 7, 2, 3)
+        hp, wp = max(2 * (ho - 1) + 7, h + 3), max(2 * (wo - 1) + 8, w + 3)
+        wp += wp & 1
+        x = ops.pack_image(im, dtype, hp, wp)
+        x = ops.conv2d(x, wts.stem, act=ACT_RELU, out_hw=(ho, wo))
+        xs.append(ops.maxpool3x3s2(x))
+    feats = []
+    for bt, bq in zip(wt.blocks, wq.blocks):
+        s = bt["stride"]
+        identity = xs if bt["ds"] is None else ops.conv2d_multi(xs, [bt["ds"], bq["ds"]], stride=s)
+        out = ops.conv2d_multi(xs, [bt["c1"], bq["c1"]], stride=s, act=ACT_RELU)
+        out = ops.conv2d_multi(out, [bt["c2"], bq["c2"]], pad=1, act=ACT_RELU)
+        xs = ops.conv2d_multi(out, [bt["c3"], bq["c3"]], act=ACT_RELU, residuals=identity)
+        if bt["last_of_stage"]:
+            feats.append(xs)
+    c3, c4, c5 = feats[1], feats[2], feats[3]
+
+    def f(name):
+        return [wt.fpn[name], wq.fpn[name]]
+    inner4 = ops.conv2d_multi(c5, f("fpn_inner4"))
+    p5 = ops.conv2d_multi(inner4, f("fpn_layer4"), pad=1)
+    inner3 = ops.conv2d_multi(c4, f("fpn_inner3"), residuals=inner4, res_mode=RES_UP2X)
+    p4 = ops.conv2d_multi(inner3, f("fpn_layer3"), pad=1)
+    inner2 = ops.conv2d_multi(c3, f("fpn_inner2"), residuals=inner3, res_mode=RES_UP2X)
+    p3 = ops.conv2d_multi(inner2, f("fpn_layer2"), pad=1)
+    p6 = ops.conv2d_multi(p5, f("top_blocks.p6"), stride=2, pad=1)
+    p7 = [ops.conv2d(p6[j], f("top_blocks.p7")[j], stride=2, pad=1, relu_in=True) for j in (0, 1)]   # relu prologue: tiny
+    return [[p3[j], p4[j], p5[j], p6[j], p7[j]] for j in (0, 1)]
+
+
 _ROI_CACHE = {}
 
 
@@ -136,8 +173,8 @@ def run_query_pool(qfeats, q_sizes, batch):
 
 
 def run_correlate(feats, pooled):
-    """generalized_rcnn.py:307-311."""
-    return [ops.correlate(f, q) for f, q in zip(feats, pooled)]
+    """generalized_rcnn.py:307-311: all five levels in one launch."""
+    return ops.correlate_levels(feats, pooled)
 
 
 def run_head_tower(hw, feats, tower):
@@ -155,17 +192,22 @@ def run_head_tower(hw, feats, tower):
 
 def run_head(hw, feats, streams=None):
     """FCOSHead.forward (fcos.py:83-99).  Per level returns (cls_ctr [N,H,W,4] = (logit, centerness, 0, 0),
-    reg [N,H,W,4] = exp(scale_l * bbox_pred)).  The two towers are independent: with `streams` the bbox tower runs on a
-    side stream beside the cls tower, so the small levels' launch-latency-bound kernels fill the CUs the P3 GEMMs leave
-    idle."""
-    if not streams:
-        return list(zip(run_head_tower(hw, feats, "cls_tower"), run_head_tower(hw, feats, "bbox_tower")))
-    main = torch.cuda.current_stream()
-    streams[0].wait_stream(main)
-    with torch.cuda.stream(streams[0]):
-        box_out = run_head_tower(hw, feats, "bbox_tower")
-    cls_out = run_head_tower(hw, feats, "cls_tower")
-    main.wait_stream(streams[0])
+    reg [N,H,W,4] = exp(scale_l * bbox_pred)).  The two towers share the geometry: each layer is ONE launch over both
+    towers and all levels (10 pairs, level-major so the tuner's large / small split keeps P3 and P4 together), then the
+    GroupNorm+ReLU of a tower's levels in two launches.  (`streams` is accepted for compatibility; nothing needs it.)"""
+    nl = len(feats)
+    towers = ("cls_tower", "bbox_tower")
+    t = {tw: list(feats) for tw in towers}
+    for i in range(spec.NUM_CONVS):
+        xs = [t[tw][l] for l in range(nl) for tw in towers]
+        pcs = [hw.towers[tw][i][0] for l in range(nl) for tw in towers]
+        us = ops.conv2d_multi(xs, pcs, pad=1)
+        for k, tw in enumerate(towers):
+            _, gamma, beta = hw.towers[tw][i]
+            t[tw], _ = ops.groupnorm_relu_levels(us[k::2], gamma, beta, spec.GN_GROUPS, spec.GN_EPS)
+    cls_out = ops.conv2d_grouped(t["cls_tower"], hw.pred_cls_ctr, pad=1)
+    box_out = ops.conv2d_grouped(t["bbox_tower"], hw.pred_box, pad=1, act=ACT_EXP_SCALE,
+                                 act_scale_devs=[hw.scales_dev[l:l + 1] for l in range(nl)])
     return list(zip(cls_out, box_out))
 
 
@@ -237,22 +279,17 @@ class HotPathEngine(object):
         return self._streams
 
     def forward_features(self, images, queries, concurrent=True, query_sizes=None):
-        """Target backbone on the current stream; the (independent, tiny) query backbone + pooling on a side stream.
-        query_sizes: true (h, w) of every query of a padded batch (default: the tensor's size)."""
+        """Both backbones in lockstep (one launch per layer), query pooling, correlation.
+        query_sizes: true (h, w) of every query of a padded batch (default: the tensor's size).
+        concurrent=False: the two backbones as separate launch sequences (A/B; identical results)."""
         batch = images.shape[0]
         q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0] if query_sizes is None else list(query_sizes)
         if concurrent:
-            main, side = torch.cuda.current_stream(), self.side_streams()[0]
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                qfeats = run_backbone(self.supp_backbone, queries, self.dtype)
-                pooled = run_query_pool(qfeats, q_sizes, batch)
-            feats = run_backbone(self.backbone, images, self.dtype)
-            main.wait_stream(side)
+            feats, qfeats = run_backbones(self.backbone, self.supp_backbone, images, queries, self.dtype)
         else:
             feats = run_backbone(self.backbone, images, self.dtype)
             qfeats = run_backbone(self.supp_backbone, queries, self.dtype)
-            pooled = run_query_pool(qfeats, q_sizes, batch)
+        pooled = run_query_pool(qfeats, q_sizes, batch)
         combined = run_correlate(feats, pooled)
         return feats, qfeats, pooled, combined
 

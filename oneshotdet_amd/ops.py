@@ -215,26 +215,41 @@ SPLIT_CACHE = {}
 def conv2d_grouped(xs, pc, pad=0, act=ACT_NONE, residuals=None, masks=None, act_scale=1.0, act_scale_devs=None, algo=None,
                    _whole=False):
     """The same stride-1 convolution (shared packed weights pc) over several NHWC tensors of different size — the FPN
-    levels of an FCOS tower / prediction conv — in ONE launch, or in TWO (large levels / small levels) where the tuner
-    measured that to be faster: 256-pixel tiles on 256 CUs quantise badly (P3..P7 at bs=8 are 534 tiles = 2 full rounds
-    plus a third with 22 tiles; P3+P4 alone are 500 = 2 rounds, and the small levels run on a small tile).
-    residuals: same-size addends; masks: ReLU-backward masks (data gradients); act_scale_devs: one device scalar per level
-    (the learnable Scale).  Returns the outputs."""
+    levels of an FCOS tower / prediction conv — in ONE launch (conv2d_multi with one weight pointer for all pairs)."""
+    return conv2d_multi(xs, [pc] * len(xs), pad=pad, act=act, residuals=residuals, masks=masks, act_scale=act_scale,
+                        act_scale_devs=act_scale_devs, algo=algo, _whole=_whole)
+
+
+def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mode=None, masks=None, act_scale=1.0,
+                 act_scale_devs=None, algo=None, _whole=False):
+    """ONE launch of the same conv geometry over several NHWC tensors, each with its own batch / spatial size and its own
+    packed weights pcs[i] (osd_conv2d_fwd_multi): the FPN levels of a tower conv (one PackedConv repeated), both towers at
+    once, or one layer of the target backbone together with the same layer of the query backbone.  Or TWO launches (large
+    segments / small segments, in the given order) where the tuner measured that to be faster: 256-pixel tiles on 256 CUs
+    quantise badly (P3..P7 at bs=8 are 534 tiles = 2 full rounds plus a third with 22 tiles).
+    residuals: addends (res_mode RES_SAME, default, or RES_UP2X: exactly half size); masks: ReLU-backward masks (data
+    gradients); act_scale_devs: one device scalar per segment (the learnable Scale).  Returns the outputs."""
     _chk_dev(*xs)
     k = len(xs)
+    pc = pcs[0]
+    assert len(pcs) == k and all((q.cout_store, q.w_rows, q.cin_k, q.r, q.s) == (pc.cout_store, pc.w_rows, pc.cin_k, pc.r, pc.s)
+                                 and not q.stem for q in pcs), "segments must share the conv geometry"
+    if res_mode is None:
+        res_mode = RES_NONE if residuals is None else RES_SAME
     if k >= 3 and algo is None and not _whole:
-        skey = ("split", _dt(xs[0]), tuple(tuple(x.shape) for x in xs), pc.cout_store, pc.r, pad, act, residuals is not None,
+        skey = ("split", _dt(xs[0]), tuple(tuple(x.shape) for x in xs), pc.cout_store, pc.r, stride, pad, act, res_mode,
                 masks is not None)
         cut = SPLIT_CACHE.get(skey)
 
         def run(c):
-            if c == 0:
-                return conv2d_grouped(xs, pc, pad, act, residuals, masks, act_scale, act_scale_devs, _whole=True)
             sl = lambda t, a, b: None if t is None else t[a:b]          # noqa: E731
-            return (conv2d_grouped(xs[:c], pc, pad, act, sl(residuals, 0, c), sl(masks, 0, c), act_scale,
-                                   sl(act_scale_devs, 0, c), _whole=True) +
-                    conv2d_grouped(xs[c:], pc, pad, act, sl(residuals, c, k), sl(masks, c, k), act_scale,
-                                   sl(act_scale_devs, c, k), _whole=True))
+            if c == 0:
+                return conv2d_multi(xs, pcs, stride, pad, act, residuals, res_mode, masks, act_scale, act_scale_devs,
+                                    _whole=True)
+            return (conv2d_multi(xs[:c], pcs[:c], stride, pad, act, sl(residuals, 0, c), res_mode, sl(masks, 0, c), act_scale,
+                                 sl(act_scale_devs, 0, c), _whole=True) +
+                    conv2d_multi(xs[c:], pcs[c:], stride, pad, act, sl(residuals, c, k), res_mode, sl(masks, c, k), act_scale,
+                                 sl(act_scale_devs, c, k), _whole=True))
         if cut is None and _TUNING[0]:
             best_t = float("inf")
             for c in range(0, k - 1):
@@ -253,20 +268,24 @@ def conv2d_grouped(xs, pc, pad=0, act=ACT_NONE, residuals=None, masks=None, act_
         if cut:
             return run(cut)
     c = xs[0].shape[-1]
-    assert c == pc.cin_k and not pc.stem, "input channels %d != packed K per tap %d" % (c, pc.cin_k)
+    assert all(x.shape[-1] == pc.cin_k for x in xs), "input channels %d != packed K per tap %d" % (c, pc.cin_k)
     d = ConvDesc()
     d.dtype = _dt(xs[0])
     d.cin, d.r, d.s = c, pc.r, pc.s
-    d.stride_h = d.stride_w = 1
+    d.stride_h = d.stride_w = stride
     d.pad_h = d.pad_w = pad
     d.cout, d.w_rows = pc.cout_store, pc.w_rows
-    outs = [torch.empty((x.shape[0], conv_out(x.shape[1], pc.r, 1, pad), conv_out(x.shape[2], pc.s, 1, pad),
+    outs = [torch.empty((x.shape[0], conv_out(x.shape[1], pc.r, stride, pad), conv_out(x.shape[2], pc.s, stride, pad),
                          pc.cout_store), device=x.device, dtype=x.dtype) for x in xs]
     d.out_stride = pc.cout_store
-    d.res_mode = RES_NONE if residuals is None else RES_SAME
-    if residuals is not None:
+    d.res_mode = res_mode
+    if res_mode != RES_NONE:
         d.res_stride = residuals[0].shape[-1]
-        assert all(r.shape == o.shape for r, o in zip(residuals, outs))
+        if res_mode == RES_SAME:
+            assert all(r.shape == o.shape for r, o in zip(residuals, outs))
+        else:
+            assert all(r.shape[1] * 2 == o.shape[1] and r.shape[2] * 2 == o.shape[2] and r.shape[3] == o.shape[3]
+                       for r, o in zip(residuals, outs)), "top-down map must be exactly half size"
     if masks is not None:
         assert all(m.shape == o.shape and m.dtype == o.dtype for m, o in zip(masks, outs))
     d.act, d.act_scale, d.relu_in, d.gn_in = act, float(act_scale), 0, 0
@@ -275,14 +294,14 @@ def conv2d_grouped(xs, pc, pad=0, act=ACT_NONE, residuals=None, masks=None, act_
     ws = (C.c_int32 * k)(*[x.shape[2] for x in xs])
     args = (k, _ptr_array(xs), _ptr_array(outs), _ptr_array(residuals) if residuals is not None else None,
             _ptr_array(masks) if masks is not None else None,
-            _ptr_array(act_scale_devs) if act_scale_devs is not None else None, ns, hs, ws, _ptr(pc.w), _ptr(pc.bias),
-            _stream())
+            _ptr_array(act_scale_devs) if act_scale_devs is not None else None, ns, hs, ws,
+            _ptr_array([q.w for q in pcs]), _ptr_array([q.bias for q in pcs]), _stream())
 
     def launch():
-        _lib.call("osd_conv2d_fwd_grouped", C.byref(d), *args)
+        _lib.call("osd_conv2d_fwd_multi", C.byref(d), *args)
     if algo is None:
-        key = ("grouped", d.dtype, tuple(tuple(o.shape[:3]) for o in outs), d.cout, d.cin, d.r, d.s, pad, d.res_mode, act,
-               masks is not None)
+        key = ("grouped", d.dtype, tuple(tuple(o.shape[:3]) for o in outs), d.cout, d.cin, d.r, d.s, stride, pad, d.res_mode,
+               act, masks is not None)
         algo = ALGO_CACHE.get(key)
         if algo is None:
             algo = _tune(key, d, launch) if _TUNING[0] else 0
@@ -346,6 +365,31 @@ def correlate(x, q, out=None):
         out = torch.empty_like(x)
     _lib.call("osd_correlate_fwd", _ptr(x), _ptr(q.contiguous()), _ptr(out), n, h * w, c, _dt(x), _stream())
     return out
+
+
+def correlate_levels(xs, qs):
+    """[x_l * q_l (broadcast over H, W)] for every FPN level in ONE launch (forward correlation, and d_feat = g * q)."""
+    _chk_dev(*xs)
+    k = len(xs)
+    n, c = xs[0].shape[0], xs[0].shape[-1]
+    assert all(x.shape[0] == n and x.shape[-1] == c and x.is_contiguous() for x in xs)
+    assert all(q.shape == (n, c) and q.dtype == torch.float32 and q.is_contiguous() for q in qs)
+    ys = [torch.empty_like(x) for x in xs]
+    hws = (C.c_int32 * k)(*[x.shape[1] * x.shape[2] for x in xs])
+    _lib.call("osd_correlate_levels", k, _ptr_array(xs), _ptr_array(qs), _ptr_array(ys), hws, n, c, _dt(xs[0]), _stream())
+    return ys
+
+
+def correlate_bwd_query_levels(gs, feats):
+    """dq_l[n][c] = sum_p g_l[n,p,c] * feat_l[n,p,c] for every level in one launch -> list of [n, c] fp32."""
+    k = len(gs)
+    n, c = gs[0].shape[0], gs[0].shape[-1]
+    dq = torch.empty((k, n, c), device=gs[0].device, dtype=torch.float32)
+    dqs = [dq[l] for l in range(k)]
+    hws = (C.c_int32 * k)(*[g.shape[1] * g.shape[2] for g in gs])
+    _lib.call("osd_correlate_bwd_query_levels", k, _ptr_array(gs), _ptr_array(feats), _ptr_array(dqs), hws, n, c, _dt(gs[0]),
+              _stream())
+    return dqs
 
 
 def nhwc_to_nchw_f32(x, c0=0, c=None):

@@ -45,12 +45,12 @@ class TrainEngine(object):
         self.pg = process_group
         # weight gradients feed nothing but the optimiser: they run on a side stream, beside the data-gradient chain
         self.wstream = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None
-        # second compute stream: the query backbone, the bbox tower and the training proposals are independent of the
-        # target backbone / cls tower / loss, so they run beside them and fill the tails of the large kernels
+        # second stream: the pooled-query gradient chain (a dozen latency-sized kernels) beside the correlation backward.
+        # The query backbone and the bbox tower need no stream of their own: they ride in the launches of the target
+        # backbone / cls tower (osd_conv2d_fwd_multi)
         self.s1 = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None
-        self.wstream2 = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None   # weight gradients of the s1 branch
-        # training proposals feed only the (out-of-path) second stage: a chain of small kernels that must not sit in
-        # front of the bbox tower's backward on s1
+        self.wstream2 = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None   # query backbone / bbox tower
+        # training proposals feed only the second stage: a chain of small kernels on a stream of their own
         self.pstream = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None
         self._keep = []
         sd = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state_dict.items()}
@@ -66,7 +66,7 @@ class TrainEngine(object):
         self.exchange = GradExchange(self.flat_g, bucket_ranges(self._plan, self.flat_g.numel()), self.pg)
         self.ustream = torch.cuda.Stream(device=self.device)
         self._overlap, self._fuse_update, self._updated = True, False, set()
-        self._wq = None
+        self._wqs = None
         self._pred_grad_bufs = {}
         self.defer_join = False       # opt-in: train_step leaves its tail on the side streams (see train_step / join)
         self._deferred, self._defer_now, self._joined_refs = None, False, None
@@ -266,85 +266,91 @@ class TrainEngine(object):
         return self.extra[name + ".weight"], self.extra[name + ".bias"]
 
     # ------------------------------------------------------------------------------------------------ forward
-    def backbone_forward(self, bb, images, after_frozen=None):
-        """after_frozen: called once the stem and layer1 (frozen: resnet.py:127-136) have been enqueued, before the first
-        layer that reads trainable weights."""
-        cv, dt = self.convs, self.dtype
-        n, _, h, w = images.shape
-        ho, wo = ops.conv_out(h, 7, 2, 3), ops.conv_out(w, 7, 2, 3)
-        hp, wp = max(2 * (ho - 1) + 7, h + 3), max(2 * (wo - 1) + 8, w + 3)
-        wp += wp & 1
-        b = bb + "body."
-        x = ops.pack_image(images, dt, hp, wp)
-        x = ops.conv2d(x, cv[b + "stem.conv1"].pc, act=ACT_RELU, out_hw=(ho, wo))
-        x = ops.maxpool3x3s2(x)
-        blocks, stage_out = [], []
+    BBS = ("backbone.", "supp_backbone.")
+
+    def backbones_forward(self, images, queries, after_frozen=None):
+        """Both R-50-FPN backbones (generalized_rcnn.py:270-272: separately parameterised, same graph) in LOCKSTEP: every
+        layer is ONE osd_conv2d_fwd_multi launch over (target, query), so the query branch's latency-sized launches (M = 8
+        .. 8192 pixels) ride in the tail of the target's instead of costing ~110 launches of their own per step.
+        after_frozen: called once the stems and layer1 (frozen: resnet.py:127-136) have been enqueued, before the first
+        layer that reads trainable weights.  Returns ([feats_target, feats_query], [ctx_target, ctx_query])."""
+        cv, dt, bbs = self.convs, self.dtype, self.BBS
+
+        def pcs(name):
+            return [cv[bb + name].pc for bb in bbs]
+        xs = []
+        for bb, im in zip(bbs, (images, queries)):
+            n, _, h, w = im.shape
+            ho, wo = ops.conv_out(h, 7, 2, 3), ops.conv_out(w, 7, 2, 3)
+            hp, wp = max(2 * (ho - 1) + 7, h + 3), max(2 * (wo - 1) + 8, w + 3)
+            wp += wp & 1
+            x = ops.pack_image(im, dt, hp, wp)
+            x = ops.conv2d(x, cv[bb + "body.stem.conv1"].pc, act=ACT_RELU, out_hw=(ho, wo))
+            xs.append(ops.maxpool3x3s2(x))
+        blocks, stage_out = ([], []), ([], [])
         for si, nblocks in enumerate(spec.STAGE_BLOCKS):
             for bi in range(nblocks):
-                p = "%slayer%d.%d." % (b, si + 1, bi)
+                p = "body.layer%d.%d." % (si + 1, bi)
                 s = 2 if (bi == 0 and si > 0) else 1
-                has_ds = (p + "downsample.0") in cv
-                identity = ops.conv2d(x, cv[p + "downsample.0"].pc, stride=s) if has_ds else x
-                o1 = ops.conv2d(x, cv[p + "conv1"].pc, stride=s, act=ACT_RELU)
-                o2 = ops.conv2d(o1, cv[p + "conv2"].pc, pad=1, act=ACT_RELU)
-                y = ops.conv2d(o2, cv[p + "conv3"].pc, act=ACT_RELU, res=identity, res_mode=RES_SAME)
+                has_ds = (bbs[0] + p + "downsample.0") in cv
+                identity = ops.conv2d_multi(xs, pcs(p + "downsample.0"), stride=s) if has_ds else xs
+                o1 = ops.conv2d_multi(xs, pcs(p + "conv1"), stride=s, act=ACT_RELU)
+                o2 = ops.conv2d_multi(o1, pcs(p + "conv2"), pad=1, act=ACT_RELU)
+                y = ops.conv2d_multi(o2, pcs(p + "conv3"), act=ACT_RELU, residuals=identity)
                 if si >= 1:
-                    blocks.append(dict(p=p, s=s, ds=has_ds, x=x, o1=o1, o2=o2, y=y, first=(si == 1 and bi == 0)))
-                x = y
-            stage_out.append(x)
+                    for j in (0, 1):
+                        blocks[j].append(dict(p=p, s=s, ds=has_ds, x=xs[j], o1=o1[j], o2=o2[j], y=y[j],
+                                              first=(si == 1 and bi == 0)))
+                xs = y
+            for j in (0, 1):
+                stage_out[j].append(xs[j])
             if si == 0 and after_frozen is not None:
                 after_frozen()
-        c3, c4, c5 = stage_out[1], stage_out[2], stage_out[3]
-        f = bb + "fpn."
-        inner4 = ops.conv2d(c5, cv[f + "fpn_inner4"].pc)
-        p5 = ops.conv2d(inner4, cv[f + "fpn_layer4"].pc, pad=1)
-        inner3 = ops.conv2d(c4, cv[f + "fpn_inner3"].pc, res=inner4, res_mode=RES_UP2X)
-        p4 = ops.conv2d(inner3, cv[f + "fpn_layer3"].pc, pad=1)
-        inner2 = ops.conv2d(c3, cv[f + "fpn_inner2"].pc, res=inner3, res_mode=RES_UP2X)
-        p3 = ops.conv2d(inner2, cv[f + "fpn_layer2"].pc, pad=1)
-        p6 = ops.conv2d(p5, cv[f + "top_blocks.p6"].pc, stride=2, pad=1)
-        p6r = ops.add_mask(p6, None, p6)                    # relu(P6), materialised: the P7 weight gradient reads it
-        p7 = ops.conv2d(p6r, cv[f + "top_blocks.p7"].pc, stride=2, pad=1)
-        ctx = dict(bb=bb, blocks=blocks, c3=c3, c4=c4, c5=c5, inner4=inner4, inner3=inner3, inner2=inner2, p5=p5, p6=p6,
-                   p6r=p6r)
-        return [p3, p4, p5, p6, p7], ctx
+        c3, c4, c5 = ([so[i] for so in stage_out] for i in (1, 2, 3))
+        f = "fpn."
+        inner4 = ops.conv2d_multi(c5, pcs(f + "fpn_inner4"))
+        p5 = ops.conv2d_multi(inner4, pcs(f + "fpn_layer4"), pad=1)
+        inner3 = ops.conv2d_multi(c4, pcs(f + "fpn_inner3"), residuals=inner4, res_mode=RES_UP2X)
+        p4 = ops.conv2d_multi(inner3, pcs(f + "fpn_layer3"), pad=1)
+        inner2 = ops.conv2d_multi(c3, pcs(f + "fpn_inner2"), residuals=inner3, res_mode=RES_UP2X)
+        p3 = ops.conv2d_multi(inner2, pcs(f + "fpn_layer2"), pad=1)
+        p6 = ops.conv2d_multi(p5, pcs(f + "top_blocks.p6"), stride=2, pad=1)
+        p6r = [ops.add_mask(t, None, t) for t in p6]        # relu(P6), materialised: the P7 weight gradient reads it
+        p7 = ops.conv2d_multi(p6r, pcs(f + "top_blocks.p7"), stride=2, pad=1)
+        feats, ctxs = [], []
+        for j in (0, 1):
+            feats.append([p3[j], p4[j], p5[j], p6[j], p7[j]])
+            ctxs.append(dict(bb=bbs[j], blocks=blocks[j], c3=c3[j], c4=c4[j], c5=c5[j], inner4=inner4[j], inner3=inner3[j],
+                             inner2=inner2[j], p5=p5[j], p6=p6[j], p6r=p6r[j]))
+        return feats, ctxs
+
+    TOWERS = ("cls_tower", "bbox_tower")
 
     def head_forward(self, feats):
-        """FCOSHead.forward (fcos.py:83-99), tower -> layer -> level so that GroupNorm+ReLU of a layer is two launches for
-        all five levels; the bbox tower runs on the second stream beside the cls tower.
-        ctx[tower] = ([per layer: (inputs per level, conv outputs per level, ab)], last activations)."""
-        main = torch.cuda.current_stream()
-        res, ctxs = {}, {}
-        if self.s1 is not None:
-            self.s1.wait_stream(main)
-            with torch.cuda.stream(self.s1):
-                res["bbox_tower"], ctxs["bbox_tower"] = self._tower_forward(feats, "bbox_tower")
-        else:
-            res["bbox_tower"], ctxs["bbox_tower"] = self._tower_forward(feats, "bbox_tower")
-        res["cls_tower"], ctxs["cls_tower"] = self._tower_forward(feats, "cls_tower")
-        if self.s1 is not None:
-            main.wait_stream(self.s1)
-        return list(zip(res["cls_tower"], res["bbox_tower"])), ctxs
-
-    def _tower_forward(self, feats, tower):
+        """FCOSHead.forward (fcos.py:83-99).  Layer by layer, BOTH towers over all five levels = ONE conv launch per layer
+        (10 pairs: they share the geometry, each tower brings its own weights; level-major order so that the tuner's
+        large / small split keeps P3 and P4 of both towers together), then GroupNorm+ReLU of a tower's five levels in two
+        launches.  ctx[tower] = ([per layer: (inputs per level, conv outputs per level, ab)], last activations)."""
         cv = self.convs
         h = "rpn.head."
         scales = self.extra[h + "scales"][0]
         nl = len(feats)
-        t, layers = list(feats), []
+        t = {tw: list(feats) for tw in self.TOWERS}
+        layers = {tw: [] for tw in self.TOWERS}
         for i in range(spec.NUM_CONVS):
-            (gw, _), (gbeta, _) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
-            c = cv["%s%s.%d" % (h, tower, 3 * i)]
-            u = ops.conv2d_grouped(t, c.pc, pad=1)                 # all FPN levels in one launch
-            t2, ab = ops.groupnorm_relu_levels(u, gw, gbeta, spec.GN_GROUPS, spec.GN_EPS)
-            layers.append((t, u, ab))
-            t = t2
-        if tower == "cls_tower":
-            out = ops.conv2d_grouped(t, cv[h + "cls_ctr"].pc, pad=1)
-        else:
-            out = ops.conv2d_grouped(t, cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE,
+            xs = [t[tw][l] for l in range(nl) for tw in self.TOWERS]
+            pcs = [cv["%s%s.%d" % (h, tw, 3 * i)].pc for l in range(nl) for tw in self.TOWERS]
+            us = ops.conv2d_multi(xs, pcs, pad=1)
+            for k, tw in enumerate(self.TOWERS):
+                (gw, _), (gbeta, _) = self.gn("%s%s.%d" % (h, tw, 3 * i + 1))
+                u = us[k::2]
+                t2, ab = ops.groupnorm_relu_levels(u, gw, gbeta, spec.GN_GROUPS, spec.GN_EPS)
+                layers[tw].append((t[tw], u, ab))
+                t[tw] = t2
+        cls_out = ops.conv2d_grouped(t["cls_tower"], cv[h + "cls_ctr"].pc, pad=1)
+        box_out = ops.conv2d_grouped(t["bbox_tower"], cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE,
                                      act_scale_devs=[scales[l:l + 1] for l in range(nl)])
-        return out, (layers, t)
+        return list(zip(cls_out, box_out)), {tw: (layers[tw], t[tw]) for tw in self.TOWERS}
 
     # ------------------------------------------------------------------------------------------------ loss
     def loss_and_grads(self, head_out, gt_boxes, gt_count):
@@ -379,10 +385,16 @@ class TrainEngine(object):
         return losses, grads
 
     # ------------------------------------------------------------------------------------------------ backward
-    def _on_wstream(self, fn, tensors):
+    def _wstream_of(self, which):
+        """Weight-gradient stream 0 (target backbone, cls tower) or 1 (query backbone, bbox tower); None = inline."""
         if self.wstream is None:
+            return None
+        return self.wstream2 if (which == 1 and self.wstream2 is not None) else self.wstream
+
+    def _on_wstream(self, fn, tensors, which=0):
+        ws = self._wstream_of(which)
+        if ws is None:
             return fn()
-        ws = self.wstream2 if (self.wstream2 is not None and torch.cuda.current_stream() == self.s1) else self.wstream
         ev = torch.cuda.Event()
         ev.record()
         ws.wait_event(ev)
@@ -390,17 +402,16 @@ class TrainEngine(object):
             fn()
         self._keep.append(tensors)        # keep the operands alive until the side stream has been joined
 
-    def _bucket_ready(self, name, extra=()):
-        """Everything that writes gradient bucket `name` has been enqueued (weight gradients on the side streams; for
-        the head also the GroupNorm / Scale gradients on the compute streams): start its all-reduce behind those
-        streams and, inside train_step, its SGD update + repack behind that.  The update also waits for the current
-        compute stream: the bucket's data-gradient convs (enqueued before this point) read the packed weights it
-        rewrites."""
+    def _bucket_ready(self, name, which=0, extra=()):
+        """Everything that writes gradient bucket `name` has been enqueued (weight gradients on side stream `which`; for
+        the head also the GroupNorm / Scale gradients on the compute stream): start its all-reduce behind those streams
+        and, inside train_step, its SGD update + repack behind that.  The update also waits for the current compute
+        stream: the bucket's data-gradient convs (enqueued before this point) read the packed weights it rewrites."""
         if not self._overlap or name is None:
             return
         cur = torch.cuda.current_stream()
-        ws = cur if self.wstream is None else (self.wstream2 if (self.wstream2 is not None and cur == self.s1) else self.wstream)
-        producers = [ws] + list(extra)
+        ws = self._wstream_of(which)
+        producers = [cur if ws is None else ws] + list(extra)
         if self._fuse_update and cur not in producers:
             producers.append(cur)
         if self.exchange.active:
@@ -416,141 +427,152 @@ class TrainEngine(object):
         with torch.cuda.stream(ust):
             self._update_bucket(name)
 
-    def _wgrad(self, c, x, dy, stride=1, pad=0):
-        if self._wq is not None:       # inside a backbone: queued, launched once per stage (all geometries together)
-            self._wq.append((c, x, dy, stride, pad))
-            return
-        self._on_wstream(lambda: ops.conv2d_wgrad(x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale,
-                                                  db=c.gb if c.has_bias else None), (x, dy))
-
-    def _flush_wgrads(self):
-        """Launch the queued weight gradients of a stage as ONE mixed-geometry launch (<= 24 convs each): all output tiles
-        share the workgroup budget in proportion to their work, so every conv runs with few pixel splits — long inner
-        loops, little atomic traffic — and the query branch's latency-sized launches disappear into it."""
-        q, self._wq = self._wq, []
+    def _flush_wgrads(self, which):
+        """Launch the queued weight gradients of backbone `which`'s stage as ONE mixed-geometry launch (<= 24 convs each):
+        all output tiles share the workgroup budget in proportion to their work, so every conv runs with few pixel splits
+        — long inner loops, little atomic traffic — and the query branch's latency-sized launches disappear into it."""
+        q, self._wqs[which] = self._wqs[which], []
         for i in range(0, len(q), 24):
             part = q[i:i + 24]
             if len(part) == 1:
                 c, x, dy, stride, pad = part[0]
                 self._on_wstream(lambda c=c, x=x, dy=dy, stride=stride, pad=pad: ops.conv2d_wgrad(
-                    x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale, db=c.gb if c.has_bias else None), (x, dy))
+                    x, dy, c.gw, c.r, c.s, stride, pad, c.cout, scale=c.bn_scale, db=c.gb if c.has_bias else None), (x, dy),
+                    which)
             else:
                 items = [(x, dy, c.gw, c.bn_scale, c.gb if c.has_bias else None, c.r, c.s, stride, pad, c.cout)
                          for c, x, dy, stride, pad in part]
-                self._on_wstream(lambda items=items: ops.conv2d_wgrad_mixed(items), items)
+                self._on_wstream(lambda items=items: ops.conv2d_wgrad_mixed(items), items, which)
 
-    def _wgrad_grouped(self, c, pairs):
+    def _wgrad_grouped(self, c, pairs, which=0):
         self._on_wstream(lambda: ops.conv2d_wgrad_grouped(pairs, c.gw, c.r, c.s, 1, c.r // 2, c.cout, scale=c.bn_scale,
-                                                          db=c.gb if c.has_bias else None), pairs)
-
-    def _dgrad(self, c, dy, res=None, mask=None):
-        """Data gradient of a stride-1 conv: the forward kernel on dy with flipped/transposed weights."""
-        return ops.conv2d(dy, c.pd, stride=1, pad=c.r - 1 - (c.r // 2), res=res,
-                          res_mode=RES_SAME if res is not None else RES_NONE, mask=mask)
+                                                          db=c.gb if c.has_bias else None), pairs, which)
 
     def _dgrad_levels(self, c, dys):
-        """Data gradient of a conv shared by the FPN levels: one grouped launch."""
+        """Data gradient of a conv shared by the FPN levels: one grouped launch (forward kernel, flipped weights)."""
         return ops.conv2d_grouped(dys, c.pd, pad=c.r - 1 - (c.r // 2))
 
     def head_backward(self, feats, ctxs, pred_grads):
-        """Loops: tower -> layer (last first) -> level: the weight gradient of each (shared) conv is ONE grouped launch
-        over the five FPN levels, GroupNorm+ReLU backward two launches.  The two towers' chains are independent until
-        their gradients w.r.t. the shared input are summed: the bbox chain runs on the second stream."""
-        nl = len(feats)
-        main = torch.cuda.current_stream()
-        if self.s1 is not None:
-            self.s1.wait_stream(main)
-            with torch.cuda.stream(self.s1):
-                d_box = self._tower_backward(ctxs, pred_grads, "bbox_tower", 1, nl)
-        else:
-            d_box = self._tower_backward(ctxs, pred_grads, "bbox_tower", 1, nl)
-        d_cls = self._tower_backward(ctxs, pred_grads, "cls_tower", 0, nl)
-        if self.s1 is not None:
-            main.wait_stream(self.s1)
-        return [ops.add_mask(d_cls[l], d_box[l]) for l in range(nl)]
-
-    def _tower_backward(self, ctxs, pred_grads, tower, gi, nl):
+        """Layer by layer (last first): GroupNorm+ReLU backward of each tower (two launches for its five levels), then the
+        data gradient of BOTH towers' conv over all levels as ONE launch; the weight gradients of a tower's four convs x
+        five levels go out as one launch on that tower's side stream once its chain is done."""
         cv = self.convs
         h = "rpn.head."
-        layers, t_last = ctxs[tower]
-        pc = cv[h + ("cls_ctr" if tower == "cls_tower" else "bbox_pred")]
-        dpred = [pred_grads[l][gi] for l in range(nl)]
-        self._wgrad_grouped(pc, [(t_last[l], dpred[l]) for l in range(nl)])
-        d_t = self._dgrad_levels(pc, dpred)
-        items = []
+        nl = len(feats)
+        d_t, items = {}, {tw: [] for tw in self.TOWERS}
+        for k, tw in enumerate(self.TOWERS):
+            layers, t_last = ctxs[tw]
+            pc = cv[h + ("cls_ctr" if tw == "cls_tower" else "bbox_pred")]
+            dpred = [pred_grads[l][k] for l in range(nl)]
+            self._wgrad_grouped(pc, [(t_last[l], dpred[l]) for l in range(nl)], k)
+            d_t[tw] = self._dgrad_levels(pc, dpred)
         for i in range(spec.NUM_CONVS - 1, -1, -1):
-            (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tower, 3 * i + 1))
-            c = cv["%s%s.%d" % (h, tower, 3 * i)]
-            t_in, u, ab = layers[i]
-            du = ops.groupnorm_relu_bwd_levels(u, d_t, ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
-            items += [(t_in[l], du[l], c.gw, c.bn_scale, c.gb if c.has_bias else None) for l in range(nl)]
-            d_t = self._dgrad_levels(c, du)
-        # the four tower convs x five levels: ONE weight-gradient launch (20 pairs, 4 distinct dW) once the chain is done —
-        # each conv gets a quarter of the pixel splits / atomic traffic of a launch of its own
-        c0 = cv["%s%s.0" % (h, tower)]
-        self._on_wstream(lambda: ops.conv2d_wgrad_multi(items, c0.r, c0.s, 1, c0.r // 2, c0.cout), items)
-        return d_t
+            dus = {}
+            for tw in self.TOWERS:
+                (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tw, 3 * i + 1))
+                c = cv["%s%s.%d" % (h, tw, 3 * i)]
+                t_in, u, ab = ctxs[tw][0][i]
+                dus[tw] = ops.groupnorm_relu_bwd_levels(u, d_t[tw], ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
+                items[tw] += [(t_in[l], dus[tw][l], c.gw, c.bn_scale, c.gb if c.has_bias else None) for l in range(nl)]
+            dys = [dus[tw][l] for l in range(nl) for tw in self.TOWERS]
+            c0 = cv["%s%s.%d" % (h, self.TOWERS[0], 3 * i)]
+            pds = [cv["%s%s.%d" % (h, tw, 3 * i)].pd for l in range(nl) for tw in self.TOWERS]
+            out = ops.conv2d_multi(dys, pds, pad=c0.r - 1 - (c0.r // 2))
+            for k, tw in enumerate(self.TOWERS):
+                d_t[tw] = out[k::2]
+        for k, tw in enumerate(self.TOWERS):
+            c0 = cv["%s%s.0" % (h, tw)]
+            self._on_wstream(lambda it=items[tw], c0=c0: ops.conv2d_wgrad_multi(it, c0.r, c0.s, 1, c0.r // 2, c0.cout),
+                             items[tw], k)
+        return [ops.add_mask(d_t["cls_tower"][l], d_t["bbox_tower"][l]) for l in range(nl)]
 
-    def backbone_backward(self, ctx, dP, need_input_grad=False):
-        cv, bb = self.convs, ctx["bb"]
-        self._wq = []
-        f = bb + "fpn."
-        dp3, dp4, dp5, dp6, dp7 = dP
-        # P7 = conv(relu(P6)), P6 = conv(P5), both 3x3 stride 2 (fpn.py:95-99)
-        c7, c6 = cv[f + "top_blocks.p7"], cv[f + "top_blocks.p6"]
-        self._wgrad(c7, ctx["p6r"], dp7, 2, 1)
-        # 3x3 stride-2 data gradient = zero-insert dY to the input grid, then the stride-1 flipped-weight conv
-        t = self._dgrad(c7, ops.scatter2x(dp7, ctx["p6"].shape[1:3]), mask=ctx["p6"])
-        d_p6 = ops.add_mask(t, dp6)
-        self._wgrad(c6, ctx["p5"], d_p6, 2, 1)
-        d_p5 = self._dgrad(c6, ops.scatter2x(d_p6, ctx["p5"].shape[1:3]), res=dp5)
-        l4, l3, l2 = cv[f + "fpn_layer4"], cv[f + "fpn_layer3"], cv[f + "fpn_layer2"]
-        self._wgrad(l4, ctx["inner4"], d_p5, 1, 1)
-        self._wgrad(l3, ctx["inner3"], dp4, 1, 1)
-        self._wgrad(l2, ctx["inner2"], dp3, 1, 1)
-        d_inner2 = self._dgrad(l2, dp3)
-        d_inner3 = self._dgrad(l3, dp4)
-        d_inner3 = ops.upsample2x_bwd(d_inner2, d_inner3)
-        d_inner4 = self._dgrad(l4, d_p5)
-        d_inner4 = ops.upsample2x_bwd(d_inner3, d_inner4)
-        i4, i3, i2 = cv[f + "fpn_inner4"], cv[f + "fpn_inner3"], cv[f + "fpn_inner2"]
-        self._wgrad(i4, ctx["c5"], d_inner4)
-        self._wgrad(i3, ctx["c4"], d_inner3)
-        self._wgrad(i2, ctx["c3"], d_inner2)
+    def backbones_backward(self, ctxs, dPs):
+        """Backward of both backbones in lockstep (the mirror of backbones_forward): every data-gradient conv is ONE launch
+        over (target, query); the weight gradients are queued per backbone and go out per stage as mixed-geometry launches
+        on that backbone's side stream; a stage's gradient bucket is announced as soon as its last writer is enqueued."""
+        cv = self.convs
+        bbs = [c["bb"] for c in ctxs]
+        nb = len(ctxs)
+        self._wqs = [[] for _ in ctxs]
+
+        def col(key):
+            return [c[key] for c in ctxs]
+
+        def W(name, xs, dys, stride=1, pad=0):
+            for j in range(nb):
+                self._wqs[j].append((cv[bbs[j] + name], xs[j], dys[j], stride, pad))
+
+        def D(name, dys, residuals=None, masks=None):
+            """Data gradient of a stride-1 conv: the forward kernel on dy with flipped/transposed weights."""
+            c = cv[bbs[0] + name]
+            return ops.conv2d_multi(dys, [cv[bb + name].pd for bb in bbs], pad=c.r - 1 - (c.r // 2), residuals=residuals,
+                                    masks=masks)
+        f = "fpn."
+        dp3, dp4, dp5, dp6, dp7 = ([dP[l] for dP in dPs] for l in range(5))
+        # P7 = conv(relu(P6)), P6 = conv(P5), both 3x3 stride 2 (fpn.py:95-99); 3x3 stride-2 data gradient = zero-insert
+        # dY to the input grid, then the stride-1 flipped-weight conv
+        W(f + "top_blocks.p7", col("p6r"), dp7, 2, 1)
+        t = D(f + "top_blocks.p7", [ops.scatter2x(d, p6.shape[1:3]) for d, p6 in zip(dp7, col("p6"))], masks=col("p6"))
+        d_p6 = [ops.add_mask(a, b) for a, b in zip(t, dp6)]
+        W(f + "top_blocks.p6", col("p5"), d_p6, 2, 1)
+        d_p5 = D(f + "top_blocks.p6", [ops.scatter2x(d, p5.shape[1:3]) for d, p5 in zip(d_p6, col("p5"))], residuals=dp5)
+        W(f + "fpn_layer4", col("inner4"), d_p5, 1, 1)
+        W(f + "fpn_layer3", col("inner3"), dp4, 1, 1)
+        W(f + "fpn_layer2", col("inner2"), dp3, 1, 1)
+        d_inner2 = D(f + "fpn_layer2", dp3)
+        d_inner3 = D(f + "fpn_layer3", dp4)
+        d_inner3 = [ops.upsample2x_bwd(a, b) for a, b in zip(d_inner2, d_inner3)]
+        d_inner4 = D(f + "fpn_layer4", d_p5)
+        d_inner4 = [ops.upsample2x_bwd(a, b) for a, b in zip(d_inner3, d_inner4)]
+        W(f + "fpn_inner4", col("c5"), d_inner4)
+        W(f + "fpn_inner3", col("c4"), d_inner3)
+        W(f + "fpn_inner2", col("c3"), d_inner2)
         # gradients w.r.t. C5 / C4 / C3 from the laterals; C5's is complete, so its ReLU mask is applied here
-        g = self._dgrad(i4, d_inner4, mask=ctx["c5"])
-        lateral = {id(ctx["c4"]): self._dgrad(i3, d_inner3), id(ctx["c3"]): self._dgrad(i2, d_inner2)}
+        g = D(f + "fpn_inner4", d_inner4, masks=col("c5"))
+        lat4, lat3 = D(f + "fpn_inner3", d_inner3), D(f + "fpn_inner2", d_inner2)
+        lateral = {}
+        for j in range(nb):
+            lateral[id(ctxs[j]["c4"])] = lat4[j]
+            lateral[id(ctxs[j]["c3"])] = lat3[j]
         # body, last block first.  `g` = gradient w.r.t. the block output, already masked by its ReLU.
-        for blk in reversed(ctx["blocks"]):
-            p, s = blk["p"], blk["s"]
-            c1, c2, c3 = cv[p + "conv1"], cv[p + "conv2"], cv[p + "conv3"]
-            self._wgrad(c3, blk["o2"], g)
-            d_o2 = self._dgrad(c3, g, mask=blk["o2"])
-            self._wgrad(c2, blk["o1"], d_o2, 1, 1)
-            d_o1 = self._dgrad(c2, d_o2, mask=blk["o1"])
-            self._wgrad(c1, blk["x"], d_o1, s, 0)
-            if blk["ds"]:
-                self._wgrad(cv[p + "downsample.0"], blk["x"], g, s, 0)
-            stage = p[len(bb + "body."):].split(".", 1)[0]
-            bucket = bb.rstrip(".") + "." + ("layer4+fpn" if stage == "layer4" else stage) if p.endswith(".0.") else None
-            if blk["first"]:
-                self._flush_wgrads()
-                self._bucket_ready(bucket)
+        for bi in range(len(ctxs[0]["blocks"]) - 1, -1, -1):
+            blks = [c["blocks"][bi] for c in ctxs]
+            p, s, has_ds = blks[0]["p"], blks[0]["s"], blks[0]["ds"]
+            bx, bo1, bo2 = ([b[k] for b in blks] for k in ("x", "o1", "o2"))
+            W(p + "conv3", bo2, g)
+            d_o2 = D(p + "conv3", g, masks=bo2)
+            W(p + "conv2", bo1, d_o2, 1, 1)
+            d_o1 = D(p + "conv2", d_o2, masks=bo1)
+            W(p + "conv1", bx, d_o1, s, 0)
+            if has_ds:
+                W(p + "downsample.0", bx, g, s, 0)
+            stage = p[len("body."):].split(".", 1)[0]
+            sname = ("layer4+fpn" if stage == "layer4" else stage) if p.endswith(".0.") else None
+
+            def stage_done():
+                for j in range(nb):
+                    self._flush_wgrads(j)
+                    self._bucket_ready(bbs[j].rstrip(".") + "." + sname, j)
+            if blks[0]["first"]:
+                stage_done()
                 break                                   # input of layer2 = frozen layer1 output: no data gradient
-            extra = lateral.get(id(blk["x"]))            # block input is C3/C4: add the FPN lateral's gradient
+            extra = [lateral.get(id(x)) for x in bx]    # block input is C3/C4: add the FPN lateral's gradient
+            has_extra = extra[0] is not None
             if s == 1:
-                a = self._dgrad(cv[p + "downsample.0"], g, res=extra) if blk["ds"] else \
-                    (g if extra is None else ops.add_mask(g, extra))
-                g = self._dgrad(c1, d_o1, res=a, mask=blk["x"])
+                if has_ds:
+                    a = D(p + "downsample.0", g, residuals=extra if has_extra else None)
+                else:
+                    a = [ops.add_mask(gg, e) for gg, e in zip(g, extra)] if has_extra else g
+                g = D(p + "conv1", d_o1, residuals=a, masks=bx)
             else:                                        # 1x1 stride 2: small-grid GEMM, then zero-insert
-                a = self._dgrad(cv[p + "downsample.0"], g)
-                bsm = self._dgrad(c1, d_o1, res=a)
-                g = ops.scatter2x(bsm, blk["x"].shape[1:3], mask=blk["x"], addend=extra)
-            if bucket is not None:      # first block of its stage done (its data-gradient convs included): the stage's
-                self._flush_wgrads()         # weight gradients go out (batched), then its gradients are final and nothing
-                self._bucket_ready(bucket)   # enqueued later reads its packed weights
-        self._flush_wgrads()
-        self._wq = None
+                a = D(p + "downsample.0", g)
+                bsm = D(p + "conv1", d_o1, residuals=a)
+                g = [ops.scatter2x(b_, x.shape[1:3], mask=x, addend=e) for b_, x, e in zip(bsm, bx, extra)]
+            if sname is not None:       # first block of its stage done (its data-gradient convs included): the stage's
+                stage_done()            # weight gradients go out, then its gradients are final and nothing enqueued
+        for j in range(nb):             # later reads its packed weights
+            self._flush_wgrads(j)
+        self._wqs = None
         return None
 
     # ------------------------------------------------------------------------------------------------ step
@@ -559,7 +581,6 @@ class TrainEngine(object):
         gt_boxes [B, G, 4] fp32 xyxy, gt_count [B] int32.  Returns losses [4] = (cls, reg, centerness, num_pos)."""
         from . import model
         main, s1 = torch.cuda.current_stream(), self.s1
-        side = s1 if s1 is not None else main
         # train_step(defer_join) left the previous step's tail (last weight gradients, exchange, update, repack, proposals)
         # running on the side streams: the frozen prefix of this forward goes first, then the main stream joins them
         deferred, self._deferred = self._deferred, None
@@ -567,36 +588,28 @@ class TrainEngine(object):
 
         def join_previous():
             if deferred is not None:
-                for ev in deferred["events"]:       # events recorded when the previous step returned: NOT the streams'
-                    main.wait_event(ev)             # current tails, which already hold this step's query branch
+                for ev in deferred["events"]:       # events recorded when the previous step returned
+                    main.wait_event(ev)
             self.flat_g.zero_()
             self.exchange.begin()
         if deferred is None:
             join_previous()
-        elif s1 is not None:
-            for ev in deferred["events"]:           # the query branch is off the critical path: it simply waits
-                s1.wait_event(ev)
         batch = images.shape[0]
         shots = queries.shape[0] // batch
         q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0]
         rois = model.whole_image_rois(q_sizes, self.device)
-        # ---- forward: query backbone + pooling beside the target backbone
-        if s1 is not None:
-            s1.wait_stream(main)
-        with torch.cuda.stream(side):
-            qfeats, qctx = self.backbone_forward("supp_backbone.", queries)
-            pooled = []
-            for feat, scale in zip(qfeats, spec.POOLER_SCALES):
-                v = ops.roi_align(feat, rois, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
-                pooled.append(ops.shot_mean(v.view(v.shape[0], -1), batch))
-        feats, tctx = self.backbone_forward("backbone.", images, after_frozen=join_previous if deferred is not None else None)
+        # ---- forward: both backbones in lockstep (one launch per layer), query pooling, correlation, head
+        (feats, qfeats), (tctx, qctx) = self.backbones_forward(images, queries,
+                                                               after_frozen=join_previous if deferred is not None else None)
         prev_keep = deferred = self._joined_refs = None   # what the previous step's side work reads is released only now
-        if s1 is not None:
-            main.wait_stream(s1)
-        combined = [ops.correlate(f, q) for f, q in zip(feats, pooled)]
+        pooled = []
+        for feat, scale in zip(qfeats, spec.POOLER_SCALES):
+            v = ops.roi_align(feat, rois, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
+            pooled.append(ops.shot_mean(v.view(v.shape[0], -1), batch))
+        combined = ops.correlate_levels(feats, pooled)
         head_out, hctx = self.head_forward(combined)
         if with_proposals:      # box_selector_train under no_grad (fcos.py:196-199): proposals for the second stage,
-            ps = self.pstream if (self.pstream is not None and s1 is not None) else main   # independent of loss/backward
+            ps = self.pstream if self.pstream is not None else main                        # independent of loss/backward
             if ps is not main:
                 ps.wait_stream(main)
             with torch.cuda.stream(ps):
@@ -609,39 +622,39 @@ class TrainEngine(object):
         losses, pred_grads = self.loss_and_grads(head_out, gt_boxes, gt_count)
         self.last_head_out, self.last_pred_grads = head_out, pred_grads      # (tests: conditioning of the Scale gradients)
         d_comb = self.head_backward(combined, hctx, pred_grads)
-        self._bucket_ready("head", [st for st in (main, s1, self.wstream, self.wstream2) if st is not None])
-        # correlation backward (generalized_rcnn.py:307-311): d feat = g * q, d q = sum_hw g * feat
-        dP = [ops.correlate(g, q) for g, q in zip(d_comb, pooled)]
-        dq = [ops.correlate_bwd_query(g, feat) for g, feat in zip(d_comb, feats)]
+        self._bucket_ready("head", 0, [st for st in (main, self.wstream, self.wstream2) if st is not None])
+        # correlation backward (generalized_rcnn.py:307-311): d q = sum_hw g * feat, d feat = g * q
+        dq = ops.correlate_bwd_query_levels(d_comb, feats)
+        side = s1 if s1 is not None else main
         if s1 is not None:
             s1.wait_stream(main)
-        with torch.cuda.stream(side):      # query branch backward beside the target backbone's
+        with torch.cuda.stream(side):      # the query branch's small pooling-backward chain beside d feat
             dQ = []
             for dql, qf, scale in zip(dq, qfeats, spec.POOLER_SCALES):
                 dv = ops.shot_mean_bwd(dql, shots)
                 gx = ops.roi_align_bwd(dv.view(-1, 1, 1, dv.shape[-1]), rois, qf.shape, scale, 1, 1,
                                        spec.POOLER_SAMPLING_RATIO)
                 dQ.append(ops.cast_f32(gx, self.dtype))
-            self.backbone_backward(qctx, dQ)
-        self.backbone_backward(tctx, dP)
-        self._keep.append((dq, dP, d_comb, pred_grads))
+        dP = ops.correlate_levels(d_comb, pooled)
+        if s1 is not None:
+            main.wait_stream(s1)
+        self.backbones_backward([tctx, qctx], [dP, dQ])
+        self._keep.append((dq, dP, dQ, d_comb, pred_grads))
         if self._defer_now:
             # leave the tail on the side streams; the next forward_backward (or join()) orders the main stream after them
             events = []
-            for st in (s1, self.wstream, self.wstream2, self.pstream, self.ustream, self.exchange.comm):
+            for st in (self.wstream, self.wstream2, self.pstream, self.ustream, self.exchange.comm):
                 if st is not None:
                     ev = torch.cuda.Event()
                     ev.record(st)
                     events.append(ev)
             self._deferred = dict(events=events, refs=(qctx, tctx, hctx, feats, qfeats, pooled, combined, head_out, dQ, rois))
             return losses
-        if s1 is not None:
-            main.wait_stream(s1)
         if self.wstream is not None:
             main.wait_stream(self.wstream)
         if self.wstream2 is not None:
             main.wait_stream(self.wstream2)
-        if with_proposals and self.pstream is not None and s1 is not None:
+        if with_proposals and self.pstream is not None:
             main.wait_stream(self.pstream)
         return losses
 
@@ -719,7 +732,7 @@ class TrainEngine(object):
         # defer_join: do not make the main stream wait for the step's tail (the last stage's weight gradients, their
         # exchange, update and repack): the next step's frozen layers (stem, layer1) run beside it.  Every bucket's update
         # already sits on the update / communication stream in fused mode, so nothing is left to enqueue here
-        self._defer_now = bool(self.defer_join and self._fuse_update and self.s1 is not None and self.wstream is not None)
+        self._defer_now = bool(self.defer_join and self._fuse_update and self.wstream is not None)
         try:
             losses = self.forward_backward(images, queries, gt_boxes, gt_count)
         finally:

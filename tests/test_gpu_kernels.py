@@ -265,9 +265,9 @@ def test_conv2d_grouped_rejects_bad_arguments():
     from oneshotdet_amd import _lib
     o = ops()
     pc = o.pack_conv((rnd(64, 64, 3, 3, seed=1) / 24).cuda(), bias=rnd(64, seed=2).cuda(), dtype=torch.float32)
-    xs = [to_nhwc(rnd(1, 64, 4, 4, seed=3), torch.float32)] * 7
+    xs = [to_nhwc(rnd(1, 64, 4, 4, seed=3), torch.float32)] * 13
     with pytest.raises(_lib.OsdError):
-        o.conv2d_grouped(xs, pc, pad=1)               # more than 6 segments
+        o.conv2d_grouped(xs, pc, pad=1, _whole=True)  # more than OSD_CONV_MAX_SEG = 12 segments
     with pytest.raises(_lib.OsdError):
         o.conv2d_grouped(xs[:2], pc, pad=1, algo=40)  # register-staged algorithms cannot run grouped
 
@@ -378,3 +378,59 @@ def test_conv_algorithm_cache_is_keyed_on_the_full_geometry():
         torch.testing.assert_close(y.float().permute(0, 3, 1, 2).cpu(), ref, rtol=2e-2, atol=2e-1)
     keys = [k for k in o.ALGO_CACHE if k[0] == o.OSD_BF16 and k[4:8] == (256, 256, 3, 3)]
     assert len({k[1:4] for k in keys}) >= 2
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv2d_multi_own_weights_strides_and_topdown_add(dt):
+    """osd_conv2d_fwd_multi: segments with their OWN weights / bias (both towers, or target + query backbone), stride 2,
+    the same-size residual with ReLU, and the nearest-2x top-down addend (FPN lateral, fpn.py:59-64) — every output equals
+    the single launch of its own (bit for bit: same kernel, same K order) ."""
+    o = ops()
+    T = DT[dt]
+    sizes = [(2, 20, 24), (3, 6, 8), (1, 13, 10)]
+    ws = [(rnd(128, 64, 1, 1, seed=10 + i) / 8).cuda() for i in range(3)]
+    bs = [rnd(128, seed=20 + i).cuda() for i in range(3)]
+    pcs = [o.pack_conv(w, bias=b, dtype=T) for w, b in zip(ws, bs)]
+    xs = [to_nhwc(rnd(n, 64, h, w, seed=30 + i), T) for i, (n, h, w) in enumerate(sizes)]
+    # 1x1 stride 2 (the first conv of a stage, STRIDE_IN_1X1), ReLU
+    ys = o.conv2d_multi(xs, pcs, stride=2, act=o.ACT_RELU, _whole=True)
+    for x, pc, y in zip(xs, pcs, ys):
+        assert torch.equal(y, o.conv2d(x, pc, stride=2, act=o.ACT_RELU, algo=None))
+    # same-size residual + ReLU (conv3 of a bottleneck)
+    res = [to_nhwc(rnd(n, 128, h, w, seed=40 + i), T) for i, (n, h, w) in enumerate(sizes)]
+    ys = o.conv2d_multi(xs, pcs, act=o.ACT_RELU, residuals=res, _whole=True)
+    for x, pc, r, y in zip(xs, pcs, res, ys):
+        assert torch.equal(y, o.conv2d(x, pc, act=o.ACT_RELU, res=r, res_mode=o.RES_SAME))
+    # top-down add: addend of exactly half size (even maps only)
+    ev = [(2, 20, 24), (3, 6, 8)]
+    top = [to_nhwc(rnd(n, 128, h // 2, w // 2, seed=50 + i), T) for i, (n, h, w) in enumerate(ev)]
+    ys = o.conv2d_multi(xs[:2], pcs[:2], residuals=top, res_mode=o.RES_UP2X, _whole=True)
+    for x, pc, r, y in zip(xs[:2], pcs[:2], top, ys):
+        assert torch.equal(y, o.conv2d(x, pc, res=r, res_mode=o.RES_UP2X))
+    # against torch on one segment (weights are really per segment: segment 1 with segment 0's weights must differ)
+    ref = F.conv2d(from_nhwc(xs[1]).to(T).float(), ws[1].cpu().to(T).float(), bs[1].cpu(), stride=2).relu()
+    y1 = o.conv2d_multi(xs, pcs, stride=2, act=o.ACT_RELU, _whole=True)[1]
+    torch.testing.assert_close(from_nhwc(y1), ref, **TOL[dt])
+    assert not torch.equal(y1, o.conv2d(xs[1], pcs[0], stride=2, act=o.ACT_RELU))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_correlate_levels_forward_and_query_gradient(dt):
+    """osd_correlate_levels / osd_correlate_bwd_query_levels: all FPN levels in one launch each equal the per-level calls
+    (forward bit for bit; the query gradient to the order of its atomics) and the broadcast multiply / its autograd."""
+    o = ops()
+    T = DT[dt]
+    n, c = 3, 256
+    sizes = [(25, 32), (13, 16), (7, 8), (4, 4), (1, 1)]
+    xs = [to_nhwc(rnd(n, c, h, w, seed=60 + i), T) for i, (h, w) in enumerate(sizes)]
+    gs = [to_nhwc(rnd(n, c, h, w, seed=70 + i), T) for i, (h, w) in enumerate(sizes)]
+    qs = [rnd(n, c, seed=80 + i).cuda() for i in range(len(sizes))]
+    ys = o.correlate_levels(xs, qs)
+    dqs = o.correlate_bwd_query_levels(gs, xs)
+    for x, g, q, y, dq in zip(xs, gs, qs, ys, dqs):
+        assert torch.equal(y, o.correlate(x, q))
+        ref = (x.float() * q[:, None, None, :]).to(T)
+        torch.testing.assert_close(y.float(), ref.float(), rtol=1e-6 if dt == "f32" else 1e-2, atol=1e-6)
+        dref = (g.float() * x.float()).sum(dim=(1, 2))
+        torch.testing.assert_close(dq, dref, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(dq, o.correlate_bwd_query(g, x), rtol=1e-5, atol=1e-4)

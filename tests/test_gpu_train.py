@@ -68,6 +68,32 @@ def test_conv_wgrad_skinny_and_bias(dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("cout", [2, 4])
+def test_prediction_conv_wgrad_levels_read_once_kernel(cout, dt):
+    """The FCOS prediction convs' weight + bias gradient over several FPN levels (osd_conv2d_wgrad_grouped with Cout <= 4
+    takes the read-once kernel: one pass over x, nine dy vectors per pixel) against autograd, incl. odd sizes whose last
+    workgroup is ragged and a 1 x 1 level where every tap but the centre falls outside."""
+    from oneshotdet_amd import ops
+    cin = 256
+    sizes = [(2, 25, 31), (2, 7, 8), (2, 1, 1), (2, 3, 2)]
+    wt = (rnd(cout, cin, 3, 3, seed=2) / 48).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    pairs, tot = [], 0
+    for i, (n, h, w) in enumerate(sizes):
+        x = rnd(n, cin, h, w, seed=10 + i).to(DT[dt]).float()
+        dy = rnd(n, cout, h, w, seed=20 + i).to(DT[dt]).float()
+        (F.conv2d(x, wt, b, padding=1) * dy).sum().backward()
+        dyp = torch.zeros(n, h, w, 64, dtype=DT[dt])          # the data-gradient conv's K padding: 64-channel rows
+        dyp[..., :cout] = dy.permute(0, 2, 3, 1)
+        pairs.append((to_nhwc(x, DT[dt]), dyp.cuda()))
+    dw, db = torch.zeros(cout, 3, 3, cin, device="cuda"), torch.zeros(cout, device="cuda")
+    ops.conv2d_wgrad_grouped(pairs, dw, 3, 3, 1, 1, cout, db=db)
+    ref = wt.grad.permute(0, 2, 3, 1)
+    assert (dw.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    assert (db.cpu() - b.grad).abs().max().item() <= 1e-4 * b.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_groupnorm_relu_backward(dt):
     from oneshotdet_amd import ops
     x = (rnd(2, 256, 13, 16, seed=1, scale=2) + 0.3)

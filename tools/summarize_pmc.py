@@ -25,7 +25,7 @@ def main():
         for r in rows:
             n = r["Kernel_Name"]
             k = "conv_fwd_dgrad" if ("conv_dma" in n or "conv_igemm" in n or "conv_xr_kernel" in n or "conv_p8_kernel" in n) else (
-                "conv_wgrad" if "conv_wgrad_kernel" in n else ("correlate" if "correlate_kernel" in n else None))
+                "conv_wgrad" if "conv_wgrad_kernel" in n else ("correlate" if ("correlate_kernel" in n or "correlate_levels_kernel" in n) else None))
             if k is None:
                 continue
             e = res.setdefault(k, {"launches": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
@@ -63,7 +63,7 @@ def main():
             f.write("| %s | %d | %.1f | %.1f | %.2f |\n" % (k, e["launches"], e["hbm_read_bytes"] / 1e6,
                                                            e["hbm_write_bytes"] / 1e6, e["hbm_bytes_per_launch"] / 1e6))
         c = res["calibration"]
-        f.write("\nCalibration: %d correlate launches (5 forward + 5 backward levels) should read and write %.1f MB each "
+        f.write("\nCalibration: %d correlate launches (forward + backward d_feat, all 5 levels each) should read and write %.1f MB each "
                 "per pass (x2 passes); measured read %.1f MB, write %.1f MB.\n" % (
                     c["launches"], cal / 1e6, c["measured_read_bytes"] / 1e6, c["measured_write_bytes"] / 1e6))
     print(open(out + ".md").read())
