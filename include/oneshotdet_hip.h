@@ -67,8 +67,6 @@ typedef struct osd_conv_desc {
   int32_t relu_in;        /* 1: apply ReLU to x while staging (P7 = conv(relu(P6)), fpn.py:98) */
   int32_t algo;           /* 0 = library heuristic; otherwise 1 + impl*32 + variant*8 + tile (see osd_conv_algo_count /
                              DESIGN.md 4.1): lets the host autotune per layer shape by measurement */
-  int32_t gn_in;          /* 1: x' = relu(x * gn_a[n,c] + gn_b[n,c]) while staging (GroupNorm+ReLU of the previous tower conv,
-                             fcos.py:37-38 fused into the consumer); gn_a/gn_b are [n][cin] fp32 from osd_groupnorm_finalize */
 } osd_conv_desc;
 
 /* number of selectable algorithms for osd_conv_desc.algo (valid values 1..count); unsupported combinations for a
@@ -392,6 +390,22 @@ int osd_box_decode(const void* pred, const float* rois, const int32_t* counts, f
 int osd_append_gt_boxes(const float* boxes, const float* scores, const int32_t* counts, const float* gt_boxes,
                         const int32_t* gt_count, float* out_boxes, float* out_scores, int32_t* out_counts, int n, int cap,
                         int max_gt, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Input transforms (data/transforms/transforms.py:27-92 in the Compose order of
+ * data/transforms/build.py:39-46) + the zero padding of to_image_list (structures/image_list.py:52-70), one image per call:
+ *   Resize = PIL.Image.resize((out_w, out_h), BILINEAR) on 8-bit RGB (Pillow's fixed-point ImagingResample: horizontal pass,
+ *   then vertical; a pass whose size does not change is skipped), hflip, ToTensor (/255), Normalize (to_bgr255: channels
+ *   reversed and * 255; then (x - mean[c]) / std[c]) — bit-exact against the reference's pipeline.
+ * src_rgb_hwc: device uint8 [in_h][in_w][3].  (out_h, out_w) = Resize.get_size of the caller.  mean3 / std3: HOST floats.
+ * The result lands in slot `batch_index` of dst, whose every image is dst_h x dst_w with this image at (pad_t, pad_l) and
+ * zeros elsewhere: layout 0 = fp32 NCHW [n][3][dst_h][dst_w] (the reference's batch tensor; dtype ignored), layout 1 =
+ * `dtype` NHWC4 [n][dst_h][dst_w][4] (the stem conv's padded input, as osd_pack_image writes it).
+ * workspace: osd_image_transform_workspace_bytes(in_h, in_w, out_h, out_w) bytes. */
+int osd_image_transform(const uint8_t* src_rgb_hwc, int in_h, int in_w, int out_h, int out_w, int flip, int to_bgr255,
+                        const float* mean3, const float* std3, void* dst, int layout, int dtype, int batch_index, int dst_h,
+                        int dst_w, int pad_t, int pad_l, void* workspace, void* stream);
+int64_t osd_image_transform_workspace_bytes(int in_h, int in_w, int out_h, int out_w);
 
 #ifdef __cplusplus
 }

@@ -316,7 +316,6 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
                               const void* res, const void* mask, const float* act_scale_dev, const void* reserved,
                               void* y, void* stream) {
   if (!d || !x || !w || !bias || !y) return osd_fail(OSD_ERR_INVALID_ARG, "conv: null argument");
-  if (d->gn_in) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: gn_in fusion not available in this build");
   if (reserved) return osd_fail(OSD_ERR_INVALID_ARG, "conv: reserved argument must be null");
   if (d->cout % 4 != 0 || d->out_stride % 4 != 0)
     return osd_fail(OSD_ERR_INVALID_ARG, "conv: cout/out_stride must be multiples of 4 (got %d/%d)", d->cout,
@@ -391,7 +390,7 @@ extern "C" int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const voi
   if (!d || !xs || !ys || !ns || !hs || !ws || !wts || !biases || n_seg < 1 || n_seg > kConvMaxSeg)
     return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad arguments (1..%d segments)", kConvMaxSeg);
   if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad dtype %d", d->dtype);
-  if (d->gn_in || d->relu_in) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: input prologues not supported");
+  if (d->relu_in) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: the relu_in prologue is not supported");
   if (d->cout % 4 != 0 || d->out_stride % 4 != 0)
     return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: cout/out_stride must be multiples of 4");
   if (d->res_mode != OSD_RES_NONE && d->res_mode != OSD_RES_SAME && d->res_mode != OSD_RES_UP2X)

@@ -69,12 +69,7 @@ class HeadWeights(object):
 
 def run_backbone(wts, images, dtype, return_body=False):
     """images NCHW fp32 -> [P3, P4, P5, P6, P7] NHWC.  resnet.py:138-145,295-315,332-337; fpn.py:43-75,95-99."""
-    n, _, h, w = images.shape
-    ho, wo = ops.conv_out(h, 7, 2, 3), ops.conv_out(w, 7, 2, 3)
-    hp, wp = 2 * (ho - 1) + 7, 2 * (wo - 1) + 8
-    hp, wp = max(hp, h + 3), max(wp, w + 3)
-    wp += wp & 1
-    x = ops.pack_image(images, dtype, hp, wp)
+    x, (ho, wo) = ops.stem_input(images, dtype)
     x = ops.conv2d(x, wts.stem, act=ACT_RELU, out_hw=(ho, wo))
     x = ops.maxpool3x3s2(x)
     feats = []
@@ -106,11 +101,7 @@ def run_backbones(wt, wq, images, queries, dtype):
     latency-sized launches ride in the tail of the target's.  -> ([P3..P7] target, [P3..P7] query), NHWC."""
     xs = []
     for wts, im in ((wt, images), (wq, queries)):
-        n, _, h, w = im.shape
-        ho, wo = ops.conv_out(h, 7, 2, 3), ops.conv_out(w, 7, 2, 3)
-        hp, wp = max(2 * (ho - 1) + 7, h + 3), max(2 * (wo - 1) + 8, w + 3)
-        wp += wp & 1
-        x = ops.pack_image(im, dtype, hp, wp)
+        x, (ho, wo) = ops.stem_input(im, dtype)
         x = ops.conv2d(x, wts.stem, act=ACT_RELU, out_hw=(ho, wo))
         xs.append(ops.maxpool3x3s2(x))
     feats = []
@@ -307,6 +298,10 @@ class HotPathEngine(object):
         image_sizes = query_sizes = None
         if isinstance(images, ImageList):       # padded batch (R0): clip to every image's own size
             images, image_sizes = images.tensors, images.image_sizes
+        elif isinstance(images, ops.PackedImages):
+            image_sizes = images.image_sizes
+        if isinstance(queries, ops.PackedImages):
+            query_sizes = queries.image_sizes
         if isinstance(queries, ImageList):
             queries, query_sizes = queries.tensors, queries.image_sizes
         out = self.forward(images, queries, concurrent, query_sizes)

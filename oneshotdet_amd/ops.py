@@ -92,6 +92,31 @@ def pack_image(images, dtype, hp, wp, pad_t=3, pad_l=3):
     return out
 
 
+class PackedImages(object):
+    """A batch already in the stem conv's input format (what pack_image produces): `tensor` [N, hp, wp, 4] zero padded NHWC4
+    with every image at (3, 3), `hw` = (H, W) of the (padded) batch, `image_sizes` = every image's true (h, w).  Written
+    directly by transforms.collate(..., stem_dtype=...), so the float NCHW batch is never materialised."""
+
+    def __init__(self, tensor, hw, image_sizes):
+        self.tensor, self.hw, self.image_sizes = tensor, tuple(hw), [tuple(s) for s in image_sizes]
+
+    @property
+    def shape(self):
+        return (self.tensor.shape[0], 3, self.hw[0], self.hw[1])
+
+
+def stem_input(images, dtype):
+    """images: NCHW fp32 [N,3,H,W] or PackedImages -> (padded NHWC4 stem input, (Ho, Wo) of the 7x7/2 stem conv)."""
+    n, _, h, w = images.shape
+    ho, wo = conv_out(h, 7, 2, 3), conv_out(w, 7, 2, 3)
+    if isinstance(images, PackedImages):
+        assert images.tensor.dtype == dtype, "PackedImages were written as %s, the engine computes in %s" % (images.tensor.dtype, dtype)
+        return images.tensor, (ho, wo)
+    hp, wp = max(2 * (ho - 1) + 7, h + 3), max(2 * (wo - 1) + 8, w + 3)
+    wp += wp & 1
+    return pack_image(images, dtype, hp, wp), (ho, wo)
+
+
 # ---- per-shape algorithm selection by measurement ("measure, don't guess") ----
 # osd_conv_desc.algo = 1 + impl*32 + variant*8 + tile; impl 0 = LDS-DMA ring kernel (variants: deep / shallow ring /
 # short stages), impl 1 = register-staged kernel; tile 0..4 = 128x128, 128x64, 64x64, 256x16, 256x256/8 waves
@@ -192,7 +217,7 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
         d.res_h, d.res_w, d.res_stride = res.shape[1], res.shape[2], res.shape[3]
         if res_mode == RES_UP2X:
             assert res.shape[1] * 2 == ho and res.shape[2] * 2 == wo, "top-down map must be exactly half size"
-    d.act, d.act_scale, d.relu_in, d.gn_in = act, float(act_scale), int(relu_in), 0
+    d.act, d.act_scale, d.relu_in = act, float(act_scale), int(relu_in)
     if mask is not None:
         assert mask.shape == out.shape and mask.dtype == out.dtype
     args = (_ptr(x), _ptr(pc.w), _ptr(pc.bias), _ptr(res), _ptr(mask), _ptr(act_scale_dev), None, _ptr(out), _stream())
@@ -236,6 +261,10 @@ def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mod
                                  and not q.stem for q in pcs), "segments must share the conv geometry"
     if res_mode is None:
         res_mode = RES_NONE if residuals is None else RES_SAME
+    if k == 1 and algo is None and not _whole:       # one pair: the plain launch (all algorithms, its own tuning entry)
+        return [conv2d(xs[0], pc, stride=stride, pad=pad, act=act, res=None if residuals is None else residuals[0],
+                       res_mode=res_mode, act_scale=act_scale, mask=None if masks is None else masks[0],
+                       act_scale_dev=None if act_scale_devs is None else act_scale_devs[0])]
     if k >= 3 and algo is None and not _whole:
         skey = ("split", _dt(xs[0]), tuple(tuple(x.shape) for x in xs), pc.cout_store, pc.r, stride, pad, act, res_mode,
                 masks is not None)
@@ -288,7 +317,7 @@ def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mod
                        for r, o in zip(residuals, outs)), "top-down map must be exactly half size"
     if masks is not None:
         assert all(m.shape == o.shape and m.dtype == o.dtype for m, o in zip(masks, outs))
-    d.act, d.act_scale, d.relu_in, d.gn_in = act, float(act_scale), 0, 0
+    d.act, d.act_scale, d.relu_in = act, float(act_scale), 0
     ns = (C.c_int32 * k)(*[x.shape[0] for x in xs])
     hs = (C.c_int32 * k)(*[x.shape[1] for x in xs])
     ws = (C.c_int32 * k)(*[x.shape[2] for x in xs])

@@ -53,6 +53,11 @@ class TrainEngine(object):
         # training proposals feed only the second stage: a chain of small kernels on a stream of their own
         self.pstream = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None
         self._keep = []
+        # A/B switches (measured on one box, tools/ab_bench.sh): both backbones per launch / both towers per launch
+        import os
+        self.lockstep = os.environ.get("OSD_LOCKSTEP", "0") != "0"
+        self.corr_levels = os.environ.get("OSD_CORR_LEVELS", "1") != "0"
+        self.towers_merged = os.environ.get("OSD_TOWERS_MERGED", "0") != "0"
         sd = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state_dict.items()}
         self._frozen_sd = sd
         self.convs = {}          # name -> TConv
@@ -269,25 +274,25 @@ class TrainEngine(object):
     BBS = ("backbone.", "supp_backbone.")
 
     def backbones_forward(self, images, queries, after_frozen=None):
+        return self._backbones_forward(self.BBS, (images, queries), after_frozen)
+
+    def _backbones_forward(self, bbs, inputs, after_frozen=None):
         """Both R-50-FPN backbones (generalized_rcnn.py:270-272: separately parameterised, same graph) in LOCKSTEP: every
         layer is ONE osd_conv2d_fwd_multi launch over (target, query), so the query branch's latency-sized launches (M = 8
         .. 8192 pixels) ride in the tail of the target's instead of costing ~110 launches of their own per step.
         after_frozen: called once the stems and layer1 (frozen: resnet.py:127-136) have been enqueued, before the first
         layer that reads trainable weights.  Returns ([feats_target, feats_query], [ctx_target, ctx_query])."""
-        cv, dt, bbs = self.convs, self.dtype, self.BBS
+        cv, dt = self.convs, self.dtype
+        nb = range(len(bbs))
 
         def pcs(name):
             return [cv[bb + name].pc for bb in bbs]
         xs = []
-        for bb, im in zip(bbs, (images, queries)):
-            n, _, h, w = im.shape
-            ho, wo = ops.conv_out(h, 7, 2, 3), ops.conv_out(w, 7, 2, 3)
-            hp, wp = max(2 * (ho - 1) + 7, h + 3), max(2 * (wo - 1) + 8, w + 3)
-            wp += wp & 1
-            x = ops.pack_image(im, dt, hp, wp)
+        for bb, im in zip(bbs, inputs):
+            x, (ho, wo) = ops.stem_input(im, dt)
             x = ops.conv2d(x, cv[bb + "body.stem.conv1"].pc, act=ACT_RELU, out_hw=(ho, wo))
             xs.append(ops.maxpool3x3s2(x))
-        blocks, stage_out = ([], []), ([], [])
+        blocks, stage_out = [[] for _ in nb], [[] for _ in nb]
         for si, nblocks in enumerate(spec.STAGE_BLOCKS):
             for bi in range(nblocks):
                 p = "body.layer%d.%d." % (si + 1, bi)
@@ -298,11 +303,11 @@ class TrainEngine(object):
                 o2 = ops.conv2d_multi(o1, pcs(p + "conv2"), pad=1, act=ACT_RELU)
                 y = ops.conv2d_multi(o2, pcs(p + "conv3"), act=ACT_RELU, residuals=identity)
                 if si >= 1:
-                    for j in (0, 1):
+                    for j in nb:
                         blocks[j].append(dict(p=p, s=s, ds=has_ds, x=xs[j], o1=o1[j], o2=o2[j], y=y[j],
                                               first=(si == 1 and bi == 0)))
                 xs = y
-            for j in (0, 1):
+            for j in nb:
                 stage_out[j].append(xs[j])
             if si == 0 and after_frozen is not None:
                 after_frozen()
@@ -318,7 +323,7 @@ class TrainEngine(object):
         p6r = [ops.add_mask(t, None, t) for t in p6]        # relu(P6), materialised: the P7 weight gradient reads it
         p7 = ops.conv2d_multi(p6r, pcs(f + "top_blocks.p7"), stride=2, pad=1)
         feats, ctxs = [], []
-        for j in (0, 1):
+        for j in nb:
             feats.append([p3[j], p4[j], p5[j], p6[j], p7[j]])
             ctxs.append(dict(bb=bbs[j], blocks=blocks[j], c3=c3[j], c4=c4[j], c5=c5[j], inner4=inner4[j], inner3=inner3[j],
                              inner2=inner2[j], p5=p5[j], p6=p6[j], p6r=p6r[j]))
@@ -331,26 +336,44 @@ class TrainEngine(object):
         (10 pairs: they share the geometry, each tower brings its own weights; level-major order so that the tuner's
         large / small split keeps P3 and P4 of both towers together), then GroupNorm+ReLU of a tower's five levels in two
         launches.  ctx[tower] = ([per layer: (inputs per level, conv outputs per level, ab)], last activations)."""
+        if self.towers_merged:
+            outs, ctx = self._towers_forward(feats, self.TOWERS)
+            return list(zip(outs["cls_tower"], outs["bbox_tower"])), ctx
+        # one stream per tower: the HBM-bound GroupNorm passes of one tower run beside the MFMA-bound convs of the other
+        main = torch.cuda.current_stream()
+        side = self.s1 if self.s1 is not None else main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ob, cb = self._towers_forward(feats, ("bbox_tower",))
+        oc, cc = self._towers_forward(feats, ("cls_tower",))
+        main.wait_stream(side)
+        cc.update(cb)
+        return list(zip(oc["cls_tower"], ob["bbox_tower"])), cc
+
+    def _towers_forward(self, feats, towers):
         cv = self.convs
         h = "rpn.head."
         scales = self.extra[h + "scales"][0]
-        nl = len(feats)
-        t = {tw: list(feats) for tw in self.TOWERS}
-        layers = {tw: [] for tw in self.TOWERS}
+        nl, nt = len(feats), len(towers)
+        t = {tw: list(feats) for tw in towers}
+        layers = {tw: [] for tw in towers}
         for i in range(spec.NUM_CONVS):
-            xs = [t[tw][l] for l in range(nl) for tw in self.TOWERS]
-            pcs = [cv["%s%s.%d" % (h, tw, 3 * i)].pc for l in range(nl) for tw in self.TOWERS]
+            xs = [t[tw][l] for l in range(nl) for tw in towers]
+            pcs = [cv["%s%s.%d" % (h, tw, 3 * i)].pc for l in range(nl) for tw in towers]
             us = ops.conv2d_multi(xs, pcs, pad=1)
-            for k, tw in enumerate(self.TOWERS):
+            for k, tw in enumerate(towers):
                 (gw, _), (gbeta, _) = self.gn("%s%s.%d" % (h, tw, 3 * i + 1))
-                u = us[k::2]
+                u = us[k::nt]
                 t2, ab = ops.groupnorm_relu_levels(u, gw, gbeta, spec.GN_GROUPS, spec.GN_EPS)
                 layers[tw].append((t[tw], u, ab))
                 t[tw] = t2
-        cls_out = ops.conv2d_grouped(t["cls_tower"], cv[h + "cls_ctr"].pc, pad=1)
-        box_out = ops.conv2d_grouped(t["bbox_tower"], cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE,
-                                     act_scale_devs=[scales[l:l + 1] for l in range(nl)])
-        return list(zip(cls_out, box_out)), {tw: (layers[tw], t[tw]) for tw in self.TOWERS}
+        outs = {}
+        if "cls_tower" in towers:
+            outs["cls_tower"] = ops.conv2d_grouped(t["cls_tower"], cv[h + "cls_ctr"].pc, pad=1)
+        if "bbox_tower" in towers:
+            outs["bbox_tower"] = ops.conv2d_grouped(t["bbox_tower"], cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE,
+                                                    act_scale_devs=[scales[l:l + 1] for l in range(nl)])
+        return outs, {tw: (layers[tw], t[tw]) for tw in towers}
 
     # ------------------------------------------------------------------------------------------------ loss
     def loss_and_grads(self, head_out, gt_boxes, gt_count):
@@ -427,11 +450,12 @@ class TrainEngine(object):
         with torch.cuda.stream(ust):
             self._update_bucket(name)
 
-    def _flush_wgrads(self, which):
-        """Launch the queued weight gradients of backbone `which`'s stage as ONE mixed-geometry launch (<= 24 convs each):
+    def _flush_wgrads(self, j, which):
+        """Launch the queued weight gradients of backbone j's stage as ONE mixed-geometry launch (<= 24 convs each) on side
+        stream `which`:
         all output tiles share the workgroup budget in proportion to their work, so every conv runs with few pixel splits
         — long inner loops, little atomic traffic — and the query branch's latency-sized launches disappear into it."""
-        q, self._wqs[which] = self._wqs[which], []
+        q, self._wqs[j] = self._wqs[j], []
         for i in range(0, len(q), 24):
             part = q[i:i + 24]
             if len(part) == 1:
@@ -456,11 +480,26 @@ class TrainEngine(object):
         """Layer by layer (last first): GroupNorm+ReLU backward of each tower (two launches for its five levels), then the
         data gradient of BOTH towers' conv over all levels as ONE launch; the weight gradients of a tower's four convs x
         five levels go out as one launch on that tower's side stream once its chain is done."""
+        nl = len(feats)
+        if self.towers_merged:
+            d_t = self._towers_backward(ctxs, pred_grads, self.TOWERS, nl)
+        else:
+            main = torch.cuda.current_stream()
+            side = self.s1 if self.s1 is not None else main
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                d_t = self._towers_backward(ctxs, pred_grads, ("bbox_tower",), nl)
+            d_t.update(self._towers_backward(ctxs, pred_grads, ("cls_tower",), nl))
+            main.wait_stream(side)
+        return [ops.add_mask(d_t["cls_tower"][l], d_t["bbox_tower"][l]) for l in range(nl)]
+
+    def _towers_backward(self, ctxs, pred_grads, towers, nl):
         cv = self.convs
         h = "rpn.head."
-        nl = len(feats)
-        d_t, items = {}, {tw: [] for tw in self.TOWERS}
-        for k, tw in enumerate(self.TOWERS):
+        nt = len(towers)
+        d_t, items = {}, {tw: [] for tw in towers}
+        for tw in towers:
+            k = self.TOWERS.index(tw)
             layers, t_last = ctxs[tw]
             pc = cv[h + ("cls_ctr" if tw == "cls_tower" else "bbox_pred")]
             dpred = [pred_grads[l][k] for l in range(nl)]
@@ -468,25 +507,25 @@ class TrainEngine(object):
             d_t[tw] = self._dgrad_levels(pc, dpred)
         for i in range(spec.NUM_CONVS - 1, -1, -1):
             dus = {}
-            for tw in self.TOWERS:
+            for tw in towers:
                 (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tw, 3 * i + 1))
                 c = cv["%s%s.%d" % (h, tw, 3 * i)]
                 t_in, u, ab = ctxs[tw][0][i]
                 dus[tw] = ops.groupnorm_relu_bwd_levels(u, d_t[tw], ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
                 items[tw] += [(t_in[l], dus[tw][l], c.gw, c.bn_scale, c.gb if c.has_bias else None) for l in range(nl)]
-            dys = [dus[tw][l] for l in range(nl) for tw in self.TOWERS]
-            c0 = cv["%s%s.%d" % (h, self.TOWERS[0], 3 * i)]
-            pds = [cv["%s%s.%d" % (h, tw, 3 * i)].pd for l in range(nl) for tw in self.TOWERS]
+            dys = [dus[tw][l] for l in range(nl) for tw in towers]
+            c0 = cv["%s%s.%d" % (h, towers[0], 3 * i)]
+            pds = [cv["%s%s.%d" % (h, tw, 3 * i)].pd for l in range(nl) for tw in towers]
             out = ops.conv2d_multi(dys, pds, pad=c0.r - 1 - (c0.r // 2))
-            for k, tw in enumerate(self.TOWERS):
-                d_t[tw] = out[k::2]
-        for k, tw in enumerate(self.TOWERS):
+            for k, tw in enumerate(towers):
+                d_t[tw] = out[k::nt]
+        for tw in towers:
             c0 = cv["%s%s.0" % (h, tw)]
             self._on_wstream(lambda it=items[tw], c0=c0: ops.conv2d_wgrad_multi(it, c0.r, c0.s, 1, c0.r // 2, c0.cout),
-                             items[tw], k)
-        return [ops.add_mask(d_t["cls_tower"][l], d_t["bbox_tower"][l]) for l in range(nl)]
+                             items[tw], self.TOWERS.index(tw))
+        return d_t
 
-    def backbones_backward(self, ctxs, dPs):
+    def backbones_backward(self, ctxs, dPs, which0=0):
         """Backward of both backbones in lockstep (the mirror of backbones_forward): every data-gradient conv is ONE launch
         over (target, query); the weight gradients are queued per backbone and go out per stage as mixed-geometry launches
         on that backbone's side stream; a stage's gradient bucket is announced as soon as its last writer is enqueued."""
@@ -551,8 +590,8 @@ class TrainEngine(object):
 
             def stage_done():
                 for j in range(nb):
-                    self._flush_wgrads(j)
-                    self._bucket_ready(bbs[j].rstrip(".") + "." + sname, j)
+                    self._flush_wgrads(j, which0 + j)
+                    self._bucket_ready(bbs[j].rstrip(".") + "." + sname, which0 + j)
             if blks[0]["first"]:
                 stage_done()
                 break                                   # input of layer2 = frozen layer1 output: no data gradient
@@ -571,7 +610,7 @@ class TrainEngine(object):
             if sname is not None:       # first block of its stage done (its data-gradient convs included): the stage's
                 stage_done()            # weight gradients go out, then its gradients are final and nothing enqueued
         for j in range(nb):             # later reads its packed weights
-            self._flush_wgrads(j)
+            self._flush_wgrads(j, which0 + j)
         self._wqs = None
         return None
 
@@ -599,14 +638,34 @@ class TrainEngine(object):
         q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0]
         rois = model.whole_image_rois(q_sizes, self.device)
         # ---- forward: both backbones in lockstep (one launch per layer), query pooling, correlation, head
-        (feats, qfeats), (tctx, qctx) = self.backbones_forward(images, queries,
-                                                               after_frozen=join_previous if deferred is not None else None)
+        lock = self.lockstep
+        side = s1 if s1 is not None else main
+        af = join_previous if deferred is not None else None
+
+        def pool(qf):
+            out = []
+            for feat, scale in zip(qf, spec.POOLER_SCALES):
+                v = ops.roi_align(feat, rois, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
+                out.append(ops.shot_mean(v.view(v.shape[0], -1), batch))
+            return out
+        if lock:
+            (feats, qfeats), (tctx, qctx) = self.backbones_forward(images, queries, after_frozen=af)
+            pooled = pool(qfeats)
+        else:       # the query backbone + pooling on the second stream beside the target backbone
+            if deferred is not None and s1 is not None:
+                for ev in deferred["events"]:
+                    s1.wait_event(ev)
+            side.wait_stream(main)
+            if s1 is None and af is not None:       # single stream: the join cannot be deferred past the query backbone
+                af()
+                af = None
+            with torch.cuda.stream(side):
+                (qfeats,), (qctx,) = self._backbones_forward(self.BBS[1:], (queries,))
+                pooled = pool(qfeats)
+            (feats,), (tctx,) = self._backbones_forward(self.BBS[:1], (images,), af)
+            main.wait_stream(side)
         prev_keep = deferred = self._joined_refs = None   # what the previous step's side work reads is released only now
-        pooled = []
-        for feat, scale in zip(qfeats, spec.POOLER_SCALES):
-            v = ops.roi_align(feat, rois, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
-            pooled.append(ops.shot_mean(v.view(v.shape[0], -1), batch))
-        combined = ops.correlate_levels(feats, pooled)
+        combined = ops.correlate_levels(feats, pooled) if self.corr_levels else [ops.correlate(f, q) for f, q in zip(feats, pooled)]
         head_out, hctx = self.head_forward(combined)
         if with_proposals:      # box_selector_train under no_grad (fcos.py:196-199): proposals for the second stage,
             ps = self.pstream if self.pstream is not None else main                        # independent of loss/backward
@@ -624,8 +683,8 @@ class TrainEngine(object):
         d_comb = self.head_backward(combined, hctx, pred_grads)
         self._bucket_ready("head", 0, [st for st in (main, self.wstream, self.wstream2) if st is not None])
         # correlation backward (generalized_rcnn.py:307-311): d q = sum_hw g * feat, d feat = g * q
-        dq = ops.correlate_bwd_query_levels(d_comb, feats)
-        side = s1 if s1 is not None else main
+        dq = ops.correlate_bwd_query_levels(d_comb, feats) if self.corr_levels else \
+            [ops.correlate_bwd_query(g, f) for g, f in zip(d_comb, feats)]
         if s1 is not None:
             s1.wait_stream(main)
         with torch.cuda.stream(side):      # the query branch's small pooling-backward chain beside d feat
@@ -635,21 +694,28 @@ class TrainEngine(object):
                 gx = ops.roi_align_bwd(dv.view(-1, 1, 1, dv.shape[-1]), rois, qf.shape, scale, 1, 1,
                                        spec.POOLER_SAMPLING_RATIO)
                 dQ.append(ops.cast_f32(gx, self.dtype))
-        dP = ops.correlate_levels(d_comb, pooled)
-        if s1 is not None:
-            main.wait_stream(s1)
-        self.backbones_backward([tctx, qctx], [dP, dQ])
+            if not lock:
+                self.backbones_backward([qctx], [dQ], which0=1)
+        dP = ops.correlate_levels(d_comb, pooled) if self.corr_levels else [ops.correlate(g, q) for g, q in zip(d_comb, pooled)]
+        if lock:
+            if s1 is not None:
+                main.wait_stream(s1)
+            self.backbones_backward([tctx, qctx], [dP, dQ])
+        else:
+            self.backbones_backward([tctx], [dP])
         self._keep.append((dq, dP, dQ, d_comb, pred_grads))
         if self._defer_now:
             # leave the tail on the side streams; the next forward_backward (or join()) orders the main stream after them
             events = []
-            for st in (self.wstream, self.wstream2, self.pstream, self.ustream, self.exchange.comm):
+            for st in (s1, self.wstream, self.wstream2, self.pstream, self.ustream, self.exchange.comm):
                 if st is not None:
                     ev = torch.cuda.Event()
                     ev.record(st)
                     events.append(ev)
             self._deferred = dict(events=events, refs=(qctx, tctx, hctx, feats, qfeats, pooled, combined, head_out, dQ, rois))
             return losses
+        if s1 is not None:
+            main.wait_stream(s1)
         if self.wstream is not None:
             main.wait_stream(self.wstream)
         if self.wstream2 is not None:

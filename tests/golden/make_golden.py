@@ -436,6 +436,57 @@ def gen_add_gt(model):
     np.savez_compressed(os.path.join(HERE, "add_gt.npz"), **out)
 
 
+from make_golden_cases import TRANSFORM_CASES, TRANSFORM_SIZES, transform_source  # noqa: E402
+
+
+def gen_transforms(cfg):
+    """SURVEY.md 8f #4 (transforms only): fixtures recorded through the reference's data/transforms (build.py Compose:
+    Resize -> RandomHorizontalFlip -> ToTensor -> Normalize) and BoxList.resize / transpose on synthetic uint8 images; the
+    oracle restatement (oracle/transforms_ref.py) must agree bit for bit before anything is written."""
+    import hashlib
+    import random
+    from PIL import Image
+    from maskrcnn_benchmark.data.transforms import transforms as T
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    from oracle import transforms_ref as otr
+    out = {}
+    tensors = {}
+    for name, hw, pipe, flip in TRANSFORM_CASES:
+        mn, mx = TRANSFORM_SIZES[pipe]
+        src = transform_source(name, hw)
+        norm = T.Normalize(mean=cfg.INPUT.PIXEL_MEAN, std=cfg.INPUT.PIXEL_STD, to_bgr255=cfg.INPUT.TO_BGR255)
+        comp = T.Compose([T.Resize(mn, mx), T.RandomHorizontalFlip(1.0 if flip else 0.0), T.ToTensor(), norm])
+        h, w = hw
+        boxes = np.array([[10.0, 5.0, w * 0.6, h * 0.7], [w * 0.25, h * 0.1, w - 1.0, h - 1.0], [0.0, 0.0, 7.5, 9.25]], np.float32)
+        tgt = BoxList(torch.from_numpy(boxes.copy()), (w, h), mode="xyxy")
+        random.seed(0)
+        img_t, tgt_t = comp(Image.fromarray(src), tgt)
+        ref = img_t.numpy()
+        mine = otr.transform_image(src, mn, mx, flip)
+        assert ref.shape == mine.shape and np.array_equal(ref, mine), (name, ref.shape, mine.shape, np.abs(ref - mine).max())
+        nb = otr.transform_boxes(boxes, (w, h), (ref.shape[2], ref.shape[1]), flip)
+        assert np.array_equal(nb, tgt_t.bbox.numpy()), (name, nb, tgt_t.bbox.numpy())
+        flat = ref.reshape(-1)
+        out[name + ".shape"] = np.asarray(ref.shape, np.int64)
+        out[name + ".sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(ref).tobytes()).digest(), dtype=np.uint8)
+        out[name + ".samples"] = flat[gu.sample_indices(flat.size, "transform." + name)]
+        out[name + ".boxes_in"] = boxes
+        out[name + ".boxes_out"] = tgt_t.bbox.numpy()
+        if pipe == "tiny":
+            out[name + ".full"] = ref
+        tensors[name] = img_t
+        print("transform %-22s %s -> %s  oracle == reference (bit exact)" % (name, hw, ref.shape[1:]))
+    batch = to_image_list([tensors[n] for n in ("landscape", "portrait_maxsize", "landscape_flip")], cfg.DATALOADER.SIZE_DIVISIBILITY)
+    bt = batch.tensors.numpy()
+    mine, sizes = otr.batch_images([tensors[n].numpy() for n in ("landscape", "portrait_maxsize", "landscape_flip")], 32)
+    assert np.array_equal(bt, mine) and [tuple(s) for s in batch.image_sizes] == [tuple(s) for s in sizes]
+    out["batch.shape"] = np.asarray(bt.shape, np.int64)
+    out["batch.sizes"] = np.asarray([tuple(s) for s in batch.image_sizes], np.int64)
+    out["batch.sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(bt).tobytes()).digest(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "transforms.npz"), **out)
+
+
 def gen_keys(model):
     import json
     sd = model.state_dict()
@@ -454,9 +505,12 @@ def main():
     ap.add_argument("--only-train", action="store_true", help="regenerate only the training fixtures")
     ap.add_argument("--box-cases", default="small,nonsquare,shots5,tall,config1")
     ap.add_argument("--only-box", action="store_true", help="regenerate only the second-stage fixtures (+ key list)")
+    ap.add_argument("--only-transforms", action="store_true", help="regenerate only tests/golden/transforms.npz")
     args = ap.parse_args()
     torch.set_num_threads(8)
     model, cfg = rh.build_reference_model()
+    if args.only_transforms:
+        return gen_transforms(cfg)
     np_sd = load_synth_weights(model)
     if args.only_box:
         gen_keys(model)
@@ -473,6 +527,7 @@ def main():
         gen_roialign()
         gen_add_gt(model)
         gen_ragged(model, np_sd)
+        gen_transforms(cfg)
         for name in [c for c in args.cases.split(",") if c]:
             gen_case(model, np_sd, name)
     if not args.skip_train:

@@ -12,6 +12,11 @@ The reference cannot be imported as shipped in this image: four
      merge_from_list, freeze/defrost/clone).
   3. `cv2`, `pycocotools(.mask)`: empty stub modules (imported at module scope by code that is never executed here).
   4. `torch._six`: removed from torch; `PY3 = True`.
+  5. `torchvision.transforms.functional` (torchvision is absent): the four thin wrappers the reference's
+     data/transforms/transforms.py calls — resize / hflip / to_tensor / normalize — written as torchvision==0.2.1
+     (INSTALL.md:5) has them: `img.resize(size[::-1], BILINEAR)`, `img.transpose(FLIP_LEFT_RIGHT)`, uint8 HWC -> float CHW
+     `.div(255)`, per-channel `t.sub_(m).div_(s)`.  The arithmetic they forward to is PIL's and torch's own; the
+     reference's Resize.get_size, Compose order, Normalize (BGR255) and BoxList code run unmodified.
 """
 import os
 import re
@@ -148,6 +153,30 @@ def _install_shims():
         tvf = types.ModuleType("torchvision.transforms.functional")
         sys.modules["torchvision.transforms.functional"] = tvf
         tv.transforms.functional = tvf
+
+        def _resize(img, size, interpolation=2):                     # torchvision 0.2.1 functional.py: resize
+            from PIL import Image
+            assert not isinstance(size, int) and len(size) == 2 and interpolation == Image.BILINEAR
+            return img.resize(size[::-1], interpolation)
+
+        def _hflip(img):                                             # functional.py: hflip
+            from PIL import Image
+            return img.transpose(Image.FLIP_LEFT_RIGHT)
+
+        def _to_tensor(pic):                                         # functional.py: to_tensor (PIL RGB branch)
+            import numpy as np
+            import torch
+            assert pic.mode == "RGB"
+            img = torch.from_numpy(np.frombuffer(pic.tobytes(), dtype=np.uint8).copy())
+            img = img.view(pic.size[1], pic.size[0], 3)
+            img = img.transpose(0, 1).transpose(0, 2).contiguous()
+            return img.float().div(255)
+
+        def _normalize(tensor, mean, std):                           # functional.py: normalize
+            for t, m, s in zip(tensor, mean, std):
+                t.sub_(m).div_(s)
+            return tensor
+        tvf.resize, tvf.hflip, tvf.to_tensor, tvf.normalize = _resize, _hflip, _to_tensor, _normalize
         tvc = types.ModuleType("torchvision.datasets.coco")
 
         class _CocoDetection(object):

@@ -241,3 +241,60 @@ def test_ragged_batch_matches_reference(sd_full):
     for i in range(2):
         db, ds = r["detections"][i]
         assert gu.match_boxes(f["box.detections.%d.boxes" % i], f["box.detections.%d.scores" % i], db.numpy(), ds.numpy()) >= 0.99
+
+
+# ---- input transforms: oracle/transforms_ref.py vs fixtures recorded through the reference ----
+from oracle import transforms_ref as otr  # noqa: E402
+
+
+def _transform_cases():
+    from golden.make_golden_cases import TRANSFORM_CASES, TRANSFORM_SIZES, transform_source
+    return TRANSFORM_CASES, TRANSFORM_SIZES, transform_source
+
+
+def test_transforms_oracle_matches_reference_fixture():
+    """Resize (PIL bilinear) -> flip -> ToTensor -> Normalize(BGR255 - mean) and BoxList.resize / transpose: bit-exact
+    against tests/golden/transforms.npz (recorded through the reference's data/transforms + BoxList)."""
+    import hashlib
+    cases, sizes, source = _transform_cases()
+    f = gu.load("transforms.npz")
+    tensors = {}
+    for name, hw, pipe, flip in cases:
+        mn, mx = sizes[pipe]
+        src = source(name, hw)
+        out = otr.transform_image(src, mn, mx, flip)
+        assert tuple(f[name + ".shape"]) == out.shape, name
+        assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest() == f[name + ".sha256"].tobytes(), name
+        flat = out.reshape(-1)
+        assert np.array_equal(flat[gu.sample_indices(flat.size, "transform." + name)], f[name + ".samples"]), name
+        if name + ".full" in f.files:
+            assert np.array_equal(out, f[name + ".full"]), name
+        nb = otr.transform_boxes(f[name + ".boxes_in"], (hw[1], hw[0]), (out.shape[2], out.shape[1]), flip)
+        assert np.array_equal(nb, f[name + ".boxes_out"]), name
+        tensors[name] = out
+    batch, bsizes = otr.batch_images([tensors[n] for n in ("landscape", "portrait_maxsize", "landscape_flip")], 32)
+    assert tuple(f["batch.shape"]) == batch.shape and [tuple(s) for s in f["batch.sizes"]] == [tuple(s) for s in bsizes]
+    assert hashlib.sha256(np.ascontiguousarray(batch).tobytes()).digest() == f["batch.sha256"].tobytes()
+
+
+def test_pil_resize_restatement_is_bit_exact_against_pillow():
+    """The third-party arithmetic under F.resize: Pillow's 8-bit ImagingResample, restated in the oracle, against the
+    installed Pillow on random images (up- and down-scaling, one axis unchanged, extreme ratios)."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    for (h, w, oh, ow) in [(37, 53, 80, 113), (120, 90, 40, 33), (64, 64, 64, 100), (100, 64, 31, 64), (9, 300, 200, 7),
+                           (333, 500, 799, 1199), (50, 70, 50, 70)]:
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        assert np.array_equal(ref, otr.pil_bilinear_resize(img, oh, ow)), (h, w, oh, ow)
+
+
+def test_resize_get_size_reference_cases():
+    """Resize.get_size (transforms.py:35-57) on the config's (800, 1200) and (200, 400): short side to min_size unless the
+    long side would exceed max_size; an image that already fits keeps its size."""
+    assert otr.get_size((500, 375), 800, 1200) == (800, 1066)
+    assert otr.get_size((333, 500), 800, 1200) == (1199, 799)
+    assert otr.get_size((1000, 800), 800, 1200) == (800, 1000)
+    assert otr.get_size((127, 127), 200, 400) == (200, 200)
+    assert otr.get_size((160, 90), 200, 400) == (200, 355)
