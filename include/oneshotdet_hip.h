@@ -392,6 +392,50 @@ int osd_append_gt_boxes(const float* boxes, const float* scores, const int32_t* 
                         int max_gt, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Second stage, TRAINING path: FastRCNNLossComputation (modeling/roi_heads/box_head/loss.py).
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* subsample (loss.py:234-301): per image match the proposals (boxes [n][max_props][4], counts [n]; the ground truth already
+ * appended, fcos/inference.py:139-160) to the ground truth (gt_boxes [n][max_gt][4], gt_count [n], gt_labels [n][max_gt] or
+ * NULL = all 1) by IoU with "+1" areas (boxlist_ops.py:221-256; Matcher with high = low = iou_thresh, matcher.py:52-83):
+ * label 0 below the threshold, else the matched box's label; then BalancedPositiveNegativeSampler
+ * (balanced_positive_negative_sampler.py:19-62): at most int(batch_per_image * positive_fraction) positives and
+ * batch_per_image rows in all.  The reference draws torch.randperm(n)[:k]; here the caller supplies keys [n][max_props]
+ * (uniform randoms) and the k smallest keys of each class win (ties: lower index) = the reference with randperm(n) :=
+ * argsort(keys of that class's members), which is how the fixtures pin it.  Outputs, rows in ascending proposal order
+ * (loss.py:292), rows past s_count[image] zero / label -1: s_boxes [n][batch][4], s_labels [n][batch], s_targets
+ * [n][batch][4] = BoxCoder.encode(matched box, proposal) with reg_weights[4] (HOST; box_coder.py:21-50; background rows
+ * against box 0 like matched_idxs.clamp(min=0), loss.py:70), s_index [n][batch] (proposal index), s_count [n]; optional
+ * all_labels / all_matched [n][max_props] (label / matched box or -1 of every proposal). */
+int osd_box_match_sample(const float* boxes, const int32_t* counts, const float* gt_boxes, const int32_t* gt_count,
+                         const int32_t* gt_labels, const float* keys, int n, int max_props, int max_gt, int batch_per_image,
+                         float positive_fraction, float iou_thresh, const float* reg_weights, float* s_boxes,
+                         int32_t* s_labels, float* s_targets, int32_t* s_index, int32_t* s_count, int32_t* all_labels,
+                         int32_t* all_matched, void* stream);
+/* __call__ (loss.py:306-381, 'ce_loss', class-specific regression) with the weights of box_head.py:193-194: pred
+ * [n*rois_per_image][pred_stride] `dtype` (columns 0..1 class logits, 2..9 box deltas, as osd_box_decode reads them) ->
+ * losses[3] = {w_cls * cross_entropy (mean over the valid rows), w_box * smooth_l1(beta 1, summed over the positives' class
+ * deltas) / valid rows, valid rows}; d_pred (nullable) [..][grad_stride] `dtype` = the gradient w.r.t. pred (zero rows past
+ * s_count[image]). */
+int osd_box_loss(const void* pred, const int32_t* labels, const float* targets, const int32_t* s_count, int n,
+                 int rois_per_image, int pred_stride, float w_cls, float w_box, float* losses, void* d_pred, int grad_stride,
+                 int dtype, void* stream);
+/* backward of osd_groupnorm_act_rois: dx from dy (same arguments; statistics recomputed from x [+ addend]); dgamma / dbeta
+ * [c] fp32 are ACCUMULATED; part_ws: n_samples * 2 * c floats.  The gradient w.r.t. the addend map of an image is the sum
+ * of dx over that image's ROIs: osd_rois_sum. */
+int osd_groupnorm_act_rois_bwd(const void* x, const void* addend, const float* gamma, const float* beta, const void* dy,
+                               void* dx, float* part_ws, float* dgamma, float* dbeta, int n_samples, int hw, int c,
+                               int groups, float eps, float slope, int rois_per_add, int add_stride, int add_offset,
+                               int dtype, void* stream);
+/* out[img][e] = sum_r x[img * rois_per_image + r][e], e < elems */
+int osd_rois_sum(const void* x, void* out, int n, int rois_per_image, int64_t elems, int dtype, void* stream);
+/* backward of osd_roi_pool_levels (Pooler + _C.roi_align_backward, csrc/cuda/ROIAlign_cuda.cu:178-254): dy
+ * [n*max_rois][pool][pool][dy_stride] `dtype` is scattered into the fp32 level maps gxs[l] [n][h_l][w_l][c] (HOST array of
+ * device pointers; ACCUMULATED with atomics: zero them first). */
+int osd_roi_pool_levels_bwd(int n_levels, float* const* gxs, const int32_t* hs, const int32_t* ws, const float* scales,
+                            const float* boxes, const int32_t* counts, const void* dy, int n, int c, int max_rois, int pool,
+                            int sampling_ratio, int dy_stride, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Input transforms (data/transforms/transforms.py:27-92 in the Compose order of
  * data/transforms/build.py:39-46) + the zero padding of to_image_list (structures/image_list.py:52-70), one image per call:
  *   Resize = PIL.Image.resize((out_w, out_h), BILINEAR) on 8-bit RGB (Pillow's fixed-point ImagingResample: horizontal pass,

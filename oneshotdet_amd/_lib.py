@@ -88,6 +88,11 @@ SIGNATURES = {
     "osd_append_gt_boxes": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "osd_proposals_sort_nms": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _i, _i, _p, _p, _p, _p, _p]),
     "osd_proposals_workspace_bytes": (_i64, [_i, _i, _i, _i]),
+    "osd_box_match_sample": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "osd_box_loss": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _f, _p, _p, _i, _i, _p]),
+    "osd_groupnorm_act_rois_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i, _p]),
+    "osd_rois_sum": (_i, [_p, _p, _i, _i, _i64, _i, _p]),
+    "osd_roi_pool_levels_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "osd_image_transform": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "osd_image_transform_workspace_bytes": (_i64, [_i, _i, _i, _i]),
 }

@@ -28,13 +28,16 @@ def bucket_ranges(plan, total):
     """Contiguous ranges of the flat gradient buffer in the order their gradients become final during backward.
     plan: [(parameter name, shape)] in buffer order (TrainEngine._plan); total: padded length of the buffer.
     Returns [(bucket name, lo, hi)] covering [0, total) exactly once: per backbone `layer2`, `layer3`, `layer4+fpn`
-    (the FPN and layer4 finish first, layer2 last), then the FCOS head (finishes before either backbone starts)."""
+    (the FPN and layer4 finish first, layer2 last), then the FCOS head (finishes before either backbone starts) and, when
+    the second stage trains too, its box head."""
     import math
     out, off = [], 0
     cur, lo = None, 0
     for name, shape in plan:
         if name.startswith("rpn."):
             b = "head"
+        elif name.startswith("roi_heads."):
+            b = "box_head"        # second stage (TrainEngine(second_stage=True)): final after the first-stage head, before the backbones
         else:
             bb = name.split(".", 1)[0]
             rest = name.split(".body.", 1)[1] if ".body." in name else "fpn"

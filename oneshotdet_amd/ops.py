@@ -951,6 +951,76 @@ def box_decode(pred, rois, counts, reg_weights, img_h, img_w, score_thresh, want
     return (scores, boxes, lo, ro) if want_raw else (scores, boxes)
 
 
+def box_match_sample(boxes, counts, gt_boxes, gt_count, keys, batch_per_image, positive_fraction, iou_thresh, reg_weights,
+                     gt_labels=None, want_all=False):
+    """FastRCNNLossComputation.subsample on the device (osd_box_match_sample): boxes [N,P,4] (ground truth appended),
+    counts [N], gt_boxes [N,G,4], gt_count [N], keys [N,P] fp32 uniform randoms -> sampled boxes [N,S,4], labels [N,S]
+    int32, regression targets [N,S,4], proposal index [N,S] int32, counts [N] int32 (+ per-proposal labels / matches)."""
+    _chk_dev(boxes, counts, gt_boxes, gt_count, keys)
+    n, p, _ = boxes.shape
+    s = int(batch_per_image)
+    dev = boxes.device
+    sb = torch.empty((n, s, 4), device=dev, dtype=torch.float32)
+    sl = torch.empty((n, s), device=dev, dtype=torch.int32)
+    st = torch.empty((n, s, 4), device=dev, dtype=torch.float32)
+    si = torch.empty((n, s), device=dev, dtype=torch.int32)
+    sc = torch.empty((n,), device=dev, dtype=torch.int32)
+    al = torch.empty((n, p), device=dev, dtype=torch.int32) if want_all else None
+    am = torch.empty((n, p), device=dev, dtype=torch.int32) if want_all else None
+    rw = (C.c_float * 4)(*[float(v) for v in reg_weights])
+    assert keys.shape == (n, p) and keys.dtype == torch.float32
+    _lib.call("osd_box_match_sample", _ptr(boxes.contiguous()), _ptr(counts), _ptr(gt_boxes.contiguous().float()), _ptr(gt_count),
+              _ptr(gt_labels), _ptr(keys.contiguous()), n, p, gt_boxes.shape[1], s, float(positive_fraction), float(iou_thresh),
+              rw, _ptr(sb), _ptr(sl), _ptr(st), _ptr(si), _ptr(sc), _ptr(al), _ptr(am), _stream())
+    return (sb, sl, st, si, sc, al, am) if want_all else (sb, sl, st, si, sc)
+
+
+def box_loss(pred, labels, targets, s_count, n, rois_per_image, w_cls, w_box, grad_stride=0):
+    """loss.py:306-381 ('ce_loss') x the weights of box_head.py:193-194.  pred [M, stride] (cols 0..1 logits, 2..9 deltas)
+    -> losses [3] = (classification, box regression, valid rows) and, with grad_stride, d_pred [M, grad_stride]."""
+    m = n * rois_per_image
+    pred2 = pred.reshape(m, -1)
+    losses = torch.empty((3,), device=pred.device, dtype=torch.float32)
+    d = torch.empty((m, grad_stride), device=pred.device, dtype=pred.dtype) if grad_stride else None
+    _lib.call("osd_box_loss", _ptr(pred2), _ptr(labels), _ptr(targets), _ptr(s_count), n, rois_per_image, pred2.shape[1],
+              float(w_cls), float(w_box), _ptr(losses), _ptr(d), int(grad_stride), _dt(pred), _stream())
+    return losses, d
+
+
+def groupnorm_act_rois_bwd(x, gamma, beta, dy, dgamma, dbeta, groups=32, eps=1e-5, slope=0.2, addend=None, rois_per_add=1,
+                           add_stride=1, add_offset=0):
+    """Backward of groupnorm_act_rois: -> dx; dgamma / dbeta [C] fp32 accumulated."""
+    r, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    ws = torch.empty((r * 2 * c,), device=x.device, dtype=torch.float32)
+    _lib.call("osd_groupnorm_act_rois_bwd", _ptr(x), _ptr(addend), _ptr(gamma), _ptr(beta), _ptr(dy.contiguous()), _ptr(dx), _ptr(ws),
+              _ptr(dgamma), _ptr(dbeta), r, h * w, c, groups, float(eps), float(slope), rois_per_add, add_stride, add_offset,
+              _dt(x), _stream())
+    return dx
+
+
+def rois_sum(x, n, rois_per_image):
+    """[n * rois_per_image, ...] -> [n, ...]: the sum over each image's ROIs."""
+    elems = x[0].numel()
+    out = torch.empty((n,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+    _lib.call("osd_rois_sum", _ptr(x), _ptr(out), n, rois_per_image, elems, _dt(x), _stream())
+    return out
+
+
+def roi_pool_levels_bwd(shapes, scales, boxes, counts, dy, pool, sampling_ratio):
+    """Backward of roi_pool_levels: dy [N*R, pool, pool, C] -> fp32 level maps [N, H_l, W_l, C] (zeroed here, then atomics)."""
+    n, r, _ = boxes.shape
+    c = dy.shape[-1]
+    k = len(shapes)
+    gxs = [torch.zeros((n, h, w, c), device=dy.device, dtype=torch.float32) for (h, w) in shapes]
+    hs = (C.c_int32 * k)(*[h for h, _ in shapes])
+    ws = (C.c_int32 * k)(*[w for _, w in shapes])
+    sc = (C.c_float * k)(*[float(v) for v in scales])
+    _lib.call("osd_roi_pool_levels_bwd", k, _ptr_array(gxs), hs, ws, sc, _ptr(boxes.contiguous()), _ptr(counts), _ptr(dy.contiguous()),
+              n, c, r, pool, sampling_ratio, dy.shape[-1], _dt(dy), _stream())
+    return gxs
+
+
 def append_gt_boxes(boxes, scores, counts, gt_boxes, gt_count):
     """add_gt_proposals (fcos/inference.py:139-160): boxes [N,P,4], scores [N,P], counts [N] + gt_boxes [N,G,4], gt_count [N]
     -> boxes [N,P+G,4], scores [N,P+G], counts [N]."""

@@ -40,6 +40,11 @@ BOX_SCORE_THRESH = 0.0                # ROI_HEADS.SCORE_THRESH
 BOX_NMS_THRESH = 0.5                  # ROI_HEADS.NMS
 BOX_DETECTIONS_PER_IMG = 2000         # ROI_HEADS.DETECTIONS_PER_IMG
 BOX_LEAKY_SLOPE = 0.2                 # box_head.py:46,49,64
+# second stage, training (defaults.py:190-203, box_head.py:193-194)
+BOX_FG_IOU_THRESH = 0.5               # ROI_HEADS.FG_IOU_THRESHOLD == BG_IOU_THRESHOLD
+BOX_BATCH_PER_IMAGE = 128             # ROI_HEADS.BATCH_SIZE_PER_IMAGE
+BOX_POSITIVE_FRACTION = 0.25          # ROI_HEADS.POSITIVE_FRACTION
+BOX_LOSS_WEIGHTS = (5.0, 2.5)         # loss_classifier *= 5; loss_box_reg *= 2.5
 LEVEL_MAP_SCALE = 224                 # poolers.py:16 LevelMapper canonical_scale / canonical_level / eps
 LEVEL_MAP_LEVEL = 4
 LEVEL_MAP_EPS = 1e-6

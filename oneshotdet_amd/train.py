@@ -37,7 +37,7 @@ class TConv(object):
 
 class TrainEngine(object):
     def __init__(self, state_dict, dtype=torch.bfloat16, device="cuda", lr=0.0005, momentum=0.9, weight_decay=0.0001,
-                 process_group=None, wgrad_side_stream=True, optimizer="fused"):
+                 process_group=None, wgrad_side_stream=True, optimizer="fused", second_stage=False):
         if not torch.cuda.is_available():
             raise ops._lib.OsdError("TrainEngine needs an MI355X: no GPU visible and there is no CPU fallback")
         ops._lib.load()
@@ -53,6 +53,8 @@ class TrainEngine(object):
         # training proposals feed only the second stage: a chain of small kernels on a stream of their own
         self.pstream = torch.cuda.Stream(device=self.device) if wgrad_side_stream else None
         self._keep = []
+        self.second_stage = bool(second_stage)
+        self.box_keys, self.box_losses = None, None       # sampler keys for the next step (None: torch.rand), last losses
         # A/B switches (measured on one box, tools/ab_bench.sh): both backbones per launch / both towers per launch
         import os
         self.lockstep = os.environ.get("OSD_LOCKSTEP", "0") != "0"
@@ -137,40 +139,134 @@ class TrainEngine(object):
         self._plan.append((h + "cls_ctr.bias", (2,)))
         self._add_conv(h + "bbox_pred", sd, bias=True)
         self._plan.append((h + "scales", (5,)))
+        if self.second_stage:
+            self._build_box_head(sd)
+
+    def _build_box_head(self, sd):
+        """roi_heads.box.* (modeling/roi_heads/box_head/box_head.py:36-79) as this build lays it out: the first 1x1 conv split
+        at the concatenation into its ROI half (no bias) and its query half (+ bias), fc6 as a 1x1 conv over the (h, w, c)
+        flattening of the NHWC ROI maps, cls_score + bbox_pred as one 10-row conv.  Appended to the plan after the FCOS head:
+        one more gradient bucket ('box_head')."""
+        b = "roi_heads.box."
+        missing = [k for k in spec.box_head_shapes() if k not in sd]
+        if missing:
+            raise KeyError("second_stage=True needs the roi_heads.box.* entries, e.g. %s" % missing[:2])
+        c, mid, p = spec.FPN_OUT, spec.FPN_OUT // 2, spec.BOX_POOL
+
+        def conv(name, cout, cin, r, s, has_bias):
+            t = TConv(name, cout, cin, r, s, True, has_bias)
+            self.convs[name] = t
+            self._plan.append((name + ".weight", (cout, r, s, cin)))
+            if has_bias:
+                self._plan.append((name + ".bias", (cout,)))
+        conv(b + "compress_dim_conv.0x", 2 * c, c, 1, 1, False)
+        conv(b + "compress_dim_conv.0q", 2 * c, c, 1, 1, True)
+        for gn_name in ("compress_dim_conv.1",):
+            self._plan += [(b + gn_name + ".weight", (2 * c,)), (b + gn_name + ".bias", (2 * c,))]
+        conv(b + "compress_dim_conv.3", c, 2 * c, 1, 1, True)
+        self._plan += [(b + "compress_dim_conv.4.weight", (c,)), (b + "compress_dim_conv.4.bias", (c,))]
+        conv(b + "feature_aggreg.0", mid, c, 3, 3, True)
+        self._plan += [(b + "feature_aggreg.1.weight", (mid,)), (b + "feature_aggreg.1.bias", (mid,))]
+        conv(b + "fc6", spec.BOX_MLP_DIM, mid * p * p, 1, 1, True)
+        conv(b + "fc7", spec.BOX_MLP_DIM, spec.BOX_MLP_DIM, 1, 1, True)
+        conv(b + "pred", 5 * spec.BOX_NUM_CLASSES, spec.BOX_MLP_DIM, 1, 1, True)
+
+    def _codecs(self):
+        """master tensor name -> (reference keys, import(list of reference tensors) -> master-shaped tensor, export(master-
+        shaped tensor) -> {reference key or key#part: tensor}).  Conv weights live in [cout][r][s][cin] order; the fused /
+        split tensors of this build are assembled from / taken apart into the reference's entries here, in ONE place, for
+        state_dict(), named_grads() and the optimizer state alike."""
+        h, b = "rpn.head.", "roi_heads.box."
+        c, mid, p = spec.FPN_OUT, spec.FPN_OUT // 2, spec.BOX_POOL
+        nc = spec.BOX_NUM_CLASSES
+        out = {}
+        for name, shape in self._plan:
+            base, leaf = name.rsplit(".", 1)
+            if name == h + "scales":
+                keys = ["%sscales.%d.scale" % (h, i) for i in range(5)]
+                out[name] = (keys, lambda ts: torch.cat([t.reshape(1) for t in ts]),
+                             lambda v, keys=keys: {k: v[i:i + 1] for i, k in enumerate(keys)})
+            elif base == h + "cls_ctr":
+                keys = [h + "cls_logits." + leaf, h + "centerness." + leaf]
+                if leaf == "weight":
+                    out[name] = (keys, lambda ts: torch.cat(ts, 0).permute(0, 2, 3, 1),
+                                 lambda v, keys=keys: {keys[0]: v[0:1].permute(0, 3, 1, 2), keys[1]: v[1:2].permute(0, 3, 1, 2)})
+                else:
+                    out[name] = (keys, lambda ts: torch.cat(ts, 0), lambda v, keys=keys: {keys[0]: v[0:1], keys[1]: v[1:2]})
+            elif base in (b + "compress_dim_conv.0x", b + "compress_dim_conv.0q"):
+                key = b + "compress_dim_conv.0." + leaf
+                if leaf == "bias":
+                    out[name] = ([key], lambda ts: ts[0], lambda v, key=key: {key: v})
+                else:
+                    lo = 0 if base.endswith("0x") else c
+                    part = "#0" if base.endswith("0x") else "#1"          # merged along the input channels on export
+                    out[name] = ([key], lambda ts, lo=lo: ts[0][:, lo:lo + c].permute(0, 2, 3, 1),
+                                 lambda v, key=key, part=part: {key + part: v.permute(0, 3, 1, 2)})
+            elif base == b + "fc6" and leaf == "weight":
+                # Linear over x.view(N, -1) of NCHW maps (box_head.py:151): columns (c, h, w) -> this build's (h, w, c)
+                out[name] = ([name], lambda ts: ts[0].view(-1, mid, p, p).permute(0, 2, 3, 1).reshape(-1, 1, 1, mid * p * p),
+                             lambda v, name=name: {name: v.reshape(-1, p, p, mid).permute(0, 3, 1, 2).reshape(-1, mid * p * p)})
+            elif base == b + "fc7" and leaf == "weight":
+                out[name] = ([name], lambda ts: ts[0][:, None, None, :], lambda v, name=name: {name: v.reshape(v.shape[0], -1)})
+            elif base == b + "pred":
+                keys = [b + "predictor.cls_score." + leaf, b + "predictor.bbox_pred." + leaf]
+                if leaf == "weight":
+                    out[name] = (keys, lambda ts: torch.cat(ts, 0)[:, None, None, :],
+                                 lambda v, keys=keys: {keys[0]: v[:nc].reshape(nc, -1), keys[1]: v[nc:].reshape(4 * nc, -1)})
+                else:
+                    out[name] = (keys, lambda ts: torch.cat(ts, 0), lambda v, keys=keys: {keys[0]: v[:nc], keys[1]: v[nc:]})
+            elif base in self.convs and leaf == "weight":
+                out[name] = ([name], lambda ts: ts[0].permute(0, 2, 3, 1), lambda v, name=name: {name: v.permute(0, 3, 1, 2)})
+            else:                                       # conv bias, GroupNorm affine
+                out[name] = ([name], lambda ts: ts[0], lambda v, name=name: {name: v})
+        return out
+
+    def _import_flat(self, flat, ref):
+        """Fill a buffer laid out like the masters from reference-named tensors (weights, momentum, ...)."""
+        off = 0
+        for name, shape in self._plan:
+            n = int(math.prod(shape))
+            keys, imp, _ = self._codec[name]
+            flat[off:off + n].view(shape).copy_(imp([torch.as_tensor(ref[k]).to(self.device, torch.float32) for k in keys]))
+            off += n
+
+    def _export_flat(self, flat):
+        """Reference-named, reference-shaped copies of a buffer laid out like the masters."""
+        out, parts, off = {}, {}, 0
+        for name, shape in self._plan:
+            n = int(math.prod(shape))
+            _, _, exp = self._codec[name]
+            for k, v in exp(flat[off:off + n].view(shape)).items():
+                v = v.clone(memory_format=torch.contiguous_format)
+                if "#" in k:
+                    parts.setdefault(k.split("#")[0], {})[int(k.split("#")[1])] = v
+                else:
+                    out[k] = v
+            off += n
+        for k, ps in parts.items():
+            out[k] = torch.cat([ps[i] for i in sorted(ps)], 1)
+        return out
 
     def _allocate(self, sd):
         total = sum(int(math.prod(s)) for _, s in self._plan)
         total = (total + 63) // 64 * 64
         self.flat_w = torch.zeros(total, device=self.device, dtype=torch.float32)
         self.flat_g = torch.zeros(total, device=self.device, dtype=torch.float32)
+        self._codec = self._codecs()
+        self._import_flat(self.flat_w, sd)
         off = 0
-        h = "rpn.head."
         for name, shape in self._plan:
             n = int(math.prod(shape))
             wv, gv = self.flat_w[off:off + n].view(shape), self.flat_g[off:off + n].view(shape)
             off += n
             wv.grad = gv
             base, leaf = name.rsplit(".", 1)
-            if name == h + "scales":
-                wv.copy_(torch.cat([sd["%sscales.%d.scale" % (h, i)] for i in range(5)]))
-                self.extra[name] = (wv, gv)
-            elif base == h + "cls_ctr":
+            if base in self.convs:
                 if leaf == "weight":
-                    src = torch.cat([sd[h + "cls_logits.weight"], sd[h + "centerness.weight"]], 0)
-                    wv.copy_(src.permute(0, 2, 3, 1))
                     self.convs[base].w, self.convs[base].gw = wv, gv
                 else:
-                    wv.copy_(torch.cat([sd[h + "cls_logits.bias"], sd[h + "centerness.bias"]], 0))
                     self.convs[base].b, self.convs[base].gb = wv, gv
-            elif base in self.convs:
-                if leaf == "weight":
-                    wv.copy_(sd[name].permute(0, 2, 3, 1))              # OIHW -> [O][R][S][I]
-                    self.convs[base].w, self.convs[base].gw = wv, gv
-                else:
-                    wv.copy_(sd[name])
-                    self.convs[base].b, self.convs[base].gb = wv, gv
-            else:                                                        # GroupNorm affine
-                wv.copy_(sd[name])
+            else:                                                        # GroupNorm affine, Scale scalars
                 self.extra[name] = (wv, gv)
 
     def _bucket_of(self, tensor):
@@ -614,6 +710,99 @@ class TrainEngine(object):
         self._wqs = None
         return None
 
+    # ------------------------------------------------------------------------------------------------ second stage
+    def box_head_forward_backward(self, feats, qfeats, q_sizes, shots, proposals, gt_boxes, gt_count, keys=None,
+                                  want_debug=False):
+        """ROIBoxHead in training (box_head.py:100-203) on the training proposals (ground truth appended): subsample on the
+        device, box head forward on the 128 sampled ROIs per image with the FIRST query of every image (the reference returns
+        the losses from inside its loop over shots), cross-entropy + smooth-L1 with the weights 5 / 2.5, and the whole
+        backward on the current stream: weight / bias / GroupNorm gradients into the flat buffer, the gradient w.r.t. the
+        target FPN features as fp32 level maps and w.r.t. the query features' level.
+        proposals = (boxes [N,P,4], scores, counts).  keys [N,P]: uniform randoms of the sampler (default: torch.rand).
+        -> (losses [3] = (loss_classifier, loss_box_reg, sampled rows), gx: 5 fp32 maps, (query level, fp32 map [N,h,w,C]))"""
+        from . import box_head as bh
+        from . import model
+        b, cv, dt = "roi_heads.box.", self.convs, self.dtype
+        pb, _, pc = proposals
+        n, P, _ = pb.shape
+        S = spec.BOX_BATCH_PER_IMAGE
+        if keys is None:
+            keys = torch.rand((n, P), device=self.device, dtype=torch.float32)
+        sb, sl, st, si, sc = ops.box_match_sample(pb, pc, gt_boxes, gt_count, keys, S, spec.BOX_POSITIVE_FRACTION,
+                                                  spec.BOX_FG_IOU_THRESH, spec.BOX_REG_WEIGHTS)
+        M = n * S
+        slope, gr, eps = spec.BOX_LEAKY_SLOPE, spec.GN_GROUPS, spec.GN_EPS
+        (g0, dg0), (b0, db0) = self.extra[b + "compress_dim_conv.1.weight"], self.extra[b + "compress_dim_conv.1.bias"]
+        (g1, dg1), (b1, db1) = self.extra[b + "compress_dim_conv.4.weight"], self.extra[b + "compress_dim_conv.4.bias"]
+        (g2, dg2), (b2, db2) = self.extra[b + "feature_aggreg.1.weight"], self.extra[b + "feature_aggreg.1.bias"]
+        c0x, c0q, c3, ca = (cv[b + k] for k in ("compress_dim_conv.0x", "compress_dim_conv.0q", "compress_dim_conv.3",
+                                                 "feature_aggreg.0"))
+        fc6, fc7, cp = cv[b + "fc6"], cv[b + "fc7"], cv[b + "pred"]
+        # ---- forward
+        qf1 = qfeats if shots == 1 else [q[::shots].contiguous() for q in qfeats]
+        qs1 = [q_sizes[i * shots] for i in range(n)]
+        uniform = len(set(qs1)) == 1
+        q = bh.run_query_roi(qf1, qs1[0] if uniform else qs1, dt)                                # [N,7,7,C]
+        qh = ops.conv2d(q, c0q.pc)                                                               # W_q q + b
+        x = ops.roi_pool_levels(feats, spec.POOLER_SCALES, sb, sc, spec.BOX_POOL, spec.POOLER_SAMPLING_RATIO)
+        u0 = ops.conv2d(x, c0x.pc)
+        t0 = ops.groupnorm_act_rois(u0, g0, b0, gr, eps, slope, addend=qh, rois_per_add=S, add_stride=1, add_offset=0)
+        u1 = ops.conv2d(t0, c3.pc)
+        t1 = ops.groupnorm_act_rois(u1, g1, b1, gr, eps, slope)
+        u2 = ops.conv2d(t1, ca.pc, pad=1)
+        t2 = ops.groupnorm_act_rois(u2, g2, b2, gr, eps, slope)
+        t2f = t2.view(M, 1, 1, -1)
+        f6 = ops.conv2d(t2f, fc6.pc, act=ACT_RELU)
+        f7 = ops.conv2d(f6, fc7.pc, act=ACT_RELU)
+        pred = ops.conv2d(f7, cp.pc)
+        losses, d_pred = ops.box_loss(pred, sl, st, sc, n, S, spec.BOX_LOSS_WEIGHTS[0], spec.BOX_LOSS_WEIGHTS[1],
+                                      grad_stride=cp.pd.cin_k)
+        # ---- backward (inline on this stream: M = 1024 ROIs)
+
+        def wg(c, xin, dy, pad=0):
+            ops.conv2d_wgrad(xin, dy, c.gw, c.r, c.s, 1, pad, c.cout, db=c.gb if c.has_bias else None)
+
+        def dg(c, dy, mask=None):
+            return ops.conv2d(dy, c.pd, pad=c.r - 1 - (c.r // 2), mask=mask)
+        d_pred = d_pred.view(M, 1, 1, -1)
+        wg(cp, f7, d_pred)
+        d_f7 = dg(cp, d_pred, mask=f7)
+        wg(fc7, f6, d_f7)
+        d_f6 = dg(fc7, d_f7, mask=f6)
+        wg(fc6, t2f, d_f6)
+        d_t2 = dg(fc6, d_f6).view(t2.shape)
+        d_u2 = ops.groupnorm_act_rois_bwd(u2, g2, b2, d_t2, dg2, db2, gr, eps, slope)
+        wg(ca, t1, d_u2, pad=1)
+        d_t1 = dg(ca, d_u2)
+        d_u1 = ops.groupnorm_act_rois_bwd(u1, g1, b1, d_t1, dg1, db1, gr, eps, slope)
+        wg(c3, t0, d_u1)
+        d_t0 = dg(c3, d_u1)
+        d_u0 = ops.groupnorm_act_rois_bwd(u0, g0, b0, d_t0, dg0, db0, gr, eps, slope, addend=qh, rois_per_add=S, add_stride=1,
+                                          add_offset=0)
+        wg(c0x, x, d_u0)
+        d_x = dg(c0x, d_u0)
+        d_qh = ops.rois_sum(d_u0, n, S)                     # the query half was added to every ROI of its image
+        wg(c0q, q, d_qh)
+        d_q = dg(c0q, d_qh)
+        gx = ops.roi_pool_levels_bwd([(f.shape[1], f.shape[2]) for f in feats], spec.POOLER_SCALES, sb, sc, d_x, spec.BOX_POOL,
+                                     spec.POOLER_SAMPLING_RATIO)
+        if uniform:
+            lvl = bh.query_level(*qs1[0])
+            rois = model.whole_image_rois(qs1, self.device)
+            gq = ops.roi_align_bwd(d_q.float(), rois, qf1[lvl].shape, spec.POOLER_SCALES[lvl], spec.BOX_POOL, spec.BOX_POOL,
+                                   spec.POOLER_SAMPLING_RATIO)
+            gqs = [(lvl, gq)]
+        else:                                                # padded query batch: every whole-image box picks its own level
+            boxes = model.whole_image_rois(qs1, self.device)[:, 1:].reshape(n, 1, 4).contiguous()
+            maps = ops.roi_pool_levels_bwd([(f.shape[1], f.shape[2]) for f in qf1], spec.POOLER_SCALES, boxes, None, d_q,
+                                           spec.BOX_POOL, spec.POOLER_SAMPLING_RATIO)
+            gqs = list(enumerate(maps))
+        self._keep.append((sb, sl, st, si, sc, q, qh, x, u0, t0, u1, t1, u2, t2, f6, f7, pred, d_pred, d_f7, d_f6, d_t2, d_u2,
+                           d_t1, d_u1, d_t0, d_u0, d_x, d_qh, d_q, keys))
+        if want_debug:
+            self.last_box = dict(boxes=sb, labels=sl, targets=st, index=si, counts=sc, pred=pred)
+        return losses, gx, gqs
+
     # ------------------------------------------------------------------------------------------------ step
     def forward_backward(self, images, queries, gt_boxes, gt_count, with_proposals=True, image_sizes=None):
         """One training forward + backward.  images [B,3,H,W], queries [B*S,3,h,w] fp32 NCHW on the device;
@@ -677,6 +866,10 @@ class TrainEngine(object):
                                                   image_sizes=image_sizes)   # padded batch: clip to each image's size
                 # add_gt_proposals (fcos/inference.py:139-160,279): the ground-truth boxes join the training proposals
                 self.proposals = ops.append_gt_boxes(pb, ps_, pc, gt_boxes, gt_count)
+                if self.second_stage:       # roi_heads on the plain target / query features (generalized_rcnn.py:317), beside
+                    box_out = self.box_head_forward_backward(feats, qfeats, q_sizes, shots, self.proposals, gt_boxes, gt_count,
+                                                             keys=self.box_keys)    # the first stage's loss and backward
+                    self._bucket_ready("box_head", 0, [ps])
         # ---- loss + backward
         losses, pred_grads = self.loss_and_grads(head_out, gt_boxes, gt_count)
         self.last_head_out, self.last_pred_grads = head_out, pred_grads      # (tests: conditioning of the Scale gradients)
@@ -685,18 +878,36 @@ class TrainEngine(object):
         # correlation backward (generalized_rcnn.py:307-311): d q = sum_hw g * feat, d feat = g * q
         dq = ops.correlate_bwd_query_levels(d_comb, feats) if self.corr_levels else \
             [ops.correlate_bwd_query(g, f) for g, f in zip(d_comb, feats)]
+        second = self.second_stage and with_proposals
+        ps = self.pstream if self.pstream is not None else main
         if s1 is not None:
             s1.wait_stream(main)
+            if second and ps is not main:
+                s1.wait_stream(ps)
+        if second:
+            if ps is not main:
+                main.wait_stream(ps)
+            self.box_losses, gx, gqs = box_out
         with torch.cuda.stream(side):      # the query branch's small pooling-backward chain beside d feat
             dQ = []
             for dql, qf, scale in zip(dq, qfeats, spec.POOLER_SCALES):
                 dv = ops.shot_mean_bwd(dql, shots)
-                gx = ops.roi_align_bwd(dv.view(-1, 1, 1, dv.shape[-1]), rois, qf.shape, scale, 1, 1,
-                                       spec.POOLER_SAMPLING_RATIO)
-                dQ.append(ops.cast_f32(gx, self.dtype))
+                gxq = ops.roi_align_bwd(dv.view(-1, 1, 1, dv.shape[-1]), rois, qf.shape, scale, 1, 1,
+                                        spec.POOLER_SAMPLING_RATIO)
+                dQ.append(ops.cast_f32(gxq, self.dtype))
+            if second:                  # the second stage's gradient w.r.t. the query features joins the first stage's
+                for lvl, gq in gqs:
+                    if shots > 1:       # only the first query of every image reached the second stage's loss
+                        full = torch.zeros((gq.shape[0] * shots,) + tuple(gq.shape[1:]), device=self.device, dtype=torch.float32)
+                        full[::shots] = gq
+                        gq = full
+                    dQ[lvl] = ops.add_mask(dQ[lvl], ops.cast_f32(gq, self.dtype))
             if not lock:
                 self.backbones_backward([qctx], [dQ], which0=1)
         dP = ops.correlate_levels(d_comb, pooled) if self.corr_levels else [ops.correlate(g, q) for g, q in zip(d_comb, pooled)]
+        if second:                      # ... and w.r.t. the target FPN outputs (generalized_rcnn.py:317: the plain features)
+            dP = [ops.add_mask(d, ops.cast_f32(g, self.dtype)) for d, g in zip(dP, gx)]
+            self._keep.append((gx, gqs))
         if lock:
             if s1 is not None:
                 main.wait_stream(s1)
@@ -850,80 +1061,14 @@ class TrainEngine(object):
         (stem, layer1, every FrozenBN buffer) are returned unchanged."""
         self.join()
         out = {k: v.clone() for k, v in self._frozen_sd.items()}
-        h = "rpn.head."
-        for name, c in self.convs.items():
-            if not c.trainable:
-                continue
-            w = c.w.permute(0, 3, 1, 2).clone(memory_format=torch.contiguous_format)   # never a view of the master
-            if name == h + "cls_ctr":
-                out[h + "cls_logits.weight"], out[h + "centerness.weight"] = w[0:1].clone(), w[1:2].clone()
-                out[h + "cls_logits.bias"], out[h + "centerness.bias"] = c.b[0:1].clone(), c.b[1:2].clone()
-                continue
-            out[name + ".weight"] = w
-            if c.has_bias:
-                out[name + ".bias"] = c.b.clone()
-        for name, (p, _) in self.extra.items():
-            if name == h + "scales":
-                for i in range(5):
-                    out["%sscales.%d.scale" % (h, i)] = p[i:i + 1].clone()
-            else:
-                out[name] = p.clone()
+        out.update(self._export_flat(self.flat_w))
         return out
 
     def named_grads(self):
         """Reference-named gradients (OIHW) for parity tests."""
-        out = {}
-        h = "rpn.head."
-        for name, c in self.convs.items():
-            if not c.trainable:
-                continue
-            g = c.gw.permute(0, 3, 1, 2).contiguous()
-            if name == h + "cls_ctr":
-                out[h + "cls_logits.weight"], out[h + "centerness.weight"] = g[0:1], g[1:2]
-                out[h + "cls_logits.bias"], out[h + "centerness.bias"] = c.gb[0:1], c.gb[1:2]
-                continue
-            out[name + ".weight"] = g
-            if c.has_bias:
-                out[name + ".bias"] = c.gb
-        for name, (p, g) in self.extra.items():
-            if name == h + "scales":
-                for i in range(5):
-                    out["%sscales.%d.scale" % (h, i)] = g[i:i + 1]
-            else:
-                out[name] = g
-        return out
+        return self._export_flat(self.flat_g)
 
     # ------------------------------------------------------------------------------------------------ optimiser state
-    def _named_views(self, flat):
-        """Reference-named OIHW copies of a flat buffer laid out like the masters (momentum, gradients...)."""
-        out = {}
-        h = "rpn.head."
-        base = self.flat_w.data_ptr()
-
-        def view(t):
-            off = (t.data_ptr() - base) // 4
-            return flat[off:off + t.numel()].view(t.shape)
-        for name, c in self.convs.items():
-            if not c.trainable:
-                continue
-            w = view(c.w).permute(0, 3, 1, 2).clone(memory_format=torch.contiguous_format)
-            if name == h + "cls_ctr":
-                b = view(c.b)
-                out[h + "cls_logits.weight"], out[h + "centerness.weight"] = w[0:1].clone(), w[1:2].clone()
-                out[h + "cls_logits.bias"], out[h + "centerness.bias"] = b[0:1].clone(), b[1:2].clone()
-                continue
-            out[name + ".weight"] = w
-            if c.has_bias:
-                out[name + ".bias"] = view(c.b).clone()
-        for name, (p, _) in self.extra.items():
-            v = view(p)
-            if name == h + "scales":
-                for i in range(5):
-                    out["%sscales.%d.scale" % (h, i)] = v[i:i + 1].clone()
-            else:
-                out[name] = v.clone()
-        return out
-
     def optimizer_state_dict(self):
         """What the reference checkpoint stores under 'optimizer' (utils/checkpoint.py:42-46: torch.optim.SGD.state_dict()),
         keyed by reference parameter NAME instead of torch's positional ids: momentum buffers (OIHW, reference names), the
@@ -932,40 +1077,17 @@ class TrainEngine(object):
         self.join()
         if self.opt is not None:
             raise NotImplementedError("optimizer='torch' (A/B mode): use self.opt.state_dict()")
-        return {"momentum_buffer": self._named_views(self._sgd["buf"]), "steps": int(self._sgd["steps"]),
+        return {"momentum_buffer": self._export_flat(self._sgd["buf"]), "steps": int(self._sgd["steps"]),
                 "lr": float(self.lr), "momentum": float(self.momentum), "weight_decay": float(self.weight_decay)}
 
     def load_optimizer_state_dict(self, state):
         self.join()
         if self.opt is not None:
             raise NotImplementedError("optimizer='torch' (A/B mode): use self.opt.load_state_dict()")
-        h = "rpn.head."
-        mb = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state["momentum_buffer"].items()}
-        base = self.flat_w.data_ptr()
-        buf = self._sgd["buf"]
-
-        def view(t):
-            off = (t.data_ptr() - base) // 4
-            return buf[off:off + t.numel()].view(t.shape)
-        for name, c in self.convs.items():
-            if not c.trainable:
-                continue
-            if name == h + "cls_ctr":
-                w = torch.cat([mb[h + "cls_logits.weight"], mb[h + "centerness.weight"]], 0)
-                view(c.w).copy_(w.permute(0, 2, 3, 1))
-                view(c.b).copy_(torch.cat([mb[h + "cls_logits.bias"], mb[h + "centerness.bias"]], 0))
-                continue
-            view(c.w).copy_(mb[name + ".weight"].permute(0, 2, 3, 1))
-            if c.has_bias:
-                view(c.b).copy_(mb[name + ".bias"])
-        for name, (p, _) in self.extra.items():
-            if name == h + "scales":
-                view(p).copy_(torch.cat([mb["%sscales.%d.scale" % (h, i)].reshape(1) for i in range(5)]))
-            else:
-                view(p).copy_(mb[name])
-        self._sgd["steps"] = int(state["steps"])
-        self.lr = float(state.get("lr", self.lr))
-        self.momentum = float(state.get("momentum", self.momentum))
         if float(state.get("weight_decay", self.weight_decay)) != self.weight_decay:
             raise ValueError("weight decay is baked into the update tables: construct the engine with weight_decay=%r"
                              % state["weight_decay"])
+        self._import_flat(self._sgd["buf"], state["momentum_buffer"])
+        self._sgd["steps"] = int(state["steps"])
+        self.lr = float(state.get("lr", self.lr))
+        self.momentum = float(state.get("momentum", self.momentum))

@@ -436,6 +436,114 @@ def gen_add_gt(model):
     np.savez_compressed(os.path.join(HERE, "add_gt.npz"), **out)
 
 
+BOXTRAIN_GRAD_KEYS = ["roi_heads.box.compress_dim_conv.0.weight", "roi_heads.box.compress_dim_conv.0.bias",
+                      "roi_heads.box.compress_dim_conv.1.weight", "roi_heads.box.compress_dim_conv.3.weight",
+                      "roi_heads.box.compress_dim_conv.4.bias", "roi_heads.box.feature_aggreg.0.weight",
+                      "roi_heads.box.feature_aggreg.1.weight", "roi_heads.box.fc6.weight", "roi_heads.box.fc6.bias",
+                      "roi_heads.box.fc7.weight", "roi_heads.box.predictor.cls_score.weight",
+                      "roi_heads.box.predictor.cls_score.bias", "roi_heads.box.predictor.bbox_pred.weight",
+                      "roi_heads.box.predictor.bbox_pred.bias"]
+
+
+def gen_box_train_case(model, np_sd, name):
+    """Second stage, TRAINING: the REAL reference's FastRCNNLossComputation.subsample and ROIBoxHead in
+    train mode on its own features, its eval proposals + the ground truth (add_gt_proposals), with torch.randperm replaced
+    by argsort of recorded keys (oracle/box_train_ref.py).  Recorded: the proposals, every image's sampled rows / labels /
+    regression targets, both losses, gradient samples of the box head's parameters (reference autograd; the features do
+    not require grad there: the reference has no CPU ROIAlign backward, csrc/ROIAlign.h:44) and — oracle only, flagged —
+    the gradients w.r.t. the target / query FPN features through the differentiable restatement of the Pooler."""
+    rh.load_reference()
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from oracle import box_train_ref as obt
+    B, H, W, S, qh, qw = gu.CASES[name]
+    img_np, q_np = gu.case_inputs(name)
+    images, queries = torch.from_numpy(img_np), torch.from_numpy(q_np)
+    cap = run_reference(model, images, queries, B)
+    feats, qfeats = [f.detach() for f in cap["features"]], [f.detach() for f in cap["query_features"]]
+    gts = synth.make_gt_boxes(B, H, W, seed=3, max_boxes=3)
+    targets = []
+    for g in gts:
+        bl = BoxList(torch.from_numpy(g), (W, H), mode="xyxy")
+        bl.add_field("labels", torch.ones(len(g), dtype=torch.int64))
+        targets.append(bl)
+    props = model.rpn.box_selector_train.add_gt_proposals([bl for bl in cap["proposals"]], targets)
+    pmax = max(len(p) for p in props)
+    keys = synth.uniform01("boxtrain.keys." + name, B * pmax, seed=9).reshape(B, pmax).astype(np.float32)
+    samp, perms = [], []
+    for i in range(B):
+        k = torch.from_numpy(keys[i, :len(props[i])].copy())
+        sm = obt.subsample(props[i].bbox, torch.from_numpy(gts[i]), k)
+        _, p1, p2 = obt.sample(sm["all_labels"], k)
+        samp.append(sm)
+        perms += [p1, p2]
+    counts = {len(sm["index"]) for sm in samp}
+    assert len(counts) == 1, ("the reference's Pooler needs equal counts per image (poolers.py:80)", counts)
+    it = iter(perms)
+    orig_randperm = torch.randperm
+
+    def recorded_randperm(n, **kw):
+        p = next(it)
+        assert len(p) == n, (len(p), n)
+        return p.clone()
+    torch.randperm = recorded_randperm
+    try:
+        model.train()
+        model.zero_grad()
+        with torch.no_grad():
+            supp_boxes = [BoxList([[0, 0, qh, qw]], image_size=(qh, qw), mode="xyxy") for _ in range(B * S)]
+            supp_roi = model.supproi_pooling(qfeats, supp_boxes)
+        x, sampled_props, loss_dict = model.roi_heads(feats, [p for p in props], targets, supp_roi, target_ids=[1] * B)
+    finally:
+        torch.randperm = orig_randperm
+    lc, lb = loss_dict["loss_classifier"], loss_dict["loss_box_reg"]
+    (lc + lb).backward()
+    ref_grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.eval()
+    # ---- reference's sampling vs the oracle's
+    for i, (bl, sm) in enumerate(zip(sampled_props, samp)):
+        assert torch.equal(bl.bbox, sm["boxes"]), (name, i)
+        assert torch.equal(bl.get_field("labels"), sm["labels"]), (name, i)
+        assert torch.equal(bl.get_field("regression_targets"), sm["targets"]), (name, i)
+    # ---- oracle with autograd, features attached
+    sd = orc.to_torch_state_dict(np_sd)
+    for k in sd:
+        if k.startswith("roi_heads.box."):
+            sd[k].requires_grad_(True)
+    fg = [f.clone().requires_grad_(True) for f in feats]
+    qg = [f.clone().requires_grad_(True) for f in qfeats]
+    olc, olb, ologits, oreg = obt.box_train_forward(fg, qg, samp, [(qh, qw)] * (B * S), sd, shots=S)
+    (olc + olb).backward()
+    print(name, "box train: %d sampled per image (%d positives), losses ref %.6f %.6f | oracle %.6f %.6f"
+          % (len(samp[0]["index"]), int(sum((sm["labels"] > 0).sum() for sm in samp)), lc.item(), lb.item(), olc.item(), olb.item()))
+    assert abs(lc.item() - olc.item()) <= 1e-5 * max(1.0, abs(lc.item())) and abs(lb.item() - olb.item()) <= 1e-5 * max(1.0, abs(lb.item()))
+    worst = 0.0
+    for k, g in ref_grads.items():
+        if not k.startswith("roi_heads.box."):
+            continue
+        e = (sd[k].grad - g).abs().max().item() / max(g.abs().max().item(), 1e-12)
+        worst = max(worst, e)
+    print("   worst relative parameter-gradient error oracle-vs-reference: %.2e over %d tensors" % (worst, len(ref_grads)))
+    assert worst < 1e-3, worst
+    out = {"losses": np.array([lc.item(), lb.item()], dtype=np.float64), "n_props": np.asarray([len(p) for p in props], np.int64),
+           "n_sampled": np.int64(len(samp[0]["index"]))}
+    for i in range(B):
+        out["props.%d" % i] = t2n(props[i].bbox)
+        out["gt.%d" % i] = gts[i]
+        out["index.%d" % i] = t2n(samp[i]["index"]).astype(np.int32)
+        out["labels.%d" % i] = t2n(sampled_props[i].get_field("labels")).astype(np.int32)
+        out["targets.%d" % i] = t2n(sampled_props[i].get_field("regression_targets"))
+    for k in BOXTRAIN_GRAD_KEYS:
+        g = t2n(ref_grads[k]).reshape(-1)
+        idx = gu.sample_indices(g.size, "boxgrad." + k)[:256]
+        out["refgrad.%s.samples" % k] = g[idx]
+        out["refgrad.%s.absmax" % k] = np.float32(np.abs(g).max())
+    for lvl in range(5):
+        for tag, t in (("dfeat", fg[lvl]), ("dqfeat", qg[lvl])):
+            g = t2n(t.grad) if t.grad is not None else np.zeros(tuple(t.shape), np.float32)
+            out.update(gu.checksum(g, "oracle_only.%s.%d" % (tag, lvl)))
+    np.savez_compressed(os.path.join(HERE, "boxtrain_%s.npz" % name), **out)
+
+
 from make_golden_cases import TRANSFORM_CASES, TRANSFORM_SIZES, transform_source  # noqa: E402
 
 
@@ -506,12 +614,18 @@ def main():
     ap.add_argument("--box-cases", default="small,nonsquare,shots5,tall,config1")
     ap.add_argument("--only-box", action="store_true", help="regenerate only the second-stage fixtures (+ key list)")
     ap.add_argument("--only-transforms", action="store_true", help="regenerate only tests/golden/transforms.npz")
+    ap.add_argument("--boxtrain-cases", default="small,nonsquare,shots5,tall,config1")
+    ap.add_argument("--only-boxtrain", action="store_true", help="regenerate only tests/golden/boxtrain_*.npz")
     args = ap.parse_args()
     torch.set_num_threads(8)
     model, cfg = rh.build_reference_model()
     if args.only_transforms:
         return gen_transforms(cfg)
     np_sd = load_synth_weights(model)
+    if args.only_boxtrain:
+        for name in [c for c in args.boxtrain_cases.split(",") if c]:
+            gen_box_train_case(model, np_sd, name)
+        return
     if args.only_box:
         gen_keys(model)
         gen_add_gt(model)
@@ -533,6 +647,8 @@ def main():
     if not args.skip_train:
         for name in [c for c in args.train_cases.split(",") if c]:
             gen_train_case(model, np_sd, name)
+        for name in [c for c in args.boxtrain_cases.split(",") if c]:
+            gen_box_train_case(model, np_sd, name)
 
 
 if __name__ == "__main__":

@@ -298,3 +298,53 @@ def test_resize_get_size_reference_cases():
     assert otr.get_size((1000, 800), 800, 1200) == (800, 1000)
     assert otr.get_size((127, 127), 200, 400) == (200, 200)
     assert otr.get_size((160, 90), 200, 400) == (200, 355)
+
+
+# ---- second stage, TRAINING: oracle/box_train_ref.py vs fixtures recorded through the reference ----
+from oracle import box_train_ref as obt  # noqa: E402
+
+
+def _boxtrain_inputs(name):
+    f = gu.load("boxtrain_%s.npz" % name)
+    B = gu.CASES[name][0]
+    n_props = [int(v) for v in f["n_props"]]
+    keys = synth.uniform01("boxtrain.keys." + name, B * max(n_props), seed=9).reshape(B, max(n_props)).astype(np.float32)
+    return f, B, n_props, keys
+
+
+@pytest.mark.parametrize("name", ["small", "nonsquare", "shots5", "tall", "config1"])
+def test_box_train_subsample_matches_reference(name):
+    """Matcher + BalancedPositiveNegativeSampler (randperm := argsort(keys)) + BoxCoder.encode: the sampled rows, labels and
+    regression targets the REAL reference's FastRCNNLossComputation.subsample produced."""
+    f, B, n_props, keys = _boxtrain_inputs(name)
+    for i in range(B):
+        sm = obt.subsample(torch.from_numpy(f["props.%d" % i]), torch.from_numpy(f["gt.%d" % i]),
+                           torch.from_numpy(keys[i, :n_props[i]].copy()))
+        assert np.array_equal(sm["index"].numpy(), f["index.%d" % i])
+        assert np.array_equal(sm["labels"].numpy(), f["labels.%d" % i])
+        np.testing.assert_allclose(sm["targets"].numpy(), f["targets.%d" % i], rtol=1e-6, atol=1e-6)
+        assert len(sm["index"]) == int(f["n_sampled"]) == obt.BATCH_PER_IMAGE
+        assert int((sm["labels"] > 0).sum()) <= int(obt.BATCH_PER_IMAGE * obt.POSITIVE_FRACTION)
+
+
+@pytest.mark.parametrize("name", ["small", "shots5", "tall"])
+def test_box_train_losses_and_gradients_match_reference(name, sd_full):
+    """ROIBoxHead in train mode: both losses (x5 / x2.5) and the box head's parameter gradients against the reference's
+    autograd (recorded); the oracle's backbone supplies the features (another host CPU: 1e-3-level agreement)."""
+    f, B, n_props, keys = _boxtrain_inputs(name)
+    _, H, W, S, qh, qw = gu.CASES[name]
+    img, q = gu.case_inputs(name)
+    with torch.no_grad():
+        o = orc.hot_path_forward(torch.from_numpy(img), torch.from_numpy(q), sd_full, shots=S)
+    sd = {k: (v.clone().requires_grad_(True) if k.startswith("roi_heads.box.") else v) for k, v in sd_full.items()}
+    samp = [obt.subsample(torch.from_numpy(f["props.%d" % i]), torch.from_numpy(f["gt.%d" % i]),
+                          torch.from_numpy(keys[i, :n_props[i]].copy())) for i in range(B)]
+    lc, lb, _, _ = obt.box_train_forward(o["features"], o["query_features"], samp, [(qh, qw)] * (B * S), sd, shots=S)
+    np.testing.assert_allclose([lc.item(), lb.item()], f["losses"], rtol=1e-3)
+    (lc + lb).backward()
+    for key in f.files:
+        if key.startswith("refgrad.") and key.endswith(".samples"):
+            k = key[len("refgrad."):-len(".samples")]
+            g = sd[k].grad.numpy().reshape(-1)
+            idx = gu.sample_indices(g.size, "boxgrad." + k)[:256]
+            assert np.abs(g[idx] - f[key]).max() <= 2e-3 * float(f["refgrad.%s.absmax" % k]), k
