@@ -60,7 +60,8 @@ class ConvTimer(object):
         self._orig_cg = ops.conv2d_multi
 
         def timed_conv2d_multi(xs, pcs, *a, **kw):
-            if not (kw.get("_whole") or len(xs) < 3 or kw.get("algo") is not None):
+            one = len(xs) == 1 and not kw.get("_whole") and kw.get("algo") is None     # goes out as a plain conv2d launch
+            if one or not (kw.get("_whole") or len(xs) < 3 or kw.get("algo") is not None):
                 return timer._orig_cg(xs, pcs, *a, **kw)     # dispatcher call: the launches inside are bracketed
             s = torch.cuda.Event(enable_timing=True)
             e = torch.cuda.Event(enable_timing=True)
@@ -423,7 +424,9 @@ def main_train(args, rank, world):
     import numpy as np
     from oneshotdet_amd import ops, spec, synth, train
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
-    eng = train.TrainEngine(synth.make_state_dict(spec.hot_path_shapes()), dtype=dtype)
+    two = bool(args.second_stage)      # opt-in: the reference's COMPLETE training step (roi_heads.box losses + backward)
+    eng = train.TrainEngine(synth.make_state_dict(spec.full_model_shapes() if two else spec.hot_path_shapes()), dtype=dtype,
+                            second_stage=two)
     B = args.batch
     images = torch.from_numpy(synth.make_images("bench.target", B, 800, 1024, seed=1000 + rank)).cuda()
     queries = torch.from_numpy(synth.make_images("bench.query", B, 127, 127, seed=1000 + rank)).cuda()
@@ -508,6 +511,9 @@ def main_train(args, rank, world):
         workload = ("BASELINE.json configs[2]: bs=%d/GPU, 800x1024 target + 127x127 query, %s MFMA convs, forward "
                     "(two R-50-FPN backbones, query pooling, correlation, FCOS head, training proposals) + FCOS loss + "
                     "backward (stem/layer1 frozen) + gradient all-reduce + SGD(momentum) + weight repack" % (B, args.dtype))
+        if two:
+            workload += (" + second stage (subsample 128 ROIs per image, few-shot ROI box head forward, cross-entropy + "
+                         "smooth-L1, backward into both backbones)")
         cpu = cpu_baseline(args.dtype, train=True) if (world == 1 and not args.no_cpu_baseline) else None
         line = result_line(args, world, B, elapsed, workload, launch, roofline, cpu)
         if roofline is not None:
@@ -542,8 +548,9 @@ def main():
                     help="train = forward + loss + backward + gradient all-reduce + SGD (the headline metric); "
                          "forward = BASELINE.json configs[1] (inference forward incl. proposals)")
     ap.add_argument("--second-stage", action="store_true",
-                    help="forward mode: also run the few-shot ROI box head on the 2000 proposals per image "
-                         "(SURVEY.md 8f #1) = the reference's complete eval forward")
+                    help="forward mode: also run the few-shot ROI box head on the 2000 proposals per image (SURVEY.md 8f "
+                         "#1) = the reference's complete eval forward; train mode: also the second stage's losses and "
+                         "backward = the reference's complete training step (engine/trainer.py:79-93)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="exercise only the multi-process plumbing (gloo, no GPU work): used by tests/test_dist_cpu.py")
     args = ap.parse_args()

@@ -293,6 +293,10 @@ int dispatch_tile_dma(int tile, const ConvKParams& p, hipStream_t s) {
     case 4:   // 256 x 256, 8 waves: half the operand bytes per MFMA of the 128 x 128 tile (the L1/TA path is the bound there)
       if constexpr (NST * 512 * KB <= 131072) return launch_dma<T, 256, 256, KB, 2, 4, NST>(p, s);
       else return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the 256x256 tile does not fit LDS with this ring");
+    case 7:   // 256 pixels x 128 channels, 8 waves (4 x 2, 64 x 64 per wave): twice the workgroups of the 256 x 256 tile for
+              // the layers whose pixel count gives that tile only 50-100 workgroups on 256 CUs (layer3 / layer4 at bs = 8)
+      if constexpr (NST * 384 * KB <= 155648) return launch_dma<T, 256, 128, KB, 4, 2, NST>(p, s);
+      else return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the 256x128 tile does not fit LDS with this ring");
   }
   return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad tile id %d", tile);
 }

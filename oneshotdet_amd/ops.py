@@ -119,8 +119,8 @@ def stem_input(images, dtype):
 
 # ---- per-shape algorithm selection by measurement ("measure, don't guess") ----
 # osd_conv_desc.algo = 1 + impl*32 + variant*8 + tile; impl 0 = LDS-DMA ring kernel (variants: deep / shallow ring /
-# short stages), impl 1 = register-staged kernel; tile 0..4 = 128x128, 128x64, 64x64, 256x16, 256x256/8 waves
-# (pixels x channels).
+# short stages), impl 1 = register-staged kernel; tile 0..4 = 128x128, 128x64, 64x64, 256x16, 256x256/8 waves, 5 = ping-pong
+# 256x256, 6 = row-reuse 3x3, 7 = 256x128/8 waves (pixels x channels).
 ALGO_CACHE = {}
 _TUNING = [False]
 
@@ -136,6 +136,8 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
         cands.append(1 + 0 * 32 + 0 * 8 + 5)          # 256x256 tile, two wave groups one barrier apart (bf16 only)
         if not os.environ.get("OSD_NO_XR"):           # (A/B switch for tools and benches)
             cands.append(1 + 0 * 32 + 0 * 8 + 6)      # 3x3/1: pixel rows fetched once per filter row (bf16, W in 64/128/256)
+    if cout_store >= 128 and not relu_in:
+        cands += [1 + 0 * 32 + v * 8 + 7 for v in (0, 1, 2)]      # 256x128 tile on 8 waves: deep / shallow ring / short stages
     if not relu_in and not has_mask:
         cands += [1 + 1 * 32 + t for t in tiles]
     return cands
