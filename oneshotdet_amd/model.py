@@ -15,6 +15,9 @@ from . import ops, spec
 from .ops import ACT_EXP_SCALE, ACT_NONE, ACT_RELU, RES_SAME, RES_UP2X
 
 
+SKIP_UNUSED_C2 = os.environ.get("OSD_FULL_C2", "0") == "0"     # A/B switch: compute all of layer1's last block anyway
+
+
 def _bn(sd, p):
     return (sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"])
 
@@ -73,11 +76,22 @@ def run_backbone(wts, images, dtype, return_body=False):
     x = ops.conv2d(x, wts.stem, act=ACT_RELU, out_hw=(ho, wo))
     x = ops.maxpool3x3s2(x)
     feats = []
-    for blk in wts.blocks:
+    halved = False
+    for bi, blk in enumerate(wts.blocks):
         s = blk["stride"]
+        if s == 2 and halved:
+            s, halved = 1, False
+        # C2 is read only by layer2.0's stride-2 1x1 convs (the FPN skips it): the last block of layer1 computes just the
+        # even pixels (3x3 at stride 2, then the 1x1 + residual on the quarter-size map); return_body keeps the full map
+        quarter = SKIP_UNUSED_C2 and not return_body and bi == spec.STAGE_BLOCKS[0] - 1
         identity = x if blk["ds"] is None else ops.conv2d(x, blk["ds"], stride=s)
         out = ops.conv2d(x, blk["c1"], stride=s, act=ACT_RELU)
-        out = ops.conv2d(out, blk["c2"], pad=1, act=ACT_RELU)
+        if quarter:
+            out = ops.conv2d(out, blk["c2"], stride=2, pad=1, act=ACT_RELU)
+            identity = identity[:, ::2, ::2].contiguous()
+            halved = True
+        else:
+            out = ops.conv2d(out, blk["c2"], pad=1, act=ACT_RELU)
         x = ops.conv2d(out, blk["c3"], act=ACT_RELU, res=identity, res_mode=RES_SAME)
         if blk["last_of_stage"]:
             feats.append(x)
@@ -105,11 +119,20 @@ def run_backbones(wt, wq, images, queries, dtype):
         x = ops.conv2d(x, wts.stem, act=ACT_RELU, out_hw=(ho, wo))
         xs.append(ops.maxpool3x3s2(x))
     feats = []
-    for bt, bq in zip(wt.blocks, wq.blocks):
+    halved = False
+    for bi, (bt, bq) in enumerate(zip(wt.blocks, wq.blocks)):
         s = bt["stride"]
+        if s == 2 and halved:
+            s, halved = 1, False
+        quarter = SKIP_UNUSED_C2 and bi == spec.STAGE_BLOCKS[0] - 1         # see run_backbone
         identity = xs if bt["ds"] is None else ops.conv2d_multi(xs, [bt["ds"], bq["ds"]], stride=s)
         out = ops.conv2d_multi(xs, [bt["c1"], bq["c1"]], stride=s, act=ACT_RELU)
-        out = ops.conv2d_multi(out, [bt["c2"], bq["c2"]], pad=1, act=ACT_RELU)
+        if quarter:
+            out = ops.conv2d_multi(out, [bt["c2"], bq["c2"]], stride=2, pad=1, act=ACT_RELU)
+            identity = [t[:, ::2, ::2].contiguous() for t in identity]
+            halved = True
+        else:
+            out = ops.conv2d_multi(out, [bt["c2"], bq["c2"]], pad=1, act=ACT_RELU)
         xs = ops.conv2d_multi(out, [bt["c3"], bq["c3"]], act=ACT_RELU, residuals=identity)
         if bt["last_of_stage"]:
             feats.append(xs)

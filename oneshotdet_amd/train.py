@@ -59,6 +59,7 @@ class TrainEngine(object):
         import os
         self.lockstep = os.environ.get("OSD_LOCKSTEP", "0") != "0"
         self.corr_levels = os.environ.get("OSD_CORR_LEVELS", "1") != "0"
+        self.skip_unused_c2 = os.environ.get("OSD_FULL_C2", "0") == "0"
         self.towers_merged = os.environ.get("OSD_TOWERS_MERGED", "0") != "0"
         sd = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state_dict.items()}
         self._frozen_sd = sd
@@ -389,14 +390,27 @@ class TrainEngine(object):
             x = ops.conv2d(x, cv[bb + "body.stem.conv1"].pc, act=ACT_RELU, out_hw=(ho, wo))
             xs.append(ops.maxpool3x3s2(x))
         blocks, stage_out = [[] for _ in nb], [[] for _ in nb]
+        halved = False
         for si, nblocks in enumerate(spec.STAGE_BLOCKS):
             for bi in range(nblocks):
                 p = "body.layer%d.%d." % (si + 1, bi)
                 s = 2 if (bi == 0 and si > 0) else 1
+                if s == 2 and halved:        # the stride already happened in the producer (see below)
+                    s, halved = 1, False
                 has_ds = (bbs[0] + p + "downsample.0") in cv
+                # C2 (layer1's output) is read by nothing but layer2.0's two stride-2 1x1 convs (the FPN skips it, fpn.py:33,
+                # backbone.py:59): only its even pixels are ever used, so the last block of the FROZEN layer1 computes
+                # just those — its 3x3 at stride 2, its 1x1 + residual on the quarter-size map — and layer2.0 reads
+                # them at stride 1.  Same values, 3/4 of two convs and of a 210 MB tensor gone.
+                quarter = self.skip_unused_c2 and si == 0 and bi == nblocks - 1 and len(spec.STAGE_BLOCKS) > 1
                 identity = ops.conv2d_multi(xs, pcs(p + "downsample.0"), stride=s) if has_ds else xs
                 o1 = ops.conv2d_multi(xs, pcs(p + "conv1"), stride=s, act=ACT_RELU)
-                o2 = ops.conv2d_multi(o1, pcs(p + "conv2"), pad=1, act=ACT_RELU)
+                if quarter:
+                    o2 = ops.conv2d_multi(o1, pcs(p + "conv2"), stride=2, pad=1, act=ACT_RELU)
+                    identity = [t[:, ::2, ::2].contiguous() for t in identity]
+                    halved = True
+                else:
+                    o2 = ops.conv2d_multi(o1, pcs(p + "conv2"), pad=1, act=ACT_RELU)
                 y = ops.conv2d_multi(o2, pcs(p + "conv3"), act=ACT_RELU, residuals=identity)
                 if si >= 1:
                     for j in nb:
