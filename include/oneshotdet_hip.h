@@ -221,6 +221,15 @@ int64_t osd_nms_single_workspace_bytes(int num_boxes);
 int osd_proposals_sort_nms(const float* keys, const float* boxes, int n, int total, int max_count, const int32_t* level_lo,
                            const int32_t* level_cnt, int n_levels, int topn, float thresh, int cuda_semantics, int max_keep,
                            void* workspace, float* out_boxes, float* out_scores, int32_t* out_count, void* stream);
+/* The same with the size of the exactly sorted head under the caller's control: head_hint (0 = the default above) is the
+ * number of candidates phase 1 may read; depth_out [n] (nullable, device) receives how deep the greedy scan actually read
+ * (position of the last survivor + 1).  A trained head puts neighbouring locations on the same object, NMS suppresses
+ * more, and the scan needs 1.3-1.4 x max_keep candidates instead of 1.0: callers feed depth_out of an earlier step back
+ * (without synchronising: a lagged, non-blocking read) so that phase 2 stays the exception.  Exact for every hint. */
+int osd_proposals_sort_nms_hint(const float* keys, const float* boxes, int n, int total, int max_count,
+                                const int32_t* level_lo, const int32_t* level_cnt, int n_levels, int topn, float thresh,
+                                int cuda_semantics, int max_keep, int head_hint, void* workspace, float* out_boxes,
+                                float* out_scores, int32_t* out_count, int32_t* depth_out, void* stream);
 int64_t osd_proposals_workspace_bytes(int n, int total, int max_count, int max_keep);
 
 /* ------------------------------------------------------------------------------------------------------------------

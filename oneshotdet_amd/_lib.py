@@ -87,6 +87,7 @@ SIGNATURES = {
     "osd_box_decode": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _f, _f, _p, _f, _i, _p]),
     "osd_append_gt_boxes": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "osd_proposals_sort_nms": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _i, _i, _p, _p, _p, _p, _p]),
+    "osd_proposals_sort_nms_hint": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "osd_proposals_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "osd_box_match_sample": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_box_loss": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _f, _p, _p, _i, _i, _p]),

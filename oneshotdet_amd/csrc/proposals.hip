@@ -443,7 +443,8 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
                                                        float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                                        int* __restrict__ out_pos, int* __restrict__ out_count, int limit,
                                                        int* __restrict__ need_full, int phase,
-                                                       const int* __restrict__ counts_full = nullptr) {
+                                                       const int* __restrict__ counts_full = nullptr,
+                                                       int* __restrict__ depth_out = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* remv = reinterpret_cast<unsigned long long*>(smem);   // [col_blocks]
   int* kept_list = reinterpret_cast<int*>(remv + col_blocks);                // [max_keep] positions of the survivors
@@ -576,6 +577,9 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const float* __restrict__
     // more candidates, the full problem is redone by the (otherwise idle) phase-2 launches
     // (counts_full: `counts` only covers the part of the order that has been sorted so far, the candidates go on)
     if (phase == 1) need_full[img] = (s_kept[blk & 1] < max_keep && (counts_full ? counts_full[img] : n_all) > n) ? 1 : 0;
+    // how deep into the score order the greedy scan had to read: position of the last survivor + 1 (callers size the next
+    // call's exactly-sorted head from it)
+    if (depth_out) depth_out[img] = s_kept[blk & 1] > 0 ? kept_list[s_kept[blk & 1] - 1] + 1 : 0;
   }
 }
 
@@ -788,10 +792,11 @@ extern "C" int64_t osd_proposals_workspace_bytes(int n, int total, int max_count
   return (int64_t)b + osd_nms_workspace_bytes(n, max_count);
 }
 
-extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int n, int total, int max_count,
-                                      const int32_t* level_lo, const int32_t* level_cnt, int n_levels, int topn, float thresh,
-                                      int cuda_semantics, int max_keep, void* workspace, float* out_boxes, float* out_scores,
-                                      int32_t* out_count, void* stream) {
+extern "C" int osd_proposals_sort_nms_hint(const float* keys, const float* boxes, int n, int total, int max_count,
+                                           const int32_t* level_lo, const int32_t* level_cnt, int n_levels, int topn,
+                                           float thresh, int cuda_semantics, int max_keep, int head_hint, void* workspace,
+                                           float* out_boxes, float* out_scores, int32_t* out_count, int32_t* depth_out,
+                                           void* stream) {
   if (!keys || !boxes || !workspace || !out_boxes || !out_scores || !out_count)
     return osd_fail(OSD_ERR_INVALID_ARG, "proposals_sort_nms: null argument");
   if (n == 0) return OSD_OK;
@@ -832,7 +837,12 @@ extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int
   uint64_t* mask_ws = reinterpret_cast<uint64_t*>(w);
   hipStream_t st = OSD_STREAM(stream);
   if (hipMemsetAsync(valid, 0, align256((size_t)n * 4) * 3, st) != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "proposals_sort_nms: memset failed");
+  // phase 1 reads the first `limit` candidates of the order.  Default 1.25 x max_keep: enough while the boxes are spread
+  // out (an untrained head); once the regression has learnt to put neighbouring locations on the same object the scan
+  // needs 1.3-1.4 x max_keep and more, and falling through to phase 2 costs 4x the call.  head_hint (from depth_out of an
+  // earlier call on similar data) enlarges the head instead; the result is exact either way.
   int limit = cdiv(max_keep * 5 / 4 + 64, 64) * 64;
+  if (head_hint > limit) limit = cdiv(head_hint, 64) * 64;
   if (limit > max_count) limit = max_count;
   const int want = limit + 256;
   hipLaunchKernelGGL(select_head_kernel, dim3(n), dim3(1024), 0, st, keys, total, max_count, topn, lt, want, keys_sel, idx_sel, meta);
@@ -852,7 +862,8 @@ extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int
   rc = osd_check_launch("nms_mask");
   if (rc) return rc;
   hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8 + max_keep * 4, st, boxes_sorted, scores_sorted, valid, max_count,
-                     col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, limit, need_full, 1, (const int*)counts);
+                     col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, limit, need_full, 1, (const int*)counts,
+                     depth_out);
   rc = osd_check_launch("nms_scan");
   if (rc || limit >= max_count) return rc;
   // phase 2, flagged images only: the whole order, then NMS over all of it
@@ -866,7 +877,15 @@ extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int
   if (rc) return rc;
   hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8 + max_keep * 4, st, boxes_sorted, scores_sorted, counts, max_count,
                      col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, max_count, need_full, 2,
-                     (const int*)nullptr);
+                     (const int*)nullptr, depth_out);
   return osd_check_launch("nms_scan(full)");
+}
+
+extern "C" int osd_proposals_sort_nms(const float* keys, const float* boxes, int n, int total, int max_count,
+                                      const int32_t* level_lo, const int32_t* level_cnt, int n_levels, int topn, float thresh,
+                                      int cuda_semantics, int max_keep, void* workspace, float* out_boxes, float* out_scores,
+                                      int32_t* out_count, void* stream) {
+  return osd_proposals_sort_nms_hint(keys, boxes, n, total, max_count, level_lo, level_cnt, n_levels, topn, thresh, cuda_semantics,
+                                     max_keep, 0, workspace, out_boxes, out_scores, out_count, nullptr, stream);
 }
 

@@ -225,8 +225,35 @@ def run_head(hw, feats, streams=None):
     return list(zip(cls_out, box_out))
 
 
+class ProposalDepth(object):
+    """Lagged feedback for the proposal pipeline (osd_proposals_sort_nms_hint): how deep into the score order the greedy
+    NMS had to read in recent calls decides how many candidates the next call sorts exactly in its first phase.  The
+    depth travels device -> pinned host memory by a non-blocking copy behind the call; the host looks at it only once
+    that copy's event has completed (no synchronisation: a step or two of lag), so the pipeline itself never waits."""
+
+    def __init__(self):
+        self.hint, self._pending = 0, None
+
+    def before(self, n, device):
+        if self._pending is not None and self._pending[1].query():
+            host = self._pending[0]
+            d = int(host.max())
+            # a quarter of headroom over the deepest image, never below the default (0 = let the library decide)
+            self.hint = d + d // 4 + 320
+            self._pending = None
+        return torch.empty((n,), device=device, dtype=torch.int32)
+
+    def after(self, depth_dev):
+        if self._pending is None:
+            host = torch.empty(depth_dev.shape, dtype=torch.int32, pin_memory=True)
+            host.copy_(depth_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (host, ev, depth_dev)
+
+
 def run_proposals(head_out, img_h, img_w, pre_nms_top_n, post_nms_top_n, nms_thresh, cuda_nms=True, workspace=None,
-                  image_sizes=None):
+                  image_sizes=None, depth=None):
     """FCOSPostProcessor.forward (fcos/inference.py:251-323).  Boxes are clipped to (img_h, img_w) (the 4-D tensor path of
     to_image_list, structures/image_list.py:44-50) or, for a padded batch, to every image's own image_sizes[i] = (h, w)
     (:52-70).  Everything stays on the device; returns boxes [N, post, 4], scores [N, post] (descending), counts [N]."""
@@ -250,8 +277,14 @@ def run_proposals(head_out, img_h, img_w, pre_nms_top_n, post_nms_top_n, nms_thr
         ob, os_, op, oc = ops.nms_sorted(bs, ss, cnt, nms_thresh, post_nms_top_n, cuda_semantics=cuda_nms,
                                          workspace=workspace)
         return ob, os_, oc
-    return ops.proposals_sort_nms(scores, boxes, max_count, levels, pre_nms_top_n, nms_thresh, post_nms_top_n,
-                                  cuda_semantics=cuda_nms)
+    if depth is None:
+        return ops.proposals_sort_nms(scores, boxes, max_count, levels, pre_nms_top_n, nms_thresh, post_nms_top_n,
+                                      cuda_semantics=cuda_nms)
+    d = depth.before(n, dev)
+    out = ops.proposals_sort_nms(scores, boxes, max_count, levels, pre_nms_top_n, nms_thresh, post_nms_top_n,
+                                 cuda_semantics=cuda_nms, head_hint=depth.hint, depth_out=d)
+    depth.after(d)
+    return out
 
 
 class HotPathEngine(object):

@@ -1038,7 +1038,8 @@ def append_gt_boxes(boxes, scores, counts, gt_boxes, gt_count):
     return ob, os_, oc
 
 
-def proposals_sort_nms(keys, boxes, max_count, levels, topn, thresh, max_keep, cuda_semantics=False, workspace=None):
+def proposals_sort_nms(keys, boxes, max_count, levels, topn, thresh, max_keep, cuda_semantics=False, workspace=None,
+                       head_hint=0, depth_out=None):
     """rank_sort_gather + nms_sorted in one call that ranks only the head of the score order (osd_proposals_sort_nms).
     keys [N,T] fp32 (dropped = -1), boxes [N,T,4] -> boxes [N,max_keep,4], scores [N,max_keep] (descending), counts [N]."""
     _chk_dev(keys, boxes)
@@ -1056,6 +1057,7 @@ def proposals_sort_nms(keys, boxes, max_count, levels, topn, thresh, max_keep, c
         nl = len(levels)
     else:
         lo, lc, nl = None, None, 0
-    _lib.call("osd_proposals_sort_nms", _ptr(keys), _ptr(boxes), n, total, max_count, lo, lc, nl, int(topn), float(thresh),
-              int(cuda_semantics), max_keep, _ptr(workspace), _ptr(ob), _ptr(os_), _ptr(oc), _stream())
+    _lib.call("osd_proposals_sort_nms_hint", _ptr(keys), _ptr(boxes), n, total, max_count, lo, lc, nl, int(topn), float(thresh),
+              int(cuda_semantics), max_keep, int(head_hint), _ptr(workspace), _ptr(ob), _ptr(os_), _ptr(oc), _ptr(depth_out),
+              _stream())
     return ob, os_, oc

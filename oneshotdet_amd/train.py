@@ -13,6 +13,7 @@ bf16/fp32 packers all share it, and the gradient all-reduce is a handful of larg
 `state_dict()` converts back to the reference's OIHW names/shapes.
 """
 import math
+import os
 
 import torch
 
@@ -55,8 +56,9 @@ class TrainEngine(object):
         self._keep = []
         self.second_stage = bool(second_stage)
         self.box_keys, self.box_losses = None, None       # sampler keys for the next step (None: torch.rand), last losses
+        from .model import ProposalDepth
+        self._prop_depth = None if os.environ.get("OSD_NO_PROP_HINT") else ProposalDepth()
         # A/B switches (measured on one box, tools/ab_bench.sh): both backbones per launch / both towers per launch
-        import os
         self.lockstep = os.environ.get("OSD_LOCKSTEP", "0") != "0"
         self.corr_levels = os.environ.get("OSD_CORR_LEVELS", "1") != "0"
         self.skip_unused_c2 = os.environ.get("OSD_FULL_C2", "0") == "0"
@@ -877,7 +879,8 @@ class TrainEngine(object):
             with torch.cuda.stream(ps):
                 pb, ps_, pc = model.run_proposals(head_out, images.shape[-2], images.shape[-1],
                                                   spec.PRE_NMS_TOP_N_TRAIN, spec.POST_NMS_TOP_N_TRAIN, spec.NMS_THRESH,
-                                                  image_sizes=image_sizes)   # padded batch: clip to each image's size
+                                                  image_sizes=image_sizes,    # padded batch: clip to each image's size
+                                                  depth=self._prop_depth)     # lagged hint: how deep NMS has to read
                 # add_gt_proposals (fcos/inference.py:139-160,279): the ground-truth boxes join the training proposals
                 self.proposals = ops.append_gt_boxes(pb, ps_, pc, gt_boxes, gt_count)
                 if self.second_stage:       # roi_heads on the plain target / query features (generalized_rcnn.py:317), beside

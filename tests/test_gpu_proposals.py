@@ -280,6 +280,18 @@ def test_proposals_sort_nms_equals_the_two_call_pipeline(case):
         for i in range(n_img):
             c = int(rc[i])
             assert torch.equal(ob[i, :c], rb[i, :c]) and torch.equal(os_[i, :c], rs[i, :c]), (case, i)
+        # any size of the exactly sorted head gives the same result; depth_out = how deep the scan read (position of the
+        # last survivor + 1 in the score order), whichever phase produced the result
+        _, _, rpos, _ = ops.nms_sorted(bs, ss, cnt, 0.8 if case != "needs_full_order" else 0.5, max_keep, cuda_semantics=rule)
+        want_depth = [int(rpos[i, :int(rc[i])].max()) + 1 if int(rc[i]) else 0 for i in range(n_img)]
+        for hint in (1, max_keep + max_keep // 2, max_count + 999):
+            depth = torch.full((n_img,), -7, device="cuda", dtype=torch.int32)
+            hb_, hs_, hc_ = ops.proposals_sort_nms(k, b, max_count, levels, topn, 0.8 if case != "needs_full_order" else 0.5,
+                                                  max_keep, cuda_semantics=rule, head_hint=hint, depth_out=depth)
+            assert torch.equal(hc_, rc) and depth.tolist() == want_depth, (case, hint, depth.tolist(), want_depth)
+            for i in range(n_img):
+                c = int(rc[i])
+                assert torch.equal(hb_[i, :c], rb[i, :c]) and torch.equal(hs_[i, :c], rs[i, :c]), (case, hint, i)
     if case == "needs_full_order":      # the head (2564 candidates) did not fill max_keep: the second phase really ran
         hb, hs, _, hc = ops.nms_sorted(bs[:, :2564].contiguous(), ss[:, :2564].contiguous(), cnt.clamp(max=2564), 0.5, max_keep,
                                        cuda_semantics=True)
@@ -305,3 +317,28 @@ def test_osd_nms_single_entry_matches_the_oracle_for_any_scores():
             assert np.array_equal(got, ref), (n, cuda)
     keep, count = ops.nms(torch.zeros(0, 4, device="cuda"), torch.zeros(0, device="cuda"), 0.5)
     assert int(count.item()) == 0 and keep.shape == (0,)
+
+
+def test_proposal_depth_feedback_tracks_a_deepening_scan():
+    """model.ProposalDepth: the lagged hint follows the scan depth of earlier calls (a trained head clusters its boxes, NMS
+    reads deeper) without ever blocking, and never changes the result."""
+    from oneshotdet_amd import model, ops
+    rng = np.random.RandomState(5)
+    levels, topn, max_keep = [(0, 12800), (12800, 3200), (16000, 1064)], 12000, 4000
+    total = 17064
+    scores = torch.from_numpy((rng.rand(2, total).astype(np.float32) ** 2) * 0.9 + 1e-4).cuda()
+    ctr = (rng.rand(2, total, 2).astype(np.float32) * np.array([1000.0, 780.0], np.float32))
+    depth = model.ProposalDepth()
+    hints = []
+    for spread in (90.0, 40.0, 20.0, 20.0, 20.0, 20.0):       # smaller boxes jitter -> more overlap -> deeper scans
+        c2 = (ctr // spread) * spread
+        boxes = torch.from_numpy(np.concatenate([c2 - 60, c2 + 60], -1).astype(np.float32)).cuda()
+        d = depth.before(2, "cuda")
+        out = ops.proposals_sort_nms(scores, boxes, total, levels, topn, 0.8, max_keep, cuda_semantics=True, head_hint=depth.hint,
+                                     depth_out=d)
+        depth.after(d)
+        ref = ops.proposals_sort_nms(scores, boxes, total, levels, topn, 0.8, max_keep, cuda_semantics=True)
+        assert all(torch.equal(a, b) for a, b in zip(out, ref))
+        torch.cuda.synchronize()
+        hints.append((depth.hint, d.tolist()))
+    assert hints[-1][0] >= max(hints[-2][1]), hints          # the last call's head covered what the previous call needed
