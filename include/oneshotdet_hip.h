@@ -265,6 +265,14 @@ int osd_conv2d_wgrad(const osd_conv_desc* d, const void* x, const void* dy, cons
 int osd_conv2d_wgrad_grouped(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
                              const int32_t* ns, const int32_t* hs, const int32_t* ws, const float* scale, float* dw,
                              float* db, void* stream);
+/* The FCOS prediction convs (cls_logits + centerness fused, bbox_pred: fcos.py:50-61; 3x3 / stride 1 / pad 1, cout <= 4,
+ * cin a multiple of 256) over the FPN levels: a read-once kernel (one pass over x, the nine dy vectors of every pixel) with
+ * per-workgroup partials folded by a second launch (16 adders per address instead of 500), instead of a 128-channel MFMA
+ * tile spent on 2-4 channels.  dw [cout][3][3][cin] and db [cout] (nullable) are ACCUMULATED.  workspace:
+ * osd_conv2d_wgrad_pred_workspace_bytes(n_seg, ns, hs, ws, cin) bytes. */
+int osd_conv2d_wgrad_pred(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys, const int32_t* ns,
+                          const int32_t* hs, const int32_t* ws, float* dw, float* db, void* workspace, void* stream);
+int64_t osd_conv2d_wgrad_pred_workspace_bytes(int n_seg, const int32_t* ns, const int32_t* hs, const int32_t* ws, int cin);
 /* n_seg <= 24 convs of IDENTICAL geometry (d: the shared forward descriptor incl. n, h, w) but different tensors AND
  * different weights — the repeated bottleneck blocks of a ResNet stage (resnet.py:295-315) — in one launch; xs / dys /
  * scales / dws / dbs: HOST arrays of per-conv device pointers (scales, dbs nullable as a whole or per entry).  The output

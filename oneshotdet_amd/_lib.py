@@ -65,6 +65,8 @@ SIGNATURES = {
     "osd_sgd_momentum_multi": (_i, [_p, _p, _i, _p, _p, _p, _f, _f, _i, _p]),
     "osd_pack_multi": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _p]),
     "osd_conv2d_wgrad_grouped": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "osd_conv2d_wgrad_pred": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "osd_conv2d_wgrad_pred_workspace_bytes": (_i64, [_i, _p, _p, _p, _i]),
     "osd_conv2d_wgrad_batched": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_wgrad_multi": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_wgrad_mixed": (_i, [_i, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),

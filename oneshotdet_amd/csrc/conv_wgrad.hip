@@ -418,8 +418,8 @@ struct PredWgradLevels {
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256) pred_wgrad_kernel(PredWgradLevels L, float* __restrict__ dw, float* __restrict__ db,
-                                                         int C, int cout, int dy_stride, int pix_per_block) {
+__global__ void __launch_bounds__(256) pred_wgrad_kernel(PredWgradLevels L, float* __restrict__ part, float* __restrict__ part_b,
+                                                         int C, int dy_stride, int pix_per_block) {
   __shared__ float red[64 * 144];
   const int b = blockIdx.x, cg = blockIdx.y;          // cg: group of 256 input channels
   int lvl = 0;
@@ -446,44 +446,55 @@ __global__ void __launch_bounds__(256) pred_wgrad_kernel(PredWgradLevels L, floa
       for (int k = 0; k < 4; ++k) acc[co][t][k] = 0.f;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const int tr = lane / 3, ts = lane - tr * 3;         // the tap this lane fetches dy for (lanes 0..8)
-  for (int q = q0 + wave; q < q1; q += 4) {
-    const int img = q / HW, rem = q - img * HW, qy = rem / W, qx = rem - qy * W;
-    float xk[4];
-    if constexpr (sizeof(T) == 2) {
-      const bf16x4 v = *reinterpret_cast<const bf16x4*>(x + (size_t)q * C + c0);
+  // U pixels per wave and iteration: all 2 x U loads are issued before the first use (one load in flight per wave made the
+  // kernel latency bound: 211 us for 70 MB)
+  constexpr int U = 8;
+  for (int qb = q0 + wave * U; qb < q1; qb += 4 * U) {
+    float xk[U][4], d[U][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) xk[k] = (float)v[k];
-    } else {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)q * C + c0);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) xk[k] = v[k];
-    }
-    // output pixel whose tap (tr, ts) reads input pixel q: (qy - tr + 1, qx - ts + 1)
-    const int py = qy - tr + 1, px = qx - ts + 1;
-    float d[4] = {0.f, 0.f, 0.f, 0.f};
-    if (lane < 9 && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
-      const T* dp = dy + ((size_t)(img * H + py) * W + px) * dy_stride;
+    for (int u = 0; u < U; ++u) {
+      const int q = min(qb + u, q1 - 1);                 // clamped: a repeated pixel is masked below
+      const int img = q / HW, rem = q - img * HW, qy = rem / W, qx = rem - qy * W;
       if constexpr (sizeof(T) == 2) {
-        const bf16x4 v = *reinterpret_cast<const bf16x4*>(dp);
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(x + (size_t)q * C + c0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = (float)v[k];
+        for (int k = 0; k < 4; ++k) xk[u][k] = (float)v[k];
       } else {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(dp);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)q * C + c0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = v[k];
+        for (int k = 0; k < 4; ++k) xk[u][k] = v[k];
+      }
+      // output pixel whose tap (tr, ts) reads input pixel q: (qy - tr + 1, qx - ts + 1)
+      const int py = qy - tr + 1, px = qx - ts + 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[u][k] = 0.f;
+      if (lane < 9 && qb + u < q1 && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
+        const T* dp = dy + ((size_t)(img * H + py) * W + px) * dy_stride;
+        if constexpr (sizeof(T) == 2) {
+          const bf16x4 v = *reinterpret_cast<const bf16x4*>(dp);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[u][k] = (float)v[k];
+        } else {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(dp);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[u][k] = v[k];
+        }
       }
     }
-    if (lane == 4) {                                   // the centre tap is the pixel itself: bias gradient (cg 0 only)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) bsum[k] += d[k];
-    }
+    for (int u = 0; u < U; ++u) {
+      if (lane == 4) {                                   // the centre tap is the pixel itself: bias gradient (cg 0 only)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+        for (int k = 0; k < 4; ++k) bsum[k] += d[u][k];
+      }
 #pragma unroll
-      for (int co = 0; co < 4; ++co) {
-        const float dv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d[co]), t));
+      for (int t = 0; t < 9; ++t) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[co][t][k] += dv * xk[k];
+        for (int co = 0; co < 4; ++co) {
+          const float dv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d[u][co]), t));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[co][t][k] += dv * xk[u][k];
+        }
       }
     }
   }
@@ -508,21 +519,51 @@ __global__ void __launch_bounds__(256) pred_wgrad_kernel(PredWgradLevels L, floa
     }
     __syncthreads();
   }
-  if (wave == 0 && q0 < q1) {
-#pragma unroll
-    for (int co = 0; co < 4; ++co) {
-      if (co < cout) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) atomicAdd(dw + ((size_t)co * 9 + t) * C + c0 + k, acc[co][t][k]);
-      }
-    }
-  }
-  if (db != nullptr && cg == 0 && lane == 4 && q0 < q1) {
+  // the workgroup's partial: part[block][co][tap][C] (plain coalesced stores; 500 workgroups adding atomically into the same
+  // 36 KB serialise at the memory-side atomic units: 57-114 us of a 170 us kernel), folded in fixed order by
+  // pred_wgrad_reduce_kernel
+  if (wave == 0) {
+    float* pp = part + ((size_t)blockIdx.x * gridDim.y + cg) * 36 * 256 + lane * 4;
 #pragma unroll
     for (int co = 0; co < 4; ++co)
-      if (co < cout) atomicAdd(db + co, bsum[co]);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        *reinterpret_cast<f32x4*>(pp + (co * 9 + t) * 256) = f32x4{acc[co][t][0], acc[co][t][1], acc[co][t][2], acc[co][t][3]};
+  }
+  if (cg == 0) {                                         // bias partials: lane 4 of every wave -> part_b[block][wave][4]
+    if (lane == 4) {
+#pragma unroll
+      for (int co = 0; co < 4; ++co) part_b[((size_t)blockIdx.x * 4 + wave) * 4 + co] = bsum[co];
+    }
+  }
+}
+
+// dw[co][tap][c] += sum over workgroups of part[block][cg][co][tap][c & 255]; db[co] += sum of part_b.  blockIdx.y = one of
+// `chunks` slices of the workgroup list: each thread sums its slice with four independent loads in flight, then ONE atomic
+// per (element, slice) — 16 adders per address instead of 500.
+__global__ void pred_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_b, float* __restrict__ dw,
+                                         float* __restrict__ db, int blocks, int groups, int C, int cout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = cout * 9 * C;
+  const int per = (blocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(blocks, b0 + per);
+  if (i < n) {
+    const int c = i % C, ct = i / C;                     // ct = co * 9 + tap
+    const int cg = c >> 8, cl = c & 255;
+    const size_t stride = (size_t)groups * 36 * 256;
+    const float* p = part + ((size_t)cg * 36 + ct) * 256 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+      s0 += p[(size_t)b * stride]; s1 += p[(size_t)(b + 1) * stride]; s2 += p[(size_t)(b + 2) * stride]; s3 += p[(size_t)(b + 3) * stride];
+    }
+    for (; b < b1; ++b) s0 += p[(size_t)b * stride];
+    if (b0 < b1) atomicAdd(dw + i, (s0 + s1) + (s2 + s3));
+  } else if (db != nullptr && i < n + cout) {
+    const int co = i - n;
+    float s = 0.f;
+    for (int b = b0 * 4; b < b1 * 4; ++b) s += part_b[(size_t)b * 4 + co];
+    if (b0 < b1) atomicAdd(db + co, s);
   }
 }
 
@@ -685,34 +726,77 @@ extern "C" int osd_conv2d_wgrad_grouped(const osd_conv_desc* d, int n_seg, const
   if (!d || !xs || !dys || !ns || !hs || !ws || !dw || n_seg < 1 || n_seg > kMaxSeg)
     return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_grouped: bad arguments");
   if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad dtype");
-  static int no_pred = -1;
-  if (no_pred < 0) { const char* e = getenv("OSD_NO_PRED_WGRAD"); no_pred = e ? atoi(e) : 0; }     // A/B switch
-  if (!no_pred && d->cout <= 4 && d->r == 3 && d->s == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 &&
-      d->pad_w == 1 && d->cin % 256 == 0 && !scale && n_seg <= kPredLevels && d->out_stride % 4 == 0) {
-    // prediction convs (Cout 2 / 4): the read-once kernel instead of a 128-channel MFMA tile for 2-4 channels
-    PredWgradLevels L;
-    L.n_levels = 0;
-    const int ppb = 256;
-    int blocks = 0;
-    for (int i = 0; i < n_seg; ++i) {
-      const long long npix = (long long)ns[i] * hs[i] * ws[i];
-      if (npix <= 0 || npix > 0x7fffffffLL / d->cin || !xs[i] || !dys[i])
-        return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_grouped: bad segment %d", i);
-      const int k = L.n_levels++;
-      L.x[k] = xs[i]; L.dy[k] = dys[i]; L.H[k] = hs[i]; L.W[k] = ws[i]; L.npix[k] = (int)npix; L.begin[k] = blocks;
-      blocks += cdiv((int)npix, ppb);
-    }
-    for (int k = L.n_levels; k < kPredLevels; ++k) { L.x[k] = L.x[0]; L.dy[k] = L.dy[0]; L.H[k] = 1; L.W[k] = 1; L.npix[k] = 0; L.begin[k] = 0x7fffffff; }
-    dim3 grid(blocks, d->cin / 256);
-    if (d->dtype == OSD_F32)
-      hipLaunchKernelGGL(pred_wgrad_kernel<float>, grid, dim3(256), 0, OSD_STREAM(stream), L, dw, db, d->cin, d->cout, d->out_stride, ppb);
-    else
-      hipLaunchKernelGGL(pred_wgrad_kernel<__bf16>, grid, dim3(256), 0, OSD_STREAM(stream), L, dw, db, d->cin, d->cout, d->out_stride, ppb);
-    return osd_check_launch("pred_wgrad");
-  }
   WgradProblem pr[kMaxSeg];
   for (int i = 0; i < n_seg; ++i) pr[i] = WgradProblem{d, ns[i], hs[i], ws[i], xs[i], dys[i], scale, dw, db};
   return wgrad_launch(n_seg, pr, OSD_STREAM(stream));
+}
+
+static int pred_blocks(int n_seg, const int32_t* ns, const int32_t* hs, const int32_t* ws, int ppb) {
+  long long b = 0;
+  for (int i = 0; i < n_seg; ++i) b += cdiv((int)((long long)ns[i] * hs[i] * ws[i]), ppb);
+  return (int)b;
+}
+
+// pixels per workgroup: a multiple of the 32 pixels a workgroup reads per iteration, at least 256, and large enough that
+// all workgroups are resident at once (2 per CU: the kernel is VALU bound, a second round of a few workgroups costs a
+// whole round's time)
+static int pred_ppb(int n_seg, const int32_t* ns, const int32_t* hs, const int32_t* ws) {
+  long long tot = 0;
+  for (int i = 0; i < n_seg; ++i) tot += (long long)ns[i] * hs[i] * ws[i];
+  int ppb = (int)((tot + 479) / 480 + 31) / 32 * 32;
+  if (ppb < 256) ppb = 256;
+  while (pred_blocks(n_seg, ns, hs, ws, ppb) > 512) ppb += 32;
+  return ppb;
+}
+
+extern "C" int64_t osd_conv2d_wgrad_pred_workspace_bytes(int n_seg, const int32_t* ns, const int32_t* hs, const int32_t* ws,
+                                                         int cin) {
+  if (n_seg < 1 || !ns || !hs || !ws || cin <= 0) return 0;
+  const long long blocks = pred_blocks(n_seg, ns, hs, ws, pred_ppb(n_seg, ns, hs, ws));
+  return (int64_t)(blocks * ((cin + 255) / 256) * 36 * 256 * 4 + blocks * 16 * 4 + 256);
+}
+
+// The prediction convs' weight + bias gradient (3x3 / stride 1 / pad 1, Cout <= 4, Cin a multiple of 256) over n_seg FPN
+// levels: the read-once kernel + a fixed-order reduction of the per-workgroup partials (deterministic, no atomics)
+extern "C" int osd_conv2d_wgrad_pred(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys,
+                                     const int32_t* ns, const int32_t* hs, const int32_t* ws, float* dw, float* db,
+                                     void* workspace, void* stream) {
+  if (!d || !xs || !dys || !ns || !hs || !ws || !dw || !workspace || n_seg < 1 || n_seg > kPredLevels)
+    return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred: bad arguments (1..%d levels)", kPredLevels);
+  if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred: bad dtype");
+  if (d->cout < 1 || d->cout > 4 || d->r != 3 || d->s != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 ||
+      d->pad_w != 1 || d->cin % 256 != 0 || d->out_stride % 4 != 0)
+    return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad_pred: 3x3 / stride 1 / pad 1, cout <= 4, cin %% 256 == 0, dy rows of >= 4 channels");
+  PredWgradLevels L;
+  L.n_levels = 0;
+  for (int i = 0; i < n_seg; ++i)
+    if (ns[i] <= 0 || hs[i] <= 0 || ws[i] <= 0) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred: bad segment %d", i);
+  const int ppb = pred_ppb(n_seg, ns, hs, ws);
+  int blocks = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    const long long npix = (long long)ns[i] * hs[i] * ws[i];
+    if (npix <= 0 || npix > 0x7fffffffLL / d->cin || !xs[i] || !dys[i])
+      return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred: bad segment %d", i);
+    const int k = L.n_levels++;
+    L.x[k] = xs[i]; L.dy[k] = dys[i]; L.H[k] = hs[i]; L.W[k] = ws[i]; L.npix[k] = (int)npix; L.begin[k] = blocks;
+    blocks += cdiv((int)npix, ppb);
+  }
+  for (int k = L.n_levels; k < kPredLevels; ++k) { L.x[k] = L.x[0]; L.dy[k] = L.dy[0]; L.H[k] = 1; L.W[k] = 1; L.npix[k] = 0; L.begin[k] = 0x7fffffff; }
+  const int groups = d->cin / 256;
+  float* part = static_cast<float*>(workspace);
+  float* part_b = part + (size_t)blocks * groups * 36 * 256;
+  dim3 grid(blocks, groups);
+  hipStream_t st = OSD_STREAM(stream);
+  if (d->dtype == OSD_F32)
+    hipLaunchKernelGGL(pred_wgrad_kernel<float>, grid, dim3(256), 0, st, L, part, part_b, d->cin, d->out_stride, ppb);
+  else
+    hipLaunchKernelGGL(pred_wgrad_kernel<__bf16>, grid, dim3(256), 0, st, L, part, part_b, d->cin, d->out_stride, ppb);
+  int rc = osd_check_launch("pred_wgrad");
+  if (rc) return rc;
+  const int n = d->cout * 9 * d->cin + d->cout;
+  hipLaunchKernelGGL(pred_wgrad_reduce_kernel, dim3(cdiv(n, 256), 16), dim3(256), 0, st, (const float*)part, (const float*)part_b, dw, db,
+                     blocks, groups, d->cin, d->cout);
+  return osd_check_launch("pred_wgrad(reduce)");
 }
 
 // n_seg convs of IDENTICAL geometry (same x / dy shapes, different tensors and different weights: the repeated bottleneck

@@ -865,8 +865,9 @@ extern "C" int osd_proposals_sort_nms_hint(const float* keys, const float* boxes
                      col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, limit, need_full, 1, (const int*)counts,
                      depth_out);
   rc = osd_check_launch("nms_scan");
-  if (rc || limit >= max_count) return rc;
-  // phase 2, flagged images only: the whole order, then NMS over all of it
+  if (rc) return rc;
+  // phase 2, flagged images only: the whole order, then NMS over all of it (launched even when phase 1 was given the whole
+  // order: whether the exactly sorted head really covered every candidate is known on the device only)
   hipLaunchKernelGGL(rank_sort_gather_kernel<false>, dim3(cdiv(total, 256), n), dim3(256), 0, st, keys, boxes, total, max_count, topn, lt,
                      boxes_sorted, scores_sorted, idx_sorted, counts2, (const int*)need_full);
   rc = osd_check_launch("rank_sort_gather(full)");

@@ -629,6 +629,13 @@ def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, 
     hs = (C.c_int32 * k)(*[x.shape[1] for x, _ in pairs])
     ws = (C.c_int32 * k)(*[x.shape[2] for x, _ in pairs])
     st = _stream()
+    if (cout <= 4 and (r, s, stride, pad) == (3, 3, 1, 1) and x0.shape[-1] % 256 == 0 and scale is None and k <= 6
+            and not os.environ.get("OSD_NO_PRED_WGRAD")):
+        # prediction convs (2 / 4 output channels): the read-once kernel, not a 128-channel MFMA tile
+        need = int(_lib.load().osd_conv2d_wgrad_pred_workspace_bytes(k, ns, hs, ws, x0.shape[-1]))
+        wsp = torch.empty((need // 4 + 1,), device=x0.device, dtype=torch.float32)
+        _lib.call("osd_conv2d_wgrad_pred", C.byref(d), k, xs, dys, ns, hs, ws, _ptr(dw_packed), _ptr(db), _ptr(wsp), st)
+        return
 
     def launch(dw, dbias):
         _lib.call("osd_conv2d_wgrad_grouped", C.byref(d), k, xs, dys, ns, hs, ws, _ptr(scale), _ptr(dw), _ptr(dbias), st)
