@@ -447,8 +447,11 @@ def main_train(args, rank, world):
             for k, a in ops.ALGO_CACHE.items():
                 f.write("conv %s -> %d\n" % (k, a))
 
-    launch = ("eager, 6 streams (main chain: both backbones in lockstep + both towers per launch; 2 x weight gradients; "
-              "proposals; pooled-query gradient chain; exchange + update)")
+    launch = ("eager, 7 streams (target backbone + head chain; query backbone; 2 x weight gradients; proposals%s; "
+              "pooled-query gradient chain; exchange + update)%s%s"
+              % (" + second-stage box head" if args.second_stage else "",
+                 "; backbones in lockstep (one launch per layer pair)" if eng.lockstep else "",
+                 "; both towers per launch" if eng.towers_merged else ""))
     # the step's tail (last weight gradients, exchange, update, repack) overlaps the next step's frozen layers; an
     # explicit device synchronisation brackets the timed region as always (OSD_NO_DEFER_JOIN=1: A/B switch)
     eng.defer_join = not os.environ.get("OSD_NO_DEFER_JOIN")

@@ -319,11 +319,6 @@ int osd_roialign_bwd(const float* gy, const float* rois, float* gx, int b, int h
                      float spatial_scale, int ph, int pw, int sampling_ratio, void* stream);
 int osd_shot_mean_bwd(const float* gy, float* gx, int b, int shots, int c, void* stream);
 int osd_cast_f32(const float* src, void* dst, int64_t numel, int dtype, void* stream);
-/* backward of t = relu(GroupNorm(u)): du from dt; a, b = the forward's per-(image, channel) scale/shift
- * (osd_groupnorm_finalize); ws: (n*OSD_GN_SPLITS*groups*2 + n*groups*2) floats; dgamma/dbeta [c] fp32 accumulated */
-int osd_groupnorm_relu_bwd(const void* u, const void* dt, const float* a, const float* b, const float* gamma,
-                           const float* beta, float* ws, float* dgamma, float* dbeta, void* du, int n, int hw, int c,
-                           int groups, int dtype, void* stream);
 /* SGD with momentum over the flat fp32 master / gradient / momentum buffers in ONE launch (the reference uses
  * torch.optim.SGD with per-parameter groups, solver/build.py:8-26; same update rule: g += wd*p; buf = momentum*buf + g
  * (buf = g on the first step); p -= lr*lr_mult*buf).  table: device array of
@@ -335,7 +330,8 @@ int osd_sgd_momentum_multi(const void* table, const int32_t* block_entry, int n_
 /* GroupNorm + ReLU of one tower layer over ALL FPN levels (separate tensors sharing gamma/beta) in two launches, and
  * its backward in two launches: statistics per (level, image, slab), finalised inside the apply kernels.
  * xs/ys/us/dts/dus: HOST arrays of n_levels device pointers to [n][hw_l][c] tensors; hws: HOST array;
- * ab [n_levels][2][n][c] fp32 (written by fwd, read by bwd); ws: fwd n_levels*n*OSD_GN_SPLITS*groups*2 floats,
+ * ab [n_levels][4][n][c] fp32 (written by fwd, read by bwd: planes a, b with y = relu(a x + b), then xa, xb with
+ * xhat = xa x + xb, so that the backward pass never divides by gamma); ws: fwd n_levels*n*OSD_GN_SPLITS*groups*2 floats,
  * bwd n_levels*n*OSD_GN_SPLITS*(groups*2 + 2*c) floats (group sums + per-slab d gamma / d beta partials). */
 int osd_groupnorm_relu_fwd_levels(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
                                   const float* gamma, const float* beta, float* ab, float* ws, int n, int c, int groups,

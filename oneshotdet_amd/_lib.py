@@ -80,7 +80,6 @@ SIGNATURES = {
     "osd_roialign_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p]),
     "osd_shot_mean_bwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "osd_cast_f32": (_i, [_p, _p, _i64, _i, _p]),
-    "osd_groupnorm_relu_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "osd_fcos_loss_level": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _p, _p, _p, _p, _i, _p, _i, _p]),
     "osd_fcos_loss_levels": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p, _i, _p, _i, _p]),
     "osd_fcos_loss_finalize": (_i, [_p, _p, _i, _p]),

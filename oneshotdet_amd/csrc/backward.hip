@@ -455,134 +455,9 @@ template <typename T> __global__ void cast_from_f32_kernel(const float* __restri
 // ---- GroupNorm + ReLU backward.  Forward: z = u*a[n,c] + b[n,c], t = relu(z), a = gamma*rstd, b = beta - mean*a.
 // With dz = dt*(z>0), xhat = (u-mean)*rstd and m = hw*cpg:  du = rstd*(dz*gamma - S1/m - xhat*S2/m),
 // S1 = sum_g dz*gamma, S2 = sum_g dz*gamma*xhat; dgamma_c = sum dz*xhat, dbeta_c = sum dz.
-// pass 1: per (image, slab) partial S1,S2 per group (two-stage, deterministic) and per-channel dgamma/dbeta (atomics).
+// xhat comes from the saved per-(image, channel) normalisation xa = rstd, xb = -mean * rstd (never (z - beta) / gamma:
+// gamma == 0 is a legal parameter value).  The kernels (all FPN levels of a tower layer per launch) follow further down.
 constexpr int kGnSplits = 64;
-template <typename T>
-__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__ u, const T* __restrict__ dt,
-                                                           const float* __restrict__ a, const float* __restrict__ bb,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ ws, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int hw, int c, int groups) {
-  constexpr int E = Chunk<T>::N;
-  const int cch = c / E, lanes = 256 / cch;
-  const int img = blockIdx.y, split = blockIdx.x;
-  const int cc = threadIdx.x % cch, pl = threadIdx.x / cch;
-  const int per = (hw + kGnSplits - 1) / kGnSplits;
-  const int p0 = split * per, p1 = min(hw, p0 + per);
-  float av[E], bv[E], gm[E], bt[E], s1 = 0.f, s2 = 0.f, dg[E], db[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    av[e] = a[(size_t)img * c + cc * E + e];
-    bv[e] = bb[(size_t)img * c + cc * E + e];
-    gm[e] = gamma[cc * E + e];
-    bt[e] = beta[cc * E + e];
-    dg[e] = 0.f; db[e] = 0.f;
-  }
-  if (pl < lanes)
-    for (int p = p0 + pl; p < p1; p += lanes) {
-      Chunk<T> uu, gg;
-      const size_t off = ((size_t)img * hw + p) * c + cc * E;
-      uu.load(u + off);
-      gg.load(dt + off);
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const float z = fmaf(uu.v[e], av[e], bv[e]);
-        const float dz = z > 0.f ? gg.v[e] : 0.f;
-        const float xhat = (z - bt[e]) / gm[e];          // gamma != 0 (synthetic and trained GN scales are positive)
-        s1 += dz * gm[e];
-        s2 += dz * gm[e] * xhat;
-        dg[e] += dz * xhat;
-        db[e] += dz;
-      }
-    }
-  __shared__ float red[2][256];
-  red[0][threadIdx.x] = s1;
-  red[1][threadIdx.x] = s2;
-  __syncthreads();
-  const int cpg_chunks = (c / groups) / E > 0 ? (c / groups) / E : 1;
-  if (threadIdx.x < groups) {
-    const int g = threadIdx.x;
-    float t1 = 0.f, t2 = 0.f;
-    for (int l = 0; l < lanes; ++l)
-      for (int k = 0; k < cpg_chunks; ++k) {
-        const int idx = l * cch + g * cpg_chunks + k;
-        t1 += red[0][idx];
-        t2 += red[1][idx];
-      }
-    float* o = ws + (((size_t)img * kGnSplits + split) * groups + g) * 2;
-    o[0] = t1;
-    o[1] = t2;
-  }
-  // per-channel dgamma / dbeta: reduce over the block's pixel lanes in LDS first, then ONE atomic per channel and block
-  // (every workgroup adding 256 x lanes values to the same 256 addresses is an order of magnitude slower)
-  __syncthreads();
-  __shared__ float redc[2][256 * 8 / 8];   // [2][c <= 256]
-  for (int e = 0; e < E; ++e) {
-    __syncthreads();
-    red[0][threadIdx.x] = dg[e];
-    red[1][threadIdx.x] = db[e];
-    __syncthreads();
-    if (threadIdx.x < cch) {
-      float t1 = 0.f, t2 = 0.f;
-      for (int l = 0; l < lanes; ++l) {
-        t1 += red[0][l * cch + threadIdx.x];
-        t2 += red[1][l * cch + threadIdx.x];
-      }
-      redc[0][threadIdx.x * E + e] = t1;
-      redc[1][threadIdx.x * E + e] = t2;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < c) {
-    atomicAdd(dgamma + threadIdx.x, redc[0][threadIdx.x]);
-    atomicAdd(dbeta + threadIdx.x, redc[1][threadIdx.x]);
-  }
-}
-
-__global__ void gn_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ sums, int n, int groups) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * groups) return;
-  const int img = i / groups, g = i % groups;
-  float s1 = 0.f, s2 = 0.f;
-  for (int k = 0; k < kGnSplits; ++k) {
-    const float* o = ws + (((size_t)img * kGnSplits + k) * groups + g) * 2;
-    s1 += o[0];
-    s2 += o[1];
-  }
-  sums[i * 2] = s1;
-  sums[i * 2 + 1] = s2;
-}
-
-template <typename T>
-__global__ void gn_bwd_apply_kernel(const T* __restrict__ u, const T* __restrict__ dt, const float* __restrict__ a,
-                                    const float* __restrict__ bb, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ ws, T* __restrict__ du, int n, int hw, int c, int groups) {
-  constexpr int E = Chunk<T>::N;
-  const int cch = c / E;
-  const int cpg = c / groups;
-  const long long total = (long long)n * hw * cch;
-  const float inv_m = 1.f / ((float)hw * cpg);
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % cch);
-    const int img = (int)(i / ((long long)cch * hw));
-    const int g = (cc * E) / cpg;
-    const float s1 = ws[((size_t)img * groups + g) * 2], s2 = ws[((size_t)img * groups + g) * 2 + 1];
-    Chunk<T> uu, gg;
-    uu.load(u + i * E);
-    gg.load(dt + i * E);
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int ch = cc * E + e;
-      const float av = a[(size_t)img * c + ch], bv = bb[(size_t)img * c + ch], gm = gamma[ch];
-      const float z = fmaf(uu.v[e], av, bv);
-      const float dz = z > 0.f ? gg.v[e] : 0.f;
-      const float xhat = (z - beta[ch]) / gm;
-      const float rstd = av / gm;
-      uu.v[e] = rstd * (dz * gm - s1 * inv_m - xhat * s2 * inv_m);
-    }
-    uu.store(du + i * E);
-  }
-}
 
 // naive data gradient for strided convs (used for the two 3x3/2 convs P6, P7: M <= 1664 pixels):
 // dx[n,hi,wi,ci] = sum_{r,s,co : (hi+pad-r) % stride == 0 ...} dy[n,ho,wo,co] * w[co][r][s][ci]  (forward-packed weights)
@@ -835,29 +710,6 @@ extern "C" int osd_cast_f32(const float* src, void* dst, int64_t numel, int dtyp
   return osd_check_launch("cast_f32");
 }
 
-extern "C" int osd_groupnorm_relu_bwd(const void* u, const void* dt, const float* a, const float* b, const float* gamma,
-                                      const float* beta, float* ws, float* dgamma, float* dbeta, void* du, int n, int hw, int c,
-                                      int groups, int dtype, void* stream) {
-  const int e = dtype == OSD_BF16 ? 8 : 4;
-  if (!u || !dt || !a || !b || !gamma || !beta || !ws || !dgamma || !dbeta || !du)
-    return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_relu_bwd: null argument");
-  if (c % e != 0 || c / e > 256 || 256 % (c / e) != 0 || groups > 256 || c % groups != 0 || (c / groups) % e != 0)
-    return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_relu_bwd: unsupported shape c=%d groups=%d", c, groups);
-  dim3 grid(kGnSplits, n);
-  OSD_DISPATCH_DTYPE(dtype,
-      hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, grid, dim3(256), 0, OSD_STREAM(stream), (const float*)u, (const float*)dt, a, b, gamma, beta, ws, dgamma, dbeta, hw, c, groups),
-      hipLaunchKernelGGL(gn_bwd_stats_kernel<__bf16>, grid, dim3(256), 0, OSD_STREAM(stream), (const __bf16*)u, (const __bf16*)dt, a, b, gamma, beta, ws, dgamma, dbeta, hw, c, groups));
-  int rc = osd_check_launch("gn_bwd_stats");
-  if (rc) return rc;
-  float* sums = ws + (size_t)n * kGnSplits * groups * 2;     // reduced [n][groups][2] behind the partial slabs
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(cdiv(n * groups, 256)), dim3(256), 0, OSD_STREAM(stream), ws, sums, n, groups);
-  const int g = grid_for((long long)n * hw * (c / e), 256);
-  OSD_DISPATCH_DTYPE(dtype,
-      hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const float*)u, (const float*)dt, a, b, gamma, beta, sums, (float*)du, n, hw, c, groups),
-      hipLaunchKernelGGL(gn_bwd_apply_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const __bf16*)u, (const __bf16*)dt, a, b, gamma, beta, sums, (__bf16*)du, n, hw, c, groups));
-  return osd_check_launch("gn_bwd_apply");
-}
-
 extern "C" int osd_conv2d_dgrad_naive(const osd_conv_desc* d, const void* dy, const void* w_fwd_packed, const void* mask,
                                       const void* addend, void* dx, void* stream) {
   if (!d || !dy || !w_fwd_packed || !dx) return osd_fail(OSD_ERR_INVALID_ARG, "dgrad_naive: null argument");
@@ -963,9 +815,12 @@ __global__ void __launch_bounds__(256) gnl_apply_kernel(GnLevels L, const float*
     const float bv = beta[ch] - sm[0][g] * av;
     sa[ch] = av;
     sb[ch] = bv;
-    if (blockIdx.x == 0) {          // saved for the backward pass: ab[level][2][n][c]
-      ab[(((size_t)lvl * 2 + 0) * n + img) * c + ch] = av;
-      ab[(((size_t)lvl * 2 + 1) * n + img) * c + ch] = bv;
+    if (blockIdx.x == 0) {          // saved for the backward pass: ab[level][4][n][c] = a, b (y = a u + b) and the
+      // normalisation itself, xhat = xa u + xb, so that the backward pass never divides by gamma (gamma == 0 is legal)
+      ab[(((size_t)lvl * 4 + 0) * n + img) * c + ch] = av;
+      ab[(((size_t)lvl * 4 + 1) * n + img) * c + ch] = bv;
+      ab[(((size_t)lvl * 4 + 2) * n + img) * c + ch] = sm[1][g];
+      ab[(((size_t)lvl * 4 + 3) * n + img) * c + ch] = -sm[0][g] * sm[1][g];
     }
   }
   __syncthreads();
@@ -1014,18 +869,16 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
   const int cc = threadIdx.x % cch, pl = threadIdx.x / cch;
   const int per = (hw + kGnSplits - 1) / kGnSplits;
   const int p0 = split * per, p1 = min(hw, p0 + per);
-  float av[E], bv[E], gm[E], bt[E], s1 = 0.f, s2 = 0.f, dg[E], db[E];
+  float av[E], bv[E], gm[E], xa[E], xb[E], s1 = 0.f, s2 = 0.f, dg[E], db[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    av[e] = ab[(((size_t)lvl * 2 + 0) * n + img) * c + cc * E + e];
-    bv[e] = ab[(((size_t)lvl * 2 + 1) * n + img) * c + cc * E + e];
+    av[e] = ab[(((size_t)lvl * 4 + 0) * n + img) * c + cc * E + e];
+    bv[e] = ab[(((size_t)lvl * 4 + 1) * n + img) * c + cc * E + e];
+    xa[e] = ab[(((size_t)lvl * 4 + 2) * n + img) * c + cc * E + e];
+    xb[e] = ab[(((size_t)lvl * 4 + 3) * n + img) * c + cc * E + e];
     gm[e] = gamma[cc * E + e];
-    bt[e] = beta[cc * E + e];
     dg[e] = 0.f; db[e] = 0.f;
   }
-  float igm[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) igm[e] = 1.f / gm[e];
   if (pl < lanes) {
     constexpr int U = 4;          // pixels in flight per thread: 2 * U 16-byte loads issued before the arithmetic
     for (int p = p0 + pl; p < p1; p += U * lanes) {
@@ -1044,7 +897,7 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
         for (int e = 0; e < E; ++e) {
           const float z = fmaf(uu[k].v[e], av[e], bv[e]);
           const float dz = z > 0.f ? gg[k].v[e] : 0.f;
-          const float xhat = (z - bt[e]) * igm[e];
+          const float xhat = fmaf(uu[k].v[e], xa[e], xb[e]);
           s1 += dz * gm[e];
           s2 += dz * gm[e] * xhat;
           dg[e] += dz * xhat;
@@ -1143,16 +996,15 @@ __global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const fl
   const int cc = (int)((i0 + threadIdx.x) % cch);
   const int g = (cc * E) / cpg;
   const float c1 = ssum[0][g] * inv_m, c2 = ssum[1][g] * inv_m;
-  float av[E], bv[E], gm[E], bt[E], igm[E], rstd[E];
+  float av[E], bv[E], gm[E], xa[E], xb[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int ch = cc * E + e;
-    av[e] = ab[(((size_t)lvl * 2 + 0) * n + img) * c + ch];
-    bv[e] = ab[(((size_t)lvl * 2 + 1) * n + img) * c + ch];
+    av[e] = ab[(((size_t)lvl * 4 + 0) * n + img) * c + ch];
+    bv[e] = ab[(((size_t)lvl * 4 + 1) * n + img) * c + ch];
+    xa[e] = ab[(((size_t)lvl * 4 + 2) * n + img) * c + ch];      // rstd of the channel's group
+    xb[e] = ab[(((size_t)lvl * 4 + 3) * n + img) * c + ch];
     gm[e] = gamma[ch];
-    bt[e] = beta[ch];
-    igm[e] = 1.f / gm[e];
-    rstd[e] = av[e] * igm[e];
   }
   constexpr int U = 4;
   const size_t base = (size_t)img * hw * c;
@@ -1173,8 +1025,8 @@ __global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const fl
       for (int e = 0; e < E; ++e) {
         const float z = fmaf(uu[k].v[e], av[e], bv[e]);
         const float dz = z > 0.f ? gg[k].v[e] : 0.f;
-        const float xhat = (z - bt[e]) * igm[e];
-        uu[k].v[e] = rstd[e] * (dz * gm[e] - c1 - xhat * c2);
+        const float xhat = fmaf(uu[k].v[e], xa[e], xb[e]);
+        uu[k].v[e] = xa[e] * (dz * gm[e] - c1 - xhat * c2);
       }
       uu[k].store(du + base + ik * E);
     }

@@ -826,26 +826,13 @@ def cast_f32(x, dtype):
 
 
 def groupnorm_relu_train(x, gamma, beta, groups=32, eps=1e-5):
-    """relu(GroupNorm(x)) keeping x and the per-(image, channel) scale/shift for the backward pass."""
-    n, h, w, c = x.shape
-    ws = torch.empty((n, GN_SPLITS, groups, 2), device=x.device, dtype=torch.float32)
-    ab = torch.empty((2, n, c), device=x.device, dtype=torch.float32)
-    st = _stream()
-    _lib.call("osd_groupnorm_stats", _ptr(x), _ptr(ws), n, h * w, c, groups, _dt(x), st)
-    _lib.call("osd_groupnorm_finalize", _ptr(ws), _ptr(gamma), _ptr(beta), _ptr(ab[0]), _ptr(ab[1]), n, h * w, c, groups,
-              float(eps), st)
-    out = torch.empty_like(x)
-    _lib.call("osd_groupnorm_relu_apply", _ptr(x), _ptr(ab[0]), _ptr(ab[1]), _ptr(out), n, h * w, c, _dt(x), st)
-    return out, ab
+    """relu(GroupNorm(x)) of ONE tensor keeping what the backward pass needs: the one-level case of groupnorm_relu_levels."""
+    ys, ab = groupnorm_relu_levels([x], gamma, beta, groups, eps)
+    return ys[0], ab
 
 
 def groupnorm_relu_bwd(u, dt, ab, gamma, beta, dgamma, dbeta, groups=32):
-    n, h, w, c = u.shape
-    ws = torch.empty((n * GN_SPLITS * groups * 2 + n * groups * 2,), device=u.device, dtype=torch.float32)
-    du = torch.empty_like(u)
-    _lib.call("osd_groupnorm_relu_bwd", _ptr(u), _ptr(dt), _ptr(ab[0]), _ptr(ab[1]), _ptr(gamma), _ptr(beta), _ptr(ws),
-              _ptr(dgamma), _ptr(dbeta), _ptr(du), n, h * w, c, groups, _dt(u), _stream())
-    return du
+    return groupnorm_relu_bwd_levels([u], [dt], ab, gamma, beta, dgamma, dbeta, groups)[0]
 
 
 def fcos_loss_level(phase, cls_ctr, reg, gt_boxes, gt_count, stride, size_lo, size_hi, radius, gamma, alpha, scale_dev,
@@ -882,12 +869,12 @@ def fcos_loss_levels(phase, head_out, gt_boxes, gt_count, strides, size_ranges, 
 
 def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5):
     """relu(GroupNorm(x_l)) for the FPN levels of one tower layer in two launches.  Returns (ys, ab) with
-    ab [L][2][N][C] fp32 (per-image scale/shift, kept for the backward pass)."""
+    ab [L][4][N][C] fp32 (per-image scale/shift a, b and the normalisation xa, xb, kept for the backward pass)."""
     n, _, _, c = xs[0].shape
     k = len(xs)
     dev = xs[0].device
     ys = [torch.empty_like(x) for x in xs]
-    ab = torch.empty((k, 2, n, c), device=dev, dtype=torch.float32)
+    ab = torch.empty((k, 4, n, c), device=dev, dtype=torch.float32)
     ws = torch.empty((k * n * GN_SPLITS * groups * 2,), device=dev, dtype=torch.float32)
     hws = (C.c_int32 * k)(*[x.shape[1] * x.shape[2] for x in xs])
     _lib.call("osd_groupnorm_relu_fwd_levels", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),

@@ -490,6 +490,38 @@ def test_conv_wgrad_batched_equals_one_launch_per_conv(dt):
                 torch.testing.assert_close(db, rb, rtol=1e-3, atol=1e-3 * float(rb.abs().max()))
 
 
+def test_groupnorm_relu_backward_with_zero_negative_and_tiny_scales():
+    """gamma == 0, gamma < 0 and |gamma| ~ 1e-6 are legal GroupNorm parameters (nothing in the reference's optimiser keeps
+    them positive): the backward pass takes xhat from the saved normalisation, never from (z - beta) / gamma, so the
+    gradients stay finite and equal to autograd's — including d gamma of the channels whose gamma is exactly zero."""
+    from oneshotdet_amd import ops
+    g = rnd(256, seed=3) * 0.7
+    g[::7] = 0.0
+    g[1::11] = 1e-6
+    g[2::13] = -0.4
+    g.requires_grad_(True)
+    b = rnd(256, seed=4).requires_grad_(True)
+    sizes = [(25, 32), (7, 8)]
+    xs, dys = [], []
+    for i, (h, w) in enumerate(sizes):
+        x = (rnd(2, 256, h, w, seed=10 + i, scale=2) + 0.3).requires_grad_(True)
+        dy = rnd(2, 256, h, w, seed=20 + i)
+        (F.relu(F.group_norm(x, 32, g, b, eps=1e-5)) * dy).sum().backward()
+        xs.append(x); dys.append(dy)
+    xx = [to_nhwc(x.detach(), torch.float32) for x in xs]
+    _, ab = ops.groupnorm_relu_levels(xx, g.detach().cuda(), b.detach().cuda(), 32, 1e-5)
+    dg, db = torch.zeros(256, device="cuda"), torch.zeros(256, device="cuda")
+    dus = ops.groupnorm_relu_bwd_levels(xx, [to_nhwc(d, torch.float32) for d in dys], ab, g.detach().cuda(), b.detach().cuda(),
+                                        dg, db, 32)
+    for x, du in zip(xs, dus):
+        got = du.cpu().permute(0, 3, 1, 2)
+        assert torch.isfinite(got).all()
+        assert (got - x.grad).abs().max() <= 2e-4 * x.grad.abs().max()
+    assert (dg.cpu() - g.grad).abs().max() <= 2e-4 * g.grad.abs().max()
+    assert g.grad[::7].abs().max() > 0 and (dg.cpu()[::7] - g.grad[::7]).abs().max() <= 2e-4 * g.grad.abs().max()
+    assert (db.cpu() - b.grad).abs().max() <= 2e-4 * b.grad.abs().max()
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("n", [1, 2])
 def test_groupnorm_relu_levels_forward_backward_at_fpn_sizes(n, dt):
