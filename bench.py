@@ -443,7 +443,7 @@ def main_train(args, rank, world):
     if os.environ.get("OSD_DUMP_ALGOS") and rank == 0:
         with open(os.environ["OSD_DUMP_ALGOS"], "w") as f:
             for k, a in ops.WGRAD_ALGO_CACHE.items():
-                f.write("wgrad %s -> variant %d target_code %d\n" % (k, (a - 1) & 7, (a - 1) >> 3))
+                f.write("wgrad %s -> variant %d target_code %d\n" % (k, (a - 1) & 15, (a - 1) >> 4))
             for k, a in ops.ALGO_CACHE.items():
                 f.write("conv %s -> %d\n" % (k, a))
 

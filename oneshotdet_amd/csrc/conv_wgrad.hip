@@ -42,6 +42,13 @@ struct WgradParams {
   int n_seg;
 };
 
+// fp32 add into GLOBAL memory.  The dW / db pointers come out of the kernarg table as integers, so plain atomicAdd sees a
+// generic pointer and emits flat_atomic_add_f32 (aperture check, counted on both lgkmcnt and vmcnt)
+typedef __attribute__((address_space(1))) float wg_gfloat;
+__device__ __forceinline__ void wg_atomic_add(float* ptr, float v) {
+  (void)__hip_atomic_fetch_add((wg_gfloat*)ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ void wg_dma16(const void* gsrc, unsigned lds_dst) {
@@ -62,7 +69,7 @@ template <typename T> __device__ __forceinline__ int wg_swz(int row) {
 // (2 x 2, 64 x 64 channels each) or 2 x 2 on 8 waves (2 x 4: 128 co x 64 ci each — half the operand bytes per MFMA and
 // twice the MFMAs per barrier).  LDS stage = [dY sub-tiles | X sub-tiles], each [BKP pixels][256 B].
 template <typename T, int BKP, int NST, int WCO, int WCI, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN) conv_wgrad_kernel(WgradParams gp) {
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3) ? 2 : 1) conv_wgrad_kernel(WgradParams gp) {
   constexpr int NW = WM * WN;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int TWS = 256 / (int)sizeof(T);   // channels per sub-tile row (256 bytes)
@@ -316,7 +323,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_wgrad_kernel(WgradParams gp
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
 
-  if (do_bias && co0 + tid < p.Cout) atomicAdd(p.db + co0 + tid, bsum);
+  if (do_bias && co0 + tid < p.Cout) wg_atomic_add(p.db + co0 + tid, bsum);
 #ifdef OSD_WG_NO_ATOMICS
   if (acc[0][0][0] != 12345.678f) return;
 #endif
@@ -341,7 +348,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_wgrad_kernel(WgradParams gp
       for (int e = 0; e < 4; ++e) {
         float* row = base + (size_t)(i * 16 + e) * p.Ktot;
 #pragma unroll
-        for (int j = 0; j < TB; ++j) atomicAdd(row + j * 16, acc[i][j][e] * scv[i][e]);
+        for (int j = 0; j < TB; ++j) wg_atomic_add(row + j * 16, acc[i][j][e] * scv[i][e]);
       }
     return;
   }
@@ -357,7 +364,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_wgrad_kernel(WgradParams gp
         const int co = co_w + i * 16 + e;
         if (co < p.Cout) {
           const float sc = p.scale ? p.scale[co] : 1.f;
-          atomicAdd(dw + (size_t)co * p.Ktot + tap * p.Cin + ci, acc[i][j][e] * sc);
+          wg_atomic_add(dw + (size_t)co * p.Ktot + tap * p.Cin + ci, acc[i][j][e] * sc);
         }
       }
     }
@@ -591,9 +598,11 @@ struct WgradProblem {      // host-side description of one segment
   const void* x; const void* dy; const float* scale; float* dw; float* db;
 };
 
-// dtype and algo (0 = default, else 1 + variant + 8 * target_code) come from the first problem's descriptor.
+// dtype and algo (0 = default, else 1 + variant + 16 * target_code) come from the first problem's descriptor.
 // variant 0..3: 128 x 128 channel tile on 4 waves, pixels per stage x ring depth = 32x3 / 64x2 / 32x4 / 64x3 (bf16;
-// fp32 always 32x3); variant 4: 256 x 256 channel tile on 8 waves, 32 px x 3 stages (bf16)
+// fp32 always 32x3); variants 4..7: 256-wide tiles on 8 waves; 8, 9: 256 x 256 with a 5- / 4-deep ring of 32-pixel stages
+// (the whole 160 KB / 128 KB of LDS as prefetch distance: one workgroup per CU has nothing else to hide the operand
+// latency behind); 10..12: 128 x 256 / 256 x 128 tiles on FOUR waves (64 x 128 per wave, 72 KB: two workgroups per CU)
 static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   if (n_seg < 1 || n_seg > kMaxSeg) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: 1..%d segments", kMaxSeg);
   const osd_conv_desc* d0 = pr[0].d;
@@ -607,9 +616,9 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   int target = env_target, variant = env_variant;
   if (d0->algo > 0) {
     const int a = d0->algo - 1;
-    if (a >= 64) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d0->algo);
-    variant = a & 7;
-    target = kTargets[a >> 3];
+    if (a >= 128 || (a & 15) > 12) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d0->algo);
+    variant = a & 15;
+    target = kTargets[a >> 4];
   }
   // exact-fp32 MFMA runs at 1/16 of the bf16 rate and its channel tile is 64 wide (4x the output tiles): a workgroup's
   // fixed costs and its atomic epilogue weigh 16x less, so the same codes mean 8x the workgroups (finer pixel splits
@@ -618,8 +627,8 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   // channel tile (co x ci) in 256-byte sub-tiles: variants 4 / 5 = 2 x 2, 6 = 1 x 2, 7 = 2 x 1 (bf16, 8 waves); else 1 x 1
   const bool bf = d0->dtype == OSD_BF16;
   if (!bf && variant != 0) variant = 0;
-  const int sub_co = bf && (variant == 4 || variant == 5 || variant == 7) ? 2 : 1;
-  const int sub_ci = bf && (variant == 4 || variant == 5 || variant == 6) ? 2 : 1;
+  const int sub_co = bf && (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 9 || variant == 11) ? 2 : 1;
+  const int sub_ci = bf && (variant == 4 || variant == 5 || variant == 6 || variant == 8 || variant == 9 || variant == 10 || variant == 12) ? 2 : 1;
   const int tw = bf ? 128 : 64;
   const int epc = d0->dtype == OSD_BF16 ? 8 : 4;
   WgradParams p;
@@ -682,6 +691,11 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
       case 5: OSD_WG_LAUNCH(__bf16, 64, 2, 2, 2, 4); break;          // 256 co x 256 ci
       case 6: OSD_WG_LAUNCH2(__bf16, 64, 2, 1, 2, 2, 4); break;      // 128 co x 256 ci
       case 7: OSD_WG_LAUNCH2(__bf16, 64, 2, 2, 1, 4, 2); break;      // 256 co x 128 ci
+      case 8: OSD_WG_LAUNCH(__bf16, 32, 5, 2, 2, 4); break;          // 256 x 256, 5 x 32 KB: all of the LDS
+      case 9: OSD_WG_LAUNCH(__bf16, 32, 4, 2, 2, 4); break;          // 256 x 256, 4 x 32 KB
+      case 10: OSD_WG_LAUNCH2(__bf16, 32, 3, 1, 2, 2, 2); break;     // 128 co x 256 ci on 4 waves, 3 x 24 KB
+      case 11: OSD_WG_LAUNCH2(__bf16, 32, 3, 2, 1, 2, 2); break;     // 256 co x 128 ci on 4 waves
+      case 12: OSD_WG_LAUNCH2(__bf16, 32, 6, 1, 2, 2, 2); break;     // 128 co x 256 ci on 4 waves, 6 x 24 KB
       default: OSD_WG_LAUNCH(__bf16, 32, 3, 1, 2, 2); break;
     }
   }

@@ -566,16 +566,17 @@ WGRAD_ALGO_CACHE = {}
 
 
 def wgrad_algo_candidates(dtype, cout=0, cin=0):
-    """osd_conv2d_wgrad's algo field = 1 + variant + 8 * split-target code.  Variants 0..3: 128 x 128 channel tile with
-    different stage shapes (bf16; fp32 has one); variant 4: 256 x 256 channel tile on 8 waves (bf16, wide layers)."""
+    """osd_conv2d_wgrad's algo field = 1 + variant + 16 * split-target code.  Variants 0..3: 128 x 128 channel tile with
+    different stage shapes (bf16; fp32 has one); 4..9: 256-wide channel tiles on 8 waves (bf16, wide layers; 8 / 9 with
+    the deepest rings the LDS holds); 10..12: 128 x 256 / 256 x 128 on four waves."""
     variants = [0, 1, 2, 3] if dtype == OSD_BF16 else [0]
     if dtype == OSD_BF16 and cout >= 256 and cin >= 256:
-        variants += [4, 5]
+        variants += [4, 5, 8, 9]
     if dtype == OSD_BF16 and cin >= 256:
-        variants.append(6)          # 128 co x 256 ci
+        variants += [6, 10, 12]     # 128 co x 256 ci
     if dtype == OSD_BF16 and cout >= 256:
-        variants.append(7)          # 256 co x 128 ci
-    return [1 + v + 8 * t for t in (0, 1, 2, 3, 4, 5, 6, 7) for v in variants]
+        variants += [7, 11]         # 256 co x 128 ci
+    return [1 + v + 16 * t for t in (0, 1, 2, 3, 4, 5, 6, 7) for v in variants]
 
 
 def _tune_wgrad(key, d, launch, dw, db):

@@ -449,14 +449,14 @@ def test_conv_wgrad_every_algorithm_matches_autograd(case):
     ref, refb = wt.grad.permute(0, 2, 3, 1), b.grad
     xx, dd = to_nhwc(x, torch.bfloat16), to_nhwc(dy, torch.bfloat16)
     cands = ops.wgrad_algo_candidates(ops.OSD_BF16, cout, cin)
-    assert {(a - 1) & 7 for a in cands} >= {0, 1, 2, 3, 4, 5, 6, 7}
+    assert {(a - 1) & 15 for a in cands} >= set(range(13))
     for algo in cands:
         dw, db = torch.zeros(cout, k, k, cin, device="cuda"), torch.zeros(cout, device="cuda")
         ops.conv2d_wgrad(xx, dd, dw, k, k, s, p, cout, db=db, algo=algo)
         assert (dw.cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item(), algo
         assert (db.cpu() - refb).abs().max().item() <= 2e-2 * refb.abs().max().item(), algo
     if s == 1:      # grouped: the same tensors as two "levels" -> twice the gradient
-        for algo in (1 + 4, 1 + 4 + 8 * 4, 1 + 0, 1 + 5, 1 + 6 + 8 * 2, 1 + 7):
+        for algo in (1 + 4, 1 + 4 + 16 * 4, 1 + 0, 1 + 5, 1 + 6 + 16 * 2, 1 + 7, 1 + 8, 1 + 10 + 16, 1 + 11, 1 + 12):
             dw = torch.zeros(cout, k, k, cin, device="cuda")
             ops.conv2d_wgrad_grouped([(xx, dd), (xx, dd)], dw, k, k, 1, p, cout, algo=algo)
             assert (dw.cpu() - 2 * ref).abs().max().item() <= 2e-2 * 2 * ref.abs().max().item(), algo
@@ -478,7 +478,7 @@ def test_conv_wgrad_batched_equals_one_launch_per_conv(dt):
         ops.conv2d_wgrad(x, dy, rw, k, k, stride, pad, cout, scale=scale, db=rb)
         items.append((x, dy, dw, scale, db))
         refs.append((rw, rb))
-    for algo in (None, 1 + 0 + 8 * 3, 1 + 1 + 8 * 0):
+    for algo in (None, 1 + 0 + 16 * 3, 1 + 1 + 16 * 0):
         for it in items:
             it[2].zero_()
             if it[4] is not None:
@@ -661,7 +661,7 @@ def test_conv_wgrad_multi_mixes_shared_and_own_weights():
             dy = to_nhwc(rnd(n, cout, h, w, seed=100 * conv + 50 + i), torch.bfloat16)
             items.append((x, dy, dws[conv], None, dbs[conv]))
             ops.conv2d_wgrad(x, dy, refs[conv], 3, 3, 1, 1, cout, db=refb[conv])
-    for algo in (None, 1 + 0 + 8 * 2, 1 + 4 + 8 * 0):
+    for algo in (None, 1 + 0 + 16 * 2, 1 + 4 + 16 * 0):
         for t in dws + dbs:
             t.zero_()
         ops.conv2d_wgrad_multi(items, 3, 3, 1, 1, cout, algo=algo)
@@ -689,7 +689,7 @@ def test_conv_wgrad_mixed_geometries_in_one_launch(dt):
         ops.conv2d_wgrad(x, dy, rw, k, k, stride, pad, cout, scale=scale, db=rb)
         items.append((x, dy, dw, scale, db, k, k, stride, pad, cout))
         refs.append((rw, rb))
-    algos = (None, 1 + 0 + 8 * 3, 1 + 0 + 8 * 4) + ((1 + 1 + 8 * 0, 1 + 4 + 8 * 1) if dt == "bf16" else ())
+    algos = (None, 1 + 0 + 16 * 3, 1 + 0 + 16 * 4) + ((1 + 1 + 16 * 0, 1 + 4 + 16 * 1, 1 + 8, 1 + 10) if dt == "bf16" else ())
     for algo in algos:
         for it in items:
             it[2].zero_()

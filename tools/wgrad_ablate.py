@@ -9,7 +9,7 @@ for (n, h, w, cin, cout, k, s, p) in [(8, 100, 128, 256, 256, 3, 1, 1), (8, 50, 
     dw = torch.zeros(cout, k, k, cin, device="cuda")
     fl = 2.0 * n * ho * wo * cout * cin * k * k
     out = []
-    for algo in (1 + 0 + 8 * 0, 1 + 0 + 8 * 4, 1 + 4 + 8 * 1, 1 + 4 + 8 * 2, 1 + 4 + 8 * 0, 1 + 1 + 8 * 0, 1 + 3 + 8 * 0):
+    for algo in (1 + 0 + 16 * 0, 1 + 0 + 16 * 4, 1 + 4 + 16 * 1, 1 + 4 + 16 * 2, 1 + 4 + 16 * 0, 1 + 1 + 16 * 0, 1 + 3 + 16 * 0):
         ops.conv2d_wgrad(x, dy, dw, k, k, s, p, cout, algo=algo)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -12,7 +12,7 @@ for (n, h, w, cin, cout, k, s, p) in shapes:
     dw = torch.zeros(cout, k, k, cin, device="cuda")
     fl = 2.0 * n * ho * wo * cout * cin * k * k
     res = []
-    for algo in ops.wgrad_algo_candidates(ops.OSD_BF16, cout, cin) + [1 + 4 + 8 * 5, 1 + 4 + 8 * 6]:
+    for algo in ops.wgrad_algo_candidates(ops.OSD_BF16, cout, cin) + [1 + 4 + 16 * 5, 1 + 4 + 16 * 6]:
         ops.conv2d_wgrad(x, dy, dw, k, k, s, p, cout, algo=algo)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -30,7 +30,7 @@ def time_it(fn, reps=5):
 def sweep(name, launch, flops, cout, cin):
     best = {}
     for algo in ops.wgrad_algo_candidates(ops.OSD_BF16, cout, cin):
-        v, t = (algo - 1) & 7, (algo - 1) >> 3
+        v, t = (algo - 1) & 15, (algo - 1) >> 4
         try:
             us = time_it(lambda: launch(algo))
         except Exception as e:
