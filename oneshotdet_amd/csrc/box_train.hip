@@ -71,35 +71,100 @@ __global__ void __launch_bounds__(1024) box_match_sample_kernel(
   __syncthreads();
   const int num_pos = min(tot[0], num_pos_max);
   const int num_neg = min(tot[1], batch - num_pos);
-  // rank inside the own class by (key, index); selected: rank below the class quota (flags reuse keyv[] afterwards)
-  int sel_local[kMaxProps / 1024];
-  int k = 0;
-  for (int i = t; i < P; i += 1024, ++k) {
-    const int l = lab[i];
-    int s = 0;
-    if (l >= 0) {
-      const bool pos = l >= 1;
-      const float ki = keyv[i];
-      int r = 0;
-      for (int j = 0; j < cnt; ++j) {
-        const int lj = lab[j];
-        const bool same = pos ? (lj >= 1) : (lj == 0);
-        const float kj = keyv[j];
-        r += (same && (kj < ki || (kj == ki && j < i))) ? 1 : 0;
-      }
-      s = r < (pos ? num_pos : num_neg);
+  // The class quota takes the elements with the smallest (key, index).  Instead of ranking every element against every
+  // other one (P^2 / 1024 compares per thread: 2.2 ms per step at 4000 proposals), find the quota-th smallest key of either
+  // class by building its order-preserving bit pattern from the top bit down (32 counting rounds over the thread's own
+  // <= 8 elements), then take everything below it and, in index order, as many of the elements EQUAL to it as still fit.
+  constexpr int kPer = kMaxProps / 1024;
+  unsigned uk[kPer];
+  int cls[kPer];                           // 0 positive, 1 negative, 2 neither
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int i = t + k * 1024;
+    cls[k] = 2;
+    uk[k] = 0u;
+    if (i < P) {
+      const int l = lab[i];
+      cls[k] = l >= 1 ? 0 : (l == 0 ? 1 : 2);
+      const unsigned bits = __float_as_uint(keyv[i]);
+      uk[k] = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);      // float order -> unsigned order
     }
-    sel_local[k] = s;
   }
-  __syncthreads();                       // everyone has finished reading lab[] / keyv[]
-  k = 0;
-  for (int i = t; i < P; i += 1024, ++k) keyv[i] = sel_local[k] ? 1.f : 0.f;
+  __shared__ int cntb[3][2];             // rotating: a round adds into its buffer and clears the next round's (last read two rounds ago)
+  unsigned T[2] = {0u, 0u};                // quota-th smallest key (mapped) of the positives / negatives
+  const int quota[2] = {num_pos, num_neg};
+  if (t < 6) cntb[t >> 1][t & 1] = 0;
   __syncthreads();
-  // ordered compaction: thread t owns a contiguous chunk
+  for (int bit = 31; bit >= 0; --bit) {
+    const int buf = bit % 3, clr = (bit + 2) % 3;      // bit counts down: the NEXT round uses (bit - 1) % 3 == (bit + 2) % 3
+    const unsigned c0 = T[0] | (1u << bit), c1 = T[1] | (1u << bit);
+    int n0 = 0, n1 = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      n0 += (cls[k] == 0 && uk[k] < c0) ? 1 : 0;
+      n1 += (cls[k] == 1 && uk[k] < c1) ? 1 : 0;
+    }
+    int packed = n0 | (n1 << 16);          // <= 8 per thread, <= 512 per wave: no carry between the halves
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) packed += __shfl_xor(packed, d, 64);
+    if ((t & 63) == 0) { atomicAdd(&cntb[buf][0], packed & 0xffff); atomicAdd(&cntb[buf][1], packed >> 16); }
+    if (t < 2) cntb[clr][t] = 0;           // read for the last time two rounds ago, i.e. before the previous barrier
+    __syncthreads();
+    if (cntb[buf][0] < quota[0]) T[0] = c0;           // fewer than quota keys below the candidate: the answer has this bit
+    if (cntb[buf][1] < quota[1]) T[1] = c1;
+  }
+  __syncthreads();
+  // flags into keyv[]: 1 = below the threshold key (selected), 2 + class = equal to it (resolved in index order below)
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int i = t + k * 1024;
+    if (i < P) {
+      float f = 0.f;
+      if (cls[k] < 2 && quota[cls[k]] > 0) {
+        if (uk[k] < T[cls[k]]) f = 1.f;
+        else if (uk[k] == T[cls[k]]) f = 2.f + (float)cls[k];
+      }
+      keyv[i] = f;
+    }
+  }
+  __syncthreads();
+  // thread t owns a contiguous chunk: counts of (sure, tied positive, tied negative) -> exclusive scans over the threads
   const int per = (P + 1023) / 1024;
   const int lo = min(t * per, P), hi = min(lo + per, P);
+  __shared__ int part2[1024];
+  __shared__ int sure[2];
+  if (t < 2) sure[t] = 0;
+  int ns0 = 0, ns1 = 0, ne0 = 0, ne1 = 0;
+  for (int i = lo; i < hi; ++i) {
+    const float f = keyv[i];
+    const bool pos = lab[i] >= 1;
+    ns0 += (f == 1.f && pos); ns1 += (f == 1.f && !pos);
+    ne0 += f == 2.f; ne1 += f == 3.f;
+  }
+  part[t] = ne0;
+  part2[t] = ne1;
+  __syncthreads();
+  if (ns0) atomicAdd(&sure[0], ns0);
+  if (ns1) atomicAdd(&sure[1], ns1);
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = t >= d ? part[t - d] : 0, v2 = t >= d ? part2[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    part2[t] += v2;
+    __syncthreads();
+  }
+  int e0 = part[t] - ne0, e1 = part2[t] - ne1;         // tied elements of either class before this chunk
+  const int room0 = num_pos - sure[0], room1 = num_neg - sure[1];
+  __syncthreads();
   int c = 0;
-  for (int i = lo; i < hi; ++i) c += keyv[i] != 0.f;
+  for (int i = lo; i < hi; ++i) {
+    const float f = keyv[i];
+    float s = f == 1.f ? 1.f : 0.f;
+    if (f == 2.f) { s = e0 < room0 ? 1.f : 0.f; ++e0; }
+    if (f == 3.f) { s = e1 < room1 ? 1.f : 0.f; ++e1; }
+    keyv[i] = s;
+    c += s != 0.f;
+  }
   part[t] = c;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {
@@ -304,15 +369,35 @@ __global__ __launch_bounds__(256) void gn_act_rois_bwd_kernel(const T* __restric
   pp[c + 2 * t] = db0; pp[c + 2 * t + 1] = db1;
 }
 
-// dgamma[ch] += sum_samples part[s][0][ch]; dbeta likewise (fixed order: deterministic)
-__global__ void gn_rois_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                            float* __restrict__ dbeta, int n_samples, int c) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= 2 * c) return;
-  float s = 0.f;
-  for (int i = 0; i < n_samples; ++i) s += part[(size_t)i * 2 * c + ch];
-  if (ch < c) dgamma[ch] += s;
-  else dbeta[ch - c] += s;
+// dgamma[ch] += sum_samples part[s][0][ch]; dbeta likewise.  32 channels x 32 sample lanes per workgroup: a lane adds the
+// samples s = lane, lane + 32, ... in order, the 32 lane sums are folded in a fixed tree (deterministic).  (One thread per
+// channel walking all 1,024 samples was a 330 us serial chain of dependent strided loads, three times per step.)
+__global__ void __launch_bounds__(1024) gn_rois_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, int n_samples, int c) {
+  __shared__ float red[32][33];
+  const int chl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + chl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (ch < 2 * c) {
+    int i = sl;
+    for (; i + 96 < n_samples; i += 128) {          // four independent loads in flight
+      s0 += part[(size_t)i * 2 * c + ch];
+      s1 += part[(size_t)(i + 32) * 2 * c + ch];
+      s2 += part[(size_t)(i + 64) * 2 * c + ch];
+      s3 += part[(size_t)(i + 96) * 2 * c + ch];
+    }
+    for (; i < n_samples; i += 32) s0 += part[(size_t)i * 2 * c + ch];
+  }
+  red[sl][chl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  for (int d = 16; d >= 1; d >>= 1) {
+    if (sl < d) red[sl][chl] += red[sl + d][chl];
+    __syncthreads();
+  }
+  if (sl == 0 && ch < 2 * c) {
+    if (ch < c) dgamma[ch] += red[0][chl];
+    else dbeta[ch - c] += red[0][chl];
+  }
 }
 
 // out[img][e] = sum over the ROIs r < rois_per_image of x[img * rois_per_image + r][e]   (e over hw * c elements)
@@ -336,7 +421,11 @@ struct PoolGradLevels {
 };
 
 // Backward of roi_pool_levels_kernel (box_head.hip): the same level routing and sample geometry; every sample's
-// gradient dy / count goes to its four taps with the bilinear weights (ROIAlign_cuda.cu:178-254), fp32 atomics.
+// gradient dy / count goes to its four taps with the bilinear weights (ROIAlign_cuda.cu:178-254), fp32 atomics: 784 per ROI
+// and channel, 0.8 GB of memory-side atomic traffic per step, 0.72 ms = the rate those run at.  Measured alternatives, both
+// slower (tools/roi_bwd_bench.py): summing a ROI's footprint in LDS first (helps only ROIs narrower than ~14 map pixels; the
+// 64 KB LDS image costs the direct path its occupancy: 0.99 ms) and a per-tile gather without atomics (one thread per
+// channel walking the image's ROIs: a chain of dependent dy loads per contributing cell, 0.9-3.8 ms).
 template <typename T>
 __global__ __launch_bounds__(256) void roi_pool_levels_bwd_kernel(PoolGradLevels lv, const float* __restrict__ boxes,
                                                                   const int32_t* __restrict__ counts, const T* __restrict__ dy,
@@ -456,7 +545,7 @@ extern "C" int osd_groupnorm_act_rois_bwd(const void* x, const void* addend, con
     return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_act_rois_bwd: bad dtype");
   int rc = osd_check_launch("groupnorm_act_rois_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_rois_param_reduce_kernel, dim3(cdiv(2 * c, 256)), dim3(256), 0, st, (const float*)part_ws, dgamma, dbeta,
+  hipLaunchKernelGGL(gn_rois_param_reduce_kernel, dim3(cdiv(2 * c, 32)), dim3(1024), 0, st, (const float*)part_ws, dgamma, dbeta,
                      n_samples, c);
   return osd_check_launch("groupnorm_act_rois_bwd(reduce)");
 }

@@ -83,6 +83,40 @@ def test_match_sample_edge_cases():
     assert si[0, :4].tolist() == idx.tolist()
 
 
+@pytest.mark.parametrize("keys_kind", ["constant", "few_values", "negative", "random_large"])
+def test_match_sample_ties_and_key_order(keys_kind):
+    """The sampler keeps the quota smallest (key, index) pairs of either class.  Equal keys must fall back to the lower index
+    exactly as a stable argsort does (oracle: box_train_ref.sample), also when EVERY key is equal and at the quota boundary;
+    negative keys order as floats; 4,000 proposals (the training size) with random keys agree element for element."""
+    from oneshotdet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    P = 4000 if keys_kind == "random_large" else 700
+    gt = torch.tensor([[[100., 100., 300., 320.], [400., 50., 640., 200.]]])
+    props = torch.rand(1, P, 4, generator=g) * 300
+    props[..., 2:] += props[..., :2] + 20
+    near = torch.rand(P, generator=g) < 0.2                 # every fifth proposal is a jittered ground-truth box: positives
+    which = (torch.rand(P, generator=g) < 0.5).long()
+    props[0, near] = gt[0, which[near]] + torch.randn(int(near.sum()), 4, generator=g) * 6
+    if keys_kind == "constant":
+        keys = torch.full((1, P), 0.25)
+    elif keys_kind == "few_values":
+        keys = torch.randint(0, 5, (1, P), generator=g).float() / 4
+    elif keys_kind == "negative":
+        keys = torch.randn(1, P, generator=g)
+        keys[0, ::9] = keys[0, 1::9][:keys[0, ::9].numel()]       # some exact duplicates too
+    else:
+        keys = torch.rand(1, P, generator=g)
+    cnt = torch.tensor([P], dtype=torch.int32)
+    gcnt = torch.tensor([2], dtype=torch.int32)
+    sb, sl, st, si, sc = ops.box_match_sample(props.cuda(), cnt.cuda(), gt.cuda(), gcnt.cuda(), keys.cuda(), 128, 0.25, 0.5,
+                                              spec.BOX_REG_WEIGHTS)
+    lab, _ = obt.match_labels(props[0], gt[0])
+    assert int((lab >= 1).sum()) > 32 and int((lab == 0).sum()) > 96          # both quotas bind
+    idx, _, _ = obt.sample(lab, keys[0], 128, 0.25)
+    assert int(sc[0]) == 128 and si[0].cpu().tolist() == idx.tolist()
+    assert sl[0].cpu().tolist() == lab[idx].tolist()
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_box_loss_values_and_gradient(dt):
     from oneshotdet_amd import ops
