@@ -463,6 +463,16 @@ int osd_image_transform(const uint8_t* src_rgb_hwc, int in_h, int in_w, int out_
                         const float* mean3, const float* std3, void* dst, int layout, int dtype, int batch_index, int dst_h,
                         int dst_w, int pad_t, int pad_l, void* workspace, void* stream);
 int64_t osd_image_transform_workspace_bytes(int in_h, int in_w, int out_h, int out_w);
+/* The same for a whole batch in THREE launches (tap tables of both axes, horizontal pass, vertical pass + normalise + pad
+ * write): what BatchCollator does to the images the dataset returns (data/collate_batch.py:15-20 over
+ * data/transforms/build.py:39-46).  srcs / in_hs / in_ws / out_hs / out_ws / flips (nullable = no flip) are HOST arrays
+ * of n_images entries, srcs holding device pointers; image i goes to batch slot first_batch_index + i of dst.
+ * workspace: the SUM of osd_image_transform_workspace_bytes over the images. */
+int osd_image_transform_batch(int n_images, const uint8_t* const* srcs_rgb_hwc, const int32_t* in_hs, const int32_t* in_ws,
+                              const int32_t* out_hs, const int32_t* out_ws, const int32_t* flips, int to_bgr255,
+                              const float* mean3, const float* std3, void* dst, int layout, int dtype,
+                              int first_batch_index, int dst_h, int dst_w, int pad_t, int pad_l, void* workspace,
+                              void* stream);
 
 #ifdef __cplusplus
 }

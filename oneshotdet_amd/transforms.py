@@ -155,6 +155,23 @@ def _launch(image, mean, std, to_bgr255, dst, layout, batch_index, dst_h, dst_w,
               layout, dt, batch_index, dst_h, dst_w, pad_t, pad_l, ops._ptr(ws), ops._stream())
 
 
+def _launch_batch(images, mean, std, to_bgr255, dst, layout, dst_h, dst_w, pad_t, pad_l):
+    """All images of a batch in one launch chain (osd_image_transform_batch): image i -> batch slot i of dst."""
+    n = len(images)
+    lib = _lib.load()
+    need = sum(int(lib.osd_image_transform_workspace_bytes(int(im.src.shape[0]), int(im.src.shape[1]), im.out_hw[0], im.out_hw[1]))
+               for im in images)
+    ws = torch.empty((need // 8 + 1,), device=dst.device, dtype=torch.int64)
+    srcs = (C.c_void_p * n)(*[im.src.data_ptr() for im in images])
+    arr = lambda vals: (C.c_int32 * n)(*[int(v) for v in vals])      # noqa: E731
+    m3 = (C.c_float * 3)(*[float(v) for v in mean])
+    s3 = (C.c_float * 3)(*[float(v) for v in std])
+    dt = ops.OSD_F32 if dst.dtype == torch.float32 else ops.OSD_BF16
+    _lib.call("osd_image_transform_batch", n, srcs, arr(im.src.shape[0] for im in images), arr(im.src.shape[1] for im in images),
+              arr(im.out_hw[0] for im in images), arr(im.out_hw[1] for im in images), arr(im.flip for im in images),
+              int(bool(to_bgr255)), m3, s3, ops._ptr(dst), layout, dt, 0, dst_h, dst_w, pad_t, pad_l, ops._ptr(ws), ops._stream())
+
+
 class Normalize(object):
     def __init__(self, mean, std, to_bgr255=True):
         self.mean, self.std, self.to_bgr255 = tuple(mean), tuple(std), to_bgr255
@@ -179,7 +196,8 @@ def build_transforms(min_size=800, max_size=1200, supp_min_size=200, supp_max_si
 
 def collate(images, size_divisible=32, mean=PIXEL_MEAN, std=PIXEL_STD, to_bgr255=True, stem_dtype=None):
     """Normalize + BatchCollator / to_image_list (collate_batch.py:15-20, image_list.py:52-70) in one pass per image: the
-    DeviceImages (as they come out of Resize / RandomHorizontalFlip) are written straight into the zero-padded batch.
+    DeviceImages (as they come out of Resize / RandomHorizontalFlip) are written straight into the zero-padded batch, the
+    whole batch in three launches.
     -> layers.ImageList of float32 [N, 3, Hp, Wp] with every image's true (h, w); with stem_dtype (torch.bfloat16 /
     float32) instead a `PackedImages`: the stem conv's NHWC4 input (what osd_pack_image would produce from that batch)."""
     from .layers import ImageList
@@ -193,13 +211,11 @@ def collate(images, size_divisible=32, mean=PIXEL_MEAN, std=PIXEL_STD, to_bgr255
     sizes = [im.out_hw for im in images]
     if stem_dtype is None:
         batch = torch.empty((n, 3, mh, mw), device=dev, dtype=torch.float32)
-        for i, im in enumerate(images):
-            _launch(im, mean, std, to_bgr255, batch, 0, i, mh, mw, 0, 0)
+        _launch_batch(images, mean, std, to_bgr255, batch, 0, mh, mw, 0, 0)
         return ImageList(batch, sizes)
     ho, wo = ops.conv_out(mh, 7, 2, 3), ops.conv_out(mw, 7, 2, 3)
     hp, wp = max(2 * (ho - 1) + 7, mh + 3), max(2 * (wo - 1) + 8, mw + 3)
     wp += wp & 1
     packed = torch.empty((n, hp, wp, 4), device=dev, dtype=stem_dtype)
-    for i, im in enumerate(images):
-        _launch(im, mean, std, to_bgr255, packed, 1, i, hp, wp, 3, 3)
+    _launch_batch(images, mean, std, to_bgr255, packed, 1, hp, wp, 3, 3)
     return ops.PackedImages(packed, (mh, mw), sizes)

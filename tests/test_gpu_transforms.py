@@ -88,6 +88,34 @@ def test_random_sizes_against_the_oracle():
         assert got.shape == ref.shape and np.array_equal(got.cpu().numpy(), ref), (h, w, mn, mx)
 
 
+def test_batched_chain_equals_the_per_image_one_for_mixed_batches():
+    """collate runs the whole batch through osd_image_transform_batch (three launches, a kernarg table of <= 16 images per
+    chain): 19 images of different sizes, flips, up- / down-scaling and unchanged axes land in their slots exactly as the
+    per-image transform (pinned to the reference above) writes them, zero padding included, in both layouts."""
+    from oneshotdet_amd import ops, transforms as T
+    rng = np.random.RandomState(11)
+    imgs, singles = [], []
+    norm = T.Normalize(T.PIXEL_MEAN, T.PIXEL_STD, to_bgr255=True)
+    for i in range(19):
+        h, w = int(rng.randint(20, 140)), int(rng.randint(20, 140))
+        src = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        im = T.DeviceImage(src)
+        if i % 5 != 4:                                   # every fifth image keeps its size (both passes skipped)
+            im, _ = T.Resize(int(rng.randint(30, 90)), 160)(im, None)
+        if i % 2:
+            im = im.flipped()
+        imgs.append(im)
+        singles.append(norm(im, None)[0])
+    batch = T.collate(imgs, 32)
+    for i, t in enumerate(singles):
+        hh, ww = t.shape[1:]
+        assert torch.equal(batch.tensors[i, :, :hh, :ww], t), i
+        assert not batch.tensors[i, :, hh:].any() and not batch.tensors[i, :, :, ww:].any()
+    packed = T.collate(imgs, 32, stem_dtype=torch.bfloat16)
+    ref, _ = ops.stem_input(batch.tensors, torch.bfloat16)
+    assert torch.equal(packed.tensor, ref)
+
+
 def test_engine_accepts_the_packed_stem_input():
     """HotPathEngine.detect on transforms.collate(..., stem_dtype) gives the same proposals as on the float batch."""
     from oneshotdet_amd import model, spec, synth, transforms as T
