@@ -68,7 +68,7 @@ template <typename T> __device__ __forceinline__ int wg_swz(int row) {
 // Output tile = (WCO x WCI) sub-tiles of TWS channels (TWS = one 256-byte row: 128 bf16 / 64 fp32): 1 x 1 on 4 waves
 // (2 x 2, 64 x 64 channels each) or 2 x 2 on 8 waves (2 x 4: 128 co x 64 ci each — half the operand bytes per MFMA and
 // twice the MFMAs per barrier).  LDS stage = [dY sub-tiles | X sub-tiles], each [BKP pixels][256 B].
-template <typename T, int BKP, int NST, int WCO, int WCI, int WM, int WN>
+template <typename T, int BKP, int NST, int WCO, int WCI, int WM, int WN, bool ILV = false>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3) ? 2 : 1) conv_wgrad_kernel(WgradParams gp) {
   constexpr int NW = WM * WN;
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -179,42 +179,44 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3)
 #pragma unroll
   for (int i = 0; i < IPA; ++i) a_ptr[i] = dyg + (size_t)(p_lo + a_row[i]) * p.dy_stride + a_col[i];
   int stage_m = p_lo;   // first pixel of the NEXT stage to issue
+  auto issue_a = [&](int i, unsigned st) {
+    const bool ok = (stage_m + a_row[i] < p_hi) && a_cok[i];
+#ifdef OSD_WG_CHEAP_ADDR        // diagnostic: every piece reads the zero page (no address arithmetic, always cached)
+    wg_dma16(zero, st + a_dst[i]);
+#else
+    wg_dma16(ok ? a_ptr[i] : zero, st + a_dst[i]);
+#endif
+#ifndef OSD_WG_SAME_ADDR        // diagnostic: every stage re-reads the first stage's rows (full address arithmetic, cached data)
+    a_ptr[i] += a_step;
+#endif
+  };
+  auto issue_b = [&](int i, unsigned st) {
+    const int hi = b_ho[i] * p.sh - p.ph + fr, wi = b_wo[i] * p.sw - p.pw + fs;
+    const bool ok = (stage_m + b_row[i] < p_hi) && b_cok[i] && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+    const int off = ((b_n[i] * p.H + hi) * p.W + wi) * p.Cin + b_col[i];      // < 2^31 elements (checked by the host)
+#ifdef OSD_WG_CHEAP_ADDR
+    wg_dma16(zero, st + b_dst[i]);
+#else
+    wg_dma16(ok ? xg + off : zero, st + b_dst[i]);
+#endif
+    int wo = b_wo[i] + dwo, ho = b_ho[i] + dho;
+    const bool c1 = wo >= p.Wo;
+    wo -= c1 ? p.Wo : 0;
+    ho += c1 ? 1 : 0;
+    const bool c2 = ho >= p.Ho;
+    ho -= c2 ? p.Ho : 0;
+#ifndef OSD_WG_SAME_ADDR
+    b_wo[i] = wo; b_ho[i] = ho; b_n[i] += dn + (c2 ? 1 : 0);
+#else
+    asm volatile("" ::"v"(wo), "v"(ho), "v"(c2 ? 1 : 0));
+#endif
+  };
   auto issue_stage = [&](int buf) {
     const unsigned st = lds0 + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < IPA; ++i) {
-      const bool ok = (stage_m + a_row[i] < p_hi) && a_cok[i];
-#ifdef OSD_WG_CHEAP_ADDR        // diagnostic: every piece reads the zero page (no address arithmetic, always cached)
-      wg_dma16(zero, st + a_dst[i]);
-#else
-      wg_dma16(ok ? a_ptr[i] : zero, st + a_dst[i]);
-#endif
-#ifndef OSD_WG_SAME_ADDR        // diagnostic: every stage re-reads the first stage's rows (full address arithmetic, cached data)
-      a_ptr[i] += a_step;
-#endif
-    }
+    for (int i = 0; i < IPA; ++i) issue_a(i, st);
 #pragma unroll
-    for (int i = 0; i < IPB; ++i) {
-      const int hi = b_ho[i] * p.sh - p.ph + fr, wi = b_wo[i] * p.sw - p.pw + fs;
-      const bool ok = (stage_m + b_row[i] < p_hi) && b_cok[i] && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
-      const int off = ((b_n[i] * p.H + hi) * p.W + wi) * p.Cin + b_col[i];      // < 2^31 elements (checked by the host)
-#ifdef OSD_WG_CHEAP_ADDR
-      wg_dma16(zero, st + b_dst[i]);
-#else
-      wg_dma16(ok ? xg + off : zero, st + b_dst[i]);
-#endif
-      int wo = b_wo[i] + dwo, ho = b_ho[i] + dho;
-      const bool c1 = wo >= p.Wo;
-      wo -= c1 ? p.Wo : 0;
-      ho += c1 ? 1 : 0;
-      const bool c2 = ho >= p.Ho;
-      ho -= c2 ? p.Ho : 0;
-#ifndef OSD_WG_SAME_ADDR
-      b_wo[i] = wo; b_ho[i] = ho; b_n[i] += dn + (c2 ? 1 : 0);
-#else
-      asm volatile("" ::"v"(wo), "v"(ho), "v"(c2 ? 1 : 0));
-#endif
-    }
+    for (int i = 0; i < IPB; ++i) issue_b(i, st);
     stage_m += BKP;
   };
 
@@ -229,7 +231,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3)
   const int a_sub = (wm * WCOL_A) / TWS, a_c0 = (wm * WCOL_A) % TWS;
   const int b_sub = (wn * WCOL_B) / TWS, b_c0 = (wn * WCOL_B) % TWS;
 
-  auto compute_stage = [&](int buf) {
+  // ILV: the next stage's DMA pieces are issued BETWEEN the rows of MFMAs (one piece every few rows) instead of in a burst
+  // after the barrier: a piece costs the issuing wave 60-180 cycles during which its MFMA stream stands still; spread
+  // out, the other wave of the SIMD is (mostly) in an MFMA row at that moment instead of in its own burst
+  auto compute_stage = [&](int buf, int nbuf, bool issue) {
+    const unsigned nst = lds0 + nbuf * STAGE;
     const char* sa = smem + buf * STAGE + a_sub * OPB;
     const char* sb = smem + buf * STAGE + (WCO + b_sub) * OPB;
     if constexpr (sizeof(T) == 2) {
@@ -263,11 +269,26 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3)
         for (int e = 0; e < 4; ++e) { bfr[j][e] = b_lo[e]; bfr[j][e + 4] = b_hi[e]; }
       }
 #pragma unroll
-      for (int i = 0; i < TA; ++i)
+      for (int i = 0; i < TA; ++i) {
 #pragma unroll
         for (int j = 0; j < TB; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if constexpr (ILV) {
+          constexpr int SLOTS = (BKP / 32) * TA;
+          const int slot = k32 * TA + i;                         // compile-time after unrolling
+          const int p0 = slot * LPS / SLOTS, p1 = (slot + 1) * LPS / SLOTS;
+#pragma unroll
+          for (int pc = 0; pc < LPS; ++pc)
+            if (pc >= p0 && pc < p1 && issue) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (pc < IPA) issue_a(pc, nst);
+              else issue_b(pc - IPA, nst);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+      }
      }
+      if constexpr (ILV) { if (issue) stage_m += BKP; }
     } else {
       const int k = lane >> 4, e16 = lane & 15;
 #pragma unroll
@@ -314,11 +335,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3)
     if (kt + NST - 2 < KT) wg_wait_vmcnt<LPS * (NST - 2)>();
     else wg_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    const bool more = kt + NST - 1 < KT;
 #ifndef OSD_WG_NO_DMA            // diagnostic builds: timing of the loop without one of its parts (results are garbage)
-    if (kt + NST - 1 < KT) issue_stage(nxt);
+    if (!ILV && more) issue_stage(nxt);
 #endif
     if (do_bias) bias_stage(cur);
-    compute_stage(cur);
+    compute_stage(cur, nxt, more);
     cur = cur + 1 == NST ? 0 : cur + 1;
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
@@ -368,6 +390,234 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3)
         }
       }
     }
+  }
+}
+
+// ---- 3x3 / stride 1 / pad 1: one workgroup per FILTER ROW (three taps), bf16 ----
+// The kernel above gives every tap its own workgroup, so nine workgroups fetch the same dY tile and nine one-pixel-shifted
+// copies of the same X rows; diagnostic builds put that operand traffic (L2 -> LDS by DMA, 7-12 TB/s chip-wide) at 26-39 % of
+// the tower launch.  Here a stage is a run of SP = min(BKP, Wo) output pixels of ONE image row: the dY tile [BKP][128 co]
+// and ONE X tile [BKP + 4][128 ci] holding input row ho - 1 + fr from column wo0 - 1 on; tap s of the filter row pairs dY
+// row r with X row r + s (the k slot <-> tile row mapping of the transposed reads is free, and a row offset keeps both the
+// 16-byte alignment and the 8-row bank pattern), so three taps' MFMAs run on one dY fragment set: 17 (33) KB per 3.1
+// (6.3) MFLOP instead of 16 KB per 1.05.  The image border is the DMA's zero page as before; rows narrower than BKP
+// (P6, P7) are padded with zero rows (1.5 % of the tower's pixels).  128 x 128 channels x 3 taps on 8 waves (2 x 4: 64 co x
+// 32 ci per wave and tap, 96 accumulator registers); requires Cout, Cin multiples of 128 and Wo a multiple of BKP or
+// a divisor of it.
+template <int BKP, int NST>
+__global__ void __launch_bounds__(512) conv_wgrad_xr_kernel(WgradParams gp) {
+  typedef __bf16 T;
+  constexpr int NW = 8, WN = 4;
+  constexpr int XR = BKP + 4;                      // X tile rows (BKP + 2 needed; whole 4-row DMA pieces)
+  constexpr int AP = BKP / 4, BP = XR / 4;         // 1 KiB DMA pieces per stage: dY, X
+  constexpr int IPA = (AP + NW - 1) / NW, IPB = (BP + NW - 1) / NW;
+  constexpr int LPS = IPA + IPB;                   // DMA instructions per stage of wave 0; the other waves issue one less
+  static_assert(AP % NW == 0 && BP % NW == 1, "the one surplus X piece belongs to wave 0");
+  constexpr int STAGE = (BKP + XR) * 256;
+  constexpr int TA = 4, TB = 2;                    // 16-wide MFMA tiles per wave: 64 co x 32 ci (per tap)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  int bid;
+  {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int sidx = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxSeg; ++i)
+    if (i < gp.n_seg && bid >= gp.seg[i].block_begin) sidx = i;
+  typedef const __attribute__((address_space(4))) char* kptr;
+  typedef unsigned long long u64;
+  kptr sb = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WgradParams, seg) + sidx * (int)sizeof(WgradSeg);
+#define OSD_WSEG(type, field) (*reinterpret_cast<const __attribute__((address_space(4))) type*>(sb + offsetof(WgradSeg, field)))
+  const T* __restrict__ xg = (const T*)OSD_WSEG(u64, x);
+  const T* __restrict__ dyg = (const T*)OSD_WSEG(u64, dy);
+  float* __restrict__ dw = (float*)OSD_WSEG(u64, dw);
+  const float* __restrict__ scale = (const float*)OSD_WSEG(u64, scale);
+  float* __restrict__ db = (float*)OSD_WSEG(u64, db);
+  const int H = OSD_WSEG(int, H), W = OSD_WSEG(int, W), M = OSD_WSEG(int, M), Cin = OSD_WSEG(int, Cin);
+  const int rows_per_split = OSD_WSEG(int, rows_per_split), dy_stride = OSD_WSEG(int, dy_stride);
+  const int tilesCo = OSD_WSEG(int, tilesCo), tilesCi = OSD_WSEG(int, tilesCi), Ktot = OSD_WSEG(int, Ktot);
+  bid -= OSD_WSEG(int, block_begin);
+#undef OSD_WSEG
+  const int SP = W < BKP ? W : BKP;                // valid pixels per stage (stride 1, pad 1: Ho == H, Wo == W)
+  const int co_tile = bid % tilesCo;
+  bid /= tilesCo;
+  const int ntile = 3 * tilesCi;
+  const int nt = bid % ntile, split = bid / ntile;
+  const int fr = nt / tilesCi, ci_tile = nt % tilesCi;
+  const int co0 = co_tile * 128, ci0 = ci_tile * 128;
+  const int p_lo = split * rows_per_split, p_hi = min(M, p_lo + rows_per_split);
+  if (p_lo >= p_hi) return;
+  const int KT = (p_hi - p_lo) / SP;               // M and rows_per_split are multiples of SP
+  const T* zero = reinterpret_cast<const T*>(g_wzero) + (lane & 15) * 8;
+
+  // ---- DMA coordinates.  Piece q = wave + 8 i covers tile rows 4 q .. 4 q + 3; lane -> (row, 16-byte chunk) ----
+  const int lrow = lane >> 4, lpos = lane & 15;
+  const T* a_ptr[IPA];
+  bool a_ok[IPA];
+  unsigned a_dst[IPA];
+#pragma unroll
+  for (int i = 0; i < IPA; ++i) {
+    const int q = wave + NW * i, row = q * 4 + lrow;
+    a_ok[i] = row < SP;
+    a_ptr[i] = dyg + (size_t)(p_lo + row) * dy_stride + co0 + (lpos ^ wg_swz<T>(row)) * 8;
+    a_dst[i] = q * 1024;
+  }
+  const size_t a_step = (size_t)SP * dy_stride;
+  int b_j[IPB], b_col[IPB];
+  bool b_real[IPB];
+  unsigned b_dst[IPB];
+#pragma unroll
+  for (int i = 0; i < IPB; ++i) {
+    const int q = wave + NW * i, row = q * 4 + lrow;
+    b_real[i] = q < BP;
+    b_j[i] = row;
+    b_col[i] = ci0 + (lpos ^ wg_swz<T>(row)) * 8;
+    b_dst[i] = BKP * 256 + q * 1024;
+  }
+  // the stage's position (uniform over the workgroup): image, output row, first output column
+  int s_n, s_ho, s_wo;
+  {
+    const int HW = H * W;
+    s_n = p_lo / HW;
+    const int rem = p_lo - s_n * HW;
+    s_ho = rem / W;
+    s_wo = rem - s_ho * W;
+  }
+  auto issue_stage = [&](int buf) {
+    const unsigned st = lds0 + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < IPA; ++i) {
+#ifdef OSD_WG_CHEAP_ADDR
+      wg_dma16(zero, st + a_dst[i]);
+#else
+      wg_dma16(a_ok[i] ? a_ptr[i] : zero, st + a_dst[i]);
+#endif
+      a_ptr[i] += a_step;
+    }
+    const int hi = s_ho - 1 + fr;
+    const bool row_ok = (unsigned)hi < (unsigned)H;
+    const int base = ((s_n * H + hi) * W + s_wo - 1) * Cin;      // element offset of X tile row 0 (may point before the row)
+#pragma unroll
+    for (int i = 0; i < IPB; ++i) {
+      const int wi = s_wo - 1 + b_j[i];
+      const bool ok = row_ok && b_j[i] < SP + 2 && (unsigned)wi < (unsigned)W;
+#ifdef OSD_WG_CHEAP_ADDR
+      if (b_real[i]) wg_dma16(zero, st + b_dst[i]);
+#else
+      if (b_real[i]) wg_dma16(ok ? xg + (base + b_j[i] * Cin + b_col[i]) : zero, st + b_dst[i]);      // wave-uniform branch
+#endif
+    }
+    s_wo += SP;
+    if (s_wo >= W) { s_wo = 0; if (++s_ho >= H) { s_ho = 0; ++s_n; } }
+  };
+
+  f32x4 acc[3][TA][TB];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+      for (int j = 0; j < TB; ++j) acc[s][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int a_c0 = wm * 64, b_c0 = wn * 32;
+
+  auto compute_stage = [&](int buf) {
+    const char* sa = smem + buf * STAGE;
+    const char* sx = sa + BKP * 256;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+    typedef __attribute__((address_space(3))) bf4* lds_bf4_ptr;
+    const int g = lane >> 4, t = lane & 15, q = t >> 2, pp = t & 3;
+    const int h8 = (pp & 1) * 8;
+#pragma unroll
+    for (int k32 = 0; k32 < BKP / 32; ++k32) {
+      const int r1 = k32 * 32 + 4 * g + q, r2 = r1 + 16;
+      bf16x8 af[TA];
+#pragma unroll
+      for (int i = 0; i < TA; ++i) {
+        const int chunk = ((a_c0 + i * 16) >> 3) + (pp >> 1);
+        const bf4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(sa + r1 * 256 + ((chunk ^ wg_swz<T>(r1)) << 4) + h8));
+        const bf4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(sa + r2 * 256 + ((chunk ^ wg_swz<T>(r2)) << 4) + h8));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { af[i][e] = lo[e]; af[i][e + 4] = hi[e]; }
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        bf16x8 bfr[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+          const int chunk = ((b_c0 + j * 16) >> 3) + (pp >> 1);
+          const int x1 = r1 + s, x2 = r2 + s;
+          const bf4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(sx + x1 * 256 + ((chunk ^ wg_swz<T>(x1)) << 4) + h8));
+          const bf4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(sx + x2 * 256 + ((chunk ^ wg_swz<T>(x2)) << 4) + h8));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bfr[j][e] = lo[e]; bfr[j][e + 4] = hi[e]; }
+        }
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+          for (int j = 0; j < TB; ++j)
+            acc[s][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[s][i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  const bool do_bias = (db != nullptr) && (nt == 0) && (tid < 128);
+  float bsum = 0.f;
+  auto bias_stage = [&](int buf) {
+    const char* sa = smem + buf * STAGE;
+    const int chunk = tid / 8, within = tid % 8;
+#pragma unroll 8
+    for (int row = 0; row < BKP; ++row)
+      bsum += to_f32(*reinterpret_cast<const T*>(sa + row * 256 + ((chunk ^ wg_swz<T>(row)) << 4) + within * 2));
+  };
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < KT) issue_stage(s);
+  int cur = 0, nxt = NST - 1;
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + NST - 2 >= KT) wg_wait_vmcnt<0>();
+    else if (wave == 0) wg_wait_vmcnt<LPS * (NST - 2)>();
+    else wg_wait_vmcnt<(LPS - 1) * (NST - 2)>();
+    __builtin_amdgcn_s_barrier();
+#ifndef OSD_WG_NO_DMA            // diagnostic builds (results are garbage)
+    if (kt + NST - 1 < KT) issue_stage(nxt);
+#endif
+    if (do_bias) bias_stage(cur);
+    compute_stage(cur);
+    cur = cur + 1 == NST ? 0 : cur + 1;
+    nxt = nxt + 1 == NST ? 0 : nxt + 1;
+  }
+
+  if (do_bias) wg_atomic_add(db + co0 + tid, bsum);
+#ifdef OSD_WG_NO_ATOMICS
+  if (acc[0][0][0][0] != 12345.678f) return;
+#endif
+  // ---- three partial tiles (one per tap of the filter row) into dW; whole tiles by construction ----
+  const int co_w = co0 + wm * 64 + (lane >> 4) * 4;
+  const int ci_w = ci0 + wn * 32 + (lane & 15);
+  float scv[TA][4];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) scv[i][e] = scale ? scale[co_w + i * 16 + e] : 1.f;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    float* base = dw + (size_t)co_w * Ktot + (fr * 3 + s) * Cin + ci_w;
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float* row = base + (size_t)(i * 16 + e) * Ktot;
+#pragma unroll
+        for (int j = 0; j < TB; ++j) wg_atomic_add(row + j * 16, acc[s][i][j][e] * scv[i][e]);
+      }
   }
 }
 
@@ -598,6 +848,65 @@ struct WgradProblem {      // host-side description of one segment
   const void* x; const void* dy; const float* scale; float* dw; float* db;
 };
 
+// Filter-row kernel (conv_wgrad_xr_kernel): algo = 1 + 128 + x + 16 * target_code, x: 0 = 32-pixel stages x 6, 1 = 64 x 4, 2 = 32 x 8.
+static int wgrad_xr_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
+  if (n_seg < 1 || n_seg > kMaxSeg) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: 1..%d segments", kMaxSeg);
+  const osd_conv_desc* d0 = pr[0].d;
+  static const int kTargets[8] = {512, 256, 128, 64, 1024, 768, 1536, 2048};
+  const int a = d0->algo - 1 - 128;
+  const int x = a & 15, target = kTargets[(a >> 4) & 7];
+  if (a < 0 || a >= 128 || x > 2) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d0->algo);
+  const int bkp = x == 1 ? 64 : 32;
+  WgradParams p;
+  p.n_seg = n_seg;
+  long long work = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    const osd_conv_desc* d = pr[i].d;
+    WgradSeg& g = p.seg[i];
+    const int h = pr[i].h, w = pr[i].w;
+    if (d->dtype != OSD_BF16 || d->r != 3 || d->s != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1 ||
+        d->cout % 128 || d->cin % 128 || d->out_stride % 8 || !(w % bkp == 0 || bkp % w == 0))
+      return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad (filter-row kernel): bf16 3x3 / 1 / 1, channels in 128s, width %d vs %d-pixel stages", w, bkp);
+    const long long M = (long long)pr[i].n * h * w;
+    if (M <= 0 || M > 0x7fffffffLL || !pr[i].x || !pr[i].dy || !pr[i].dw) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad segment %d", i);
+    if (M * d->cin > 0x7fffffffLL) return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: input of segment %d has more than 2^31 elements", i);
+    g.x = pr[i].x; g.dy = pr[i].dy; g.dw = pr[i].dw; g.scale = pr[i].scale; g.db = pr[i].db;
+    g.H = h; g.W = w; g.Ho = h; g.Wo = w; g.M = (int)M;
+    g.Cin = d->cin; g.Cout = d->cout; g.R = 3; g.S = 3; g.sh = g.sw = 1; g.ph = g.pw = 1;
+    g.dy_stride = d->out_stride; g.Ktot = 9 * d->cin;
+    g.tilesCo = d->cout / 128; g.tilesCi = d->cin / 128;
+    work += M * g.tilesCo * g.tilesCi * 3;
+  }
+  long long rows = (work + target - 1) / target;
+  rows = (rows + 63) / 64 * 64;                  // whole stages for every width (stages are min(bkp, w) pixels, all divide 64)
+  if (rows < 128) rows = 128;
+  long long nblocks = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    WgradSeg& g = p.seg[i];
+    int sp = (int)((g.M + rows - 1) / rows);
+    if (sp < 1) sp = 1;
+    g.rows_per_split = cdiv(cdiv(g.M, sp), 64) * 64;
+    const int splits = cdiv(g.M, g.rows_per_split);
+    g.block_begin = (int)nblocks;
+    nblocks += (long long)g.tilesCo * g.tilesCi * 3 * splits;
+    if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
+  }
+  for (int i = n_seg; i < kMaxSeg; ++i) p.seg[i] = p.seg[0];
+#define OSD_WGX(BK, NS)                                                                                               \
+  do {                                                                                                                \
+    auto kern = conv_wgrad_xr_kernel<BK, NS>;                                                                         \
+    constexpr int lds = NS * (BK + BK + 4) * 256;                                                                     \
+    static bool attr = false;                                                                                         \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; } \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(512), lds, s, p);                                         \
+  } while (0)
+  if (x == 0) OSD_WGX(32, 6);
+  else if (x == 1) OSD_WGX(64, 4);
+  else OSD_WGX(32, 8);
+#undef OSD_WGX
+  return osd_check_launch("conv_wgrad_xr");
+}
+
 // dtype and algo (0 = default, else 1 + variant + 16 * target_code) come from the first problem's descriptor.
 // variant 0..3: 128 x 128 channel tile on 4 waves, pixels per stage x ring depth = 32x3 / 64x2 / 32x4 / 64x3 (bf16;
 // fp32 always 32x3); variants 4..7: 256-wide tiles on 8 waves; 8, 9: 256 x 256 with a 5- / 4-deep ring of 32-pixel stages
@@ -606,6 +915,7 @@ struct WgradProblem {      // host-side description of one segment
 static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   if (n_seg < 1 || n_seg > kMaxSeg) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: 1..%d segments", kMaxSeg);
   const osd_conv_desc* d0 = pr[0].d;
+  if (d0->algo > 128) return wgrad_xr_launch(n_seg, pr, s);
   static int env_target = -1, env_variant = -1;
   if (env_target < 0) { const char* e = getenv("OSD_WGRAD_BLOCKS"); env_target = e ? atoi(e) : 512; }
   if (env_variant < 0) { const char* e = getenv("OSD_WGRAD_VARIANT"); env_variant = e ? atoi(e) : 0; }
@@ -616,7 +926,7 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   int target = env_target, variant = env_variant;
   if (d0->algo > 0) {
     const int a = d0->algo - 1;
-    if (a >= 128 || (a & 15) > 12) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d0->algo);
+    if (a >= 128) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d0->algo);
     variant = a & 15;
     target = kTargets[a >> 4];
   }
@@ -627,8 +937,8 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   // channel tile (co x ci) in 256-byte sub-tiles: variants 4 / 5 = 2 x 2, 6 = 1 x 2, 7 = 2 x 1 (bf16, 8 waves); else 1 x 1
   const bool bf = d0->dtype == OSD_BF16;
   if (!bf && variant != 0) variant = 0;
-  const int sub_co = bf && (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 9 || variant == 11) ? 2 : 1;
-  const int sub_ci = bf && (variant == 4 || variant == 5 || variant == 6 || variant == 8 || variant == 9 || variant == 10 || variant == 12) ? 2 : 1;
+  const int sub_co = bf && (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 9 || variant == 11 || variant == 13 || variant == 14) ? 2 : 1;
+  const int sub_ci = bf && (variant == 4 || variant == 5 || variant == 6 || variant == 8 || variant == 9 || variant == 10 || variant == 12 || variant == 13) ? 2 : 1;
   const int tw = bf ? 128 : 64;
   const int epc = d0->dtype == OSD_BF16 ? 8 : 4;
   WgradParams p;
@@ -670,10 +980,11 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   for (int i = n_seg; i < kMaxSeg; ++i) p.seg[i] = p.seg[0];
   const osd_conv_desc* d = d0;
   // variant: 0 = 32 px x 3 stages, 1 = 64 px x 2, 2 = 32 px x 4, 3 = 64 px x 3 (bf16; fp32 always 32 x 3)
-#define OSD_WG_LAUNCH(TT, BK, NS, WC, WMM, WNN) OSD_WG_LAUNCH2(TT, BK, NS, WC, WC, WMM, WNN)
-#define OSD_WG_LAUNCH2(TT, BK, NS, WCOO, WCII, WMM, WNN)                                                            \
+#define OSD_WG_LAUNCH(TT, BK, NS, WC, WMM, WNN) OSD_WG_LAUNCH3(TT, BK, NS, WC, WC, WMM, WNN, false)
+#define OSD_WG_LAUNCH2(TT, BK, NS, WCOO, WCII, WMM, WNN) OSD_WG_LAUNCH3(TT, BK, NS, WCOO, WCII, WMM, WNN, false)
+#define OSD_WG_LAUNCH3(TT, BK, NS, WCOO, WCII, WMM, WNN, IL)                                                        \
   do {                                                                                                               \
-    auto kern = conv_wgrad_kernel<TT, BK, NS, WCOO, WCII, WMM, WNN>;                                                 \
+    auto kern = conv_wgrad_kernel<TT, BK, NS, WCOO, WCII, WMM, WNN, IL>;                                                 \
     constexpr int lds = NS * (WCOO + WCII) * BK * 256;                                                               \
     static bool attr = false;                                                                                        \
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; } \
@@ -696,11 +1007,16 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
       case 10: OSD_WG_LAUNCH2(__bf16, 32, 3, 1, 2, 2, 2); break;     // 128 co x 256 ci on 4 waves, 3 x 24 KB
       case 11: OSD_WG_LAUNCH2(__bf16, 32, 3, 2, 1, 2, 2); break;     // 256 co x 128 ci on 4 waves
       case 12: OSD_WG_LAUNCH2(__bf16, 32, 6, 1, 2, 2, 2); break;     // 128 co x 256 ci on 4 waves, 6 x 24 KB
+      // 13..15: variants 5, 11 and 0 with the DMA pieces issued between the MFMA rows
+      case 13: OSD_WG_LAUNCH3(__bf16, 64, 2, 2, 2, 2, 4, true); break;
+      case 14: OSD_WG_LAUNCH3(__bf16, 32, 3, 2, 1, 2, 2, true); break;
+      case 15: OSD_WG_LAUNCH3(__bf16, 32, 3, 1, 1, 2, 2, true); break;
       default: OSD_WG_LAUNCH(__bf16, 32, 3, 1, 2, 2); break;
     }
   }
 #undef OSD_WG_LAUNCH
 #undef OSD_WG_LAUNCH2
+#undef OSD_WG_LAUNCH3
   return osd_check_launch("conv_wgrad");
 }
 

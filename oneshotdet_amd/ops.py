@@ -565,26 +565,41 @@ def pack_conv_master_dgrad(w_orsi, scale, dtype):
 WGRAD_ALGO_CACHE = {}
 
 
+def wgrad_xr_candidates(dtype, cout, cin, r, s, stride, pad, widths):
+    """The filter-row kernel (one workgroup per 3 taps; conv_wgrad_xr_kernel): algo = 1 + 128 + x + 16 * split-target code,
+    x = 0: 32-pixel stages x 6, 1: 64 x 4, 2: 32 x 8.  bf16 3x3 / 1 / 1, channels in 128s, every map width a multiple or
+    a divisor of the stage."""
+    if dtype != OSD_BF16 or (r, s, stride, pad) != (3, 3, 1, 1) or cout % 128 or cin % 128 or not widths:
+        return []
+    xs = [x for x, bk in ((0, 32), (1, 64), (2, 32)) if all(w % bk == 0 or bk % w == 0 for w in widths)]
+    return [1 + 128 + x + 16 * t for t in (0, 1, 2, 4, 5, 6, 7) for x in xs]
+
+
 def wgrad_algo_candidates(dtype, cout=0, cin=0):
     """osd_conv2d_wgrad's algo field = 1 + variant + 16 * split-target code.  Variants 0..3: 128 x 128 channel tile with
     different stage shapes (bf16; fp32 has one); 4..9: 256-wide channel tiles on 8 waves (bf16, wide layers; 8 / 9 with
     the deepest rings the LDS holds); 10..12: 128 x 256 / 256 x 128 on four waves."""
     variants = [0, 1, 2, 3] if dtype == OSD_BF16 else [0]
+    if dtype == OSD_BF16:
+        variants.append(15)         # variant 0 with the DMA pieces issued between the MFMA rows
     if dtype == OSD_BF16 and cout >= 256 and cin >= 256:
-        variants += [4, 5, 8, 9]
+        variants += [4, 5, 8, 9, 13]
     if dtype == OSD_BF16 and cin >= 256:
         variants += [6, 10, 12]     # 128 co x 256 ci
     if dtype == OSD_BF16 and cout >= 256:
-        variants += [7, 11]         # 256 co x 128 ci
+        variants += [7, 11, 14]     # 256 co x 128 ci (14: 11 interleaved)
     return [1 + v + 16 * t for t in (0, 1, 2, 3, 4, 5, 6, 7) for v in variants]
 
 
-def _tune_wgrad(key, d, launch, dw, db):
+def _tune_wgrad(key, d, launch, dw, db, widths=None):
     """Time every candidate on scratch outputs (the kernel accumulates) and cache the winner for this shape."""
     sdw = torch.empty_like(dw)
     sdb = None if db is None else torch.empty_like(db)
     best, best_t = 0, float("inf")
-    for algo in wgrad_algo_candidates(d.dtype, d.cout, d.cin):
+    cands = wgrad_algo_candidates(d.dtype, d.cout, d.cin)
+    if os.environ.get("OSD_WGRAD_XR"):      # the filter-row kernel: correct, never the winner so far (DESIGN 6b) — opt-in
+        cands = cands + wgrad_xr_candidates(d.dtype, d.cout, d.cin, d.r, d.s, d.stride_h, d.pad_h, widths)
+    for algo in cands:
         d.algo = algo
         launch(sdw, sdb)
         torch.cuda.synchronize()
@@ -614,7 +629,7 @@ def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None, db=None,
     if algo is None:
         algo = WGRAD_ALGO_CACHE.get(key)
     if algo is None:
-        algo = _tune_wgrad(key, d, launch, dw_packed, db) if _TUNING[0] else 0
+        algo = _tune_wgrad(key, d, launch, dw_packed, db, [x.shape[2]]) if _TUNING[0] else 0
     d.algo = algo
     launch(dw_packed, db)
 
@@ -644,7 +659,7 @@ def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, 
     if algo is None:
         algo = WGRAD_ALGO_CACHE.get(key)
     if algo is None:
-        algo = _tune_wgrad(key, d, launch, dw_packed, db) if _TUNING[0] else 0
+        algo = _tune_wgrad(key, d, launch, dw_packed, db, [x.shape[2] for x, _ in pairs]) if _TUNING[0] else 0
     d.algo = algo
     launch(dw_packed, db)
 
@@ -673,7 +688,7 @@ def conv2d_wgrad_batched(items, r, s, stride, pad, cout, algo=None):
         if _TUNING[0]:
             sdw = [torch.empty_like(it[2]) for it in items]
             sdb = [None if it[4] is None else torch.empty_like(it[4]) for it in items]
-            algo = _tune_wgrad(key, d, lambda a, b: launch(sdw, sdb), items[0][2], None)
+            algo = _tune_wgrad(key, d, lambda a, b: launch(sdw, sdb), items[0][2], None, [x0.shape[2]])
         else:
             algo = 0
     d.algo = algo
@@ -708,7 +723,7 @@ def conv2d_wgrad_multi(items, r, s, stride, pad, cout, algo=None):
             scratch = {}
             sdw = [scratch.setdefault(id(t), torch.empty_like(t)) for t in real_dws]
             sdb = [None if t is None else scratch.setdefault(id(t), torch.empty_like(t)) for t in real_dbs]
-            algo = _tune_wgrad(key, d, lambda a, b: launch(sdw, sdb), real_dws[0], None)
+            algo = _tune_wgrad(key, d, lambda a, b: launch(sdw, sdb), real_dws[0], None, [it[0].shape[2] for it in items])
         else:
             algo = 0
     d.algo = algo

@@ -449,17 +449,53 @@ def test_conv_wgrad_every_algorithm_matches_autograd(case):
     ref, refb = wt.grad.permute(0, 2, 3, 1), b.grad
     xx, dd = to_nhwc(x, torch.bfloat16), to_nhwc(dy, torch.bfloat16)
     cands = ops.wgrad_algo_candidates(ops.OSD_BF16, cout, cin)
-    assert {(a - 1) & 15 for a in cands} >= set(range(13))
+    assert {(a - 1) & 15 for a in cands} >= set(range(16))
     for algo in cands:
         dw, db = torch.zeros(cout, k, k, cin, device="cuda"), torch.zeros(cout, device="cuda")
         ops.conv2d_wgrad(xx, dd, dw, k, k, s, p, cout, db=db, algo=algo)
         assert (dw.cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item(), algo
         assert (db.cpu() - refb).abs().max().item() <= 2e-2 * refb.abs().max().item(), algo
     if s == 1:      # grouped: the same tensors as two "levels" -> twice the gradient
-        for algo in (1 + 4, 1 + 4 + 16 * 4, 1 + 0, 1 + 5, 1 + 6 + 16 * 2, 1 + 7, 1 + 8, 1 + 10 + 16, 1 + 11, 1 + 12):
+        for algo in (1 + 4, 1 + 4 + 16 * 4, 1 + 0, 1 + 5, 1 + 6 + 16 * 2, 1 + 7, 1 + 8, 1 + 10 + 16, 1 + 11, 1 + 12, 1 + 13, 1 + 14 + 16, 1 + 15):
             dw = torch.zeros(cout, k, k, cin, device="cuda")
             ops.conv2d_wgrad_grouped([(xx, dd), (xx, dd)], dw, k, k, 1, p, cout, algo=algo)
             assert (dw.cpu() - 2 * ref).abs().max().item() <= 2e-2 * 2 * ref.abs().max().item(), algo
+
+
+@pytest.mark.parametrize("widths", [(32,), (64, 32, 16, 8), (128, 4), (96, 1)])
+def test_conv_wgrad_filter_row_kernel_matches_autograd(widths):
+    """conv_wgrad_xr_kernel (opt-in tuner candidate, OSD_WGRAD_XR=1; one workgroup per filter row: three taps on one dY fragment set, X tile read at row offsets
+    0 / 1 / 2): every stage shape x several split targets against autograd — map widths that are multiples of the stage,
+    equal to it, and NARROWER than it (zero-padded stages: P6 / P7), several levels adding into one dW, image borders
+    (pad 1), the FrozenBN row scale and the fused bias gradient."""
+    from oneshotdet_amd import ops
+    cin, cout = 128, 256
+    wt = (rnd(cout, cin, 3, 3, seed=2) / np.sqrt(cin * 9)).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    scale = rnd(cout, seed=9).abs() + 0.5
+    pairs, loss = [], 0
+    for i, w in enumerate(widths):
+        n, h = (2, 5) if w >= 16 else (3, 7)
+        x = rnd(n, cin, h, w, seed=10 + i).bfloat16().float()
+        dy = rnd(n, cout, h, w, seed=20 + i).bfloat16().float()
+        loss = loss + (F.conv2d(x, wt * scale.view(-1, 1, 1, 1), b, padding=1) * dy).sum()
+        pairs.append((to_nhwc(x, torch.bfloat16), to_nhwc(dy, torch.bfloat16)))
+    loss.backward()
+    ref, refb = wt.grad.permute(0, 2, 3, 1), b.grad
+    cands = ops.wgrad_xr_candidates(ops.OSD_BF16, cout, cin, 3, 3, 1, 1, list(widths))
+    assert cands and all(a > 128 for a in cands)
+    if widths == (96, 1):
+        assert {(a - 129) & 15 for a in cands} == {0, 2}          # 96 is no multiple of the 64-pixel stage
+    for algo in cands:
+        dw, db = torch.zeros(cout, 3, 3, cin, device="cuda"), torch.zeros(cout, device="cuda")
+        ops.conv2d_wgrad_grouped(pairs, dw, 3, 3, 1, 1, cout, scale=scale.cuda(), db=db, algo=algo)
+        assert (dw.cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item(), algo
+        assert (db.cpu() - refb).abs().max().item() <= 2e-2 * refb.abs().max().item(), algo
+    assert not ops.wgrad_xr_candidates(ops.OSD_BF16, cout, cin, 3, 3, 2, 1, [32])       # stride 2: not this kernel
+    assert not ops.wgrad_xr_candidates(ops.OSD_BF16, cout, 64, 3, 3, 1, 1, [32])        # channels in 128s
+    with pytest.raises(Exception):
+        ops.conv2d_wgrad(pairs[0][0][..., :64].contiguous(), pairs[0][1], torch.zeros(cout, 3, 3, 64, device="cuda"), 3, 3, 1, 1, cout,
+                         algo=129)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

@@ -27,10 +27,15 @@ def time_it(fn, reps=5):
     return ev[0].elapsed_time(ev[1]) / reps * 1e3
 
 
-def sweep(name, launch, flops, cout, cin):
+def sweep(name, launch, flops, cout, cin, xr=None):
     best = {}
-    for algo in ops.wgrad_algo_candidates(ops.OSD_BF16, cout, cin):
-        v, t = (algo - 1) & 15, (algo - 1) >> 4
+    cands = ops.wgrad_algo_candidates(ops.OSD_BF16, cout, cin)
+    if xr is not None:
+        cands = cands + ops.wgrad_xr_candidates(ops.OSD_BF16, cout, cin, 3, 3, 1, 1, xr)
+    for algo in cands:
+        v, t = (algo - 1) & 15, ((algo - 1) >> 4) & 7
+        if algo > 128:
+            v += 100
         try:
             us = time_it(lambda: launch(algo))
         except Exception as e:
@@ -50,7 +55,7 @@ if which in ("tower", "all"):
             items.append((rnd(n, h, w, 256), rnd(n, h, w, 256), dws[i], None, None))
     m = sum(n * h * w for n, h, w in levels) * 4
     sweep("tower: 4 convs x 5 levels 3x3 256->256", lambda a: ops.conv2d_wgrad_multi(items, 3, 3, 1, 1, 256, algo=a),
-          2.0 * m * 256 * 2304, 256, 256)
+          2.0 * m * 256 * 2304, 256, 256, xr=[w for _, _, w in levels])
 if which in ("backbone", "all"):
     for (name, n, h, w, cin, cout, k, stride, pad) in (
             ("layer3 conv2 3x3 256->256 M=25600", 8, 50, 64, 256, 256, 3, 1, 1),
@@ -66,4 +71,4 @@ if which in ("backbone", "all"):
         dy = rnd(n, ho, wo, cout)
         dw = torch.zeros(cout, k, k, cin, device="cuda")
         sweep(name, lambda a: ops.conv2d_wgrad(x, dy, dw, k, k, stride, pad, cout, algo=a), 2.0 * n * ho * wo * cout * cin * k * k,
-              cout, cin)
+              cout, cin, xr=[w] if (k, stride, pad) == (3, 1, 1) else None)
