@@ -15,6 +15,8 @@ from . import ops, spec
 from .ops import ACT_EXP_SCALE, ACT_NONE, ACT_RELU, RES_SAME, RES_UP2X
 
 
+LOCKSTEP = os.environ.get("OSD_LOCKSTEP", "0") != "0"            # inference engine: both backbones per launch (A/B)
+TOWERS_MERGED = os.environ.get("OSD_TOWERS_MERGED", "0") != "0"  # inference engine: both towers per launch (A/B)
 SKIP_UNUSED_C2 = os.environ.get("OSD_FULL_C2", "0") == "0"     # A/B switch: compute all of layer1's last block anyway
 
 
@@ -206,9 +208,27 @@ def run_head_tower(hw, feats, tower):
 
 def run_head(hw, feats, streams=None):
     """FCOSHead.forward (fcos.py:83-99).  Per level returns (cls_ctr [N,H,W,4] = (logit, centerness, 0, 0),
-    reg [N,H,W,4] = exp(scale_l * bbox_pred)).  The two towers share the geometry: each layer is ONE launch over both
-    towers and all levels (10 pairs, level-major so the tuner's large / small split keeps P3 and P4 together), then the
-    GroupNorm+ReLU of a tower's levels in two launches.  (`streams` is accepted for compatibility; nothing needs it.)"""
+    reg [N,H,W,4] = exp(scale_l * bbox_pred)).  The two towers are independent: with `streams` the bbox tower runs on a
+    side stream beside the cls tower, so the HBM-bound GroupNorm passes of one tower overlap the MFMA-bound convs of the
+    other and the small levels' launch-latency-bound kernels fill the CUs the P3 GEMMs leave idle.  OSD_TOWERS_MERGED=1
+    runs each layer of both towers as ONE launch instead (fewer launches, less total kernel time, but measured SLOWER end
+    to end: 5.5 vs 4.7 ms per forward step — DESIGN 6b)."""
+    if TOWERS_MERGED:
+        return run_head_merged(hw, feats)
+    if not streams:
+        return list(zip(run_head_tower(hw, feats, "cls_tower"), run_head_tower(hw, feats, "bbox_tower")))
+    main = torch.cuda.current_stream()
+    streams[0].wait_stream(main)
+    with torch.cuda.stream(streams[0]):
+        box_out = run_head_tower(hw, feats, "bbox_tower")
+    cls_out = run_head_tower(hw, feats, "cls_tower")
+    main.wait_stream(streams[0])
+    return list(zip(cls_out, box_out))
+
+
+def run_head_merged(hw, feats):
+    """Both towers per launch: each layer is ONE launch over both towers and all levels (10 pairs, level-major so the
+    tuner's large / small split keeps P3 and P4 together), then the GroupNorm+ReLU of a tower's levels in two launches."""
     nl = len(feats)
     towers = ("cls_tower", "bbox_tower")
     t = {tw: list(feats) for tw in towers}
@@ -326,17 +346,26 @@ class HotPathEngine(object):
         return self._streams
 
     def forward_features(self, images, queries, concurrent=True, query_sizes=None):
-        """Both backbones in lockstep (one launch per layer), query pooling, correlation.
-        query_sizes: true (h, w) of every query of a padded batch (default: the tensor's size).
-        concurrent=False: the two backbones as separate launch sequences (A/B; identical results)."""
+        """Target backbone on the current stream; the (independent, tiny) query backbone + pooling on a side stream
+        (concurrent=False: one after the other on the current stream; OSD_LOCKSTEP=1: both backbones per launch, A/B).
+        query_sizes: true (h, w) of every query of a padded batch (default: the tensor's size)."""
         batch = images.shape[0]
         q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0] if query_sizes is None else list(query_sizes)
-        if concurrent:
+        if concurrent and LOCKSTEP:
             feats, qfeats = run_backbones(self.backbone, self.supp_backbone, images, queries, self.dtype)
+            pooled = run_query_pool(qfeats, q_sizes, batch)
+        elif concurrent:
+            main, side = torch.cuda.current_stream(), self.side_streams()[0]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                qfeats = run_backbone(self.supp_backbone, queries, self.dtype)
+                pooled = run_query_pool(qfeats, q_sizes, batch)
+            feats = run_backbone(self.backbone, images, self.dtype)
+            main.wait_stream(side)
         else:
             feats = run_backbone(self.backbone, images, self.dtype)
             qfeats = run_backbone(self.supp_backbone, queries, self.dtype)
-        pooled = run_query_pool(qfeats, q_sizes, batch)
+            pooled = run_query_pool(qfeats, q_sizes, batch)
         combined = run_correlate(feats, pooled)
         return feats, qfeats, pooled, combined
 
