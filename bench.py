@@ -308,7 +308,7 @@ def measured_traffic(mode, dtype):
         with open(files[-1]) as f:
             j = json.load(f)
         src = "OFFLINE, not measured by this run: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, at commit %s)" % (
-            os.path.basename(files[-1]), j.get("commit", "c80270d (round 1)"))
+            os.path.basename(files[-1]), j.get("commit") or "unknown")
         return round(j["conv_family"]["hbm_bytes_per_launch"]), src
     except Exception as e:
         return None, "unreadable PMC profile: %r" % (e,)

@@ -6,6 +6,7 @@ gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE and WRITE_SIZE are in 
 atomics.  Calibration on correlate_kernel (known bytes: read = write = elements * 2 B) is printed beside it."""
 import csv
 import json
+import os
 import sys
 
 
@@ -48,11 +49,19 @@ def main():
                           "measured_read_bytes": res["correlate"]["hbm_read_bytes"],
                           "measured_write_bytes": res["correlate"]["hbm_write_bytes"],
                           "launches": res["correlate"]["launches"]}
+    # the GPU box has no .git: tools/stamp_commit.sh (run in the build container before gpurun) leaves the commit in
+    # .commit_stamp at the repo root, which travels with the snapshot
     import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    commit = ""
     try:
-        res["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    except Exception:
-        res["commit"] = "unknown"
+        commit = open(os.path.join(root, ".commit_stamp")).read().strip()
+    except OSError:
+        try:
+            commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=root).stdout.strip()
+        except Exception:
+            commit = ""
+    res["commit"] = commit or "unknown"
     json.dump(res, open(out + ".json", "w"), indent=1)
     with open(out + ".md", "w") as f:
         f.write("# HBM traffic from PMC counters (rocprofv3 --pmc, separate passes), one training step, bf16, bs=8\n\n")
