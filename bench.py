@@ -462,7 +462,7 @@ def main_train(args, rank, world):
                  "; both towers per launch" if eng.towers_merged else ""))
     # the step's tail (last weight gradients, exchange, update, repack) overlaps the next step's frozen layers; an
     # explicit device synchronisation brackets the timed region as always (OSD_NO_DEFER_JOIN=1: A/B switch)
-    eng.defer_join = not os.environ.get("OSD_NO_DEFER_JOIN")
+    eng.defer_join = not os.environ.get("OSD_NO_DEFER_JOIN") and not args.graph
     step = lambda: eng.train_step(images, queries, gt_boxes, gt_count)     # noqa: E731
     if args.graph:
         try:

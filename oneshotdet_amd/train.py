@@ -1047,6 +1047,9 @@ class TrainEngine(object):
         rate is baked in at capture time; call capture() again after changing it."""
         self._static = [t.clone() for t in (images, queries, gt_boxes, gt_count)]
         self._overlap = False          # no collectives inside a captured graph: the exchange runs between the two graphs
+        self.join()
+        self.defer_join = False        # a captured graph must join every stream it forked
+        self._prop_depth = None        # the lagged NMS-depth feedback queries events from the host: not capturable
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -51,6 +51,24 @@ class DeviceImage(object):
     def flipped(self):
         return DeviceImage(self.src, self.out_hw, not self.flip)
 
+    def crop(self, box):
+        """PIL.Image.crop((left, upper, right, lower)) — how the dataset cuts a support patch out of its image
+        (data/datasets/coco.py:350: `img.crop((x, y, x + w, y + h))` on COCO's float boxes): the coordinates are rounded
+        (`int(round(v))`, as Image.crop does), the part outside the image is black.  Only before any Resize / flip."""
+        if self.flip or self.out_hw != (int(self.src.shape[0]), int(self.src.shape[1])):
+            raise ValueError("DeviceImage.crop applies to the untransformed image")
+        x0, y0, x1, y1 = [int(round(float(v))) for v in box]
+        if x1 <= x0 or y1 <= y0:
+            raise ValueError("empty crop %r" % (box,))
+        h, w = int(self.src.shape[0]), int(self.src.shape[1])
+        cx0, cy0, cx1, cy1 = max(x0, 0), max(y0, 0), min(x1, w), min(y1, h)
+        if (cx0, cy0, cx1, cy1) == (x0, y0, x1, y1):
+            return DeviceImage(self.src[y0:y1, x0:x1])
+        out = torch.zeros((y1 - y0, x1 - x0, 3), device=self.src.device, dtype=torch.uint8)
+        if cx1 > cx0 and cy1 > cy0:
+            out[cy0 - y0:cy1 - y0, cx0 - x0:cx1 - x0] = self.src[cy0:cy1, cx0:cx1]
+        return DeviceImage(out)
+
 
 def _resize_boxes(target, new_size_wh):
     """BoxList.resize (structures/bounding_box.py:91-128): boxes scale with the image; one ratio when both agree."""

@@ -881,6 +881,46 @@ def test_image_without_ground_truth_and_empty_second_stage_inputs():
     assert torch.equal(det["boxes"][0, :k], ref["boxes"][0, :k])
 
 
+def test_captured_training_step_matches_eager_steps():
+    """TrainEngine.capture / replay_step (hipGraph replay of forward + loss + backward, then of the optimiser; bench.py
+    --graph): three replayed steps on changing data give the losses and the weights of three eager steps (fp32; atomics
+    order aside).  capture() must work on an engine that has already run deferred-join steps with the proposal-depth
+    feedback armed — both are switched off for the captured graph."""
+    from oneshotdet_amd import train
+    np_sd = synth.make_state_dict(spec.hot_path_shapes())
+    B, h, w = 2, 128, 160
+    q = torch.from_numpy(synth.make_images("cg.q", B, 63, 63, seed=1)).cuda()
+    batches = []
+    for step in range(4):
+        img = torch.from_numpy(synth.make_images("cg.img.%d" % step, B, h, w, seed=step)).cuda()
+        gts = synth.make_gt_boxes(B, h, w, seed=60 + step, max_boxes=3)
+        gtb = torch.zeros(B, 3, 4)
+        for i, g in enumerate(gts):
+            gtb[i, :len(g)] = torch.from_numpy(g)
+        batches.append((img, gtb.cuda(), torch.tensor([len(g) for g in gts], dtype=torch.int32).cuda()))
+    out = {}
+    for graphed in (False, True):
+        eng = train.TrainEngine(np_sd, dtype=torch.float32, lr=0.002)
+        eng.defer_join = True
+        first = eng.train_step(batches[0][0], q, batches[0][1], batches[0][2]).clone()
+        if graphed:
+            eng.join()
+            w0, m0, n0 = eng.flat_w.clone(), eng._sgd["buf"].clone(), eng._sgd["steps"]
+            eng.capture(batches[0][0], q, batches[0][1], batches[0][2], warmup=1)      # runs training steps itself:
+            eng.flat_w.copy_(w0)                                                            # restore the state after step 1
+            eng._sgd["buf"].copy_(m0)
+            eng._sgd["steps"] = n0
+            eng.repack()
+            losses = [eng.replay_step(img, q, gtb, cnt).clone() for img, gtb, cnt in batches[1:]]
+        else:
+            losses = [eng.train_step(img, q, gtb, cnt).clone() for img, gtb, cnt in batches[1:]]
+        eng.join()
+        torch.cuda.synchronize()
+        out[graphed] = (torch.stack([first] + losses).cpu(), eng.flat_w.clone().cpu())
+    torch.testing.assert_close(out[True][0], out[False][0], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-4, atol=1e-6)
+
+
 def test_deferred_join_matches_joined_steps():
     """train_step(defer_join=True) leaves the step's tail (last weight gradients, update, repack, proposals) on the side
     streams and lets the next step's frozen layers run beside it.  Same data, same steps: the losses of every step and the

@@ -116,6 +116,26 @@ def test_batched_chain_equals_the_per_image_one_for_mixed_batches():
     assert torch.equal(packed.tensor, ref)
 
 
+def test_crop_matches_pil_crop():
+    """DeviceImage.crop = PIL.Image.crop as the dataset uses it to cut support patches (coco.py:350): float COCO boxes are
+    rounded, regions outside the image come back black; the cropped patch then runs through the support transform exactly
+    like a PIL patch would (compared through the oracle's resize of PIL's crop)."""
+    from PIL import Image
+    from oneshotdet_amd import transforms as T
+    rng = np.random.RandomState(5)
+    src = rng.randint(0, 256, (90, 130, 3)).astype(np.uint8)
+    pil = Image.fromarray(src)
+    for box in [(10.4, 5.5, 70.6, 60.49), (0, 0, 130, 90), (-7.2, 20.0, 40.0, 95.5), (100.5, 70.5, 140.2, 99.0), (3, 4, 5, 6)]:
+        ref = np.asarray(pil.crop(box))
+        got = T.DeviceImage(src).crop(box)
+        assert got.size == (ref.shape[1], ref.shape[0]) and np.array_equal(got.src.cpu().numpy(), ref), box
+        comp = T.Compose([T.Resize(40, 80), T.RandomHorizontalFlip(0.0), T.ToTensor(), T.Normalize(T.PIXEL_MEAN, T.PIXEL_STD)])
+        out, _ = comp(got, None)
+        assert np.array_equal(out.cpu().numpy(), otr.transform_image(np.ascontiguousarray(ref), 40, 80, False, T.PIXEL_MEAN, T.PIXEL_STD, True)), box
+    with pytest.raises(ValueError):
+        T.DeviceImage(src).crop((10, 10, 10, 20))
+
+
 def test_engine_accepts_the_packed_stem_input():
     """HotPathEngine.detect on transforms.collate(..., stem_dtype) gives the same proposals as on the float batch."""
     from oneshotdet_amd import model, spec, synth, transforms as T
