@@ -291,6 +291,15 @@ int osd_conv2d_wgrad_multi(const osd_conv_desc* d, int n_seg, const void* const*
  * taken from descs[0]; descs is a HOST array of n_seg descriptors. */
 int osd_conv2d_wgrad_mixed(int n_seg, const osd_conv_desc* descs, const void* const* xs, const void* const* dys,
                            const float* const* scales, float* const* dws, float* const* dbs, void* stream);
+/* Ordered mode of the weight-gradient launches (osd_conv2d_wgrad and its _grouped / _batched / _mixed / _multi forms) on
+ * one stream: with a scratch buffer registered for the stream, every workgroup stores its partial tile there and a second
+ * launch sums the tiles in a fixed order — dW (and db) come out bit-identical from run to run, and the partial tiles
+ * travel as plain stores instead of fp32 atomics performed at the memory side.  Without one (the default) the partial
+ * tiles are added with atomics (ATen's conv backward makes no ordering promise either: engine/trainer.py:92).  A launch
+ * that needs more than `bytes` (workgroups x (tile + tile rows) x 4; 1 GiB covers every launch of the training step)
+ * fails with OSD_ERR_WORKSPACE.  workspace == NULL removes the stream's entry.  The buffer must stay alive and must not be
+ * shared by streams that run concurrently. */
+int osd_conv2d_wgrad_set_workspace(void* stream, void* workspace, int64_t bytes);
 /* packed fp32 dW [cout][r][s][cin] -> OIHW fp32 gradient, multiplied by the folded FrozenBN scale (nullable);
  * accumulate != 0 adds to grad_oihw (weights shared over FPN levels) */
 int osd_unpack_wgrad(const float* dw_packed, const float* scale, float* grad_oihw, int cout, int cin, int r, int s,

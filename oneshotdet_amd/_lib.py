@@ -97,6 +97,7 @@ SIGNATURES = {
     "osd_roi_pool_levels_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "osd_image_transform": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "osd_image_transform_workspace_bytes": (_i64, [_i, _i, _i, _i]),
+    "osd_conv2d_wgrad_set_workspace": (_i, [_p, _p, _i64]),
     "osd_image_transform_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
 }
 

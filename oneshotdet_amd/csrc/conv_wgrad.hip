@@ -40,6 +40,10 @@ struct WgradSeg {
 struct WgradParams {
   WgradSeg seg[kMaxSeg];
   int n_seg;
+  int n_blocks;       // logical workgroups of the launch (= partial tiles in ordered mode)
+  float* partials;    // ordered mode (osd_conv2d_wgrad_set_workspace): every workgroup STORES its partial tile into slot
+                      // [logical id][TCO * TCI + TCO] instead of adding it atomically; wgrad_reduce_kernel sums the slots
+                      // in a fixed order: bit-reproducible dW, plain stores instead of memory-side atomics
 };
 
 // fp32 add into GLOBAL memory.  The dW / db pointers come out of the kernarg table as integers, so plain atomicAdd sees a
@@ -124,6 +128,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3)
   p.sh = OSD_WSEG(int, sh); p.sw = OSD_WSEG(int, sw); p.ph = OSD_WSEG(int, ph); p.pw = OSD_WSEG(int, pw);
   p.dy_stride = OSD_WSEG(int, dy_stride); p.tilesCo = OSD_WSEG(int, tilesCo); p.tilesCi = OSD_WSEG(int, tilesCi);
   p.Ktot = OSD_WSEG(int, Ktot);
+  const int slot_id = bid;            // logical id over the whole launch: the partial tile's slot in ordered mode
   bid -= OSD_WSEG(int, block_begin);
 #undef OSD_WSEG
   const int co_tile = bid % p.tilesCo;
@@ -345,6 +350,20 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3)
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
 
+  if (gp.partials != nullptr) {
+    // ordered mode: the raw partial tile (and the bias partial of the tap-0 / ci-tile-0 workgroups) goes to this
+    // workgroup's slot; channels past Cout / Cin hold zeros (their operands were the zero page)
+    float* __restrict__ slot = gp.partials + (size_t)slot_id * (TCO * TCI + TCO);
+    float* __restrict__ base = slot + (wm * WCOL_A + (lane >> 4) * 4) * TCI + wn * WCOL_B + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) base[(i * 16 + e) * TCI + j * 16] = acc[i][j][e];
+    if (do_bias) slot[TCO * TCI + tid] = bsum;
+    return;
+  }
   if (do_bias && co0 + tid < p.Cout) wg_atomic_add(p.db + co0 + tid, bsum);
 #ifdef OSD_WG_NO_ATOMICS
   if (acc[0][0][0] != 12345.678f) return;
@@ -391,6 +410,71 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3)
       }
     }
   }
+}
+
+// ---- ordered mode, second pass: dW += scale * sum of the partial tiles, in a fixed order ----
+// grid (output tiles of all segments, TCO / 16): a workgroup owns 16 rows of one output tile of one LEADER segment (the
+// first segment that names a dW; the FPN levels of a conv repeat the pointer) and adds, element by element, the slots of
+// that segment's splits, then of the next segment with the same dW, ... — always in that order.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradParams gp, int TCO, int TCI) {
+  typedef const __attribute__((address_space(4))) char* kptr;
+  kptr kb = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WgradParams, seg);
+#define OSD_RSEG(idx, type, field) (*reinterpret_cast<const __attribute__((address_space(4))) type*>(kb + (idx) * (int)sizeof(WgradSeg) + offsetof(WgradSeg, field)))
+  typedef unsigned long long u64;
+  int t = blockIdx.x, s = 0, tiles = 0;
+  for (; s < gp.n_seg; ++s) {
+    tiles = OSD_RSEG(s, int, tilesCo) * OSD_RSEG(s, int, tilesCi) * OSD_RSEG(s, int, R) * OSD_RSEG(s, int, S);
+    if (t < tiles) break;
+    t -= tiles;
+  }
+  if (s >= gp.n_seg) return;
+  const u64 dwp = OSD_RSEG(s, u64, dw);
+  for (int q = 0; q < s; ++q)
+    if (OSD_RSEG(q, u64, dw) == dwp) return;            // not the leader of its dW
+  float* __restrict__ dw = (float*)dwp;
+  const float* __restrict__ scale = (const float*)OSD_RSEG(s, u64, scale);
+  float* __restrict__ db = (float*)OSD_RSEG(s, u64, db);
+  const int Cout = OSD_RSEG(s, int, Cout), Cin = OSD_RSEG(s, int, Cin), Ktot = OSD_RSEG(s, int, Ktot);
+  const int tilesCo = OSD_RSEG(s, int, tilesCo), tilesCi = OSD_RSEG(s, int, tilesCi);
+  const int co_tile = t % tilesCo, nt = t / tilesCo;
+  const int tap = nt / tilesCi, ci_tile = nt % tilesCi;
+  const int co0 = co_tile * TCO, ci0 = ci_tile * TCI;
+  const size_t slot_floats = (size_t)TCO * TCI + TCO;
+  const int r0 = blockIdx.y * 16;
+  for (int idx = threadIdx.x; idx < 16 * TCI; idx += 256) {
+    const int r = r0 + idx / TCI, c = idx % TCI;
+    float sum = 0.f;
+    for (int m = s; m < gp.n_seg; ++m) {
+      if (OSD_RSEG(m, u64, dw) != dwp) continue;
+      const int begin = OSD_RSEG(m, int, block_begin);
+      const int end = m + 1 < gp.n_seg ? OSD_RSEG(m + 1, int, block_begin) : gp.n_blocks;
+      const int splits = (end - begin) / tiles;
+      const float* __restrict__ src = gp.partials + (size_t)(begin + t) * slot_floats + (size_t)r * TCI + c;
+      const size_t step = (size_t)tiles * slot_floats;
+      int sp = 0;
+      for (; sp + 4 <= splits; sp += 4) {                // four independent loads in flight; the ADD order stays fixed
+        const float a0 = src[(size_t)sp * step], a1 = src[(size_t)(sp + 1) * step];
+        const float a2 = src[(size_t)(sp + 2) * step], a3 = src[(size_t)(sp + 3) * step];
+        sum = (((sum + a0) + a1) + a2) + a3;
+      }
+      for (; sp < splits; ++sp) sum += src[(size_t)sp * step];
+    }
+    const int co = co0 + r, ci = ci0 + c;
+    if (co < Cout && ci < Cin) dw[(size_t)co * Ktot + tap * Cin + ci] += sum * (scale ? scale[co] : 1.f);
+  }
+  if (db != nullptr && nt == 0 && blockIdx.y == 0 && (int)threadIdx.x < TCO && co0 + (int)threadIdx.x < Cout) {
+    float sum = 0.f;
+    for (int m = s; m < gp.n_seg; ++m) {
+      if (OSD_RSEG(m, u64, dw) != dwp) continue;
+      const int begin = OSD_RSEG(m, int, block_begin);
+      const int end = m + 1 < gp.n_seg ? OSD_RSEG(m + 1, int, block_begin) : gp.n_blocks;
+      const int splits = (end - begin) / tiles;
+      for (int sp = 0; sp < splits; ++sp)
+        sum += gp.partials[(size_t)(begin + co_tile + (size_t)sp * tiles) * slot_floats + (size_t)TCO * TCI + threadIdx.x];
+    }
+    db[co0 + threadIdx.x] += sum;
+  }
+#undef OSD_RSEG
 }
 
 // ---- 3x3 / stride 1 / pad 1: one workgroup per FILTER ROW (three taps), bf16 ----
@@ -842,6 +926,37 @@ __global__ void __launch_bounds__(256) bias_grad_kernel(const T* __restrict__ dy
 
 extern "C" int osd_bias_grad(const void* dy, float* db, int m, int c, int stride, int dtype, void* stream);
 
+// ---- ordered mode: a scratch buffer per stream (osd_conv2d_wgrad_set_workspace) ----
+#include <mutex>
+namespace {
+struct WgradWs { hipStream_t stream; void* ptr; long long bytes; };
+WgradWs g_wgrad_ws[16];
+int g_wgrad_ws_n = 0;
+std::mutex g_wgrad_ws_mu;
+bool wgrad_ws_lookup(hipStream_t s, void** ptr, long long* bytes) {
+  std::lock_guard<std::mutex> lock(g_wgrad_ws_mu);
+  for (int i = 0; i < g_wgrad_ws_n; ++i)
+    if (g_wgrad_ws[i].stream == s) { *ptr = g_wgrad_ws[i].ptr; *bytes = g_wgrad_ws[i].bytes; return true; }
+  return false;
+}
+}  // namespace
+
+extern "C" int osd_conv2d_wgrad_set_workspace(void* stream, void* workspace, int64_t bytes) {
+  std::lock_guard<std::mutex> lock(g_wgrad_ws_mu);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int i = 0; i < g_wgrad_ws_n; ++i)
+    if (g_wgrad_ws[i].stream == s) {
+      if (workspace) { g_wgrad_ws[i].ptr = workspace; g_wgrad_ws[i].bytes = bytes; }
+      else g_wgrad_ws[i] = g_wgrad_ws[--g_wgrad_ws_n];
+      return OSD_OK;
+    }
+  if (!workspace) return OSD_OK;
+  if (bytes <= 0) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_set_workspace: bad size");
+  if (g_wgrad_ws_n == 16) return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad_set_workspace: more than 16 streams with a workspace");
+  g_wgrad_ws[g_wgrad_ws_n++] = WgradWs{s, workspace, (long long)bytes};
+  return OSD_OK;
+}
+
 struct WgradProblem {      // host-side description of one segment
   const osd_conv_desc* d;    // geometry: n, h, w, cin, cout, r, s, strides, pads, out_stride
   int n, h, w;
@@ -892,6 +1007,8 @@ static int wgrad_xr_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
     if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
   }
   for (int i = n_seg; i < kMaxSeg; ++i) p.seg[i] = p.seg[0];
+  p.n_blocks = (int)nblocks;
+  p.partials = nullptr;         // the filter-row kernel has no ordered mode
 #define OSD_WGX(BK, NS)                                                                                               \
   do {                                                                                                                \
     auto kern = conv_wgrad_xr_kernel<BK, NS>;                                                                         \
@@ -978,6 +1095,20 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
     if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
   }
   for (int i = n_seg; i < kMaxSeg; ++i) p.seg[i] = p.seg[0];
+  p.n_blocks = (int)nblocks;
+  p.partials = nullptr;
+  const int tco = tw * sub_co, tci = tw * sub_ci;
+  {
+    void* wsp = nullptr;
+    long long wsb = 0;
+    if (wgrad_ws_lookup(s, &wsp, &wsb)) {
+      const long long need = nblocks * ((long long)tco * tci + tco) * 4;
+      if (need > wsb)
+        return osd_fail(OSD_ERR_WORKSPACE, "wgrad (ordered mode): the launch needs %lld bytes of partial tiles, the stream's workspace has %lld",
+                        need, wsb);
+      p.partials = static_cast<float*>(wsp);
+    }
+  }
   const osd_conv_desc* d = d0;
   // variant: 0 = 32 px x 3 stages, 1 = 64 px x 2, 2 = 32 px x 4, 3 = 64 px x 3 (bf16; fp32 always 32 x 3)
 #define OSD_WG_LAUNCH(TT, BK, NS, WC, WMM, WNN) OSD_WG_LAUNCH3(TT, BK, NS, WC, WC, WMM, WNN, false)
@@ -1017,6 +1148,14 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
 #undef OSD_WG_LAUNCH
 #undef OSD_WG_LAUNCH2
 #undef OSD_WG_LAUNCH3
+  if (p.partials != nullptr) {
+    int rc = osd_check_launch("conv_wgrad");
+    if (rc) return rc;
+    long long tiles = 0;
+    for (int i = 0; i < n_seg; ++i) tiles += (long long)p.seg[i].tilesCo * p.seg[i].tilesCi * p.seg[i].R * p.seg[i].S;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)tiles, tco / 16), dim3(256), 0, s, p, tco, tci);
+    return osd_check_launch("conv_wgrad(reduce)");
+  }
   return osd_check_launch("conv_wgrad");
 }
 

@@ -565,6 +565,29 @@ def pack_conv_master_dgrad(w_orsi, scale, dtype):
 WGRAD_ALGO_CACHE = {}
 
 
+_WGRAD_WS = {}      # stream handle -> the tensor registered as its ordered-mode workspace (kept alive here)
+
+
+def wgrad_set_workspace(stream=None, nbytes=1 << 30):
+    """Ordered mode of the weight-gradient launches on `stream` (default: the current one): partial tiles as plain stores
+    into a scratch buffer + a fixed-order reduction pass = bit-reproducible dW (osd_conv2d_wgrad_set_workspace).
+    nbytes = 0 switches back to atomics.  Tuner results are cached per mode."""
+    st = stream if stream is not None else torch.cuda.current_stream()
+    handle = C.c_void_p(st.cuda_stream)
+    if nbytes:
+        buf = torch.empty((nbytes // 4,), device=st.device, dtype=torch.float32)
+        _lib.call("osd_conv2d_wgrad_set_workspace", handle, _ptr(buf), int(nbytes))
+        _WGRAD_WS[st.cuda_stream] = buf
+    else:
+        _lib.call("osd_conv2d_wgrad_set_workspace", handle, C.c_void_p(0), 0)
+        _WGRAD_WS.pop(st.cuda_stream, None)
+
+
+def _wgrad_mode():
+    """Part of the weight-gradient tuner's cache key: the best variant differs between atomics and ordered mode."""
+    return torch.cuda.current_stream().cuda_stream in _WGRAD_WS
+
+
 def wgrad_xr_candidates(dtype, cout, cin, r, s, stride, pad, widths):
     """The filter-row kernel (one workgroup per 3 taps; conv_wgrad_xr_kernel): algo = 1 + 128 + x + 16 * split-target code,
     x = 0: 32-pixel stages x 6, 1: 64 x 4, 2: 32 x 8.  bf16 3x3 / 1 / 1, channels in 128s, every map width a multiple or
@@ -625,7 +648,7 @@ def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None, db=None,
 
     def launch(dw, dbias):
         _lib.call("osd_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(scale), _ptr(dw), _ptr(dbias), st)
-    key = (d.dtype, tuple(x.shape), cout, r, s, stride, pad, dy.shape[-1], db is not None)
+    key = (d.dtype, tuple(x.shape), cout, r, s, stride, pad, dy.shape[-1], db is not None, _wgrad_mode())
     if algo is None:
         algo = WGRAD_ALGO_CACHE.get(key)
     if algo is None:
@@ -655,7 +678,7 @@ def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, 
 
     def launch(dw, dbias):
         _lib.call("osd_conv2d_wgrad_grouped", C.byref(d), k, xs, dys, ns, hs, ws, _ptr(scale), _ptr(dw), _ptr(dbias), st)
-    key = (d.dtype, tuple(tuple(x.shape) for x, _ in pairs), cout, r, s, stride, pad, dy0.shape[-1], db is not None)
+    key = (d.dtype, tuple(tuple(x.shape) for x, _ in pairs), cout, r, s, stride, pad, dy0.shape[-1], db is not None, _wgrad_mode())
     if algo is None:
         algo = WGRAD_ALGO_CACHE.get(key)
     if algo is None:
@@ -681,7 +704,7 @@ def conv2d_wgrad_batched(items, r, s, stride, pad, cout, algo=None):
         dwp = (C.c_void_p * k)(*[t.data_ptr() for t in dws])
         dbp = (C.c_void_p * k)(*[(t.data_ptr() if t is not None else 0) for t in dbs])
         _lib.call("osd_conv2d_wgrad_batched", C.byref(d), k, xs, dys, scales, dwp, dbp, st)
-    key = ("batched", k, d.dtype, tuple(x0.shape), cout, r, s, stride, pad, dy0.shape[-1], has_db)
+    key = ("batched", k, d.dtype, tuple(x0.shape), cout, r, s, stride, pad, dy0.shape[-1], has_db, _wgrad_mode())
     if algo is None:
         algo = WGRAD_ALGO_CACHE.get(key)
     if algo is None:
@@ -715,7 +738,7 @@ def conv2d_wgrad_multi(items, r, s, stride, pad, cout, algo=None):
         dbp = (C.c_void_p * k)(*[(t.data_ptr() if t is not None else 0) for t in dbs])
         _lib.call("osd_conv2d_wgrad_multi", C.byref(d), k, xs, dys, ns, hs, ws, scales, dwp, dbp, st)
     key = ("multi", d.dtype, tuple(tuple(it[0].shape) for it in items), tuple(id(it[2]) == id(items[0][2]) for it in items),
-           cout, r, s, stride, pad, dy0.shape[-1], any(b is not None for b in real_dbs))
+           cout, r, s, stride, pad, dy0.shape[-1], any(b is not None for b in real_dbs), _wgrad_mode())
     if algo is None:
         algo = WGRAD_ALGO_CACHE.get(key)
     if algo is None:
@@ -750,7 +773,7 @@ def conv2d_wgrad_mixed(items, algo=None):
         dbp = (C.c_void_p * k)(*[(t.data_ptr() if t is not None else 0) for t in dbs])
         _lib.call("osd_conv2d_wgrad_mixed", k, descs, xs, dys, scales, dwp, dbp, st)
     key = ("mixed", descs[0].dtype, tuple((tuple(it[0].shape), tuple(it[1].shape)) + tuple(it[5:]) for it in items),
-           tuple([id(u) for u in real_dws].index(id(t)) for t in real_dws))
+           tuple([id(u) for u in real_dws].index(id(t)) for t in real_dws), _wgrad_mode())
     if algo is None:
         algo = WGRAD_ALGO_CACHE.get(key)
     if algo is None:

@@ -462,6 +462,57 @@ def test_conv_wgrad_every_algorithm_matches_autograd(case):
             assert (dw.cpu() - 2 * ref).abs().max().item() <= 2e-2 * 2 * ref.abs().max().item(), algo
 
 
+def test_conv_wgrad_ordered_mode_is_bit_reproducible():
+    """osd_conv2d_wgrad_set_workspace: with a scratch buffer registered for the stream the partial tiles are STORED and
+    summed in a fixed order by a second launch.  For every launch form (single conv with ragged channel tiles, FPN levels
+    sharing one dW, a mixed 1x1 / 3x3 / stride-2 launch with FrozenBN scales and bias gradients) and several variants /
+    split targets: dW and db are BIT-IDENTICAL across repeats, equal the atomic path to rounding, and the atomic path
+    itself is what differs from run to run; a workspace that is too small fails loudly."""
+    from oneshotdet_amd import ops, _lib
+    g = torch.Generator().manual_seed(3)
+    mk = lambda *s: to_nhwc(torch.randn(*s, generator=g) * 0.5, torch.bfloat16)       # noqa: E731
+    x1, dy1 = mk(3, 320, 40, 36), mk(3, 192, 40, 36)                                   # ragged: 320 / 192 channels
+    lv = [(mk(2, 256, h, w), mk(2, 256, h, w)) for (h, w) in ((48, 64), (24, 32), (12, 16), (6, 8))]
+    xm = [(mk(2, 256, 24, 32), mk(2, 128, 24, 32), 1, 1, 0), (mk(2, 128, 24, 32), mk(2, 128, 24, 32), 3, 1, 1),
+          (mk(2, 256, 24, 32), mk(2, 512, 12, 16), 1, 2, 0)]
+    scales = [(torch.rand(c, generator=g) + 0.5).cuda() for c in (128, 128, 512)]
+
+    def run(algo):
+        outs = []
+        dw = torch.zeros(192, 3, 3, 320, device="cuda"); db = torch.zeros(192, device="cuda")
+        ops.conv2d_wgrad(x1, dy1, dw, 3, 3, 1, 1, 192, db=db, algo=algo)
+        outs += [dw, db]
+        dw = torch.zeros(256, 3, 3, 256, device="cuda"); db = torch.zeros(256, device="cuda")
+        ops.conv2d_wgrad_grouped(lv, dw, 3, 3, 1, 1, 256, db=db, algo=algo)
+        outs += [dw, db]
+        items = []
+        for (x, dy, k, st, pd), sc in zip(xm, scales):
+            cout = dy.shape[-1]
+            items.append((x, dy, torch.zeros(cout, k, k, x.shape[-1], device="cuda"), sc, torch.zeros(cout, device="cuda"), k, k, st, pd, cout))
+        ops.conv2d_wgrad_mixed(items, algo=algo)
+        outs += [it[2] for it in items] + [it[4] for it in items]
+        torch.cuda.synchronize()
+        return outs
+    algos = (1 + 0 + 16 * 4, 1 + 11 + 16 * 7, 1 + 5 + 16 * 0, 1 + 1 + 16 * 6)
+    atomic = {a: run(a) for a in algos}
+    try:
+        ops.wgrad_set_workspace(nbytes=1 << 30)
+        for a in algos:
+            first = run(a)
+            for _ in range(3):
+                again = run(a)
+                assert all(torch.equal(u, v) for u, v in zip(first, again)), a
+            for u, v in zip(first, atomic[a]):
+                assert (u - v).abs().max().item() <= 1e-4 * v.abs().max().item() + 1e-6, a
+        ops.wgrad_set_workspace(nbytes=1 << 16)
+        with pytest.raises(_lib.OsdError):
+            run(algos[1])
+    finally:
+        ops.wgrad_set_workspace(nbytes=0)
+    differs = any(not torch.equal(u, v) for a in algos for u, v in zip(run(a), atomic[a]))
+    assert differs          # the default path adds with atomics: its rounding depends on the arrival order
+
+
 @pytest.mark.parametrize("widths", [(32,), (64, 32, 16, 8), (128, 4), (96, 1)])
 def test_conv_wgrad_filter_row_kernel_matches_autograd(widths):
     """conv_wgrad_xr_kernel (opt-in tuner candidate, OSD_WGRAD_XR=1; one workgroup per filter row: three taps on one dY fragment set, X tile read at row offsets
@@ -879,6 +930,35 @@ def test_image_without_ground_truth_and_empty_second_stage_inputs():
     assert int(det["counts"][1]) == 0 and int(det["counts"][0]) == int(ref["counts"][0]) > 0
     k = int(ref["counts"][0])
     assert torch.equal(det["boxes"][0, :k], ref["boxes"][0, :k])
+
+
+def test_engine_with_ordered_weight_gradients_matches_default_engine():
+    """TrainEngine(ordered_wgrad=True): every conv_wgrad launch of the step goes through the stored-partials + ordered
+    reduction path (its own tuner cache entries, 1 GiB of scratch per weight-gradient stream): same losses, the same
+    gradients to rounding and the same weights after two steps as the default (atomic) engine."""
+    from oneshotdet_amd import ops, train
+    outs = {}
+    try:
+        for ordered in (False, True):
+            eng, img, q, gtb, cnt = _engine_and_inputs("f32", "small")
+            if ordered:
+                eng = train.TrainEngine(synth.make_state_dict(spec.hot_path_shapes()), dtype=torch.float32, ordered_wgrad=True)
+                assert eng.ordered_wgrad and len(ops._WGRAD_WS) == 2
+            with ops.tuning():
+                l0 = eng.forward_backward(img, q, gtb, cnt).clone()
+            g0 = eng.flat_g.clone()
+            eng.optimizer_step()
+            eng.train_step(img, q, gtb, cnt)
+            eng.join()
+            torch.cuda.synchronize()
+            outs[ordered] = (l0.cpu(), g0.cpu(), eng.flat_w.clone().cpu())
+    finally:
+        for h in list(ops._WGRAD_WS):
+            ops._lib.call("osd_conv2d_wgrad_set_workspace", ops.C.c_void_p(h), ops.C.c_void_p(0), 0)
+            ops._WGRAD_WS.pop(h, None)
+    torch.testing.assert_close(outs[True][0], outs[False][0], rtol=1e-6, atol=0)
+    assert (outs[True][1] - outs[False][1]).abs().max() <= 1e-4 * outs[False][1].abs().max()
+    torch.testing.assert_close(outs[True][2], outs[False][2], rtol=1e-4, atol=1e-6)
 
 
 def test_captured_training_step_matches_eager_steps():

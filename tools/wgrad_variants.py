@@ -7,6 +7,9 @@ import torch
 from oneshotdet_amd import ops
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if os.environ.get("WG_ORDERED"):          # ordered mode: partial tiles stored + fixed-order reduction pass
+    ops.wgrad_set_workspace(nbytes=2 << 30)
+    print("ordered mode")
 dt = torch.bfloat16
 g = torch.Generator(device="cuda").manual_seed(0)
 
