@@ -832,6 +832,18 @@ class TrainEngine(object):
         """One training forward + backward.  images [B,3,H,W], queries [B*S,3,h,w] fp32 NCHW on the device;
         gt_boxes [B, G, 4] fp32 xyxy, gt_count [B] int32.  Returns losses [4] = (cls, reg, centerness, num_pos)."""
         from . import model
+        from .layers import ImageList
+        # padded batches as the collator hands them over (layers.ImageList, or transforms.collate(..., stem_dtype) =
+        # ops.PackedImages: already in the stem conv's input format): every image's / query's true size travels along
+        query_sizes = None
+        if isinstance(images, ImageList):
+            images, image_sizes = images.tensors, images.image_sizes
+        elif isinstance(images, ops.PackedImages) and image_sizes is None:
+            image_sizes = images.image_sizes
+        if isinstance(queries, ImageList):
+            queries, query_sizes = queries.tensors, queries.image_sizes
+        elif isinstance(queries, ops.PackedImages):
+            query_sizes = queries.image_sizes
         main, s1 = torch.cuda.current_stream(), self.s1
         # train_step(defer_join) left the previous step's tail (last weight gradients, exchange, update, repack, proposals)
         # running on the side streams: the frozen prefix of this forward goes first, then the main stream joins them
@@ -848,7 +860,7 @@ class TrainEngine(object):
             join_previous()
         batch = images.shape[0]
         shots = queries.shape[0] // batch
-        q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0]
+        q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0] if query_sizes is None else [tuple(v) for v in query_sizes]
         rois = model.whole_image_rois(q_sizes, self.device)
         # ---- forward: both backbones in lockstep (one launch per layer), query pooling, correlation, head
         lock = self.lockstep

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import golden_utils as gu
+from oneshotdet_amd import spec, synth
 from golden.make_golden_cases import TRANSFORM_CASES, TRANSFORM_SIZES, transform_source
 from oracle import transforms_ref as otr
 
@@ -148,6 +149,35 @@ def test_engine_accepts_the_packed_stem_input():
     for x, y in zip(a["proposals"], b["proposals"]):
         assert torch.equal(x, y)
     assert int(a["proposals"][2].min()) > 0
+
+
+def test_train_engine_accepts_collated_batches():
+    """TrainEngine.forward_backward on what the input pipeline produces — transforms.collate(...) as layers.ImageList or,
+    with stem_dtype, as ops.PackedImages (different true sizes inside one padded batch) — gives exactly the losses and
+    gradients of the same step on the float tensors with image_sizes passed by hand."""
+    from oneshotdet_amd import train, transforms as T
+    rng = np.random.RandomState(4)
+    tg = [T.Resize(96, 160)(T.DeviceImage(rng.randint(0, 256, (60 + 14 * i, 100, 3)).astype(np.uint8)), None)[0] for i in range(2)]
+    qs = [T.Resize(48, 64)(T.DeviceImage(rng.randint(0, 256, (40, 40 + 6 * i, 3)).astype(np.uint8)), None)[0] for i in range(2)]
+    gtb = torch.tensor([[[10., 12., 60., 70.]], [[30., 20., 90., 80.]]]).cuda()
+    cnt = torch.tensor([1, 1], dtype=torch.int32).cuda()
+    sd = synth.make_state_dict(spec.hot_path_shapes())
+    outs = []
+    for mode in ("float", "imagelist", "packed"):
+        eng = train.TrainEngine(sd, dtype=torch.float32)
+        ti, qi = T.collate(tg, 32), T.collate(qs, 32)
+        if mode == "float":
+            losses = eng.forward_backward(ti.tensors, qi.tensors, gtb, cnt, image_sizes=ti.image_sizes)
+        elif mode == "imagelist":
+            losses = eng.forward_backward(ti, qi, gtb, cnt)
+        else:
+            losses = eng.forward_backward(T.collate(tg, 32, stem_dtype=torch.float32), T.collate(qs, 32, stem_dtype=torch.float32), gtb, cnt)
+        torch.cuda.synchronize()
+        outs.append((losses.clone().cpu(), eng.flat_g.clone().cpu()))
+    # the hand-fed float run pools the queries as full-size images: only the two collated forms see the true query sizes
+    torch.testing.assert_close(outs[2][0], outs[1][0], rtol=1e-6, atol=0)
+    assert (outs[2][1] - outs[1][1]).abs().max() <= 1e-5 * outs[1][1].abs().max()
+    assert torch.isfinite(outs[0][0]).all()
 
 
 def test_no_cpu_path():
