@@ -75,3 +75,22 @@ def test_documented_conv_argument_order_is_the_headers():
     names = [a.strip().split()[-1].lstrip("*") for a in m.group(1).replace("\n", " ").split(",")]
     doc = re.search(r"`osd_conv2d_fwd\((.*?)\)`", text).group(1)
     assert [a.strip() for a in doc.split(",")] == ["desc" if n == "d" else n for n in names]
+
+
+def test_training_example_runs_checkpoints_and_resumes(tmp_path):
+    """examples/train.py: synthetic dataset samples -> reference-named transforms on device images -> collate into the stem
+    input -> both-stage training steps -> reference-format checkpoints -> resume (momentum and iteration restored)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "run")
+    cmd = [sys.executable, os.path.join(root, "examples", "train.py"), "--batch", "2", "--out", out, "--checkpoint-period", "2"]
+    r = subprocess.run(cmd + ["--iters", "3"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "loss_classifier" in r.stdout and os.path.exists(os.path.join(out, "model_0000003.pth"))
+    r = subprocess.run(cmd + ["--iters", "5", "--resume"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "resumed at iteration 3" in r.stdout and os.path.exists(os.path.join(out, "model_0000005.pth"))
+    import torch
+    ck = torch.load(os.path.join(out, "model_0000005.pth"), map_location="cpu", weights_only=False)
+    assert ck["iteration"] == 5 and "momentum_buffer" in ck["optimizer"] and "rpn.head.cls_tower.0.weight" in ck["model"]
