@@ -356,7 +356,7 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
     impl = a >> 5;                 // 0 = LDS-DMA kernel, 1 = register-staged kernel
     variant = (a >> 3) & 3;
     tile = a & 7;
-    if (variant == 3 || tile > 7 || (impl == 1 && (variant != 0 || tile > 3)) || ((tile == 5 || tile == 6) && variant != 0))
+    if (tile > 7 || (impl == 1 && (variant != 0 || tile > 3)) || ((tile == 5 || tile == 6) && variant != 0))
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv: algo %d not built", d->algo);
     if (p.Cout > 16 && tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: skinny tile on a wide conv");
   }
@@ -441,7 +441,7 @@ extern "C" int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const voi
     if (a >= 32) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d is not an LDS-DMA algorithm", d->algo);
     variant = (a >> 3) & 3;
     tile = a & 7;
-    if (variant == 3 || tile > 7 || ((tile == 5 || tile == 6) && variant != 0))
+    if (tile > 7 || ((tile == 5 || tile == 6) && variant != 0))
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d not built", d->algo);
     if (tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: skinny tile on a wide conv");
   }

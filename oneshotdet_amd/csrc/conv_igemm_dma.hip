@@ -304,13 +304,16 @@ int dispatch_tile_dma(int tile, const ConvKParams& p, hipStream_t s) {
 }  // namespace
 
 // variant: 0 = deep ring (bf16 KB128 x3 / fp32 KB64 x4), 1 = shallow ring (x2: half the LDS, twice the blocks per CU),
-//          2 = short stages (bf16 KB64 x4 / fp32 KB64 x3)
+//          2 = short stages (bf16 KB64 x4 / fp32 KB64 x3), 3 = short stages x 2 (bf16; fp32 = 1): a quarter of the deep
+//          ring's LDS — for the HBM-bound 1x1 convs whose K is 2-4 stages long, where workgroups in flight per CU (latency
+//          of the first operand fetch and of the residual read in the epilogue) matter and the ring depth does not
 int osd_conv_dma_dispatch(int dtype, int tile, int variant, const ConvKParams& p, hipStream_t s) {
   if (dtype == OSD_F32) {
-    if (variant == 1) return dispatch_tile_dma<float, 64, 2>(tile, p, s);
+    if (variant == 1 || variant == 3) return dispatch_tile_dma<float, 64, 2>(tile, p, s);
     if (variant == 2) return dispatch_tile_dma<float, 64, 3>(tile, p, s);
     return dispatch_tile_dma<float, 64, 4>(tile, p, s);
   }
+  if (variant == 3) return dispatch_tile_dma<__bf16, 64, 2>(tile, p, s);
   if (p.Cin % 64 != 0 || variant == 2) return dispatch_tile_dma<__bf16, 64, 4>(tile, p, s);
   if (variant == 1) return dispatch_tile_dma<__bf16, 128, 2>(tile, p, s);
   return dispatch_tile_dma<__bf16, 128, 3>(tile, p, s);

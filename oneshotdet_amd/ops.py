@@ -129,7 +129,7 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
     tiles = [3] if cout_store <= 16 else [0, 1, 2]
     if cout_store <= 16:
         tiles = [3, 2]
-    cands = [1 + 0 * 32 + v * 8 + t for v in (0, 1, 2) for t in tiles]
+    cands = [1 + 0 * 32 + v * 8 + t for v in (0, 1, 2, 3) for t in tiles]      # v 3: two short stages (many workgroups per CU)
     if cout_store >= 256 and not relu_in:
         cands.append(1 + 0 * 32 + 1 * 8 + 4)          # 256x256 tile, shallow ring
         cands.append(1 + 0 * 32 + 2 * 8 + 4)          # 256x256 tile, short stages x 4
@@ -137,7 +137,7 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
         if not os.environ.get("OSD_NO_XR"):           # (A/B switch for tools and benches)
             cands.append(1 + 0 * 32 + 0 * 8 + 6)      # 3x3/1: pixel rows fetched once per filter row (bf16, W in 64/128/256)
     if cout_store >= 128 and not relu_in:
-        cands += [1 + 0 * 32 + v * 8 + 7 for v in (0, 1, 2)]      # 256x128 tile on 8 waves: deep / shallow ring / short stages
+        cands += [1 + 0 * 32 + v * 8 + 7 for v in (0, 1, 2, 3)]      # 256x128 tile on 8 waves: deep / shallow ring / short stages
     if not relu_in and not has_mask:
         cands += [1 + 1 * 32 + t for t in tiles]
     return cands
