@@ -69,15 +69,26 @@ typedef struct osd_conv_desc {
                              DESIGN.md 4.1): lets the host autotune per layer shape by measurement */
 } osd_conv_desc;
 
+/* second pixel source of a 1x1 convolution (osd_conv2d_fwd): dense NHWC [n][h][w][cin2]; output pixel (ho, wo) reads
+ * x[n][ho * stride][wo * stride].  cin and cin2 multiples of 64. */
+typedef struct osd_conv_src2 {
+  const void* x;
+  int32_t cin2, h, w, stride;
+} osd_conv_src2;
+
 /* number of selectable algorithms for osd_conv_desc.algo (valid values 1..count); unsupported combinations for a
  * given shape return OSD_ERR_UNSUPPORTED */
 int osd_conv_algo_count(void);
 /* mask (optional, same geometry as y, pixel stride = out_stride): y = mask > 0 ? y : 0 after the residual add — the
  * ReLU backward of the layer whose forward output is `mask`, fused into the data-gradient convolution.
  * act_scale_dev (optional device scalar) overrides d->act_scale for OSD_ACT_EXP_SCALE: the learnable Scale of fcos.py:81
- * read on the device, so training needs no host round trip.  `reserved` must be NULL. */
+ * read on the device, so training needs no host round trip.
+ * src2 (nullable): a SECOND pixel source of a 1x1 conv — y = act(W[:, :cin] x + W[:, cin:cin+cin2] x2 + bias ...), the
+ * weights packed as one 1x1 conv over cin + cin2 input channels.  This is conv3 + downsample of a bottleneck's first block
+ * (resnet.py:295-315: out = bn3(conv3(out)); identity = downsample(x); out += identity) as ONE GEMM over the concatenated
+ * K: the downsample output is never stored and never re-read as a residual. */
 int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void* w, const float* bias, const void* res,
-                   const void* mask, const float* act_scale_dev, const void* reserved, void* y, void* stream);
+                   const void* mask, const float* act_scale_dev, const osd_conv_src2* src2, void* y, void* stream);
 
 /* The same convolution applied to n_seg <= OSD_CONV_MAX_SEG dense NHWC tensors of different batch / spatial size in ONE
  * launch: the FPN levels that share an FCOS tower or prediction conv (fcos.py:83-99 loops `for l, feature in enumerate(x)`

@@ -313,10 +313,9 @@ int choose_tile(int M, int cout) {
 extern "C" int osd_conv_algo_count(void) { return 64; }
 
 extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void* w, const float* bias,
-                              const void* res, const void* mask, const float* act_scale_dev, const void* reserved,
+                              const void* res, const void* mask, const float* act_scale_dev, const osd_conv_src2* src2,
                               void* y, void* stream) {
   if (!d || !x || !w || !bias || !y) return osd_fail(OSD_ERR_INVALID_ARG, "conv: null argument");
-  if (reserved) return osd_fail(OSD_ERR_INVALID_ARG, "conv: reserved argument must be null");
   if (d->cout % 4 != 0 || d->out_stride % 4 != 0)
     return osd_fail(OSD_ERR_INVALID_ARG, "conv: cout/out_stride must be multiples of 4 (got %d/%d)", d->cout,
                     d->out_stride);
@@ -341,8 +340,23 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
   const long long M = (long long)d->n * d->ho * d->wo;
   if (M <= 0 || M > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad M");
   p.M = (int)M; p.tilesM = p.tilesN = p.KT = 0; p.n_seg = 0;
+  p.x2 = nullptr; p.cin1 = p.x2_sN = p.x2_sH = p.x2_sW = p.st2 = 0;
+  if (src2 != nullptr) {
+    // second pixel source (see osd_conv_src2): K = cin + cin2, the packed weights hold both parts side by side
+    if (!src2->x || d->r != 1 || d->s != 1 || d->pad_h || d->pad_w || d->relu_in)
+      return osd_fail(OSD_ERR_INVALID_ARG, "conv: a second source needs a plain 1x1 conv and a tensor");
+    if (src2->cin2 <= 0 || src2->cin2 % 64 || d->cin % 64 || src2->stride < 1 ||
+        (d->ho - 1) * src2->stride >= src2->h || (d->wo - 1) * src2->stride >= src2->w)
+      return osd_fail(OSD_ERR_INVALID_ARG, "conv: second source: channels in 64s, every output pixel inside its %d x %d map", src2->h,
+                      src2->w);
+    p.x2 = src2->x; p.cin1 = d->cin; p.st2 = src2->stride;
+    p.x2_sW = src2->cin2; p.x2_sH = src2->w * src2->cin2; p.x2_sN = src2->h * src2->w * src2->cin2;
+    p.Cin = d->cin + src2->cin2;
+    p.Ktot = p.Cin;
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int tile = choose_tile(p.M, p.Cout);
+  if (src2 != nullptr && tile != 0 && tile != 2 && tile != 7) tile = 0;
   static int impl_env = -1;   // OSD_CONV_IMPL=regstage selects the first-generation register-staged kernel (A/B testing)
   if (impl_env < 0) {
     const char* e = getenv("OSD_CONV_IMPL");
@@ -360,6 +374,8 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv: algo %d not built", d->algo);
     if (p.Cout > 16 && tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: skinny tile on a wide conv");
   }
+  if (src2 != nullptr && (impl != 0 || tile == 5 || tile == 6))
+    return osd_fail(OSD_ERR_UNSUPPORTED, "conv: a second source runs on the LDS-DMA kernel, tiles 0 / 2 / 7");
   if (impl == 0 && tile == 5) {
     if (d->dtype != OSD_BF16) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the ping-pong 256x256 kernel is bf16 only");
     return osd_conv_p8_launch(p, s);
@@ -409,6 +425,7 @@ extern "C" int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const voi
   p.act = d->act; p.act_scale = d->act_scale; p.act_scale_dev = nullptr; p.relu_in = 0;
   p.tilesM = p.tilesN = p.KT = 0;
   p.n_seg = n_seg;
+  p.x2 = nullptr; p.cin1 = p.x2_sN = p.x2_sH = p.x2_sW = p.st2 = 0;
   long long mtot = 0;
   for (int i = 0; i < kConvMaxSeg; ++i) {
     const int j = i < n_seg ? i : 0;

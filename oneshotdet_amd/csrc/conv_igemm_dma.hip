@@ -55,7 +55,7 @@ __device__ __forceinline__ uint4 relu_frag(uint4 v, __bf16) {
   return v;
 }
 
-template <typename T, int BM, int BN, int KB, int WM, int WN, int NST, bool RELU_IN>
+template <typename T, int BM, int BN, int KB, int WM, int WN, int NST, bool RELU_IN, bool SRC2>
 __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
   // p lives in the kernarg segment; the per-segment fields are read through the q_* locals below
   constexpr int NWV = WM * WN;            // waves per workgroup: 4 (256 threads) or 8 (512 threads, the 256x256 tile)
@@ -102,12 +102,14 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
   // ---- per-lane DMA source coordinates ----
   const int lrow = lane / CH, lpos = lane % CH;
   const T* a_base[PA];
+  const T* a_base2[SRC2 ? PA : 1];      // second source (1x1 convs only): the lane's pixel in x2, channel chunk included
   int a_hi0[PA], a_wi0[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int row = (wave * PA + i) * RPI + lrow;
     const int m = m0 + row;
     a_base[i] = zero;
+    if constexpr (SRC2) a_base2[i] = zero;
     a_hi0[i] = -0x40000000;
     a_wi0[i] = 0;
     if (m < q_M) {
@@ -118,6 +120,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
       a_base[i] = xg + (size_t)n_img * q_sN + (lpos ^ swz_g<KB>(row)) * EPC;
       a_hi0[i] = ho * p.sh - p.ph;
       a_wi0[i] = wo * p.sw - p.pw;
+      if constexpr (SRC2)
+        a_base2[i] = reinterpret_cast<const T*>(p.x2) + (size_t)n_img * p.x2_sN + (size_t)(ho * p.st2) * p.x2_sH +
+                     (size_t)(wo * p.st2) * p.x2_sW + (lpos ^ swz_g<KB>(row)) * EPC;
     }
   }
   const T* b_ptr[PB];
@@ -142,6 +147,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
       const int hi = a_hi0[j] + kr, wi = a_wi0[j] + ks;
       const bool ok = ((unsigned)hi < (unsigned)q_H) && ((unsigned)wi < (unsigned)q_W);
       const T* src = ok ? a_base[j] + (hi * q_sH + wi * p.sW + kc) : zero;
+      if constexpr (SRC2) {
+        if (kc >= p.cin1) src = a_base2[j] + (a_base2[j] == zero ? 0 : kc - p.cin1);      // uniform branch: K past source 1
+      }
       dma16(src, xs + (wave * PA + j) * 1024);
     } else {
       const int i = j - PA;
@@ -250,7 +258,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
   conv_epilogue<T, TM, TN>(acc, p, q, smem, wave, wm, wn, lane, m0, n0);
 }
 
-template <typename T, int BM, int BN, int KB, int WM, int WN, int NST, bool RELU_IN = false>
+template <typename T, int BM, int BN, int KB, int WM, int WN, int NST, bool RELU_IN = false, bool SRC2 = false>
 int launch_dma(const ConvKParams& pin, hipStream_t stream) {
   ConvKParams p = pin;
   p.tilesM = cdiv(p.M, BM);
@@ -270,7 +278,7 @@ int launch_dma(const ConvKParams& pin, hipStream_t stream) {
   constexpr int npass = TMx >= 8 ? TMx / 2 : (TMx >= 2 ? 2 : 1);
   constexpr int stagec = WM * WN * ((TMx / npass) * 16) * (TNx * 16 * 4 + 16);
   constexpr int lds = ring > stagec ? ring : stagec;
-  auto kern = conv_dma_kernel<T, BM, BN, KB, WM, WN, NST, RELU_IN>;
+  auto kern = conv_dma_kernel<T, BM, BN, KB, WM, WN, NST, RELU_IN, SRC2>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -284,6 +292,18 @@ int launch_dma(const ConvKParams& pin, hipStream_t stream) {
 
 template <typename T, int KB, int NST>
 int dispatch_tile_dma(int tile, const ConvKParams& p, hipStream_t s) {
+  if (p.x2 != nullptr) {        // two pixel sources (1x1, single problem): three tiles are built for it
+    if (p.relu_in || p.n_seg > 0 || p.R != 1 || p.S != 1 || p.ph != 0 || p.pw != 0)
+      return osd_fail(OSD_ERR_UNSUPPORTED, "conv: a second source needs a plain 1x1 conv");
+    switch (tile) {
+      case 0: return launch_dma<T, 128, 128, KB, 2, 2, NST, false, true>(p, s);
+      case 2: return launch_dma<T, 64, 64, KB, 2, 2, NST, false, true>(p, s);
+      case 7:
+        if constexpr (NST * 384 * KB <= 155648) return launch_dma<T, 256, 128, KB, 4, 2, NST, false, true>(p, s);
+        else return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the 256x128 tile does not fit LDS with this ring");
+    }
+    return osd_fail(OSD_ERR_UNSUPPORTED, "conv: tile %d is not built for two sources (0, 2, 7 are)", tile);
+  }
   if (p.relu_in) return launch_dma<T, 64, 64, KB, 2, 2, NST, true>(p, s);   // only the tiny P7 conv uses it
   switch (tile) {
     case 0: return launch_dma<T, 128, 128, KB, 2, 2, NST>(p, s);

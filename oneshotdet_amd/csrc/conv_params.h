@@ -35,6 +35,11 @@ struct ConvKParams {
   const float* act_scale_dev;   // optional device scalar overriding act_scale (the learnable Scale of fcos.py:81)
   int relu_in;
   int M, tilesM, tilesN, KT;
+  // second pixel source of a 1x1 conv (x2 != nullptr): input channels [cin1, Cin) come from x2, read at output pixel
+  // (ho, wo) -> x2[n][ho * st2][wo * st2] (dense NHWC, Cin - cin1 channels): conv3 + downsample of a bottleneck's first
+  // block as ONE GEMM over the concatenated K (conv_dma kernels only, single problem)
+  const void* x2;
+  int cin1, x2_sN, x2_sH, x2_sW, st2;
   int n_seg;          // 0 = single problem (fields above); > 0: seg[] overrides x/y/res/mask/act_scale_dev/H/W/Ho/Wo/M/sN/sH
   ConvSeg seg[kConvMaxSeg];
 };

@@ -153,7 +153,7 @@ class tuning(object):
         _TUNING[0] = False
 
 
-def _tune(key, d, launch):
+def _tune(key, d, launch, cands=None):
     """Time every candidate algorithm for this conv shape (launch() reads d.algo) and cache the fastest."""
     best, best_t = 0, float("inf")
     forced = os.environ.get("OSD_FORCE_ALGO_3X3_256")     # experiments: pin the big 3x3 256-channel convs to one algorithm
@@ -166,7 +166,7 @@ def _tune(key, d, launch):
             return int(forced)
         except _lib.OsdError:
             pass
-    for algo in conv_algo_candidates(d.cout, d.relu_in, has_mask=bool(key[-1])):
+    for algo in (cands if cands is not None else conv_algo_candidates(d.cout, d.relu_in, has_mask=bool(key[-1]))):
         d.algo = algo
         try:
             launch()
@@ -186,11 +186,19 @@ def _tune(key, d, launch):
     return best
 
 
+class ConvSrc2(C.Structure):
+    """osd_conv_src2: the second pixel source of a 1x1 conv."""
+    _fields_ = [("x", C.c_void_p), ("cin2", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("stride", C.c_int32)]
+
+
 def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, relu_in=False, act_scale=1.0, out=None,
-           out_hw=None, algo=None, mask=None, act_scale_dev=None):
+           out_hw=None, algo=None, mask=None, act_scale_dev=None, x2=None, x2_stride=1):
     """x NHWC [N,H,W,C] -> [N,Ho,Wo,cout_store].  For the stem, x is the padded NHWC4 image from pack_image and
-    out_hw gives (Ho, Wo)."""
+    out_hw gives (Ho, Wo).  x2 (1x1 convs): a second NHWC source whose channels follow x's in the packed K (pc packed from
+    cat([W_x, W_x2], dim=1)); output pixel (ho, wo) reads x2[ho * x2_stride, wo * x2_stride]."""
     _chk_dev(x, res, out)
+    if x2 is not None:
+        return _conv2d_two_sources(x, x2, x2_stride, pc, act, out, algo)
     n, h, w, c = x.shape
     d = ConvDesc()
     d.dtype = _dt(x)
@@ -231,6 +239,40 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
         algo = ALGO_CACHE.get(key)
         if algo is None:
             algo = _tune(key, d, lambda: _lib.call("osd_conv2d_fwd", C.byref(d), *args)) if _TUNING[0] else 0
+    d.algo = algo
+    _lib.call("osd_conv2d_fwd", C.byref(d), *args)
+    return out
+
+
+def _conv2d_two_sources(x, x2, x2_stride, pc, act, out, algo):
+    """conv3 + downsample of a bottleneck's first block as one GEMM over the concatenated K (osd_conv2d_fwd with src2)."""
+    _chk_dev(x, x2)
+    n, h, w, c = x.shape
+    c2 = x2.shape[-1]
+    assert (pc.r, pc.s) == (1, 1) and c + c2 == pc.cin_k and x2.shape[0] == n and x2.dtype == x.dtype
+    d = ConvDesc()
+    d.dtype = _dt(x)
+    d.n, d.h, d.w, d.cin, d.r, d.s = n, h, w, c, 1, 1
+    d.in_stride_n, d.in_stride_h, d.in_stride_w = h * w * c, w * c, c
+    d.stride_h = d.stride_w = 1
+    d.pad_h = d.pad_w = 0
+    d.ho, d.wo, d.cout, d.w_rows = h, w, pc.cout_store, pc.w_rows
+    if out is None:
+        out = torch.empty((n, h, w, pc.cout_store), device=x.device, dtype=x.dtype)
+    d.out_stride = out.shape[-1]
+    d.res_mode = RES_NONE
+    d.act, d.act_scale, d.relu_in = act, 1.0, 0
+    src2 = ConvSrc2(x2.contiguous().data_ptr(), c2, x2.shape[1], x2.shape[2], int(x2_stride))
+    args = (_ptr(x), _ptr(pc.w), _ptr(pc.bias), None, None, None, C.byref(src2), _ptr(out), _stream())
+    if algo is None:
+        key = ("src2", d.dtype, n, h, w, d.cout, c, c2, int(x2_stride), act)
+        algo = ALGO_CACHE.get(key)
+        if algo is None:
+            if _TUNING[0]:
+                cands = [1 + v * 8 + t for v in (0, 1, 2, 3) for t in (0, 2, 7)]
+                algo = _tune(key, d, lambda: _lib.call("osd_conv2d_fwd", C.byref(d), *args), cands)
+            else:
+                algo = 0
     d.algo = algo
     _lib.call("osd_conv2d_fwd", C.byref(d), *args)
     return out

@@ -70,6 +70,12 @@ class TrainEngine(object):
         self._plan = []          # (name, shape) of every trainable tensor, in registration order
         self._build(sd)
         self._allocate(sd)
+        from . import model as _model
+        self._fused_l1 = {}      # backbone prefix -> conv3 + downsample of the frozen layer1.0 as one packed 1x1 conv
+        if _model.FUSE_DOWNSAMPLE and dtype == torch.bfloat16:       # see model.BackboneWeights: bf16 engines only
+            for bb in self.BBS:
+                if (bb + "body.layer1.0.downsample.0.weight") in sd:
+                    self._fused_l1[bb] = _model.pack_conv3_downsample(sd, bb + "body.layer1.0.", dtype)
         # gradient exchange overlapped with backward (no-op with one rank): buckets in the order they become final; the
         # optimiser update + weight repack of a bucket follow its exchange on the same side stream (train_step)
         from .dist_utils import GradExchange, bucket_ranges
@@ -413,6 +419,13 @@ class TrainEngine(object):
                 # just those — its 3x3 at stride 2, its 1x1 + residual on the quarter-size map — and layer2.0 reads
                 # them at stride 1.  Same values, 3/4 of two convs and of a 210 MB tensor gone.
                 quarter = self.skip_unused_c2 and si == 0 and bi == nblocks - 1 and len(spec.STAGE_BLOCKS) > 1
+                if si == 0 and has_ds and self._fused_l1:
+                    # frozen layer1.0 (no backward through it): conv3 + downsample as one GEMM over [conv2 output | block
+                    # input] (model.pack_conv3_downsample): the 4x-wide downsample map is never written nor re-read
+                    o1 = ops.conv2d_multi(xs, pcs(p + "conv1"), stride=s, act=ACT_RELU)
+                    o2 = ops.conv2d_multi(o1, pcs(p + "conv2"), pad=1, act=ACT_RELU)
+                    xs = [ops.conv2d(o2[j], self._fused_l1[bbs[j]], act=ACT_RELU, x2=xs[j], x2_stride=s) for j in nb]
+                    continue
                 identity = ops.conv2d_multi(xs, pcs(p + "downsample.0"), stride=s) if has_ds else xs
                 o1 = ops.conv2d_multi(xs, pcs(p + "conv1"), stride=s, act=ACT_RELU)
                 if quarter:

@@ -75,6 +75,45 @@ def test_conv2d_frozenbn_residual_relu(dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv2d_two_sources_is_conv3_plus_downsample(stride, dt):
+    """osd_conv2d_fwd with src2: relu(bn3(conv3(out)) + bn_d(downsample(x))) (resnet.py:295-315, first block of a stage;
+    the downsample conv strides over the block input) as ONE 1x1 conv over the concatenated K — every algorithm the
+    two-source form is built for, odd map sizes, channel counts of layer1.0 / layer3.0."""
+    o = ops()
+    for (cm, cx, cout, h, w) in ((64, 64, 256, 13, 21), (256, 512, 1024, 7, 9)):
+        n = 2
+        t2 = rnd(n, cm, h, w, seed=1)
+        x = rnd(n, cx, (h - 1) * stride + 1 + (stride - 1), (w - 1) * stride + 1, seed=2)        # stride 2: odd / even extents
+        w3, wd = rnd(cout, cm, 1, 1, seed=3) / cm ** 0.5, rnd(cout, cx, 1, 1, seed=4) / cx ** 0.5
+        bn3 = [rnd(cout, seed=5).abs() + 0.5, rnd(cout, seed=6), rnd(cout, seed=7), rnd(cout, seed=8).abs() + 0.5]
+        bnd = [rnd(cout, seed=9).abs() + 0.5, rnd(cout, seed=10), rnd(cout, seed=11), rnd(cout, seed=12).abs() + 0.5]
+        if dt == "bf16":
+            t2, x = t2.bfloat16().float(), x.bfloat16().float()
+        sd = {"a.weight": bn3[0], "a.bias": bn3[1], "a.running_mean": bn3[2], "a.running_var": bn3[3],
+              "b.weight": bnd[0], "b.bias": bnd[1], "b.running_mean": bnd[2], "b.running_var": bnd[3]}
+        ref = F.relu(orc.frozen_bn(F.conv2d(t2, w3), sd, "a") + orc.frozen_bn(F.conv2d(x, wd, stride=stride), sd, "b"))
+        s3, sdn = bn3[0] * bn3[3].rsqrt(), bnd[0] * bnd[3].rsqrt()
+        wcat = torch.cat([w3 * s3.view(-1, 1, 1, 1), wd * sdn.view(-1, 1, 1, 1)], 1)
+        bias = (bn3[1] - bn3[2] * s3) + (bnd[1] - bnd[2] * sdn)
+        pc = o.pack_conv(wcat.cuda(), bias=bias.cuda(), dtype=DT[dt])
+        tol = TOL[dt] if dt == "f32" else dict(rtol=3e-2, atol=3e-2)
+        done = 0
+        for algo in [None] + [1 + v * 8 + t for v in (0, 1, 2, 3) for t in (0, 2, 7)]:
+            try:
+                y = o.conv2d(to_nhwc(t2, DT[dt]), pc, act=o.ACT_RELU, x2=to_nhwc(x, DT[dt]), x2_stride=stride, algo=algo)
+            except Exception as e:      # noqa: BLE001  (a tile that does not fit LDS with this ring)
+                assert "does not fit" in str(e), (algo, e)
+                continue
+            torch.testing.assert_close(from_nhwc(y), ref, **tol)
+            done += 1
+        assert done >= 8
+    with pytest.raises(Exception):       # 3x3 convs have no second source
+        o.conv2d(to_nhwc(t2, DT[dt]), o.pack_conv(rnd(cout, cm + cx, 1, 1, seed=3).cuda(), bias=bias.cuda(), dtype=DT[dt]),
+                 x2=to_nhwc(x[:, :, :2, :2], DT[dt]), x2_stride=stride)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv2d_fpn_lateral_upsample_add(dt):
     """inner = conv1x1(C) + nearest_up2x(top)  (fpn.py:59-64)."""
     n, cin, h, w, cout = 2, 128, 10, 14, 256
