@@ -70,9 +70,12 @@ typedef struct osd_conv_desc {
 } osd_conv_desc;
 
 /* second pixel source of a 1x1 convolution (osd_conv2d_fwd): dense NHWC [n][h][w][cin2]; output pixel (ho, wo) reads
- * x[n][ho * stride][wo * stride].  cin and cin2 multiples of 64. */
+ * x[n][ho * stride][wo * stride].  cin and cin2 multiples of 64.  w2 (nullable): the second part's own packed weights
+ * [w_rows][cin2] (osd_pack_conv_weight of its conv) — the `w` argument then holds the first part only, so two separately
+ * packed (and separately trained) convs run as one GEMM; NULL: `w` holds both parts side by side, K = cin + cin2. */
 typedef struct osd_conv_src2 {
   const void* x;
+  const void* w2;
   int32_t cin2, h, w, stride;
 } osd_conv_src2;
 

@@ -340,7 +340,7 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
   const long long M = (long long)d->n * d->ho * d->wo;
   if (M <= 0 || M > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad M");
   p.M = (int)M; p.tilesM = p.tilesN = p.KT = 0; p.n_seg = 0;
-  p.x2 = nullptr; p.cin1 = p.x2_sN = p.x2_sH = p.x2_sW = p.st2 = 0;
+  p.x2 = nullptr; p.w2 = nullptr; p.cin1 = p.x2_sN = p.x2_sH = p.x2_sW = p.st2 = 0;
   if (src2 != nullptr) {
     // second pixel source (see osd_conv_src2): K = cin + cin2, the packed weights hold both parts side by side
     if (!src2->x || d->r != 1 || d->s != 1 || d->pad_h || d->pad_w || d->relu_in)
@@ -352,7 +352,8 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
     p.x2 = src2->x; p.cin1 = d->cin; p.st2 = src2->stride;
     p.x2_sW = src2->cin2; p.x2_sH = src2->w * src2->cin2; p.x2_sN = src2->h * src2->w * src2->cin2;
     p.Cin = d->cin + src2->cin2;
-    p.Ktot = p.Cin;
+    p.w2 = src2->w2;
+    p.Ktot = src2->w2 ? d->cin : p.Cin;       // row stride of w: its own part only, or both parts side by side
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int tile = choose_tile(p.M, p.Cout);
@@ -425,7 +426,7 @@ extern "C" int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const voi
   p.act = d->act; p.act_scale = d->act_scale; p.act_scale_dev = nullptr; p.relu_in = 0;
   p.tilesM = p.tilesN = p.KT = 0;
   p.n_seg = n_seg;
-  p.x2 = nullptr; p.cin1 = p.x2_sN = p.x2_sH = p.x2_sW = p.st2 = 0;
+  p.x2 = nullptr; p.w2 = nullptr; p.cin1 = p.x2_sN = p.x2_sH = p.x2_sW = p.st2 = 0;
   long long mtot = 0;
   for (int i = 0; i < kConvMaxSeg; ++i) {
     const int j = i < n_seg ? i : 0;

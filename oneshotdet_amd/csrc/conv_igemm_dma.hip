@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
     }
   }
   const T* b_ptr[PB];
+  const T* b_ptr2[SRC2 ? PB : 1];       // two sources with separate weight buffers: the row's start in the second one
   int b_step[PB];
   int b_instr[PB];
 #pragma unroll
@@ -136,6 +137,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
     b_instr[i] = jb;
     b_ptr[i] = ok ? wg + (size_t)(n0 + row) * p.Ktot + (lpos ^ swz_g<KB>(row)) * EPC : zero;
     b_step[i] = ok ? BKE : 0;
+    if constexpr (SRC2)
+      b_ptr2[i] = (ok && p.w2) ? reinterpret_cast<const T*>(p.w2) + (size_t)(n0 + row) * (p.Cin - p.cin1) + (lpos ^ swz_g<KB>(row)) * EPC
+                               : zero;
   }
 
   int kr = 0, ks = 0, kc = 0;
@@ -159,6 +163,12 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
   };
   auto advance_k = [&]() {
     kc += BKE;
+    if constexpr (SRC2) {
+      if (p.w2 != nullptr && kc == p.cin1) {      // the K range of the second source starts: its own weight rows from here on
+#pragma unroll
+        for (int i = 0; i < PB; ++i) b_ptr[i] = b_ptr2[i];
+      }
+    }
     if (kc >= p.Cin) {
       kc = 0;
       if (++ks >= p.S) { ks = 0; ++kr; }
@@ -272,7 +282,7 @@ int launch_dma(const ConvKParams& pin, hipStream_t stream) {
   p.tilesN = cdiv(p.Cout, BN);
   constexpr int BKE = KB / (int)sizeof(T);
   if (p.Cin % BKE != 0) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: cin %d not a multiple of %d", p.Cin, BKE);
-  p.KT = p.Ktot / BKE;
+  p.KT = (p.x2 != nullptr ? p.Cin : p.Ktot) / BKE;      // two sources (1x1): K = both parts, Ktot = row stride of w
   constexpr int ring = NST * (BM + BN) * KB;
   constexpr int TMx = BM / WM / 16, TNx = BN / WN / 16;
   constexpr int npass = TMx >= 8 ? TMx / 2 : (TMx >= 2 ? 2 : 1);

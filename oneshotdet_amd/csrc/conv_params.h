@@ -39,6 +39,8 @@ struct ConvKParams {
   // (ho, wo) -> x2[n][ho * st2][wo * st2] (dense NHWC, Cin - cin1 channels): conv3 + downsample of a bottleneck's first
   // block as ONE GEMM over the concatenated K (conv_dma kernels only, single problem)
   const void* x2;
+  const void* w2;     // optional: the second part's own packed weights [w_rows][Cin - cin1] (w then holds [w_rows][cin1], Ktot =
+                      // cin1); nullptr: w holds both parts side by side (Ktot = Cin)
   int cin1, x2_sN, x2_sH, x2_sW, st2;
   int n_seg;          // 0 = single problem (fields above); > 0: seg[] overrides x/y/res/mask/act_scale_dev/H/W/Ho/Wo/M/sN/sH
   ConvSeg seg[kConvMaxSeg];

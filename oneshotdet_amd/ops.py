@@ -188,17 +188,20 @@ def _tune(key, d, launch, cands=None):
 
 class ConvSrc2(C.Structure):
     """osd_conv_src2: the second pixel source of a 1x1 conv."""
-    _fields_ = [("x", C.c_void_p), ("cin2", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("stride", C.c_int32)]
+    _fields_ = [("x", C.c_void_p), ("w2", C.c_void_p), ("cin2", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("stride", C.c_int32)]
 
 
 def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, relu_in=False, act_scale=1.0, out=None,
-           out_hw=None, algo=None, mask=None, act_scale_dev=None, x2=None, x2_stride=1):
+           out_hw=None, algo=None, mask=None, act_scale_dev=None, x2=None, x2_stride=1, pc2=None, bias=None):
     """x NHWC [N,H,W,C] -> [N,Ho,Wo,cout_store].  For the stem, x is the padded NHWC4 image from pack_image and
     out_hw gives (Ho, Wo).  x2 (1x1 convs): a second NHWC source whose channels follow x's in the packed K (pc packed from
-    cat([W_x, W_x2], dim=1)); output pixel (ho, wo) reads x2[ho * x2_stride, wo * x2_stride]."""
+    cat([W_x, W_x2], dim=1)); output pixel (ho, wo) reads x2[ho * x2_stride, wo * x2_stride].  With pc2 the two parts keep
+    their own packed weights (pc for x, pc2 for x2: two separately trained convs as one GEMM) and `bias` is the epilogue's
+    bias vector (the sum of both convs' folded shifts)."""
     _chk_dev(x, res, out)
     if x2 is not None:
-        return _conv2d_two_sources(x, x2, x2_stride, pc, act, out, algo)
+        return _conv2d_two_sources(x, x2, x2_stride, pc, act, out, algo, pc2, bias)
     n, h, w, c = x.shape
     d = ConvDesc()
     d.dtype = _dt(x)
@@ -244,12 +247,18 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
     return out
 
 
-def _conv2d_two_sources(x, x2, x2_stride, pc, act, out, algo):
+def _conv2d_two_sources(x, x2, x2_stride, pc, act, out, algo, pc2=None, bias=None):
     """conv3 + downsample of a bottleneck's first block as one GEMM over the concatenated K (osd_conv2d_fwd with src2)."""
     _chk_dev(x, x2)
     n, h, w, c = x.shape
     c2 = x2.shape[-1]
-    assert (pc.r, pc.s) == (1, 1) and c + c2 == pc.cin_k and x2.shape[0] == n and x2.dtype == x.dtype
+    assert (pc.r, pc.s) == (1, 1) and x2.shape[0] == n and x2.dtype == x.dtype
+    if pc2 is None:
+        assert c + c2 == pc.cin_k
+        bias = pc.bias if bias is None else bias
+    else:
+        assert (pc.cin_k, pc2.cin_k) == (c, c2) and (pc2.r, pc2.s, pc2.w_rows, pc2.cout_store) == (1, 1, pc.w_rows, pc.cout_store)
+        assert bias is not None, "two separately packed convs need their summed bias vector"
     d = ConvDesc()
     d.dtype = _dt(x)
     d.n, d.h, d.w, d.cin, d.r, d.s = n, h, w, c, 1, 1
@@ -262,10 +271,11 @@ def _conv2d_two_sources(x, x2, x2_stride, pc, act, out, algo):
     d.out_stride = out.shape[-1]
     d.res_mode = RES_NONE
     d.act, d.act_scale, d.relu_in = act, 1.0, 0
-    src2 = ConvSrc2(x2.contiguous().data_ptr(), c2, x2.shape[1], x2.shape[2], int(x2_stride))
-    args = (_ptr(x), _ptr(pc.w), _ptr(pc.bias), None, None, None, C.byref(src2), _ptr(out), _stream())
+    src2 = ConvSrc2(x2.contiguous().data_ptr(), pc2.w.data_ptr() if pc2 is not None else None, c2, x2.shape[1], x2.shape[2],
+                    int(x2_stride))
+    args = (_ptr(x), _ptr(pc.w), _ptr(bias), None, None, None, C.byref(src2), _ptr(out), _stream())
     if algo is None:
-        key = ("src2", d.dtype, n, h, w, d.cout, c, c2, int(x2_stride), act)
+        key = ("src2", d.dtype, n, h, w, d.cout, c, c2, int(x2_stride), act, pc2 is not None)
         algo = ALGO_CACHE.get(key)
         if algo is None:
             if _TUNING[0]:

@@ -108,6 +108,14 @@ def test_conv2d_two_sources_is_conv3_plus_downsample(stride, dt):
             torch.testing.assert_close(from_nhwc(y), ref, **tol)
             done += 1
         assert done >= 8
+        # the same with two separately packed convs (their own FrozenBN folds) and the summed bias: what the training
+        # engine uses for the trainable stages, whose conv3 / downsample weights are repacked every step
+        pa = o.pack_conv(w3.cuda(), bn=[t.cuda() for t in bn3], dtype=DT[dt])
+        pb = o.pack_conv(wd.cuda(), bn=[t.cuda() for t in bnd], dtype=DT[dt])
+        for algo in (None, 1 + 0, 1 + 3 * 8 + 2, 1 + 2 * 8 + 7):
+            y = o.conv2d(to_nhwc(t2, DT[dt]), pa, act=o.ACT_RELU, x2=to_nhwc(x, DT[dt]), x2_stride=stride, pc2=pb,
+                         bias=(pa.bias + pb.bias), algo=algo)
+            torch.testing.assert_close(from_nhwc(y), ref, **tol)
     with pytest.raises(Exception):       # 3x3 convs have no second source
         o.conv2d(to_nhwc(t2, DT[dt]), o.pack_conv(rnd(cout, cm + cx, 1, 1, seed=3).cuda(), bias=bias.cuda(), dtype=DT[dt]),
                  x2=to_nhwc(x[:, :, :2, :2], DT[dt]), x2_stride=stride)
