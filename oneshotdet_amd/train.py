@@ -89,9 +89,12 @@ class TrainEngine(object):
         if ordered_wgrad is None:
             ordered_wgrad = os.environ.get("OSD_WGRAD_ORDERED", "0") != "0"
         self.ordered_wgrad = bool(ordered_wgrad)
-        if self.ordered_wgrad:
-            for st in {id(x): x for x in (self.wstream, self.wstream2) if x is not None}.values() or [torch.cuda.current_stream()]:
-                ops.wgrad_set_workspace(st, 1 << 30)
+        # torch hands out stream handles from a pool, so a handle may carry an earlier engine's registration: set the mode of
+        # this engine's weight-gradient streams explicitly either way (close() / __del__ release the scratch buffers)
+        self._wgrad_streams = list({id(x): x for x in (self.wstream, self.wstream2) if x is not None}.values()) or \
+            [torch.cuda.current_stream()]
+        for st in self._wgrad_streams:
+            ops.wgrad_set_workspace(st, (1 << 30) if self.ordered_wgrad else 0)
         self.defer_join = False       # opt-in: train_step leaves its tail on the side streams (see train_step / join)
         self._deferred, self._defer_now, self._joined_refs = None, False, None
         self.repack()
@@ -539,6 +542,19 @@ class TrainEngine(object):
         # {num_pos, sum_w, sum_focal, sum_w*(1-giou), sum_bce}: the un-normalised sums are additive over images (tests)
         self.last_loss_sums = sums
         return losses, grads
+
+    def close(self):
+        """Release the ordered-mode scratch buffers registered for this engine's weight-gradient streams."""
+        if getattr(self, "ordered_wgrad", False):
+            for st in getattr(self, "_wgrad_streams", []):
+                try:
+                    ops.wgrad_set_workspace(st, 0)
+                except Exception:      # noqa: BLE001  (interpreter shutdown)
+                    pass
+            self.ordered_wgrad = False
+
+    def __del__(self):
+        self.close()
 
     # ------------------------------------------------------------------------------------------------ backward
     def _wstream_of(self, which):

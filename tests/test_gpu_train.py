@@ -937,13 +937,14 @@ def test_engine_with_ordered_weight_gradients_matches_default_engine():
     reduction path (its own tuner cache entries, 1 GiB of scratch per weight-gradient stream): same losses, the same
     gradients to rounding and the same weights after two steps as the default (atomic) engine."""
     from oneshotdet_amd import ops, train
-    outs = {}
+    outs, keep = {}, None
     try:
         for ordered in (False, True):
             eng, img, q, gtb, cnt = _engine_and_inputs("f32", "small")
             if ordered:
                 eng = train.TrainEngine(synth.make_state_dict(spec.hot_path_shapes()), dtype=torch.float32, ordered_wgrad=True)
                 assert eng.ordered_wgrad and len(ops._WGRAD_WS) == 2
+                keep = eng
             with ops.tuning():
                 l0 = eng.forward_backward(img, q, gtb, cnt).clone()
             g0 = eng.flat_g.clone()
@@ -953,9 +954,8 @@ def test_engine_with_ordered_weight_gradients_matches_default_engine():
             torch.cuda.synchronize()
             outs[ordered] = (l0.cpu(), g0.cpu(), eng.flat_w.clone().cpu())
     finally:
-        for h in list(ops._WGRAD_WS):
-            ops._lib.call("osd_conv2d_wgrad_set_workspace", ops.C.c_void_p(h), ops.C.c_void_p(0), 0)
-            ops._WGRAD_WS.pop(h, None)
+        keep.close()
+    assert not ops._WGRAD_WS            # close() released both scratch buffers
     torch.testing.assert_close(outs[True][0], outs[False][0], rtol=1e-6, atol=0)
     assert (outs[True][1] - outs[False][1]).abs().max() <= 1e-4 * outs[False][1].abs().max()
     # weights after a second step: rounding-level gradient differences (the other kernels' atomics) pass through one update
