@@ -150,14 +150,22 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
     if (j < PA) {
       const int hi = a_hi0[j] + kr, wi = a_wi0[j] + ks;
       const bool ok = ((unsigned)hi < (unsigned)q_H) && ((unsigned)wi < (unsigned)q_W);
+#ifdef OSD_CD_CHEAP_ADDR      // diagnostic builds (results are garbage): every piece reads the always-cached zero page
+      const T* src = zero;
+#else
       const T* src = ok ? a_base[j] + (hi * q_sH + wi * p.sW + kc) : zero;
+#endif
       if constexpr (SRC2) {
         if (kc >= p.cin1) src = a_base2[j] + (a_base2[j] == zero ? 0 : kc - p.cin1);      // uniform branch: K past source 1
       }
       dma16(src, xs + (wave * PA + j) * 1024);
     } else {
       const int i = j - PA;
+#ifdef OSD_CD_CHEAP_ADDR
+      dma16(zero, ws + b_instr[i] * 1024);
+#else
       dma16(b_ptr[i], ws + b_instr[i] * 1024);
+#endif
       b_ptr[i] += b_step[i];
     }
   };
@@ -252,7 +260,11 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
   for (; kt + NST - 1 < KT; ++kt) {                        // steady state: fetch stage kt+NST-1 while computing stage kt
     wait_vmcnt<LPS * (NST - 2)>();                         // stage kt has landed; later stages stay in flight
     __builtin_amdgcn_s_barrier();                          // every wave's part of stage kt is visible; buffer `nxt` is free
+#ifdef OSD_CD_NO_DMA             // diagnostic: the loop without its operand fetch
+    compute_stage(cur, nxt, std::false_type());
+#else
     compute_stage(cur, nxt, std::true_type());
+#endif
     cur = cur + 1 == NST ? 0 : cur + 1;
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
@@ -265,6 +277,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
 
   // ---- epilogue (conv_epilogue.h): LDS-staged, 16-byte-per-lane NHWC stores with bias / residual / mask / activation
   __syncthreads();
+#ifdef OSD_CD_NO_EPI             // diagnostic: no output (keeps the accumulators alive)
+  if (acc[0][0][0] != 12345.678f) return;
+#endif
   conv_epilogue<T, TM, TN>(acc, p, q, smem, wave, wm, wn, lane, m0, n0);
 }
 
