@@ -421,8 +421,9 @@ struct PoolGradLevels {
 };
 
 // Backward of roi_pool_levels_kernel (box_head.hip): the same level routing and sample geometry; every sample's
-// gradient dy / count goes to its four taps with the bilinear weights (ROIAlign_cuda.cu:178-254), fp32 atomics: 784 per ROI
-// and channel, 0.8 GB of memory-side atomic traffic per step, 0.72 ms = the rate those run at.  Measured alternatives, both
+// gradient dy / count goes to its four taps with the bilinear weights (ROIAlign_cuda.cu:178-254), fp32 atomics: up to 784
+// per ROI and channel, 0.8 GB of memory-side atomic traffic per step at 0.72 ms = the rate those run at (before the
+// per-axis tap merge below: 0.30-0.52 ms).  Measured alternatives, both
 // slower (tools/roi_bwd_bench.py): summing a ROI's footprint in LDS first (helps only ROIs narrower than ~14 map pixels; the
 // 64 KB LDS image costs the direct path its occupancy: 0.99 ms) and a per-tile gather without atomics (one thread per
 // channel walking the image's ROIs: a chain of dependent dy loads per contributing cell, 0.9-3.8 ms).
@@ -458,10 +459,44 @@ __global__ __launch_bounds__(256) void roi_pool_levels_bwd_kernel(PoolGradLevels
   const float inv_count = 1.f / (float)(gh * gw);
   const int items = pool * pool * c;
   const T* dr = dy + (size_t)roi * pool * pool * dy_stride;
+  // Bilinear weights are separable: sample (iy, ix) adds wy[iy][.] x wx[ix][.] x g, so a cell's gh x gw samples add
+  // (sum over iy of wy) x (sum over ix of wx).  With the config's sampling ratio 2 the two samples of an axis are half a bin
+  // apart — less than a pixel for every ROI up to 14 map pixels wide — and share taps: merging equal pixel indices per axis
+  // first leaves 3 x 3 (or fewer) atomics per cell and channel instead of 16.
+  const bool merge = gh <= 2 && gw <= 2;
   for (int it = threadIdx.x; it < items; it += blockDim.x) {
     const int cell = it / c, ch = it - cell * c;
     const int py = cell / pool, px = cell % pool;
     const float g = to_f32(dr[(size_t)cell * dy_stride + ch]) * inv_count;
+    if (merge) {
+      int iyv[4], ixv[4];
+      float wyv[4], wxv[4];
+      int ny = 0, nx = 0;
+      auto axis = [](float v0, int size, int* idx, float* wt, int& n) {     // one sample's two taps, merged into the list
+        float v = v0;
+        if (v < -1.0f || v > (float)size) return;                             // the sample lies outside: no contribution
+        if (v <= 0.f) v = 0.f;
+        int lo = (int)v, hi;
+        if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else { hi = lo + 1; }
+        const float fr = v - lo;
+        const int ids[2] = {lo, hi};
+        const float ws[2] = {1.f - fr, fr};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          bool found = false;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < n && idx[q] == ids[t]) { wt[q] += ws[t]; found = true; }
+          if (!found) { idx[n] = ids[t]; wt[n] = ws[t]; ++n; }
+        }
+      };
+      for (int iy = 0; iy < gh; ++iy) axis(rsh + py * bin_h + (iy + .5f) * bin_h / (float)gh, h, iyv, wyv, ny);
+      for (int ix = 0; ix < gw; ++ix) axis(rsw + px * bin_w + (ix + .5f) * bin_w / (float)gw, w, ixv, wxv, nx);
+      for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b)
+          atomicAdd(gx + ((size_t)iyv[a] * w + ixv[b]) * c + ch, wyv[a] * wxv[b] * g);
+      continue;
+    }
     for (int iy = 0; iy < gh; ++iy) {
       const float yy = rsh + py * bin_h + (iy + .5f) * bin_h / (float)gh;
       for (int ix = 0; ix < gw; ++ix) {
