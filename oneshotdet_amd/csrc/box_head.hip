@@ -126,6 +126,46 @@ __global__ __launch_bounds__(256) void roi_pool_levels_kernel(PoolLevels lv, con
     float acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    if (gh <= 2 && gw <= 2) {
+      // separable bilinear weights: the cell's samples are merged per axis first (equal pixel indices summed), so the
+      // sampling-ratio-2 cell reads 3 x 3 (or fewer) taps instead of 16 — this kernel is bound by its tap loads
+      int iyv[4], ixv[4];
+      float wyv[4], wxv[4];
+      int ny = 0, nx = 0;
+      auto axis = [](float v0, int size, int* idx, float* wt, int& n) {
+        float v = v0;
+        if (v < -1.0f || v > (float)size) return;
+        if (v <= 0.f) v = 0.f;
+        int lo = (int)v, hi;
+        if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else { hi = lo + 1; }
+        const float fr = v - lo;
+        const int ids[2] = {lo, hi};
+        const float ws[2] = {1.f - fr, fr};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          bool found = false;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < n && idx[q] == ids[t]) { wt[q] += ws[t]; found = true; }
+          if (!found) { idx[n] = ids[t]; wt[n] = ws[t]; ++n; }
+        }
+      };
+      for (int iy = 0; iy < gh; ++iy) axis(rsh + py * bin_h + (iy + .5f) * bin_h / (float)gh, h, iyv, wyv, ny);
+      for (int ix = 0; ix < gw; ++ix) axis(rsw + px * bin_w + (ix + .5f) * bin_w / (float)gw, w, ixv, wxv, nx);
+      for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
+          Chunk<T> v;
+          v.load(x + ((size_t)iyv[a] * w + ixv[b]) * c + ch);
+          const float wgt = wyv[a] * wxv[b];
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[e] += wgt * v.v[e];
+        }
+      Chunk<T> o;
+#pragma unroll
+      for (int e = 0; e < E; ++e) o.v[e] = acc[e] / count;
+      o.store(yr + (size_t)cell * y_stride + ch);
+      continue;
+    }
     for (int iy = 0; iy < gh; ++iy) {
       const float yy = rsh + py * bin_h + (iy + .5f) * bin_h / (float)gh;
       for (int ix = 0; ix < gw; ++ix) {
