@@ -52,6 +52,26 @@ for step in range(2):
     ex.finish()                           # supp_backbone.layer2 was never announced
     expect2 = base2 * (sum(r + 1 + step for r in range(world)) / world)
     ok2 = ok2 and torch.allclose(flat2, expect2, rtol=1e-6, atol=1e-6)
+# the same with the second stage's parameters (TrainEngine(second_stage=True)): one more bucket, `box_head`, announced
+# right after the first-stage head; every rank ends with the average
+plan3 = []
+for name, shape in spec.full_model_shapes().items():
+    if spec.is_frozen(name) or "running_" in name or ".bn" in name or "downsample.1" in name:
+        continue
+    plan3.append((name, (min(int(shape[0]), 8),) + tuple(min(int(d), 3) for d in shape[1:])))
+order3 = [n for n, _ in plan3]
+plan3.sort(key=lambda kv: (0 if kv[0].startswith("backbone.") else 1 if kv[0].startswith("supp_backbone.") else
+                           2 if kv[0].startswith("rpn.") else 3, 0 if ".body." in kv[0] else 1, order3.index(kv[0])))
+total3 = (sum(int(math.prod(s)) for _, s in plan3) + 63) // 64 * 64
+ranges3 = bucket_ranges(plan3, total3)
+names3 = [n for n, _, _ in ranges3]
+ok2 = ok2 and names3[-2:] == ["head", "box_head"] and ranges3[-1][2] == total3 and any(n.startswith("roi_heads.") for n, _ in plan3)
+flat3 = torch.randn(total3, generator=g) * 0 + (rank + 1.0)
+ex3 = GradExchange(flat3, ranges3)
+for n in ("head", "box_head", "backbone.layer4+fpn", "supp_backbone.layer4+fpn"):
+    ex3.ready(n)
+ex3.finish()
+ok2 = ok2 and torch.allclose(flat3, torch.full_like(flat3, sum(r + 1.0 for r in range(world)) / world))
 print("RANK %d EXCHANGE=%s" % (rank, ok2), flush=True)
 dist.destroy_process_group()
 sys.exit(0 if (ok and ok2) else 1)
