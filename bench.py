@@ -188,16 +188,56 @@ def self_launch(argv, n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    # poll: the first rank that exits non-zero takes its siblings down (they would otherwise sit in the rendezvous or the
+    # first collective until the process-group timeout) and its code is the result
     rc = 0
-    for p in procs:
-        try:
-            p.wait()
-        except KeyboardInterrupt:
-            for q in procs:
-                q.terminate()
-            raise
-        rc = rc or p.returncode
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in live:
+                        q.terminate()
+            if live:
+                time.sleep(0.05)
+    except KeyboardInterrupt:
+        for q in procs:
+            q.terminate()
+        raise
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    q.wait(timeout=10)
+                except Exception:      # noqa: BLE001
+                    q.kill()
     return rc
+
+
+def visible_gpus():
+    """Number of GPUs a child rank could use, WITHOUT any HIP call in this process: the KFD topology in sysfs (a node with
+    simd_count > 0 is a GPU), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  None = cannot tell (no
+    sysfs): the children then fail by themselves with exit code 2."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                for ln in f:
+                    if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
+                        n += 1
+        return n
+    except Exception:      # noqa: BLE001
+        return None
 
 
 def check_world(args):
@@ -206,8 +246,8 @@ def check_world(args):
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
             if not (args.dry_run_cpu or os.environ.get("OSD_BENCH_SHARE_GPU") == "1"):
-                have = torch.cuda.device_count()          # counting devices does not initialise the GPU on this image
-                if have < args.gpus:
+                have = visible_gpus()                      # sysfs / environment only: the parent never makes a HIP call
+                if have is not None and have < args.gpus:
                     print("bench.py: --gpus %d but %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
                     sys.exit(2)
             sys.exit(self_launch(sys.argv[1:], args.gpus))
@@ -527,8 +567,20 @@ def main_train(args, rank, world):
                          "smooth-L1, backward into both backbones)")
         cpu = cpu_baseline(args.dtype, train=True) if (world == 1 and not args.no_cpu_baseline) else None
         line = result_line(args, world, B, elapsed, workload, launch, roofline, cpu)
+        # which part of the reference's training step (engine/trainer.py:79-93) the line covers: the north_star hot path is
+        # the siamese-FCOS first stage; the reference's trainer also runs roi_heads on its proposals
+        line["config"]["stages"] = ("first + second stage: the reference's complete training step" if two else
+                                    "first stage (SURVEY.md 8a R0-R12 = BASELINE.json north_star); the reference's trainer also "
+                                    "runs the second-stage roi_heads losses/backward: that step is `--second-stage`, do not "
+                                    "compare this line with a full-step number")
         if roofline is not None:
             line["roofline_correlation"] = corr_roofline
+            # the same algorithmic FLOP against the WALL time of the timed multi-stream step (the figure above divides by
+            # the sum of isolated kernel times, which exceeds the wall step because streams overlap)
+            in_step = roofline["gflop_per_step"] / (elapsed / args.steps * 1e3)          # GFLOP / ms = TFLOP/s
+            roofline["in_step"] = {"achieved": round(in_step, 1), "frac": round(in_step / PEAK_TFLOPS[args.dtype], 4),
+                                   "what": "conv-family GFLOP per step / ms_per_step of the timed region (everything else "
+                                           "in the step - GroupNorm, loss, proposals, update - counts as time, not FLOP)"}
         if world > 1:
             assert eng.exchange.active and eng.exchange.world == world
             line["config"]["parallelism"] += ("; fp32 gradient averaging (%s all-reduce): %d buckets of the flat buffer, each "

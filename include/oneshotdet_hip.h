@@ -451,7 +451,8 @@ int osd_box_match_sample(const float* boxes, const int32_t* counts, const float*
  * [n*rois_per_image][pred_stride] `dtype` (columns 0..1 class logits, 2..9 box deltas, as osd_box_decode reads them) ->
  * losses[3] = {w_cls * cross_entropy (mean over the valid rows), w_box * smooth_l1(beta 1, summed over the positives' class
  * deltas) / valid rows, valid rows}; d_pred (nullable) [..][grad_stride] `dtype` = the gradient w.r.t. pred (zero rows past
- * s_count[image]). */
+ * s_count[image]).  Two classes (ROI_BOX_HEAD.NUM_CLASSES of the config of record): labels are 0 or 1; a label > 1 has no
+ * columns in a 10-wide row, so nothing is read or written for such a row and losses[0..1] come back NaN. */
 int osd_box_loss(const void* pred, const int32_t* labels, const float* targets, const int32_t* s_count, int n,
                  int rois_per_image, int pred_stride, float w_cls, float w_box, float* losses, void* d_pred, int grad_stride,
                  int dtype, void* stream);

@@ -227,12 +227,13 @@ __global__ void __launch_bounds__(1024) box_loss_kernel(const T* __restrict__ pr
                                                         int n_img, int S, int pstride, float w_cls, float w_box,
                                                         float* __restrict__ losses, T* __restrict__ d_pred, int gstride) {
   __shared__ float red[2][1024];
-  __shared__ int nval;
+  __shared__ int nval, bad_label;
   const int t = threadIdx.x;
   if (t == 0) {
     int n = 0;
     for (int i = 0; i < n_img; ++i) n += min(s_count[i], S);
     nval = n;
+    bad_label = 0;
   }
   __syncthreads();
   const int M = n_img * S;
@@ -245,6 +246,10 @@ __global__ void __launch_bounds__(1024) box_loss_kernel(const T* __restrict__ pr
     if (g) for (int q = 0; q < gstride; ++q) g[q] = from_f32<T>(0.f);
     if (!valid) continue;
     const T* p = pred + (size_t)r * pstride;
+    // two classes (background / the queried object: ROI_BOX_HEAD.NUM_CLASSES = 2 in the config of record); a row is
+    // 2 logits + 2 x 4 deltas.  A label > 1 has no columns in the row: nothing is read or written for it and the
+    // losses come back NaN (no host synchronisation to report it any other way)
+    if (labels[r] > 1) { bad_label = 1; continue; }
     const int l = labels[r] > 0 ? labels[r] : 0;
     const float x0 = to_f32(p[0]), x1 = to_f32(p[1]);
     const float m = fmaxf(x0, x1);
@@ -274,8 +279,9 @@ __global__ void __launch_bounds__(1024) box_loss_kernel(const T* __restrict__ pr
     __syncthreads();
   }
   if (t == 0) {
-    losses[0] = w_cls * red[0][0] * inv_n;     // 5 * F.cross_entropy(class_logits, labels)
-    losses[1] = w_box * red[1][0] * inv_n;     // 2.5 * smooth_l1(sum) / labels.numel()
+    const float poison = bad_label ? __builtin_nanf("") : 0.f;
+    losses[0] = w_cls * red[0][0] * inv_n + poison;     // 5 * F.cross_entropy(class_logits, labels)
+    losses[1] = w_box * red[1][0] * inv_n + poison;     // 2.5 * smooth_l1(sum) / labels.numel()
     losses[2] = (float)nval;
   }
 }

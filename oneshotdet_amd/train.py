@@ -23,6 +23,39 @@ from .ops import ACT_EXP_SCALE, ACT_NONE, ACT_RELU, RES_NONE, RES_SAME, RES_UP2X
 SIZE_RANGES = ((-1.0, 64.0), (64.0, 128.0), (128.0, 256.0), (256.0, 512.0), (512.0, float(spec.INF)))
 
 
+def _payload(t):
+    """The device tensor inside a batch as the pipeline hands it over (plain tensor, layers.ImageList, ops.PackedImages)."""
+    from .layers import ImageList
+    if isinstance(t, ops.PackedImages):
+        return t.tensor
+    if isinstance(t, ImageList):
+        return t.tensors
+    return t
+
+
+def _static_clone(t):
+    from .layers import ImageList
+    if isinstance(t, ops.PackedImages):
+        return ops.PackedImages(t.tensor.clone(), t.hw, t.image_sizes)
+    if isinstance(t, ImageList):
+        return ImageList(t.tensors.clone(), list(t.image_sizes))
+    return t.clone()
+
+
+def _static_copy(dst, src):
+    """New contents for a captured graph's static input.  The geometry (batch shape, every image's true size) is part of
+    the capture: a batch that differs in it needs a new capture()."""
+    for attr in ("image_sizes", "hw"):
+        a, b = getattr(dst, attr, None), getattr(src, attr, None)
+        if a is not None and b is not None and [tuple(v) for v in ([a] if attr == "hw" else a)] != \
+                [tuple(v) for v in ([b] if attr == "hw" else b)]:
+            raise ValueError("replay_step: the batch's %s differ from the captured ones; call capture() again" % attr)
+    d, s_ = _payload(dst), _payload(src)
+    if d.shape != s_.shape or d.dtype != s_.dtype:
+        raise ValueError("replay_step: input %s %s does not match the captured %s %s" % (tuple(s_.shape), s_.dtype, tuple(d.shape), d.dtype))
+    d.copy_(s_, non_blocking=True)
+
+
 class TConv(object):
     """One convolution of the training graph."""
 
@@ -91,8 +124,14 @@ class TrainEngine(object):
         self.ordered_wgrad = bool(ordered_wgrad)
         # torch hands out stream handles from a pool, so a handle may carry an earlier engine's registration: set the mode of
         # this engine's weight-gradient streams explicitly either way (close() / __del__ release the scratch buffers)
-        self._wgrad_streams = list({id(x): x for x in (self.wstream, self.wstream2) if x is not None}.values()) or \
-            [torch.cuda.current_stream()]
+        # (the second stage's weight gradients run on the proposal stream: box_head_forward_backward)
+        cands = (self.wstream, self.wstream2) + ((self.pstream,) if self.second_stage else ())
+        self._wgrad_streams = list({id(x): x for x in cands if x is not None}.values()) or [torch.cuda.current_stream()]
+        if self.ordered_wgrad and self.second_stage:
+            import warnings
+            warnings.warn("ordered_wgrad makes every conv_wgrad launch bit-reproducible, the second stage's included; its "
+                          "ROI-pool backward (osd_roi_pool_levels_bwd) still scatters with fp32 atomics, so the gradients it "
+                          "feeds into both backbones are reproducible only up to the order of those adds")
         for st in self._wgrad_streams:
             ops.wgrad_set_workspace(st, (1 << 30) if self.ordered_wgrad else 0)
         self.defer_join = False       # opt-in: train_step leaves its tail on the side streams (see train_step / join)
@@ -1094,7 +1133,9 @@ class TrainEngine(object):
         """Capture the training step into hipGraphs (forward+loss+backward as one graph, SGD + repack as another, with the
         RCCL all-reduce between them launched normally): ~1500 launches per step become two graph launches.  The learning
         rate is baked in at capture time; call capture() again after changing it."""
-        self._static = [t.clone() for t in (images, queries, gt_boxes, gt_count)]
+        # static copies of the inputs; a padded batch (layers.ImageList / ops.PackedImages) keeps its per-image sizes, which
+        # are baked into the captured graph together with the batch shape
+        self._static = [_static_clone(t) for t in (images, queries, gt_boxes, gt_count)]
         self._overlap = False          # no collectives inside a captured graph: the exchange runs between the two graphs
         self.join()
         self.defer_join = False        # a captured graph must join every stream it forked
@@ -1117,7 +1158,7 @@ class TrainEngine(object):
     def replay_step(self, images=None, queries=None, gt_boxes=None, gt_count=None):
         for dst, src in zip(self._static, (images, queries, gt_boxes, gt_count)):
             if src is not None:
-                dst.copy_(src, non_blocking=True)
+                _static_copy(dst, src)
         self._g_fb.replay()
         self.reduce_gradients()
         self._g_opt.replay()

@@ -616,12 +616,18 @@ def main():
     ap.add_argument("--only-transforms", action="store_true", help="regenerate only tests/golden/transforms.npz")
     ap.add_argument("--boxtrain-cases", default="small,nonsquare,shots5,tall,config1")
     ap.add_argument("--only-boxtrain", action="store_true", help="regenerate only tests/golden/boxtrain_*.npz")
+    ap.add_argument("--only-cases", default="", help="write ONLY case_<name>.npz + train_<name>.npz of the listed cases")
     args = ap.parse_args()
     torch.set_num_threads(8)
     model, cfg = rh.build_reference_model()
     if args.only_transforms:
         return gen_transforms(cfg)
     np_sd = load_synth_weights(model)
+    if args.only_cases:
+        for name in [c for c in args.only_cases.split(",") if c]:
+            gen_case(model, np_sd, name)
+            gen_train_case(model, np_sd, name)
+        return
     if args.only_boxtrain:
         for name in [c for c in args.boxtrain_cases.split(",") if c]:
             gen_box_train_case(model, np_sd, name)

@@ -80,6 +80,10 @@ CASES = {
     # two DISTINCT full-size (target, query, boxes) triples: the bs=8 benchmark batch built from them is checked per image
     # against this (cross-image aliasing at the benchmark's grid sizes)
     "config1x2": (2, 800, 1024, 1, 127, 127),
+    # BASELINE.json configs[4] / SURVEY.md 8c case (v): the multi-scale shapes (short edge 640 and 1024, long edge = short x
+    # 1.28 rounded up to /32) with the 5-shot query stack; short edge 800 with one shot is `config1`
+    "ms640": (1, 640, 832, 5, 127, 127),
+    "ms1024": (1, 1024, 1312, 5, 127, 127),
 }
 
 
