@@ -16,6 +16,17 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Launch trace (tests only): with TRACE = [] every wrapper below appends (kind, {operands and parameters}) after its launch,
+# holding references to the device tensors it read and wrote.  tests/test_gpu_launch_replay.py replays every recorded
+# launch of a real step on the CPU (oracle/launch_replay.py) from the engine's OWN inputs and compares the outputs.
+TRACE = None
+
+
+def _rec(kind, **kw):
+    if TRACE is not None and not _TUNING[0]:
+        TRACE.append((kind, kw))
+
+
 def _dt(t):
     if t.dtype == torch.float32:
         return OSD_F32
@@ -89,6 +100,7 @@ def pack_image(images, dtype, hp, wp, pad_t=3, pad_l=3):
     assert c == 3 and images.dtype == torch.float32
     out = torch.empty((n, hp, wp, 4), device=images.device, dtype=dtype)
     _lib.call("osd_pack_image", _ptr(images.contiguous()), _ptr(out), n, h, w, hp, wp, pad_t, pad_l, _dt(out), _stream())
+    _rec("pack_image", x=images, out=out, pad_t=pad_t, pad_l=pad_l)
     return out
 
 
@@ -244,6 +256,9 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
             algo = _tune(key, d, lambda: _lib.call("osd_conv2d_fwd", C.byref(d), *args)) if _TUNING[0] else 0
     d.algo = algo
     _lib.call("osd_conv2d_fwd", C.byref(d), *args)
+    _rec("conv", x=x, w=pc.w, bias=pc.bias, cout=pc.cout_store, r=pc.r, s=pc.s, stem=pc.stem, stride=stride, pad=pad, act=act,
+         res=res, res_mode=res_mode, relu_in=bool(relu_in), act_scale=float(act_scale), act_scale_dev=act_scale_dev, mask=mask,
+         out=out)
     return out
 
 
@@ -285,6 +300,9 @@ def _conv2d_two_sources(x, x2, x2_stride, pc, act, out, algo, pc2=None, bias=Non
                 algo = 0
     d.algo = algo
     _lib.call("osd_conv2d_fwd", C.byref(d), *args)
+    _rec("conv", x=x, x2=x2, x2_stride=int(x2_stride), w=pc.w, w2=None if pc2 is None else pc2.w, bias=bias, cout=pc.cout_store,
+         r=1, s=1, stem=False, stride=1, pad=0, act=act, res=None, res_mode=RES_NONE, relu_in=False, act_scale=1.0,
+         act_scale_dev=None, mask=None, out=out)
     return out
 
 
@@ -390,6 +408,11 @@ def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mod
             algo = _tune(key, d, launch) if _TUNING[0] else 0
     d.algo = algo
     launch()
+    for i in range(k):
+        _rec("conv", x=xs[i], w=pcs[i].w, bias=pcs[i].bias, cout=pc.cout_store, r=pc.r, s=pc.s, stem=False, stride=stride, pad=pad,
+             act=act, res=None if residuals is None else residuals[i], res_mode=res_mode, relu_in=False,
+             act_scale=float(act_scale), act_scale_dev=None if act_scale_devs is None else act_scale_devs[i],
+             mask=None if masks is None else masks[i], out=outs[i])
     return outs
 
 
@@ -399,6 +422,7 @@ def maxpool3x3s2(x):
     ho, wo = conv_out(h, 3, 2, 1), conv_out(w, 3, 2, 1)
     y = torch.empty((n, ho, wo, c), device=x.device, dtype=x.dtype)
     _lib.call("osd_maxpool3x3s2_fwd", _ptr(x), _ptr(y), n, h, w, c, ho, wo, _dt(x), _stream())
+    _rec("maxpool", x=x, out=y)
     return y
 
 
@@ -426,6 +450,7 @@ def roi_align(x, rois, spatial_scale, ph, pw, sampling_ratio):
     y = torch.empty((r, ph, pw, c), device=x.device, dtype=torch.float32)
     _lib.call("osd_roialign_fwd", _ptr(x), _ptr(rois.contiguous().float()), _ptr(y), n, h, w, c, r, float(spatial_scale),
               ph, pw, sampling_ratio, _dt(x), _stream())
+    _rec("roi_align", x=x, rois=rois, scale=float(spatial_scale), ph=ph, pw=pw, sampling_ratio=sampling_ratio, out=y)
     return y
 
 
@@ -436,6 +461,7 @@ def shot_mean(x, batch):
     assert d % batch == 0
     y = torch.empty((batch, c), device=x.device, dtype=torch.float32)
     _lib.call("osd_shot_mean", _ptr(x.contiguous()), _ptr(y), batch, d // batch, c, _stream())
+    _rec("shot_mean", x=x, batch=batch, out=y)
     return y
 
 
@@ -447,6 +473,7 @@ def correlate(x, q, out=None):
     if out is None:
         out = torch.empty_like(x)
     _lib.call("osd_correlate_fwd", _ptr(x), _ptr(q.contiguous()), _ptr(out), n, h * w, c, _dt(x), _stream())
+    _rec("correlate", x=x, q=q, out=out)
     return out
 
 
@@ -460,6 +487,8 @@ def correlate_levels(xs, qs):
     ys = [torch.empty_like(x) for x in xs]
     hws = (C.c_int32 * k)(*[x.shape[1] * x.shape[2] for x in xs])
     _lib.call("osd_correlate_levels", k, _ptr_array(xs), _ptr_array(qs), _ptr_array(ys), hws, n, c, _dt(xs[0]), _stream())
+    for x, q, y in zip(xs, qs, ys):
+        _rec("correlate", x=x, q=q, out=y)
     return ys
 
 
@@ -472,6 +501,8 @@ def correlate_bwd_query_levels(gs, feats):
     hws = (C.c_int32 * k)(*[g.shape[1] * g.shape[2] for g in gs])
     _lib.call("osd_correlate_bwd_query_levels", k, _ptr_array(gs), _ptr_array(feats), _ptr_array(dqs), hws, n, c, _dt(gs[0]),
               _stream())
+    for g, f, o in zip(gs, feats, dqs):
+        _rec("correlate_bwd_query", g=g, feat=f, out=o)
     return dqs
 
 
@@ -707,6 +738,7 @@ def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None, db=None,
         algo = _tune_wgrad(key, d, launch, dw_packed, db, [x.shape[2]]) if _TUNING[0] else 0
     d.algo = algo
     launch(dw_packed, db)
+    _rec("wgrad", items=[dict(x=x, dy=dy, dw=dw_packed, scale=scale, db=db, r=r, s=s, stride=stride, pad=pad, cout=cout)])
 
 
 def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, db=None, algo=None):
@@ -726,6 +758,8 @@ def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, 
         need = int(_lib.load().osd_conv2d_wgrad_pred_workspace_bytes(k, ns, hs, ws, x0.shape[-1]))
         wsp = torch.empty((need // 4 + 1,), device=x0.device, dtype=torch.float32)
         _lib.call("osd_conv2d_wgrad_pred", C.byref(d), k, xs, dys, ns, hs, ws, _ptr(dw_packed), _ptr(db), _ptr(wsp), st)
+        _rec("wgrad", items=[dict(x=x, dy=dy, dw=dw_packed, scale=None, db=db, r=r, s=s, stride=stride, pad=pad, cout=cout)
+                             for x, dy in pairs])
         return
 
     def launch(dw, dbias):
@@ -737,6 +771,8 @@ def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, 
         algo = _tune_wgrad(key, d, launch, dw_packed, db, [x.shape[2] for x, _ in pairs]) if _TUNING[0] else 0
     d.algo = algo
     launch(dw_packed, db)
+    _rec("wgrad", items=[dict(x=x, dy=dy, dw=dw_packed, scale=scale, db=db, r=r, s=s, stride=stride, pad=pad, cout=cout)
+                         for x, dy in pairs])
 
 
 def conv2d_wgrad_batched(items, r, s, stride, pad, cout, algo=None):
@@ -768,6 +804,8 @@ def conv2d_wgrad_batched(items, r, s, stride, pad, cout, algo=None):
             algo = 0
     d.algo = algo
     launch([it[2] for it in items], [it[4] for it in items])
+    _rec("wgrad", items=[dict(x=it[0], dy=it[1], dw=it[2], scale=it[3], db=it[4], r=r, s=s, stride=stride, pad=pad, cout=cout)
+                         for it in items])
 
 
 def conv2d_wgrad_multi(items, r, s, stride, pad, cout, algo=None):
@@ -803,6 +841,8 @@ def conv2d_wgrad_multi(items, r, s, stride, pad, cout, algo=None):
             algo = 0
     d.algo = algo
     launch(real_dws, real_dbs)
+    _rec("wgrad", items=[dict(x=it[0], dy=it[1], dw=it[2], scale=it[3], db=it[4], r=r, s=s, stride=stride, pad=pad, cout=cout)
+                         for it in items])
 
 
 def conv2d_wgrad_mixed(items, algo=None):
@@ -852,6 +892,8 @@ def conv2d_wgrad_mixed(items, algo=None):
             algo = 0
     descs[0].algo = algo
     launch(real_dws, real_dbs)
+    _rec("wgrad", items=[dict(x=it[0], dy=it[1], dw=it[2], scale=it[3], db=it[4], r=it[5], s=it[6], stride=it[7], pad=it[8],
+                              cout=it[9]) for it in items])
 
 
 def bias_grad(dy, db, c):
@@ -872,12 +914,14 @@ def scatter2x(src, out_hw, mask=None, addend=None):
     h, w = out_hw
     dst = torch.empty((n, h, w, c), device=src.device, dtype=src.dtype)
     _lib.call("osd_scatter2x", _ptr(src), _ptr(mask), _ptr(addend), _ptr(dst), n, h, w, ho, wo, c, _dt(src), _stream())
+    _rec("scatter2x", x=src, mask=mask, addend=addend, out=dst)
     return dst
 
 
 def add_mask(a, b=None, mask=None, out=None):
     out = torch.empty_like(a) if out is None else out
     _lib.call("osd_add_mask", _ptr(a), _ptr(b), _ptr(mask), _ptr(out), a.numel(), _dt(a), _stream())
+    _rec("add_mask", a=a, b=b, mask=mask, out=out)
     return out
 
 
@@ -885,6 +929,7 @@ def upsample2x_bwd(inner, prev=None):
     n, h2, w2, c = inner.shape
     top = torch.empty((n, h2 // 2, w2 // 2, c), device=inner.device, dtype=inner.dtype)
     _lib.call("osd_upsample2x_bwd", _ptr(inner), _ptr(prev), _ptr(top), n, h2 // 2, w2 // 2, c, _dt(inner), _stream())
+    _rec("upsample2x_bwd", inner=inner, prev=prev, out=top)
     return top
 
 
@@ -892,6 +937,7 @@ def correlate_bwd_query(g, feat):
     n, h, w, c = g.shape
     dq = torch.empty((n, c), device=g.device, dtype=torch.float32)
     _lib.call("osd_correlate_bwd_query", _ptr(g), _ptr(feat), _ptr(dq), n, h * w, c, _dt(g), _stream())
+    _rec("correlate_bwd_query", g=g, feat=feat, out=dq)
     return dq
 
 
@@ -900,6 +946,7 @@ def roi_align_bwd(gy, rois, x_shape, spatial_scale, ph, pw, sampling_ratio):
     gx = torch.empty(x_shape, device=gy.device, dtype=torch.float32)
     _lib.call("osd_roialign_bwd", _ptr(gy.contiguous()), _ptr(rois), _ptr(gx), b, h, w, c, rois.shape[0],
               float(spatial_scale), ph, pw, sampling_ratio, _stream())
+    _rec("roi_align_bwd", gy=gy, rois=rois, scale=float(spatial_scale), ph=ph, pw=pw, sampling_ratio=sampling_ratio, out=gx)
     return gx
 
 
@@ -907,12 +954,14 @@ def shot_mean_bwd(gy, shots):
     b, c = gy.shape
     gx = torch.empty((b * shots, c), device=gy.device, dtype=torch.float32)
     _lib.call("osd_shot_mean_bwd", _ptr(gy.contiguous()), _ptr(gx), b, shots, c, _stream())
+    _rec("shot_mean_bwd", gy=gy, shots=shots, out=gx)
     return gx
 
 
 def cast_f32(x, dtype):
     y = torch.empty(x.shape, device=x.device, dtype=dtype)
     _lib.call("osd_cast_f32", _ptr(x.contiguous()), _ptr(y), x.numel(), _dt(y), _stream())
+    _rec("cast", x=x, out=y)
     return y
 
 
@@ -956,6 +1005,8 @@ def fcos_loss_levels(phase, head_out, gt_boxes, gt_count, strides, size_ranges, 
               _ptr_array(scale_devs) if scale_devs is not None else none, _ptr(sums),
               _ptr_array(d_cls_ctrs) if d_cls_ctrs is not None else none, _ptr_array(d_regs) if d_regs is not None else none,
               gs, _ptr_array(d_scale_raws) if d_scale_raws is not None else none, _dt(head_out[0][0]), _stream())
+    _rec("fcos_loss", phase=phase, head_out=list(head_out), gt_boxes=gt_boxes, gt_count=gt_count, gamma=float(gamma), alpha=float(alpha),
+         scale_devs=scale_devs, sums=sums, d_cls_ctrs=d_cls_ctrs, d_regs=d_regs, d_scale_raws=d_scale_raws)
 
 
 def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5):
@@ -970,6 +1021,8 @@ def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5):
     hws = (C.c_int32 * k)(*[x.shape[1] * x.shape[2] for x in xs])
     _lib.call("osd_groupnorm_relu_fwd_levels", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),
               _ptr(ws), n, c, groups, float(eps), _dt(xs[0]), _stream())
+    for x, y in zip(xs, ys):
+        _rec("gn_relu", x=x, gamma=gamma, beta=beta, groups=groups, eps=float(eps), out=y)
     return ys, ab
 
 
@@ -982,6 +1035,7 @@ def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32
     hws = (C.c_int32 * k)(*[u.shape[1] * u.shape[2] for u in us])
     _lib.call("osd_groupnorm_relu_bwd_levels", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
               _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), _stream())
+    _rec("gn_relu_bwd", us=list(us), dts=list(dts), gamma=gamma, beta=beta, groups=groups, dgamma=dgamma, dbeta=dbeta, outs=dus)
     return dus
 
 

@@ -26,6 +26,56 @@ INF = 100000000
 
 
 # --------------------------------------------------------------------------------------------------------------------
+# reduced-precision emulation (what the bf16 engines store) — `emu=None` everywhere below is the plain fp32 restatement
+# --------------------------------------------------------------------------------------------------------------------
+class _RoundBothWays(torch.autograd.Function):
+    """A tensor the engine STORES in `dtype`: the value is rounded on the way forward and its gradient — which the engine
+    also stores in `dtype` — on the way back (the sum over all consumers is formed in fp32 and rounded once)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+class Emulation(object):
+    """Reduced-precision mode of this oracle: the SAME functions, with every tensor the bf16 engines write to HBM rounded
+    where they round it — the packed image, every conv output after its fused epilogue (bias / FrozenBN shift, residual,
+    ReLU or exp), correlation, GroupNorm+ReLU outputs, the head outputs, and on the way back every stored gradient — and
+    with FrozenBN folded into the conv rows BEFORE the weights are rounded (w' = round(w * scale), shift kept in fp32:
+    `osd_pack_conv_weight`).  Accumulation stays fp32, as in the MFMA kernels.  dtype=None switches the rounding off and
+    keeps only the folded form: that must reproduce the plain restatement to fp32 rounding (tests/test_oracle_golden.py).
+    fused_downsample: stage names whose first block computes conv3 + downsample as ONE GEMM (a single rounding of the sum):
+    the training engine fuses the frozen layer1 only, the inference engine all four stages."""
+
+    def __init__(self, dtype=torch.bfloat16, fused_downsample=("layer1",)):
+        self.dtype = dtype
+        self.fused_downsample = tuple(fused_downsample)
+
+    def act(self, x):
+        return x if self.dtype is None else _RoundBothWays.apply(x, self.dtype)
+
+    def weight(self, w):
+        """Packed weights are rounded copies of the fp32 masters; the master's gradient is not rounded (fp32 dW)."""
+        if self.dtype is None:
+            return w
+        return w + (w.to(self.dtype).to(w.dtype) - w).detach()
+
+
+def _conv_bn(x, sd, conv, bn, emu, stride=1, padding=0):
+    """conv -> FrozenBN.  emu: the folded form the kernels compute (scale into the weight rows, shift as the bias)."""
+    if emu is None:
+        return frozen_bn(F.conv2d(x, sd[conv + ".weight"], None, stride=stride, padding=padding), sd, bn)
+    scale = sd[bn + ".weight"] * sd[bn + ".running_var"].rsqrt()
+    shift = sd[bn + ".bias"] - sd[bn + ".running_mean"] * scale
+    return F.conv2d(x, emu.weight(sd[conv + ".weight"] * scale.reshape(-1, 1, 1, 1)), shift, stride=stride, padding=padding)
+
+
+# --------------------------------------------------------------------------------------------------------------------
 # backbone
 # --------------------------------------------------------------------------------------------------------------------
 def frozen_bn(x, sd, p):
@@ -35,16 +85,29 @@ def frozen_bn(x, sd, p):
     return x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
 
 
-def stem(x, sd, p):
+def stem(x, sd, p, emu=None):
     """modeling/backbone/resnet.py:332-337 (BaseStem.forward)."""
+    if emu is not None:
+        x = emu.act(F.relu(_conv_bn(emu.act(x), sd, p + "conv1", p + "bn1", emu, stride=2, padding=3)))
+        return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     x = F.conv2d(x, sd[p + "conv1.weight"], None, stride=2, padding=3)
     x = F.relu(frozen_bn(x, sd, p + "bn1"))
     return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
 
 
-def bottleneck(x, sd, p, stride):
+def bottleneck(x, sd, p, stride, emu=None):
     """modeling/backbone/resnet.py:295-315 (Bottleneck.forward); stride sits in the 1x1 conv1 and in the
     downsample 1x1 (STRIDE_IN_1X1 True, resnet.py:245-263)."""
+    if emu is not None:
+        o1 = emu.act(F.relu(_conv_bn(x, sd, p + "conv1", p + "bn1", emu, stride=stride)))
+        o2 = emu.act(F.relu(_conv_bn(o1, sd, p + "conv2", p + "bn2", emu, padding=1)))
+        out = _conv_bn(o2, sd, p + "conv3", p + "bn3", emu)                 # fp32 accumulators: not stored
+        identity = x
+        if (p + "downsample.0.weight") in sd:
+            identity = _conv_bn(x, sd, p + "downsample.0", p + "downsample.1", emu, stride=stride)
+            if not any(("." + st + ".") in ("." + p) for st in emu.fused_downsample):
+                identity = emu.act(identity)                                # its own launch: stored, then read back
+        return emu.act(F.relu(out + identity))
     identity = x
     out = F.conv2d(x, sd[p + "conv1.weight"], None, stride=stride)
     out = F.relu(frozen_bn(out, sd, p + "bn1"))
@@ -57,18 +120,18 @@ def bottleneck(x, sd, p, stride):
     return F.relu(out + identity)
 
 
-def resnet_body(x, sd, p, blocks=(3, 4, 6, 3)):
+def resnet_body(x, sd, p, blocks=(3, 4, 6, 3), emu=None):
     """modeling/backbone/resnet.py:138-145 (ResNet.forward) -> [C2, C3, C4, C5]."""
-    x = stem(x, sd, p + "stem.")
+    x = stem(x, sd, p + "stem.", emu)
     outs = []
     for si, n in enumerate(blocks):
         for b in range(n):
-            x = bottleneck(x, sd, "%slayer%d.%d." % (p, si + 1, b), stride=2 if (b == 0 and si > 0) else 1)
+            x = bottleneck(x, sd, "%slayer%d.%d." % (p, si + 1, b), stride=2 if (b == 0 and si > 0) else 1, emu=emu)
         outs.append(x)
     return outs
 
 
-def fpn(feats, sd, p):
+def fpn(feats, sd, p, emu=None):
     """modeling/backbone/fpn.py:43-75 + LastLevelP6P7.forward :95-99.  C2 is ignored (fpn.py:33); P6 comes from
     P5 because in_channels == out_channels (USE_C5 False; fpn.py:93-96); P7 sees relu(P6)."""
     c3, c4, c5 = feats[1], feats[2], feats[3]
@@ -76,6 +139,19 @@ def fpn(feats, sd, p):
     def conv(name, x, **kw):
         return F.conv2d(x, sd[p + name + ".weight"], sd[p + name + ".bias"], **kw)
 
+    if emu is not None:       # every FPN conv is one launch: output (+ the top-down addend, fused) rounded once
+        def econv(name, x, add=None, **kw):
+            y = F.conv2d(x, emu.weight(sd[p + name + ".weight"]), sd[p + name + ".bias"], **kw)
+            return emu.act(y if add is None else y + add)
+        inner4 = econv("fpn_inner4", c5)
+        p5 = econv("fpn_layer4", inner4, padding=1)
+        inner3 = econv("fpn_inner3", c4, add=F.interpolate(inner4, scale_factor=2, mode="nearest"))
+        p4 = econv("fpn_layer3", inner3, padding=1)
+        inner2 = econv("fpn_inner2", c3, add=F.interpolate(inner3, scale_factor=2, mode="nearest"))
+        p3 = econv("fpn_layer2", inner2, padding=1)
+        p6 = econv("top_blocks.p6", p5, stride=2, padding=1)
+        p7 = econv("top_blocks.p7", F.relu(p6), stride=2, padding=1)
+        return [p3, p4, p5, p6, p7]
     inner4 = conv("fpn_inner4", c5)
     p5 = conv("fpn_layer4", inner4, padding=1)
     inner3 = conv("fpn_inner3", c4) + F.interpolate(inner4, scale_factor=2, mode="nearest")
@@ -87,9 +163,9 @@ def fpn(feats, sd, p):
     return [p3, p4, p5, p6, p7]
 
 
-def backbone(x, sd, p):
+def backbone(x, sd, p, emu=None):
     """modeling/backbone/backbone.py:51-72: Sequential(body, fpn)."""
-    return fpn(resnet_body(x, sd, p + "body."), sd, p + "fpn.")
+    return fpn(resnet_body(x, sd, p + "body.", emu=emu), sd, p + "fpn.", emu)
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -175,34 +251,39 @@ def query_pool(query_feats, image_sizes, batch_size):
     return pooled
 
 
-def correlate(target_feats, pooled):
+def correlate(target_feats, pooled, emu=None):
     """generalized_rcnn.py:307-311: features[i] * pooled[i].expand(-1, -1, H, W) — depthwise x-corr, 1x1 kernel."""
-    return [f * q.expand(-1, -1, f.shape[2], f.shape[3]) for f, q in zip(target_feats, pooled)]
+    out = [f * q.expand(-1, -1, f.shape[2], f.shape[3]) for f, q in zip(target_feats, pooled)]
+    return out if emu is None else [emu.act(t) for t in out]
 
 
 # --------------------------------------------------------------------------------------------------------------------
 # FCOS head
 # --------------------------------------------------------------------------------------------------------------------
-def fcos_head(feats, sd, p="rpn.head."):
+def fcos_head(feats, sd, p="rpn.head.", emu=None):
     """modeling/rpn/fcos/fcos.py:83-99 (FCOSHead.forward).  Shared weights across levels; centerness from the CLS
-    tower (:92); bbox_reg = exp(scale_l * bbox_pred(bbox_tower)) (:95-97)."""
+    tower (:92); bbox_reg = exp(scale_l * bbox_pred(bbox_tower)) (:95-97).  emu: the conv output is stored (rounded) before
+    GroupNorm reads it, GroupNorm+ReLU is one more stored tensor, the prediction convs store their (exp'd) outputs."""
+    rw = (lambda w: w) if emu is None else emu.weight
+    ra = (lambda t: t) if emu is None else emu.act
+
     def tower(x, name):
         for i in range(4):
-            x = F.conv2d(x, sd["%s%s.%d.weight" % (p, name, 3 * i)], sd["%s%s.%d.bias" % (p, name, 3 * i)],
-                         padding=1)
+            x = ra(F.conv2d(x, rw(sd["%s%s.%d.weight" % (p, name, 3 * i)]), sd["%s%s.%d.bias" % (p, name, 3 * i)],
+                            padding=1))
             x = F.group_norm(x, 32, sd["%s%s.%d.weight" % (p, name, 3 * i + 1)],
                              sd["%s%s.%d.bias" % (p, name, 3 * i + 1)], eps=1e-5)
-            x = F.relu(x)
+            x = ra(F.relu(x))
         return x
 
     logits, bbox_reg, centerness = [], [], []
     for l, f in enumerate(feats):
         ct = tower(f, "cls_tower")
-        logits.append(F.conv2d(ct, sd[p + "cls_logits.weight"], sd[p + "cls_logits.bias"], padding=1))
-        centerness.append(F.conv2d(ct, sd[p + "centerness.weight"], sd[p + "centerness.bias"], padding=1))
+        logits.append(ra(F.conv2d(ct, rw(sd[p + "cls_logits.weight"]), sd[p + "cls_logits.bias"], padding=1)))
+        centerness.append(ra(F.conv2d(ct, rw(sd[p + "centerness.weight"]), sd[p + "centerness.bias"], padding=1)))
         bt = tower(f, "bbox_tower")
-        bp = F.conv2d(bt, sd[p + "bbox_pred.weight"], sd[p + "bbox_pred.bias"], padding=1)
-        bbox_reg.append(torch.exp(bp * sd["%sscales.%d.scale" % (p, l)]))
+        bp = F.conv2d(bt, rw(sd[p + "bbox_pred.weight"]), sd[p + "bbox_pred.bias"], padding=1)
+        bbox_reg.append(ra(torch.exp(bp * sd["%sscales.%d.scale" % (p, l)])))
     return logits, bbox_reg, centerness
 
 
@@ -230,18 +311,19 @@ def to_image_list(tensors, size_divisible=0):
     return out, [tuple(t.shape[-2:]) for t in tensors]
 
 
-def hot_path_forward(images, queries, sd, shots=1, query_sizes=None):
+def hot_path_forward(images, queries, sd, shots=1, query_sizes=None, emu=None):
     """generalized_rcnn.py:226-312 up to and including the FCOS head (eval or train; no BN/GN state differs).
     images [B,3,H,W]; queries [B*shots,3,h,w]; query_sizes: true (h, w) per query of a padded batch.
+    emu: an Emulation (reduced-precision mode: rounds where the bf16 engines store); None = the fp32 restatement.
     Returns a dict of every intermediate."""
     B = images.shape[0]
-    feats = backbone(images, sd, "backbone.")
-    qfeats = backbone(queries, sd, "supp_backbone.")
+    feats = backbone(images, sd, "backbone.", emu)
+    qfeats = backbone(queries, sd, "supp_backbone.", emu)
     # to_image_list on a 4-D tensor: image_list.py:44-50; on a list: the true sizes (:69)
     q_sizes = [tuple(queries.shape[-2:])] * queries.shape[0] if query_sizes is None else list(query_sizes)
     pooled = query_pool(qfeats, q_sizes, B)
-    combined = correlate(feats, pooled)
-    logits, bbox_reg, centerness = fcos_head(combined, sd)
+    combined = correlate(feats, pooled, emu)
+    logits, bbox_reg, centerness = fcos_head(combined, sd, emu=emu)
     return dict(features=feats, query_features=qfeats, pooled=pooled, combined=combined,
                 logits=logits, bbox_reg=bbox_reg, centerness=centerness)
 

@@ -59,7 +59,7 @@ def test_roi_align_reference_vectors():
         np.testing.assert_allclose(y.numpy(), f["y.%d" % i], rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["small", "nonsquare", "shots5", "tall", "config1"])
+@pytest.mark.parametrize("name", ["small", "nonsquare", "shots5", "tall", "config1", "ms640"])
 def test_hot_path_forward_matches_reference(name, sd):
     B, H, W, S, qh, qw = gu.CASES[name]
     img, q = gu.case_inputs(name)
