@@ -1,0 +1,328 @@
+// conv_igemm_sp — the row-reuse 3x3 convolution (conv_igemm_xr.hip: bf16, 3x3 / stride 1 / pad 1, 256 x 256 tile, 8 waves,
+// padded pixel image fetched once per filter row) with the operand fragments SOFTWARE-PIPELINED through registers.
+//
+// Why: in conv_xr_kernel every half stage (32 of K) opens with 12 ds_read_b128 per wave and the MFMAs wait for them — all 8
+// waves at once, twice per stage: ~900 of a stage's ~3,000 cycles are the matrix pipe waiting for LDS (the loop WITHOUT any
+// global traffic runs at 0.59 of the MFMA peak).  Here the fragments of half stage u + 1 are read while the MFMAs
+// of half stage u run:
+//   * the 4 weight fragments have two register sets; the 8 pixel fragments are REPLACED one by one — fragment j of the next
+//     half stage is read as soon as the 4 MFMAs that use the current fragment j have been issued (MFMA order: pixel fragment
+//     outer, weight fragment inner) — so the pipeline costs 16 more VGPRs, not 48;
+//   * reading half stage u + 1 during u needs its LDS bytes visible one half stage early, so the ONE barrier per stage moves
+//     from the stage boundary to the middle of the stage: barrier B_w sits between the two halves of weight stage w; before
+//     it every wave has waited for its own LDS-DMA of weight stage w + 1 (and, in a group's last tap, of the next pixel image)
+//     and for its last reads of stage w's buffers; after it stage w + 1 may be read and weight stage w + 2 is fetched into the
+//     buffer stage w just vacated.  Same 2-deep rings, same LDS budget, every DMA still has a full stage of flight time.
+//   * LDS-DMA by `buffer_load_dwordx4 ... lds` with hardware bounds checking: a lane whose row is zero padding (vertical
+//     border, M tail, Cout tail) presents an out-of-range offset and the hardware writes zeros — no zero page, no 64-bit
+//     per-lane pointers (8 VGPRs and two VALU selects per instruction less).
+// The accumulation order over K is conv_xr_kernel's, so the two kernels' outputs are bit-identical (tested).
+#include "osd_common.h"
+#include "conv_params.h"
+#include "conv_epilogue.h"
+#include <type_traits>
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int N> __device__ __forceinline__ void sp_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void sp_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// one LDS-DMA wave-instruction: 64 lanes x 16 bytes, lane l lands at lds_dst + 16 l; source = buffer base + voff (bytes),
+// zeros when voff is outside the buffer
+__device__ __forceinline__ void sp_dma16(i32x4 rsrc, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(lds_dst), "s"(rsrc)
+      : "memory");
+}
+
+__device__ __forceinline__ i32x4 sp_make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));       // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+
+// swizzle key of a padded pixel-image row: see conv_igemm_xr.hip (conflict-free for the three tap shifts)
+__device__ __forceinline__ int sp_key(int row) { return (int)((0x4430066774400322ull >> ((row & 15) * 4)) & 7); }
+
+constexpr int SP_BM = 256, SP_BN = 256, SP_KB = 128, SP_BKE = 64, SP_EPC = 8;
+constexpr int SP_WN = 4, SP_TM = 8, SP_TN = 4;
+constexpr int SP_AROWS = 336;
+constexpr int SP_ABYTES = SP_AROWS * SP_KB;
+constexpr int SP_BBYTES = SP_BN * SP_KB;
+constexpr int SP_LDS = 2 * SP_ABYTES + 2 * SP_BBYTES;
+constexpr unsigned SP_OOB = 0x80000000u;            // beyond any buffer of < 2 GiB: the DMA writes zeros
+
+__global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
+  typedef __bf16 T;
+  constexpr int TM = SP_TM, TN = SP_TN, KB = SP_KB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / SP_WN, wn = wave % SP_WN;
+
+  int t;
+  {
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = t % p.tilesN;
+  int tile_m = t / p.tilesN;
+  const ConvView q = conv_select_view(p, tile_m);
+  const int q_H = q.H, q_W = q.W, q_M = q.M, q_HoWo = q.HoWo;
+  const int m0 = tile_m * SP_BM, n0 = tile_n * SP_BN;
+  const int logw = __builtin_ctz((unsigned)q_W);       // W in {64, 128, 256} (checked by the launcher)
+  const int Cin = p.Cin;
+
+  const i32x4 xrs = sp_make_rsrc(q.x, (unsigned)q_M * (unsigned)Cin * 2u);            // H = Ho, W = Wo: M pixels x Cin
+  const i32x4 wrs = sp_make_rsrc(q.w, (unsigned)p.w_rows * (unsigned)p.Ktot * 2u);
+
+  // ---- zero both pixel images once: the pad rows stay zero for the whole K loop ----
+  {
+    uint4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < 2 * SP_ABYTES / 16; i += 512) *reinterpret_cast<uint4*>(smem + i * 16) = z;
+  }
+
+  // ---- per-lane DMA sources (byte offsets).  One wave-instruction = 8 rows x 128 B; wave w owns pixel instructions
+  // 4w .. 4w+3 and weight instructions 4w .. 4w+3 ----
+  const int lrow = lane >> 3, lpos = lane & 7;
+  unsigned a_off[4];        // byte offset of (image, line ho - 1, column wo, swizzled 16-byte chunk) - may wrap: guarded by a_ho
+  int a_ho[4];
+  unsigned a_dst[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + lrow;
+    const int m = m0 + row;
+    const int R = 16 + row + 16 * (row >> logw);
+    a_dst[i] = (unsigned)((16 + (wave * 4 + i) * 8 + 16 * (((wave * 4 + i) * 8) >> logw)) * KB);   // wave-uniform
+    a_off[i] = 0u;
+    a_ho[i] = -0x40000000;
+    if (m < q_M) {
+      const int n_img = m / q_HoWo;
+      const int rem = m - n_img * q_HoWo;
+      const int ho = rem >> logw;
+      const int wo = rem & (q_W - 1);
+      a_off[i] = (unsigned)(((n_img * q_H + (ho - 1)) * q_W + wo) * Cin + ((lpos ^ sp_key(R)) * SP_EPC)) * 2u;
+      a_ho[i] = ho - 1;
+    }
+  }
+  unsigned b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + lrow;
+    b_off[i] = n0 + row < p.w_rows ? (unsigned)((n0 + row) * p.Ktot + ((lpos ^ ((row >> 1) & 7)) * SP_EPC)) * 2u : SP_OOB;
+  }
+  const int line_bytes = q_W * Cin * 2;
+
+  const unsigned a_lds[2] = {lds0, lds0 + (unsigned)SP_ABYTES};
+  const unsigned b_lds[2] = {lds0 + 2u * SP_ABYTES, lds0 + 2u * SP_ABYTES + (unsigned)SP_BBYTES};
+
+  // pixel instruction i of group (kr, kc) into pixel image `buf`
+  auto issue_a = [&](int buf, int i, int kr, int kc) {
+    const int hi = a_ho[i] + kr;
+    const unsigned off = (unsigned)hi < (unsigned)q_H ? a_off[i] + (unsigned)(kr * line_bytes + kc * 2) : SP_OOB;
+    sp_dma16(xrs, off, a_lds[buf] + a_dst[i]);
+  };
+  // weight instruction i of the stage whose K offset is koff (elements) into weight stage `buf`
+  auto issue_b = [&](int buf, int i, int koff) {
+    sp_dma16(wrs, b_off[i] + (unsigned)(koff * 2), b_lds[buf] + (unsigned)((wave * 4 + i) * 1024));
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fkq = lane >> 4;
+  // fragment offsets of the first K half; the second half is the same address with bit 6 flipped (the 16-byte chunk index
+  // (kb * 4 + fkq) ^ key differs in bit 2 only, and every base added later is a multiple of 128)
+  int w_off[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int row = (wn * TN + i) * 16 + frow;
+    w_off[i] = row * KB + ((fkq ^ ((row >> 1) & 7)) << 4);
+  }
+  int x_lane[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int e = frow + s - 1;
+    x_lane[s] = e * KB + ((fkq ^ sp_key(e)) << 4);
+  }
+  int x_frag[TM];                                       // wave-uniform: first padded row of fragment j (a multiple of 16)
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int r0 = (wm * TM + j) * 16;
+    x_frag[j] = (16 + r0 + 16 * (r0 >> logw)) * KB;
+  }
+
+  const int nslab = Cin / SP_BKE;
+  const int G = 3 * nslab;                              // groups = (filter row, 64-channel slab)
+
+  // fragment registers: the pixel set is replaced in place, the weight sets alternate
+  uint4 xf[TM], wf0[TN], wf1[TN];
+
+  // One half stage: MFMAs on (wcur, xf) while the NEXT half stage's fragments are read — weights into wnxt up front, pixel
+  // fragment j into xf[j] right behind the 4 MFMAs that consumed it.  ab_n / s_n / kb_n / bb_n: pixel image, tap, K half and
+  // weight stage of the NEXT half stage.  DMA: FB -> the 4 weight instructions of the stage at K offset koff into weight
+  // buffer dma_bb; FA -> the 4 pixel instructions of group (nkr, nkc) into image dma_ab; both spread over the MFMA groups.
+  auto half_stage = [&](uint4 (&wcur)[TN], uint4 (&wnxt)[TN], int ab_n, auto sn_tag, auto kbn_tag, int bb_n, auto has_next,
+                        auto fb_tag, int dma_bb, int koff, auto fa_tag, int dma_ab, int nkr, int nkc) {
+    constexpr int s_n = decltype(sn_tag)::value, kb_n = decltype(kbn_tag)::value;
+    constexpr bool NEXT = decltype(has_next)::value, FB = decltype(fb_tag)::value, FA = decltype(fa_tag)::value;
+    const char* xs = smem + ab_n * SP_ABYTES;
+    const char* ws = smem + 2 * SP_ABYTES + bb_n * SP_BBYTES;
+    if constexpr (NEXT) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wnxt[i] = *reinterpret_cast<const uint4*>(ws + (w_off[i] ^ (kb_n * 64)));
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&wcur[i]),
+                                                            *reinterpret_cast<const bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
+      if constexpr (NEXT) xf[j] = *reinterpret_cast<const uint4*>(xs + x_frag[j] + (x_lane[s_n] ^ (kb_n * 64)));
+      if constexpr (FB) {
+        if (j < 4) issue_b(dma_bb, j, koff);
+      }
+      if constexpr (FA) {
+        if (j >= 4) issue_a(dma_ab, j - 4, nkr, nkc);
+      }
+      __builtin_amdgcn_sched_barrier(0);                // keep the replacement read behind its fragment's last MFMA
+    }
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using Y = std::true_type;
+  using N_ = std::false_type;
+
+  // ---- prologue: pixel image 0, weight stages 0 and 1; then the first fragments ----
+  __syncthreads();                                      // the zero fill is complete before any DMA lands on real rows
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue_a(0, i, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue_b(0, i, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue_b(1, i, Cin);       // tap 1 of group 0
+  sp_wait_vmcnt<4>();                                   // image 0 and weight stage 0 have landed (mine)
+  __builtin_amdgcn_s_barrier();                         // ... and everyone's
+  {
+    const char* xs = smem;
+    const char* ws = smem + 2 * SP_ABYTES;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf0[i] = *reinterpret_cast<const uint4*>(ws + w_off[i]);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const uint4*>(xs + x_frag[j] + x_lane[0]);
+  }
+  sp_wait_lgkm0();
+
+  // Group loop.  Weight stage index w = 3 g + s alternates buffers, and with 3 stages per group a group flips the parity:
+  // (ab, bb) are the image / weight buffers of the group's tap 0.
+  int ab = 0, bb = 0;
+  int kr = 0, kc = 0;
+  for (int g = 0; g + 1 < G; ++g) {                     // every group but the last
+    int nkr = kr, nkc = kc + SP_BKE;                    // next group
+    if (nkc >= Cin) { nkc = 0; ++nkr; }
+    const int kbase = kr * 3 * Cin + kc;                // K offset of tap 0 of this group; tap s adds s * Cin
+    const int knext = nkr * 3 * Cin + nkc;              // ... of the next group
+    // tap 0: the first half reads its own second half and fetches the NEXT group's pixel image (its buffer was vacated at
+    // the previous group's last barrier); the wait leaves those 4 youngest DMAs in flight
+    half_stage(wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, Y(), ab ^ 1, nkr, nkc);
+    sp_wait_lgkm0();
+    sp_wait_vmcnt<4>();
+    __builtin_amdgcn_s_barrier();                       // B(g, 0): weight stage (g, 1) visible, buffer bb vacated
+    half_stage(wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
+    sp_wait_lgkm0();
+    // tap 1
+    half_stage(wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+    sp_wait_lgkm0();
+    sp_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                       // B(g, 1): weight stage (g, 2) visible, buffer bb ^ 1 vacated
+    half_stage(wf1, wf0, ab, I2(), I0(), bb, Y(), Y(), bb ^ 1, knext, N_(), 0, 0, 0);
+    sp_wait_lgkm0();
+    // tap 2
+    half_stage(wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+    sp_wait_lgkm0();
+    sp_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                       // B(g, 2): next image + weight stage (g + 1, 0) visible; image ab vacated
+    half_stage(wf1, wf0, ab ^ 1, I0(), I0(), bb ^ 1, Y(), Y(), bb, knext + Cin, N_(), 0, 0, 0);
+    sp_wait_lgkm0();
+    ab ^= 1;
+    bb ^= 1;
+    kr = nkr;
+    kc = nkc;
+  }
+  {
+    // last group: no next image; weight stage (g, 1) is in flight, (g, 2) is fetched below
+    const int kbase = kr * 3 * Cin + kc;
+    half_stage(wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+    sp_wait_lgkm0();
+    sp_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    half_stage(wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
+    sp_wait_lgkm0();
+    half_stage(wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+    sp_wait_lgkm0();
+    sp_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    half_stage(wf1, wf0, ab, I2(), I0(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+    sp_wait_lgkm0();
+    half_stage(wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+    sp_wait_lgkm0();
+    half_stage(wf1, wf0, ab, I0(), I0(), bb, N_(), N_(), 0, 0, N_(), 0, 0, 0);
+  }
+
+  __syncthreads();
+  conv_epilogue<T, TM, TN>(acc, p, q, smem, wave, wm, wn, lane, m0, n0);
+}
+
+}  // namespace
+
+int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream) {
+  ConvKParams p = pin;
+  if (p.R != 3 || p.S != 3 || p.sh != 1 || p.sw != 1 || p.ph != 1 || p.pw != 1)
+    return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): 3x3 stride 1 pad 1 only");
+  if (p.Cin % SP_BKE != 0 || p.sW != p.Cin) return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): dense NHWC input with cin %% 64 == 0");
+  if (p.relu_in) return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): relu_in prologue not supported");
+  if ((long long)p.w_rows * p.Ktot * 2 >= 0x7fffffffLL) return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): weights over 2 GiB");
+  auto ok = [&](int w, int wo, int h, int ho, int m, int sh) {
+    return (w == 64 || w == 128 || w == 256) && wo == w && ho == h && sh == w * p.Cin && (long long)m * p.Cin * 2 < 0x7fffffffLL;
+  };
+  p.tilesM = cdiv(p.M, SP_BM);
+  if (p.n_seg > 0) {
+    p.tilesM = 0;
+    for (int i = 0; i < p.n_seg; ++i) {
+      if (!ok(p.seg[i].W, p.seg[i].Wo, p.seg[i].H, p.seg[i].Ho, p.seg[i].M, p.seg[i].sH))
+        return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): segment %d width %d (needs 64, 128 or 256, < 2 GiB)", i, p.seg[i].W);
+      p.seg[i].tile_begin = p.tilesM;
+      p.tilesM += cdiv(p.seg[i].M, SP_BM);
+    }
+  } else if (!ok(p.W, p.Wo, p.H, p.Ho, p.M, p.sH)) {
+    return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): width %d (needs 64, 128 or 256, < 2 GiB)", p.W);
+  }
+  p.tilesN = cdiv(p.Cout, SP_BN);
+  p.KT = p.Ktot / SP_BKE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    attr_done = true;
+  }
+  const long long nblocks = (long long)p.tilesM * p.tilesN;
+  if (nblocks <= 0 || nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv(sp): bad grid");
+  hipLaunchKernelGGL(conv_sp_kernel, dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+  return osd_check_launch("conv_igemm_sp");
+}

@@ -148,6 +148,8 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
         cands.append(1 + 0 * 32 + 0 * 8 + 5)          # 256x256 tile, two wave groups one barrier apart (bf16 only)
         if not os.environ.get("OSD_NO_XR"):           # (A/B switch for tools and benches)
             cands.append(1 + 0 * 32 + 0 * 8 + 6)      # 3x3/1: pixel rows fetched once per filter row (bf16, W in 64/128/256)
+            if not os.environ.get("OSD_NO_SP"):
+                cands.append(1 + 0 * 32 + 1 * 8 + 6)  # the same with software-pipelined fragments + mid-stage barrier
     if cout_store >= 128 and not relu_in:
         cands += [1 + 0 * 32 + v * 8 + 7 for v in (0, 1, 2, 3)]      # 256x128 tile on 8 waves: deep / shallow ring / short stages
     if not relu_in and not has_mask:

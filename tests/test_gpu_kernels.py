@@ -385,6 +385,38 @@ def test_conv2d_row_reuse_kernel_matches_the_dma_kernel():
             (rnd(256, 64, 3, 3, seed=2)).cuda(), dtype=torch.bfloat16), pad=1, algo=XR)
 
 
+def test_conv2d_software_pipelined_row_reuse_kernel_is_bit_identical_to_the_row_reuse_kernel():
+    """conv_igemm_sp.hip (tile id 6, variant 1): conv_xr_kernel's arithmetic in conv_xr_kernel's order — the same MFMAs on the
+    same fragments, K summed in the same (r, c, s) order — with the fragments read one half stage ahead, the barrier in the
+    middle of a stage and the LDS-DMA issued as bounds-checked buffer loads (zero padding by the hardware): outputs must be
+    BIT-IDENTICAL to conv_xr_kernel's, on every repeat (race screen: a fragment read before its DMA has landed, or a DMA into a
+    buffer still being read, shows up as a mismatch).  Shapes: every width, tiles straddling images, vertical borders inside
+    a tile, ragged M and Cout tails, 1..4 channel slabs, all epilogues, a grouped launch."""
+    o = ops()
+    XR, SP = 1 + 6, 1 + 8 + 6
+    for (n, h, w, cin, cout) in [(2, 50, 64, 256, 256), (3, 13, 128, 128, 256), (1, 5, 256, 64, 320), (8, 100, 128, 256, 256),
+                                 (2, 7, 64, 64, 260), (1, 3, 64, 192, 256), (5, 9, 64, 256, 512)]:
+        x = to_nhwc(rnd(n, cin, h, w, seed=1), torch.bfloat16)
+        wt = rnd(cout, cin, 3, 3, seed=2) / (cin * 9) ** 0.5
+        pc = o.pack_conv(wt.cuda(), bias=rnd(cout, seed=3).cuda(), dtype=torch.bfloat16)
+        res = to_nhwc(rnd(n, pc.cout_store, h, w, seed=4), torch.bfloat16)
+        mask = to_nhwc(rnd(n, pc.cout_store, h, w, seed=5), torch.bfloat16)
+        for kw in (dict(), dict(res=res, res_mode=o.RES_SAME, act=o.ACT_RELU), dict(mask=mask)):
+            ref = o.conv2d(x, pc, pad=1, algo=XR, **kw)
+            for rep in range(6):
+                y = o.conv2d(x, pc, pad=1, algo=SP, **kw)
+                assert torch.equal(y, ref), (n, h, w, cin, cout, sorted(kw), rep, (y.float() - ref.float()).abs().max().item())
+    xs = [to_nhwc(rnd(2, 256, 24, 128, seed=11), torch.bfloat16), to_nhwc(rnd(2, 256, 12, 64, seed=12), torch.bfloat16),
+          to_nhwc(rnd(1, 256, 3, 64, seed=13), torch.bfloat16)]
+    wt = rnd(256, 256, 3, 3, seed=13) / (256 * 9) ** 0.5
+    pc = o.pack_conv(wt.cuda(), bias=rnd(256, seed=14).cuda(), dtype=torch.bfloat16)
+    for ya, yb in zip(o.conv2d_grouped(xs, pc, pad=1, algo=SP, _whole=True), o.conv2d_grouped(xs, pc, pad=1, algo=XR, _whole=True)):
+        assert torch.equal(ya, yb)
+    from oneshotdet_amd import _lib
+    with pytest.raises(_lib.OsdError):
+        o.conv2d(to_nhwc(rnd(1, 256, 8, 100, seed=1), torch.bfloat16), pc, pad=1, algo=SP)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_roi_align_module_backward_matches_oracle_autograd(dt):
     """layers.ROIAlign is differentiable like the reference's (layers/roi_align.py:27-44 -> _C.roi_align_backward): the
