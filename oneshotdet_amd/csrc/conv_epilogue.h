@@ -50,7 +50,10 @@ __device__ __forceinline__ ConvView conv_select_view(const ConvKParams& p, int& 
 // reusable (barrier, no DMA in flight).
 template <typename T, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKParams& p, const ConvView& q, char* smem,
-                                              int wave, int wm, int wn, int lane, int m0, int n0) {
+                                              int wave, int wm, int wn, int lane, int m0, int n0,
+                                              const float* pre_bias = nullptr) {
+  // pre_bias (optional): the fast path's EPC bias values of this lane (channels n0 + wn * TN * 16 + (lane % CPR) * EPC ..),
+  // loaded by the caller ahead of time
   constexpr int EPC = 16 / (int)sizeof(T);
   const int q_M = q.M, q_HoWo = q.HoWo, q_Wo = q.Wo;
   const void* q_y = q.y; const void* q_res = q.res; const void* q_mask = q.mask; const float* q_scale_dev = q.scale_dev;
@@ -83,10 +86,15 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
     const int cc = lane % CPR;                 // 64 % CPR == 0: a lane keeps its channel chunk in every iteration
     const int c = cbase + cc * EPC;
     float bv[EPC];
+    if (pre_bias) {
 #pragma unroll
-    for (int e = 0; e < EPC; e += 4) {
-      const f32x4 b4 = *(const OSD_G f32x4*)(biasg + c + e);
-      bv[e] = b4[0]; bv[e + 1] = b4[1]; bv[e + 2] = b4[2]; bv[e + 3] = b4[3];
+      for (int e = 0; e < EPC; ++e) bv[e] = pre_bias[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPC; e += 4) {
+        const f32x4 b4 = *(const OSD_G f32x4*)(biasg + c + e);
+        bv[e] = b4[0]; bv[e + 1] = b4[1]; bv[e + 2] = b4[2]; bv[e + 3] = b4[3];
+      }
     }
     const float escale = p.act == OSD_ACT_EXP_SCALE ? (q_scale_dev ? *(const OSD_G float*)q_scale_dev : p.act_scale) : 1.f;
 #pragma unroll
@@ -161,7 +169,11 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
           if constexpr (sizeof(T) == 2) o[e] = (__bf16)v[it][e];
           else o[e] = v[it][e];
         }
+#ifdef OSD_EPI_NOSTORE      // diagnostic build: everything but the global stores
+        asm volatile("" ::"v"(o));
+#else
         *(OSD_G Vec*)(yg + (size_t)(mrow + it * (64 / CPR)) * p.out_stride + c) = o;
+#endif
       }
     }
     return;

@@ -172,18 +172,32 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
 
   // fragment registers: the pixel set is replaced in place, the weight sets alternate
   uint4 xf[TM], wf0[TN], wf1[TN];
+  f32x4 bq[2];
 
   // One half stage: MFMAs on (wcur, xf) while the NEXT half stage's fragments are read — weights into wnxt up front, pixel
   // fragment j into xf[j] right behind the 4 MFMAs that consumed it.  ab_n / s_n / kb_n / bb_n: pixel image, tap, K half and
   // weight stage of the NEXT half stage.  DMA: FB -> the 4 weight instructions of the stage at K offset koff into weight
   // buffer dma_bb; FA -> the 4 pixel instructions of group (nkr, nkc) into image dma_ab; both spread over the MFMA groups.
-  auto half_stage = [&](uint4 (&wcur)[TN], uint4 (&wnxt)[TN], int ab_n, auto sn_tag, auto kbn_tag, int bb_n, auto has_next,
-                        auto fb_tag, int dma_bb, int koff, auto fa_tag, int dma_ab, int nkr, int nkc) {
+  auto half_stage = [&](auto bar_tag, uint4 (&wcur)[TN], uint4 (&wnxt)[TN], int ab_n, auto sn_tag, auto kbn_tag, int bb_n,
+                        auto has_next, auto fb_tag, int dma_bb, int koff, auto fa_tag, int dma_ab, int nkr, int nkc) {
+    // BAR: 0 = no barrier in this half stage; 1 / 2 = the stage's barrier, with `vmcnt(0)` / `vmcnt(4)` before it.  The
+    // barrier sits BEHIND the first MFMA group: the last fragment read of the previous half stage was issued just before that
+    // group, so the lgkmcnt(0) the barrier needs (all my reads of the buffers it releases are complete) has 4 MFMAs of cover.
+    constexpr int BAR = decltype(bar_tag)::value;
     constexpr int s_n = decltype(sn_tag)::value, kb_n = decltype(kbn_tag)::value;
     constexpr bool NEXT = decltype(has_next)::value, FB = decltype(fb_tag)::value, FA = decltype(fa_tag)::value;
     const char* xs = smem + ab_n * SP_ABYTES;
     const char* ws = smem + 2 * SP_ABYTES + bb_n * SP_BBYTES;
-    if constexpr (NEXT) {
+#ifndef OSD_SP_BAR_AT
+#define OSD_SP_BAR_AT 1
+#endif
+    constexpr int BAR_AT = OSD_SP_BAR_AT;               // MFMA groups of this half stage issued ahead of its barrier
+    if constexpr (BAR != 0 && BAR_AT == 0) {
+      sp_wait_lgkm0();
+      if constexpr (BAR == 2) sp_wait_vmcnt<4>(); else sp_wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (NEXT && (BAR == 0 || BAR_AT == 0)) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) wnxt[i] = *reinterpret_cast<const uint4*>(ws + (w_off[i] ^ (kb_n * 64)));
     }
@@ -193,13 +207,27 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
       for (int i = 0; i < TN; ++i)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&wcur[i]),
                                                             *reinterpret_cast<const bf16x8*>(&xf[j]), acc[i][j], 0, 0, 0);
+      if constexpr (BAR != 0 && BAR_AT != 0) {
+        if (j == BAR_AT - 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          sp_wait_lgkm0();
+          if constexpr (BAR == 2) sp_wait_vmcnt<4>(); else sp_wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();
+          if constexpr (NEXT) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) wnxt[i] = *reinterpret_cast<const uint4*>(ws + (w_off[i] ^ (kb_n * 64)));
+          }
+        }
+      }
       if constexpr (NEXT) xf[j] = *reinterpret_cast<const uint4*>(xs + x_frag[j] + (x_lane[s_n] ^ (kb_n * 64)));
+#ifndef OSD_SP_NO_DMA
       if constexpr (FB) {
         if (j < 4) issue_b(dma_bb, j, koff);
       }
       if constexpr (FA) {
         if (j >= 4) issue_a(dma_ab, j - 4, nkr, nkc);
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);                // keep the replacement read behind its fragment's last MFMA
     }
   };
@@ -228,39 +256,33 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const uint4*>(xs + x_frag[j] + x_lane[0]);
   }
-  sp_wait_lgkm0();
 
   // Group loop.  Weight stage index w = 3 g + s alternates buffers, and with 3 stages per group a group flips the parity:
   // (ab, bb) are the image / weight buffers of the group's tap 0.
   int ab = 0, bb = 0;
   int kr = 0, kc = 0;
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  using B2 = std::integral_constant<int, 2>;
   for (int g = 0; g + 1 < G; ++g) {                     // every group but the last
     int nkr = kr, nkc = kc + SP_BKE;                    // next group
     if (nkc >= Cin) { nkc = 0; ++nkr; }
     const int kbase = kr * 3 * Cin + kc;                // K offset of tap 0 of this group; tap s adds s * Cin
     const int knext = nkr * 3 * Cin + nkc;              // ... of the next group
-    // tap 0: the first half reads its own second half and fetches the NEXT group's pixel image (its buffer was vacated at
-    // the previous group's last barrier); the wait leaves those 4 youngest DMAs in flight
-    half_stage(wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, Y(), ab ^ 1, nkr, nkc);
-    sp_wait_lgkm0();
-    sp_wait_vmcnt<4>();
-    __builtin_amdgcn_s_barrier();                       // B(g, 0): weight stage (g, 1) visible, buffer bb vacated
-    half_stage(wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
-    sp_wait_lgkm0();
+    // tap 0, first half: reads its own second half and fetches the NEXT group's pixel image (its buffer was vacated at the
+    // previous group's last barrier)
+    half_stage(B0(), wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, Y(), ab ^ 1, nkr, nkc);
+    // second half, barrier B(g, 0) inside (the wait leaves the 4 image DMAs in flight): weight stage (g, 1) visible, buffer bb
+    // vacated -> fetch weight stage (g, 2) into it
+    half_stage(B2(), wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
     // tap 1
-    half_stage(wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-    sp_wait_lgkm0();
-    sp_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                       // B(g, 1): weight stage (g, 2) visible, buffer bb ^ 1 vacated
-    half_stage(wf1, wf0, ab, I2(), I0(), bb, Y(), Y(), bb ^ 1, knext, N_(), 0, 0, 0);
-    sp_wait_lgkm0();
+    half_stage(B0(), wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+    // B(g, 1): weight stage (g, 2) visible, buffer bb ^ 1 vacated -> weight stage (g + 1, 0)
+    half_stage(B1(), wf1, wf0, ab, I2(), I0(), bb, Y(), Y(), bb ^ 1, knext, N_(), 0, 0, 0);
     // tap 2
-    half_stage(wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-    sp_wait_lgkm0();
-    sp_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                       // B(g, 2): next image + weight stage (g + 1, 0) visible; image ab vacated
-    half_stage(wf1, wf0, ab ^ 1, I0(), I0(), bb ^ 1, Y(), Y(), bb, knext + Cin, N_(), 0, 0, 0);
-    sp_wait_lgkm0();
+    half_stage(B0(), wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+    // B(g, 2): next image + weight stage (g + 1, 0) visible; image ab and weight buffer bb vacated -> weight stage (g + 1, 1)
+    half_stage(B1(), wf1, wf0, ab ^ 1, I0(), I0(), bb ^ 1, Y(), Y(), bb, knext + Cin, N_(), 0, 0, 0);
     ab ^= 1;
     bb ^= 1;
     kr = nkr;
@@ -269,25 +291,32 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   {
     // last group: no next image; weight stage (g, 1) is in flight, (g, 2) is fetched below
     const int kbase = kr * 3 * Cin + kc;
-    half_stage(wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-    sp_wait_lgkm0();
-    sp_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    half_stage(wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
-    sp_wait_lgkm0();
-    half_stage(wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-    sp_wait_lgkm0();
-    sp_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    half_stage(wf1, wf0, ab, I2(), I0(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-    sp_wait_lgkm0();
-    half_stage(wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-    sp_wait_lgkm0();
-    half_stage(wf1, wf0, ab, I0(), I0(), bb, N_(), N_(), 0, 0, N_(), 0, 0, 0);
+    half_stage(B0(), wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+    half_stage(B1(), wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
+    half_stage(B0(), wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+    half_stage(B1(), wf1, wf0, ab, I2(), I0(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+    // the epilogue's bias values (8 consecutive channels per lane, the same in all of its passes) travel while the last
+    // MFMAs run: loaded at the start of the epilogue they cost it a full memory latency
+    {
+      const int c = n0 + wn * (TN * 16) + (lane % (TN * 16 / SP_EPC)) * SP_EPC;
+      const float* bsrc = q.bias + (c + SP_EPC <= p.w_rows ? c : 0);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bsrc), b1 = *reinterpret_cast<const f32x4*>(bsrc + 4);
+      bq[0] = b0; bq[1] = b1;
+    }
+    half_stage(B0(), wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+    half_stage(B0(), wf1, wf0, ab, I0(), I0(), bb, N_(), N_(), 0, 0, N_(), 0, 0, 0);
   }
 
   __syncthreads();
-  conv_epilogue<T, TM, TN>(acc, p, q, smem, wave, wm, wn, lane, m0, n0);
+#ifdef OSD_SP_NO_EPI      // diagnostic build: keep the accumulators live, store nothing
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(acc[i][j]));
+  return;
+#endif
+  const float pre_bias[8] = {bq[0][0], bq[0][1], bq[0][2], bq[0][3], bq[1][0], bq[1][1], bq[1][2], bq[1][3]};
+  conv_epilogue<T, TM, TN>(acc, p, q, smem, wave, wm, wn, lane, m0, n0, pre_bias);
 }
 
 }  // namespace

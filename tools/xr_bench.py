@@ -38,14 +38,23 @@ def main():
         pc = ops.pack_conv(wt, bias=torch.zeros(cout, device="cuda"), dtype=torch.bfloat16)
         flops = sum(2.0 * n * h * w * cout * cin * 9 for n, h, w in shapes)
         out = []
-        for an, a in algos.items():
-            try:
-                if len(xs) == 1:
-                    t = bench(lambda: ops.conv2d(xs[0], pc, pad=1, algo=a))
-                else:
-                    t = bench(lambda: ops.conv2d_grouped(xs, pc, pad=1, algo=a))
-                out.append("%s %.1f us %.0f TF" % (an, t, flops / t / 1e6))
-            except Exception as e:      # noqa: BLE001
+        times = {an: [] for an in algos}
+        rounds = int(os.environ.get("XR_ROUNDS", "5"))
+        for rnd_ in range(rounds):                # interleaved rounds in one process: medians, not single shots
+            for an, a in algos.items():
+                try:
+                    if len(xs) == 1:
+                        t = bench(lambda: ops.conv2d(xs[0], pc, pad=1, algo=a), reps=10)
+                    else:
+                        t = bench(lambda: ops.conv2d_grouped(xs, pc, pad=1, algo=a, _whole=True), reps=10)
+                    times[an].append(t)
+                except Exception as e:      # noqa: BLE001
+                    pass
+        for an in algos:
+            ts = sorted(times[an])
+            if ts:
+                out.append("%s med %.1f min %.1f us %.0f TF" % (an, ts[len(ts) // 2], ts[0], flops / ts[len(ts) // 2] / 1e6))
+            else:
                 out.append("%s n/a" % an)
         print("%-28s %s" % (name, " | ".join(out)), flush=True)
 
