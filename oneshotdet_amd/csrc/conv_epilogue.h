@@ -48,10 +48,12 @@ __device__ __forceinline__ ConvView conv_select_view(const ConvKParams& p, int& 
 // pixels (wm*TM+j)*16..) through a private LDS region and writes NHWC runs of TN*16 channels with 16-byte-per-lane
 // accesses; all residual loads of a pass are issued before any arithmetic.  The caller has already made the LDS ring
 // reusable (barrier, no DMA in flight).
-template <typename T, int TM, int TN>
+template <typename T, int TM, int TN, bool TWO_REGIONS = false>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKParams& p, const ConvView& q, char* smem,
                                               int wave, int wm, int wn, int lane, int m0, int n0,
                                               const float* pre_bias = nullptr) {
+  // TWO_REGIONS: the fast path's passes alternate between two private staging regions per wave (the caller's LDS must hold
+  // 2 x waves x ROWS x CSW bytes), so the staging writes of pass p + 1 need not wait for the reads of pass p
   // pre_bias (optional): the fast path's EPC bias values of this lane (channels n0 + wn * TN * 16 + (lane % CPR) * EPC ..),
   // loaded by the caller ahead of time
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -72,7 +74,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
   constexpr int CPR = WC / EPC;                  // 16-byte output chunks per row
   constexpr int ITER = ROWS * CPR / 64;
   static_assert((ROWS * CPR) % 64 == 0 && ITER >= 1, "epilogue chunking");
-  char* stage = smem + wave * (ROWS * CSW);
+  char* stage = smem + wave * (ROWS * CSW) * (TWO_REGIONS ? 2 : 1);
   const bool vec_ok = (p.out_stride % EPC == 0) && (p.res_mode == OSD_RES_NONE || p.res_stride % EPC == 0);
   const int cbase = n0 + wn * WC;
 
@@ -99,12 +101,13 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
     const float escale = p.act == OSD_ACT_EXP_SCALE ? (q_scale_dev ? *(const OSD_G float*)q_scale_dev : p.act_scale) : 1.f;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
+      char* stage_p = stage + (TWO_REGIONS ? (ps & 1) * (ROWS * CSW) : 0);
 #pragma unroll
       for (int jj = 0; jj < TMP; ++jj) {
         const int j = ps * TMP + jj;
 #pragma unroll
         for (int i = 0; i < TN; ++i)
-          *reinterpret_cast<f32x4*>(stage + (jj * 16 + (lane & 15)) * CSW + (i * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
+          *reinterpret_cast<f32x4*>(stage_p + (jj * 16 + (lane & 15)) * CSW + (i * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
       }
       const int mrow = m0 + (wm * TM + ps * TMP) * 16 + lane / CPR;     // iteration `it` adds it * (64 / CPR) rows
       Vec rr[ITER], mm[ITER];
@@ -130,7 +133,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
       float v[ITER][EPC];
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
-        const char* src = stage + (it * (64 / CPR) + lane / CPR) * CSW + cc * EPC * 4;
+        const char* src = stage_p + (it * (64 / CPR) + lane / CPR) * CSW + cc * EPC * 4;
 #pragma unroll
         for (int e = 0; e < EPC; e += 4) {
           const f32x4 a4 = *reinterpret_cast<const f32x4*>(src + e * 4);

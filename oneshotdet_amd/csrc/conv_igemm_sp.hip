@@ -36,7 +36,7 @@ __device__ __forceinline__ void sp_dma16(i32x4 rsrc, unsigned voff, unsigned lds
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(voff), "s"(lds_dst), "s"(rsrc)
+      : "v"(voff), "s"(__builtin_amdgcn_readfirstlane((int)lds_dst)), "s"(rsrc)
       : "memory");
 }
 
@@ -95,33 +95,30 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   }
 
   // ---- per-lane DMA sources (byte offsets).  One wave-instruction = 8 rows x 128 B; wave w owns pixel instructions
-  // 4w .. 4w+3 and weight instructions 4w .. 4w+3 ----
+  // 4w .. 4w+3 and weight instructions 4w .. 4w+3; instruction i covers tile rows (4w + i) * 8 + lrow.  Few registers:
+  //   pixels:  ((n_img H + ho - 1) W + wo) Cin = (m - W) Cin is LINEAR in the pixel index m, so instruction i's offset is
+  //            a_par[i & 1] + i * 8 * Cin * 2 (the swizzled chunk depends on the row's parity group only); whether the input
+  //            line ho - 1 + kr exists is one bit per (instruction, filter row) in a_valid (M tail: all clear)
+  //   weights: b_par[i & 1] + i * 8 * Ktot * 2; rows past w_rows are past the end of the buffer by themselves
   const int lrow = lane >> 3, lpos = lane & 7;
-  unsigned a_off[4];        // byte offset of (image, line ho - 1, column wo, swizzled 16-byte chunk) - may wrap: guarded by a_ho
-  int a_ho[4];
+  unsigned a_par[2], b_par[2], a_valid = 0u;
   unsigned a_dst[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (wave * 4 + i) * 8 + lrow;
     const int m = m0 + row;
     const int R = 16 + row + 16 * (row >> logw);
-    a_dst[i] = (unsigned)((16 + (wave * 4 + i) * 8 + 16 * (((wave * 4 + i) * 8) >> logw)) * KB);   // wave-uniform
-    a_off[i] = 0u;
-    a_ho[i] = -0x40000000;
-    if (m < q_M) {
-      const int n_img = m / q_HoWo;
-      const int rem = m - n_img * q_HoWo;
-      const int ho = rem >> logw;
-      const int wo = rem & (q_W - 1);
-      a_off[i] = (unsigned)(((n_img * q_H + (ho - 1)) * q_W + wo) * Cin + ((lpos ^ sp_key(R)) * SP_EPC)) * 2u;
-      a_ho[i] = ho - 1;
+    a_dst[i] = (unsigned)__builtin_amdgcn_readfirstlane((16 + (wave * 4 + i) * 8 + 16 * (((wave * 4 + i) * 8) >> logw)) * KB);
+    if (i < 2) {
+      a_par[i] = (unsigned)((m - i * 8 - q_W) * Cin + ((lpos ^ sp_key(R)) * SP_EPC)) * 2u;      // instruction 0's row + parity chunk
+      b_par[i] = (unsigned)((n0 + row - i * 8) * p.Ktot + ((lpos ^ ((row >> 1) & 7)) * SP_EPC)) * 2u;
     }
-  }
-  unsigned b_off[4];
+    if (m < q_M) {
+      const int ho = (m % q_HoWo) >> logw;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + lrow;
-    b_off[i] = n0 + row < p.w_rows ? (unsigned)((n0 + row) * p.Ktot + ((lpos ^ ((row >> 1) & 7)) * SP_EPC)) * 2u : SP_OOB;
+      for (int kr = 0; kr < 3; ++kr)
+        if ((unsigned)(ho - 1 + kr) < (unsigned)q_H) a_valid |= 1u << (i * 3 + kr);
+    }
   }
   const int line_bytes = q_W * Cin * 2;
 
@@ -130,13 +127,12 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
 
   // pixel instruction i of group (kr, kc) into pixel image `buf`
   auto issue_a = [&](int buf, int i, int kr, int kc) {
-    const int hi = a_ho[i] + kr;
-    const unsigned off = (unsigned)hi < (unsigned)q_H ? a_off[i] + (unsigned)(kr * line_bytes + kc * 2) : SP_OOB;
+    const unsigned off = ((a_valid >> (i * 3 + kr)) & 1u) ? a_par[i & 1] + (unsigned)(i * 16 * Cin + kr * line_bytes + kc * 2) : SP_OOB;
     sp_dma16(xrs, off, a_lds[buf] + a_dst[i]);
   };
   // weight instruction i of the stage whose K offset is koff (elements) into weight stage `buf`
   auto issue_b = [&](int buf, int i, int koff) {
-    sp_dma16(wrs, b_off[i] + (unsigned)(koff * 2), b_lds[buf] + (unsigned)((wave * 4 + i) * 1024));
+    sp_dma16(wrs, b_par[i & 1] + (unsigned)((i * 8 * p.Ktot + koff) * 2), b_lds[buf] + (unsigned)((wave * 4 + i) * 1024));
   };
 
   f32x4 acc[TN][TM];
@@ -148,12 +144,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   const int frow = lane & 15, fkq = lane >> 4;
   // fragment offsets of the first K half; the second half is the same address with bit 6 flipped (the 16-byte chunk index
   // (kb * 4 + fkq) ^ key differs in bit 2 only, and every base added later is a multiple of 128)
-  int w_off[TN];
-#pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int row = (wn * TN + i) * 16 + frow;
-    w_off[i] = row * KB + ((fkq ^ ((row >> 1) & 7)) << 4);
-  }
+  const int w_off0 = (wn * TN * 16 + frow) * KB + ((fkq ^ ((frow >> 1) & 7)) << 4);      // tile i adds i * 16 rows (same key)
   int x_lane[3];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
@@ -172,18 +163,23 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
 
   // fragment registers: the pixel set is replaced in place, the weight sets alternate
   uint4 xf[TM], wf0[TN], wf1[TN];
+#ifdef OSD_SP_STAMPS      // diagnostic build: per-wave cycle stamps into the buffer passed as act_scale_dev (tools/sp_stamps.py)
+  unsigned long long st_lgkm = 0, st_vm = 0, st_bar = 0;
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
   f32x4 bq[2];
 
   // One half stage: MFMAs on (wcur, xf) while the NEXT half stage's fragments are read — weights into wnxt up front, pixel
   // fragment j into xf[j] right behind the 4 MFMAs that consumed it.  ab_n / s_n / kb_n / bb_n: pixel image, tap, K half and
   // weight stage of the NEXT half stage.  DMA: FB -> the 4 weight instructions of the stage at K offset koff into weight
   // buffer dma_bb; FA -> the 4 pixel instructions of group (nkr, nkc) into image dma_ab; both spread over the MFMA groups.
-  auto half_stage = [&](auto bar_tag, uint4 (&wcur)[TN], uint4 (&wnxt)[TN], int ab_n, auto sn_tag, auto kbn_tag, int bb_n,
+  auto half_stage = [&](auto early_tag, auto bar_tag, uint4 (&wcur)[TN], uint4 (&wnxt)[TN], int ab_n, auto sn_tag, auto kbn_tag, int bb_n,
                         auto has_next, auto fb_tag, int dma_bb, int koff, auto fa_tag, int dma_ab, int nkr, int nkc) {
     // BAR: 0 = no barrier in this half stage; 1 / 2 = the stage's barrier, with `vmcnt(0)` / `vmcnt(4)` before it.  The
     // barrier sits BEHIND the first MFMA group: the last fragment read of the previous half stage was issued just before that
     // group, so the lgkmcnt(0) the barrier needs (all my reads of the buffers it releases are complete) has 4 MFMAs of cover.
     constexpr int BAR = decltype(bar_tag)::value;
+    constexpr bool dma_early = decltype(early_tag)::value;
     constexpr int s_n = decltype(sn_tag)::value, kb_n = decltype(kbn_tag)::value;
     constexpr bool NEXT = decltype(has_next)::value, FB = decltype(fb_tag)::value, FA = decltype(fa_tag)::value;
     const char* xs = smem + ab_n * SP_ABYTES;
@@ -199,7 +195,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
     }
     if constexpr (NEXT && (BAR == 0 || BAR_AT == 0)) {
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wnxt[i] = *reinterpret_cast<const uint4*>(ws + (w_off[i] ^ (kb_n * 64)));
+      for (int i = 0; i < TN; ++i) wnxt[i] = *reinterpret_cast<const uint4*>(ws + (w_off0 ^ (kb_n * 64)) + i * 16 * KB);
     }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -210,22 +206,35 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
       if constexpr (BAR != 0 && BAR_AT != 0) {
         if (j == BAR_AT - 1) {
           __builtin_amdgcn_sched_barrier(0);
+#ifdef OSD_SP_STAMPS
+          const unsigned long long ta = __builtin_amdgcn_s_memtime();
+          sp_wait_lgkm0();
+          const unsigned long long tb = __builtin_amdgcn_s_memtime();
+          if constexpr (BAR == 2) sp_wait_vmcnt<4>(); else sp_wait_vmcnt<0>();
+          const unsigned long long tc = __builtin_amdgcn_s_memtime();
+          __builtin_amdgcn_s_barrier();
+          const unsigned long long td = __builtin_amdgcn_s_memtime();
+          st_lgkm += tb - ta; st_vm += tc - tb; st_bar += td - tc;
+#else
           sp_wait_lgkm0();
           if constexpr (BAR == 2) sp_wait_vmcnt<4>(); else sp_wait_vmcnt<0>();
           __builtin_amdgcn_s_barrier();
+#endif
           if constexpr (NEXT) {
 #pragma unroll
-            for (int i = 0; i < TN; ++i) wnxt[i] = *reinterpret_cast<const uint4*>(ws + (w_off[i] ^ (kb_n * 64)));
+            for (int i = 0; i < TN; ++i) wnxt[i] = *reinterpret_cast<const uint4*>(ws + (w_off0 ^ (kb_n * 64)) + i * 16 * KB);
           }
         }
       }
       if constexpr (NEXT) xf[j] = *reinterpret_cast<const uint4*>(xs + x_frag[j] + (x_lane[s_n] ^ (kb_n * 64)));
 #ifndef OSD_SP_NO_DMA
+      // (measured: the two waves of a SIMD issuing their DMA in opposite halves of the half stage — two copies of the K loop —
+      // is 5 % SLOWER than all waves issuing at the same place)
       if constexpr (FB) {
-        if (j < 4) issue_b(dma_bb, j, koff);
+        if ((j < 4) == dma_early) issue_b(dma_bb, j & 3, koff);
       }
       if constexpr (FA) {
-        if (j >= 4) issue_a(dma_ab, j - 4, nkr, nkc);
+        if ((j < 4) == dma_early) issue_a(dma_ab, j & 3, nkr, nkc);
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);                // keep the replacement read behind its fragment's last MFMA
@@ -252,11 +261,14 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
     const char* xs = smem;
     const char* ws = smem + 2 * SP_ABYTES;
 #pragma unroll
-    for (int i = 0; i < TN; ++i) wf0[i] = *reinterpret_cast<const uint4*>(ws + w_off[i]);
+    for (int i = 0; i < TN; ++i) wf0[i] = *reinterpret_cast<const uint4*>(ws + w_off0 + i * 16 * KB);
 #pragma unroll
     for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const uint4*>(xs + x_frag[j] + x_lane[0]);
   }
 
+#ifdef OSD_SP_STAMPS
+  const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();
+#endif
   // Group loop.  Weight stage index w = 3 g + s alternates buffers, and with 3 stages per group a group flips the parity:
   // (ab, bb) are the image / weight buffers of the group's tap 0.
   int ab = 0, bb = 0;
@@ -264,50 +276,60 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
   using B2 = std::integral_constant<int, 2>;
-  for (int g = 0; g + 1 < G; ++g) {                     // every group but the last
-    int nkr = kr, nkc = kc + SP_BKE;                    // next group
-    if (nkc >= Cin) { nkc = 0; ++nkr; }
-    const int kbase = kr * 3 * Cin + kc;                // K offset of tap 0 of this group; tap s adds s * Cin
-    const int knext = nkr * 3 * Cin + nkc;              // ... of the next group
-    // tap 0, first half: reads its own second half and fetches the NEXT group's pixel image (its buffer was vacated at the
-    // previous group's last barrier)
-    half_stage(B0(), wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, Y(), ab ^ 1, nkr, nkc);
-    // second half, barrier B(g, 0) inside (the wait leaves the 4 image DMAs in flight): weight stage (g, 1) visible, buffer bb
-    // vacated -> fetch weight stage (g, 2) into it
-    half_stage(B2(), wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
-    // tap 1
-    half_stage(B0(), wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-    // B(g, 1): weight stage (g, 2) visible, buffer bb ^ 1 vacated -> weight stage (g + 1, 0)
-    half_stage(B1(), wf1, wf0, ab, I2(), I0(), bb, Y(), Y(), bb ^ 1, knext, N_(), 0, 0, 0);
-    // tap 2
-    half_stage(B0(), wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-    // B(g, 2): next image + weight stage (g + 1, 0) visible; image ab and weight buffer bb vacated -> weight stage (g + 1, 1)
-    half_stage(B1(), wf1, wf0, ab ^ 1, I0(), I0(), bb ^ 1, Y(), Y(), bb, knext + Cin, N_(), 0, 0, 0);
-    ab ^= 1;
-    bb ^= 1;
-    kr = nkr;
-    kc = nkc;
-  }
   {
-    // last group: no next image; weight stage (g, 1) is in flight, (g, 2) is fetched below
-    const int kbase = kr * 3 * Cin + kc;
-    half_stage(B0(), wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-    half_stage(B1(), wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
-    half_stage(B0(), wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-    half_stage(B1(), wf1, wf0, ab, I2(), I0(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-    // the epilogue's bias values (8 consecutive channels per lane, the same in all of its passes) travel while the last
-    // MFMAs run: loaded at the start of the epilogue they cost it a full memory latency
-    {
-      const int c = n0 + wn * (TN * 16) + (lane % (TN * 16 / SP_EPC)) * SP_EPC;
-      const float* bsrc = q.bias + (c + SP_EPC <= p.w_rows ? c : 0);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bsrc), b1 = *reinterpret_cast<const f32x4*>(bsrc + 4);
-      bq[0] = b0; bq[1] = b1;
+    using E = std::true_type;
+    for (int g = 0; g + 1 < G; ++g) {                     // every group but the last
+      int nkr = kr, nkc = kc + SP_BKE;                    // next group
+      if (nkc >= Cin) { nkc = 0; ++nkr; }
+      const int kbase = kr * 3 * Cin + kc;                // K offset of tap 0 of this group; tap s adds s * Cin
+      const int knext = nkr * 3 * Cin + nkc;              // ... of the next group
+      // tap 0, first half: reads its own second half and fetches the NEXT group's pixel image (its buffer was vacated at the
+      // previous group's last barrier)
+      half_stage(E(), B0(), wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, Y(), ab ^ 1, nkr, nkc);
+      // second half, barrier B(g, 0) inside (the wait leaves the 4 image DMAs in flight): weight stage (g, 1) visible, buffer bb
+      // vacated -> fetch weight stage (g, 2) into it
+      half_stage(E(), B2(), wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
+      // tap 1
+      half_stage(E(), B0(), wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+      // B(g, 1): weight stage (g, 2) visible, buffer bb ^ 1 vacated -> weight stage (g + 1, 0)
+      half_stage(E(), B1(), wf1, wf0, ab, I2(), I0(), bb, Y(), Y(), bb ^ 1, knext, N_(), 0, 0, 0);
+      // tap 2
+      half_stage(E(), B0(), wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+      // B(g, 2): next image + weight stage (g + 1, 0) visible; image ab and weight buffer bb vacated -> weight stage (g + 1, 1)
+      half_stage(E(), B1(), wf1, wf0, ab ^ 1, I0(), I0(), bb ^ 1, Y(), Y(), bb, knext + Cin, N_(), 0, 0, 0);
+      ab ^= 1;
+      bb ^= 1;
+      kr = nkr;
+      kc = nkc;
     }
-    half_stage(B0(), wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-    half_stage(B0(), wf1, wf0, ab, I0(), I0(), bb, N_(), N_(), 0, 0, N_(), 0, 0, 0);
+    {
+      // last group: no next image; weight stage (g, 1) is in flight, (g, 2) is fetched below
+      const int kbase = kr * 3 * Cin + kc;
+      half_stage(E(), B0(), wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+      half_stage(E(), B1(), wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
+      half_stage(E(), B0(), wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+      half_stage(E(), B1(), wf1, wf0, ab, I2(), I0(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+      // the epilogue's bias values (8 consecutive channels per lane, the same in all of its passes) travel while the last
+      // MFMAs run: loaded at the start of the epilogue they cost it a full memory latency
+      {
+        const int c = n0 + wn * (TN * 16) + (lane % (TN * 16 / SP_EPC)) * SP_EPC;
+        const float* bsrc = q.bias + (c + SP_EPC <= p.w_rows ? c : 0);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bsrc), b1 = *reinterpret_cast<const f32x4*>(bsrc + 4);
+        bq[0] = b0; bq[1] = b1;
+      }
+      half_stage(E(), B0(), wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+      half_stage(E(), B0(), wf1, wf0, ab, I0(), I0(), bb, N_(), N_(), 0, 0, N_(), 0, 0, 0);
+    }
+
   }
 
+#ifdef OSD_SP_STAMPS
+  const unsigned long long st_t2 = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
+#ifdef OSD_SP_STAMPS
+  const unsigned long long st_t3 = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef OSD_SP_NO_EPI      // diagnostic build: keep the accumulators live, store nothing
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -316,7 +338,15 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   return;
 #endif
   const float pre_bias[8] = {bq[0][0], bq[0][1], bq[0][2], bq[0][3], bq[1][0], bq[1][1], bq[1][2], bq[1][3]};
-  conv_epilogue<T, TM, TN>(acc, p, q, smem, wave, wm, wn, lane, m0, n0, pre_bias);
+  conv_epilogue<T, TM, TN, true>(acc, p, q, smem, wave, wm, wn, lane, m0, n0, pre_bias);   // 8 waves x 2 x 8,704 B <= SP_LDS
+#ifdef OSD_SP_STAMPS
+  if (lane == 0 && p.act_scale_dev != nullptr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st_t4 = __builtin_amdgcn_s_memtime();
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.act_scale_dev)) + ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = st_t0; o[1] = st_t1 - st_t0; o[2] = st_t2 - st_t1; o[3] = st_t3 - st_t2; o[4] = st_t4 - st_t3; o[5] = st_lgkm; o[6] = st_vm; o[7] = st_bar;
+  }
+#endif
 }
 
 }  // namespace

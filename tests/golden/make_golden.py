@@ -595,6 +595,48 @@ def gen_transforms(cfg):
     np.savez_compressed(os.path.join(HERE, "transforms.npz"), **out)
 
 
+def gen_voc_eval():
+    """data/datasets/evaluation/voc/voc_eval.py of the REAL reference (eval_detection_voc, calc_detection_voc_prec_rec,
+    calc_detection_voc_ap with BoxList / boxlist_iou) on the synthetic detections of golden_utils.voc_eval_inputs: AP per class
+    for both metrics, the precision / recall arrays and the per-image match flags implied by them; the numpy restatement
+    oracle/voc_eval_ref.py must reproduce them exactly before anything is written."""
+    rh.load_reference()
+    from maskrcnn_benchmark.data.datasets.evaluation.voc import voc_eval as rv
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from oracle import voc_eval_ref as ov
+    preds, gts = gu.voc_eval_inputs()
+    size = (800, 600)
+    pbl, gbl = [], []
+    for (pb, pl, ps), (gb, gl, gd) in zip(preds, gts):
+        a = BoxList(torch.from_numpy(pb), size, mode="xyxy")
+        a.add_field("labels", torch.from_numpy(pl))
+        a.add_field("scores", torch.from_numpy(ps))
+        b = BoxList(torch.from_numpy(gb), size, mode="xyxy")
+        b.add_field("labels", torch.from_numpy(gl))
+        b.add_field("difficult", torch.from_numpy(gd))
+        pbl.append(a)
+        gbl.append(b)
+    out = {}
+    prec, rec = rv.calc_detection_voc_prec_rec(pred_boxlists=pbl, gt_boxlists=gbl, iou_thresh=0.5)
+    for tag, use07 in (("ap07", True), ("ap_area", False)):
+        r = rv.eval_detection_voc(pbl, gbl, iou_thresh=0.5, use_07_metric=use07)
+        o = ov.eval_detection_voc(preds, gts, 0.5, use07)
+        np.testing.assert_array_equal(np.nan_to_num(r["ap"], nan=-1.0), np.nan_to_num(o["ap"], nan=-1.0))
+        out[tag] = r["ap"]
+        out[tag + "_map"] = np.float64(r["map"])
+        print("voc eval %s: reference AP %s mAP %.6f == oracle" % (tag, r["ap"], r["map"]))
+    o = ov.eval_detection_voc(preds, gts, 0.5, True)
+    for l in range(len(prec)):
+        if prec[l] is not None:
+            np.testing.assert_array_equal(np.nan_to_num(prec[l]), np.nan_to_num(o["prec"][l]))
+            out["prec.%d" % l] = prec[l]
+        if rec[l] is not None:
+            np.testing.assert_array_equal(rec[l], o["rec"][l])
+            out["rec.%d" % l] = rec[l]
+    out["n_classes"] = np.int64(len(prec))
+    np.savez_compressed(os.path.join(HERE, "voc_eval.npz"), **out)
+
+
 def gen_keys(model):
     import json
     sd = model.state_dict()
@@ -616,9 +658,12 @@ def main():
     ap.add_argument("--only-transforms", action="store_true", help="regenerate only tests/golden/transforms.npz")
     ap.add_argument("--boxtrain-cases", default="small,nonsquare,shots5,tall,config1")
     ap.add_argument("--only-boxtrain", action="store_true", help="regenerate only tests/golden/boxtrain_*.npz")
+    ap.add_argument("--only-voc", action="store_true", help="regenerate only tests/golden/voc_eval.npz")
     ap.add_argument("--only-cases", default="", help="write ONLY case_<name>.npz + train_<name>.npz of the listed cases")
     args = ap.parse_args()
     torch.set_num_threads(8)
+    if args.only_voc:
+        return gen_voc_eval()
     model, cfg = rh.build_reference_model()
     if args.only_transforms:
         return gen_transforms(cfg)
@@ -648,6 +693,7 @@ def main():
         gen_add_gt(model)
         gen_ragged(model, np_sd)
         gen_transforms(cfg)
+        gen_voc_eval()
         for name in [c for c in args.cases.split(",") if c]:
             gen_case(model, np_sd, name)
     if not args.skip_train:

@@ -104,3 +104,45 @@ def ragged_inputs(seed=0):
     t = [synth.make_images("target.ragged.%d" % i, 1, h, w, seed)[0] for i, (h, w) in enumerate(RAGGED["targets"])]
     q = [synth.make_images("query.ragged.%d" % i, 1, h, w, seed)[0] for i, (h, w) in enumerate(RAGGED["queries"])]
     return t, q
+
+
+def voc_eval_inputs(seed=0, n_images=7, max_det=48, max_gt=9, n_classes=3):
+    """Synthetic detections / ground truth for the VOC evaluation fixtures (tests/golden/voc_eval.npz): per image
+    (pred boxes [n,4], labels [n], scores [n]) and (gt boxes [g,4], labels [g], difficult [g]); detections are jittered copies
+    of ground-truth boxes (several per box: duplicates), plus false positives; distinct scores (ties are order-dependent in
+    the reference's argsort); an image without ground truth of one class, one without detections of a class, difficult boxes."""
+    from oneshotdet_amd.synth import uniform01
+    preds, gts = [], []
+    for i in range(n_images):
+        u = uniform01("voc.%d" % i, 4096, seed).astype(np.float64)
+        k = 0
+
+        def nxt(n):
+            nonlocal k
+            v = u[k:k + n]
+            k += n
+            return v
+        g = 1 + int(nxt(1)[0] * (max_gt - 1)) if i != 3 else 2
+        xy = nxt(2 * g).reshape(g, 2) * 400.0
+        wh = 20.0 + nxt(2 * g).reshape(g, 2) * 180.0
+        gb = np.concatenate([xy, xy + wh], 1).round().astype(np.float32)
+        gl = (1 + (nxt(g) * n_classes).astype(np.int64)).clip(1, n_classes)
+        gd = (nxt(g) < 0.2).astype(np.uint8)
+        if i == 3:
+            gl[:] = 1                                   # no ground truth of classes 2, 3 in this image
+        n = int(nxt(1)[0] * max_det) if i != 5 else 0    # image 5: no detections at all
+        src = (nxt(n) * g).astype(np.int64).clip(0, g - 1)
+        jit = (nxt(4 * n).reshape(n, 4) - 0.5) * 60.0
+        pb = gb[src] + jit.astype(np.float32)
+        far = nxt(n) < 0.25
+        pb[far] += 300.0
+        pb[:, 2:] = np.maximum(pb[:, 2:], pb[:, :2] + 1.0)
+        pl = gl[src].copy()
+        swap = nxt(n) < 0.15
+        pl[swap] = 1 + (pl[swap] % n_classes)
+        if i == 1:
+            pl[pl == 2] = 3                              # image 1: no detections of class 2
+        ps = (nxt(n) * 0.98 + 0.01 + np.arange(n) * 1e-4).astype(np.float32)
+        preds.append((pb.astype(np.float32), pl.astype(np.int64), ps))
+        gts.append((gb, gl.astype(np.int64), gd))
+    return preds, gts
