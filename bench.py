@@ -467,12 +467,13 @@ class TrainTimer(ConvTimer):
                 "bytes_per_launch": round(self.corr_bytes / max(len(self.corr), 1))}
 
 
-def main_train(args, rank, world):
+def main_train(args, rank, world, backend="nccl"):
     """BASELINE.json configs[2]/[3]: bs=8/GPU, forward + FCOS loss + backward + gradient all-reduce (RCCL) + SGD."""
     import numpy as np
     from oneshotdet_amd import ops, spec, synth, train
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     two = bool(args.second_stage)      # opt-in: the reference's COMPLETE training step (roi_heads.box losses + backward)
+    wire = torch.bfloat16 if args.grad_wire == "bf16" else None
     eng = train.TrainEngine(synth.make_state_dict(spec.full_model_shapes() if two else spec.hot_path_shapes()), dtype=dtype,
                             second_stage=two)
     B = args.batch
@@ -486,7 +487,17 @@ def main_train(args, rank, world):
     gt_count = torch.tensor([len(g) for g in gts], dtype=torch.int32).cuda()
     with ops.tuning():
         eng.forward_backward(images, queries, gt_boxes, gt_count)
-    eng.reduce_gradients()      # N > 1: the tuning pass announced its buckets too; join that exchange before the next step
+    torch.cuda.synchronize()
+    # Process group AFTER the first step: by now every stream of the engine has been used (has its hardware queue).  With
+    # RCCL initialised first the same step measured 12-14 % slower on one GPU (streams land on other queues).
+    if args.live_exchange and "WORLD_SIZE" not in os.environ:
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=os.environ.get("MASTER_PORT", "29531"))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist_setup(backend)
+    if dist.is_initialized():
+        eng.attach_exchange(None, single_rank=bool(args.live_exchange), wire_dtype=wire)
     torch.cuda.synchronize()
     if os.environ.get("OSD_DUMP_ALGOS") and rank == 0:
         with open(os.environ["OSD_DUMP_ALGOS"], "w") as f:
@@ -586,10 +597,15 @@ def main_train(args, rank, world):
             line["config"]["parallelism"] += ("; fp32 gradient averaging (%s all-reduce): %d buckets of the flat buffer, each "
                                               "exchanged behind backward as soon as it is final"
                                               % (dist.get_backend(), len(eng.exchange.ranges)))
+        elif args.live_exchange:
+            assert eng.exchange.active and eng.exchange.world == 1
+            line["config"]["parallelism"] = ("dp1 with the gradient exchange LIVE: one rank, every bucket all-reduced by %s on the "
+                                             "communication stream behind backward (%s on the wire) - the N > 1 step's stream "
+                                             "topology on one GPU" % (dist.get_backend(), args.grad_wire))
         else:
             assert not eng.exchange.active
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -614,6 +630,10 @@ def main():
                     help="forward mode: also run the few-shot ROI box head on the 2000 proposals per image (SURVEY.md 8f "
                          "#1) = the reference's complete eval forward; train mode: also the second stage's losses and "
                          "backward = the reference's complete training step (engine/trainer.py:79-93)")
+    ap.add_argument("--live-exchange", action="store_true",
+                    help="N = 1, train mode: initialise a ONE-rank RCCL process group and run every bucket's all-reduce on the "
+                         "communication stream anyway (what the step costs with the exchange's streams and kernels live)")
+    ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"], help="dtype of the gradient buckets on the wire")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="exercise only the multi-process plumbing (gloo, no GPU work): used by tests/test_dist_cpu.py")
     args = ap.parse_args()
@@ -638,11 +658,12 @@ def main():
     # (rank-seeded data, overlapped exchange, barrier-bracketed timing, MAX over ranks) runs on a one-GPU box
     share = os.environ.get("OSD_BENCH_SHARE_GPU") == "1"
     torch.cuda.set_device(0 if share else local_rank)
-    dist_setup("gloo" if share else "nccl")
     if not args.dtype:      # configs[2] (train) is bf16, configs[1] (forward parity config) is fp32
         args.dtype = "bf16" if args.mode == "train" else "f32"
     if args.mode == "train":
-        return main_train(args, rank, world)
+        # the process group is initialised INSIDE main_train, after the engine's streams have been used once
+        return main_train(args, rank, world, "gloo" if share else "nccl")
+    dist_setup("gloo" if share else "nccl")
 
     from oneshotdet_amd import model, ops, spec, synth
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16

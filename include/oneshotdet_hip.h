@@ -342,6 +342,10 @@ int osd_roialign_bwd(const float* gy, const float* rois, float* gx, int b, int h
                      float spatial_scale, int ph, int pw, int sampling_ratio, void* stream);
 int osd_shot_mean_bwd(const float* gy, float* gx, int b, int shots, int c, void* stream);
 int osd_cast_f32(const float* src, void* dst, int64_t numel, int dtype, void* stream);
+/* Gradient bucket on its way to (to_wire = 1: fp32 src -> bf16 dst) or back from (to_wire = 0: bf16 src -> fp32 dst) a
+ * half-width all-reduce (DDP's bf16 compression hook is the reference-side equivalent; tools/train_net.py:83-88 itself
+ * exchanges fp32).  numel % 8 == 0 (the buckets of the flat buffer are cut at multiples of 64). */
+int osd_grad_wire_cast(const void* src, void* dst, int64_t numel, int to_wire, void* stream);
 /* SGD with momentum over the flat fp32 master / gradient / momentum buffers in ONE launch (the reference uses
  * torch.optim.SGD with per-parameter groups, solver/build.py:8-26; same update rule: g += wd*p; buf = momentum*buf + g
  * (buf = g on the first step); p -= lr*lr_mult*buf).  table: device array of
@@ -497,6 +501,20 @@ int osd_image_transform_batch(int n_images, const uint8_t* const* srcs_rgb_hwc, 
                               const float* mean3, const float* std3, void* dst, int layout, int dtype,
                               int first_batch_index, int dst_h, int dst_w, int pad_t, int pad_l, void* workspace,
                               void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Evaluation: the per-image matching of the PASCAL VOC detection metric, calc_detection_voc_prec_rec
+ * (data/datasets/evaluation/voc/voc_eval.py:84-137, boxlist_iou structures/boxlist_ops.py:221-256).
+ * det_boxes [n][max_det][4] xyxy, det_scores [n][max_det], det_labels [n][max_det], det_count [n]; gt_boxes [n][max_gt][4],
+ * gt_labels, gt_difficult (0 / 1) [n][max_gt], gt_count [n] (max_gt <= 512).  Per detection, in the INPUT order:
+ * matched_gt = index of the ground-truth box of its class with the largest IoU ('+1' on x2, y2 of both boxes, then the '+1'
+ * areas of boxlist_iou; first maximum; -1 when that IoU < iou_thresh or the image has no box of the class) and
+ * match = 1 (the highest-scoring detection matched to a non-difficult box; equal scores: the higher index), 0 (unmatched, or
+ * a box already claimed) or -1 (matched to a difficult box: ignored), 0 past det_count.  The precision / recall curves and
+ * AP (voc_eval.py:139-216) are host arithmetic on these flags (oneshotdet_amd/evaluation.py). */
+int osd_voc_match(const float* det_boxes, const float* det_scores, const int32_t* det_labels, const int32_t* det_count,
+                  const float* gt_boxes, const int32_t* gt_labels, const uint8_t* gt_difficult, const int32_t* gt_count,
+                  int n, int max_det, int max_gt, float iou_thresh, int8_t* match, int32_t* matched_gt, void* stream);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,7 @@ SIGNATURES = {
     "osd_roialign_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p]),
     "osd_shot_mean_bwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "osd_cast_f32": (_i, [_p, _p, _i64, _i, _p]),
+    "osd_grad_wire_cast": (_i, [_p, _p, _i64, _i, _p]),
     "osd_fcos_loss_level": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _p, _p, _p, _p, _i, _p, _i, _p]),
     "osd_fcos_loss_levels": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p, _i, _p, _i, _p]),
     "osd_fcos_loss_finalize": (_i, [_p, _p, _i, _p]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "osd_proposals_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "osd_box_match_sample": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_box_loss": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _f, _p, _p, _i, _i, _p]),
+    "osd_voc_match": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "osd_groupnorm_act_rois_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i, _p]),
     "osd_rois_sum": (_i, [_p, _p, _i, _i, _i64, _i, _p]),
     "osd_roi_pool_levels_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -710,6 +710,37 @@ extern "C" int osd_cast_f32(const float* src, void* dst, int64_t numel, int dtyp
   return osd_check_launch("cast_f32");
 }
 
+// fp32 <-> bf16 in 16-byte-per-lane pieces (the gradient buckets on their way to and from a bf16 all-reduce); numel % 8 == 0
+__global__ void __launch_bounds__(256) f32_to_bf16_vec_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n8) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + i * 8), b = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+    bf16x8 o;
+    o[0] = (__bf16)a[0]; o[1] = (__bf16)a[1]; o[2] = (__bf16)a[2]; o[3] = (__bf16)a[3];
+    o[4] = (__bf16)b[0]; o[5] = (__bf16)b[1]; o[6] = (__bf16)b[2]; o[7] = (__bf16)b[3];
+    *reinterpret_cast<bf16x8*>(dst + i * 8) = o;
+  }
+}
+__global__ void __launch_bounds__(256) bf16_to_f32_vec_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, long long n8) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + i * 8);
+    *reinterpret_cast<f32x4*>(dst + i * 8) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    *reinterpret_cast<f32x4*>(dst + i * 8 + 4) = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+  }
+}
+
+extern "C" int osd_grad_wire_cast(const void* src, void* dst, int64_t numel, int to_wire, void* stream) {
+  if (!src || !dst) return osd_fail(OSD_ERR_INVALID_ARG, "grad_wire_cast: null argument");
+  if (numel % 8) return osd_fail(OSD_ERR_INVALID_ARG, "grad_wire_cast: numel must be a multiple of 8");
+  if (numel == 0) return OSD_OK;
+  const long long n8 = numel / 8;
+  const int g = (int)(n8 + 255) / 256 > 2048 ? 2048 : (int)((n8 + 255) / 256);
+  if (to_wire)
+    hipLaunchKernelGGL(f32_to_bf16_vec_kernel, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const float*)src, (__bf16*)dst, n8);
+  else
+    hipLaunchKernelGGL(bf16_to_f32_vec_kernel, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const __bf16*)src, (float*)dst, n8);
+  return osd_check_launch("grad_wire_cast");
+}
+
 extern "C" int osd_conv2d_dgrad_naive(const osd_conv_desc* d, const void* dy, const void* w_fwd_packed, const void* mask,
                                       const void* addend, void* dx, void* stream) {
   if (!d || !dy || !w_fwd_packed || !dx) return osd_fail(OSD_ERR_INVALID_ARG, "dgrad_naive: null argument");

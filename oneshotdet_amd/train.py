@@ -71,7 +71,8 @@ class TConv(object):
 
 class TrainEngine(object):
     def __init__(self, state_dict, dtype=torch.bfloat16, device="cuda", lr=0.0005, momentum=0.9, weight_decay=0.0001,
-                 process_group=None, wgrad_side_stream=True, optimizer="fused", second_stage=False, ordered_wgrad=None):
+                 process_group=None, wgrad_side_stream=True, optimizer="fused", second_stage=False, ordered_wgrad=None,
+                 exchange_single_rank=False, grad_wire_dtype=None):
         if not torch.cuda.is_available():
             raise ops._lib.OsdError("TrainEngine needs an MI355X: no GPU visible and there is no CPU fallback")
         ops._lib.load()
@@ -112,8 +113,11 @@ class TrainEngine(object):
         # gradient exchange overlapped with backward (no-op with one rank): buckets in the order they become final; the
         # optimiser update + weight repack of a bucket follow its exchange on the same side stream (train_step)
         from .dist_utils import GradExchange, bucket_ranges
-        self.exchange = GradExchange(self.flat_g, bucket_ranges(self._plan, self.flat_g.numel()), self.pg)
+        # exchange_single_rank: run the collectives with ONE rank too (the step as it runs under RCCL, measurable on a one-GPU
+        # box); grad_wire_dtype=torch.bfloat16: half-width buckets on the wire (dist_utils.GradExchange)
         self.ustream = torch.cuda.Stream(device=self.device)
+        self.exchange = GradExchange(self.flat_g, bucket_ranges(self._plan, self.flat_g.numel()), self.pg,
+                                     single_rank_too=exchange_single_rank, wire_dtype=grad_wire_dtype, comm_stream=self.ustream)
         self._overlap, self._fuse_update, self._updated = True, False, set()
         self._wqs = None
         self._pred_grad_bufs = {}
@@ -327,6 +331,19 @@ class TrainEngine(object):
                     self.convs[base].b, self.convs[base].gb = wv, gv
             else:                                                        # GroupNorm affine, Scale scalars
                 self.extra[name] = (wv, gv)
+
+    def attach_exchange(self, process_group=None, single_rank=False, wire_dtype=None):
+        """(Re)build the gradient exchange on the engine's update stream for a process group initialised AFTER the engine —
+        the recommended order: create the engine and run one step (every stream has been used, i.e. has its hardware queue)
+        BEFORE torch.distributed / RCCL set up theirs.  Initialising RCCL first shifts which hardware queue each of the
+        engine's streams lands on, and the step measured 12-14 % slower (bench.py --live-exchange, same box)."""
+        from .dist_utils import GradExchange
+        self.join()
+        self.pg = process_group
+        ranges = [(n, lo, hi) for n, (lo, hi) in self.exchange.ranges.items()]
+        self.exchange = GradExchange(self.flat_g, ranges, process_group, single_rank_too=single_rank, wire_dtype=wire_dtype,
+                                     comm_stream=self.ustream)
+        return self.exchange
 
     def _bucket_of(self, tensor):
         off = (tensor.data_ptr() - self.flat_w.data_ptr()) // 4

@@ -407,6 +407,24 @@ def test_gradient_buckets_cover_the_flat_buffer_and_overlapped_exchange_runs():
         torch.cuda.synchronize()
         assert torch.isfinite(out).all() and torch.isfinite(eng.flat_w).all() and not torch.equal(eng.flat_w, w0)
         assert eng._sgd["steps"] == 3
+        # bf16 buckets on the wire (GradExchange(wire_dtype=bfloat16) -> osd_grad_wire_cast): with one rank the average of a
+        # bucket is the bucket itself rounded once to bf16, element for element, and the fp32 buffer receives exactly that
+        eng.defer_join = False
+        eng.exchange = GradExchange(eng.flat_g, ranges, None, single_rank_too=True, wire_dtype=torch.bfloat16)
+        eng.forward_backward(img, q, gtb, cnt)
+        eng.join()
+        before = None
+        # the exchange has already rewritten the buffer behind backward; recompute the un-exchanged gradients to compare
+        eng.reduce_gradients()
+        torch.cuda.synchronize()
+        got = eng.flat_g.clone()
+        eng.exchange = GradExchange(eng.flat_g, ranges, None, single_rank_too=False)
+        eng.forward_backward(img, q, gtb, cnt)
+        torch.cuda.synchronize()
+        want = eng.flat_g.bfloat16().float()
+        assert torch.equal(got.bfloat16().float(), got), "the exchanged gradients are not bf16 values"
+        rel = float((got - want).norm() / want.norm())
+        assert rel < 5e-3, rel          # two runs of the atomically accumulated gradients differ in their last fp32 bits -> rare bf16 flips
     finally:
         dist.destroy_process_group()
 

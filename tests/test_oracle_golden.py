@@ -348,3 +348,21 @@ def test_box_train_losses_and_gradients_match_reference(name, sd_full):
             g = sd[k].grad.numpy().reshape(-1)
             idx = gu.sample_indices(g.size, "boxgrad." + k)[:256]
             assert np.abs(g[idx] - f[key]).max() <= 2e-3 * float(f["refgrad.%s.absmax" % k]), k
+
+
+def test_voc_eval_oracle_matches_reference_fixture():
+    """oracle/voc_eval_ref.py against tests/golden/voc_eval.npz (recorded through the reference's voc_eval.py): AP of both
+    metrics and every precision / recall value exactly."""
+    from oracle import voc_eval_ref as ov
+    f = gu.load("voc_eval.npz")
+    preds, gts = gu.voc_eval_inputs()
+    for tag, use07 in (("ap07", True), ("ap_area", False)):
+        r = ov.eval_detection_voc(preds, gts, 0.5, use07)
+        np.testing.assert_array_equal(np.nan_to_num(r["ap"], nan=-1.0), np.nan_to_num(f[tag], nan=-1.0))
+        assert r["map"] == float(f[tag + "_map"])
+    r = ov.eval_detection_voc(preds, gts, 0.5, True)
+    for l in range(int(f["n_classes"])):
+        if "prec.%d" % l in f.files:
+            np.testing.assert_array_equal(np.nan_to_num(r["prec"][l]), np.nan_to_num(f["prec.%d" % l]))
+        if "rec.%d" % l in f.files:
+            np.testing.assert_array_equal(r["rec"][l], f["rec.%d" % l])
