@@ -485,12 +485,21 @@ def main_train(args, rank, world, backend="nccl"):
         gtb[i, :len(g)] = g
     gt_boxes = torch.from_numpy(gtb).cuda()
     gt_count = torch.tensor([len(g) for g in gts], dtype=torch.int32).cuda()
+    pg_early = os.environ.get("OSD_BENCH_PG_AFTER") == "warm"      # A/B: warm_streams() instead of a whole step before RCCL
+    if pg_early:
+        eng.warm_streams()
+        if args.live_exchange and "WORLD_SIZE" not in os.environ:
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                              MASTER_PORT=os.environ.get("MASTER_PORT", "29531"))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     with ops.tuning():
         eng.forward_backward(images, queries, gt_boxes, gt_count)
     torch.cuda.synchronize()
     # Process group AFTER the first step: by now every stream of the engine has been used (has its hardware queue).  With
     # RCCL initialised first the same step measured 12-14 % slower on one GPU (streams land on other queues).
-    if args.live_exchange and "WORLD_SIZE" not in os.environ:
+    if pg_early:
+        pass
+    elif args.live_exchange and "WORLD_SIZE" not in os.environ:
         os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
                           MASTER_PORT=os.environ.get("MASTER_PORT", "29531"))
         dist.init_process_group("nccl", device_id=torch.device("cuda", 0))

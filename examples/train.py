@@ -49,16 +49,11 @@ def main():
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    pg = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl")          # RCCL
-        pg = dist.group.WORLD
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     shapes = spec.hot_path_shapes() if args.first_stage_only else spec.full_model_shapes()
 
     def make_engine(sd):
-        return train.TrainEngine(sd, dtype=dtype, lr=0.0005, process_group=pg, second_stage=not args.first_stage_only)
+        return train.TrainEngine(sd, dtype=dtype, lr=0.0005, second_stage=not args.first_stage_only)
     start = 0
     last = os.path.join(args.out, "last_checkpoint")
     if args.resume and os.path.exists(last):
@@ -67,6 +62,13 @@ def main():
     else:
         eng = make_engine(synth.make_state_dict(shapes))      # or checkpoint.load_checkpoint / load_c2_resnet, see detect.py
     eng.defer_join = True
+    if world > 1:
+        # RCCL AFTER the engine's streams have their hardware queues (profiles/r3_live_exchange.md: the other order cost 14 %
+        # of the step), then the bucketed gradient exchange on the engine's update stream
+        import torch.distributed as dist
+        eng.warm_streams()
+        dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+        eng.attach_exchange(dist.group.WORLD)
     tf_img, tf_supp = T.build_transforms(min_size=480, max_size=800, supp_min_size=128, supp_max_size=192, is_train=True)
     rng = np.random.RandomState(1234 + rank)
     os.makedirs(args.out, exist_ok=True)

@@ -332,6 +332,19 @@ class TrainEngine(object):
             else:                                                        # GroupNorm affine, Scale scalars
                 self.extra[name] = (wv, gv)
 
+    def warm_streams(self):
+        """Use every stream of the engine once, in the order they were created: a stream gets its hardware queue at first use,
+        and which queue decides what can overtake what.  Call before anything else in the process creates streams of its own
+        (torch.distributed / RCCL initialisation); see attach_exchange."""
+        cur = torch.cuda.current_stream()
+        probe = torch.zeros(64, device=self.device, dtype=torch.float32)
+        for st in (cur, self.wstream, self.s1, self.wstream2, self.pstream, self.ustream):
+            if st is None:
+                continue
+            with torch.cuda.stream(st):
+                ops.add_mask(probe, None, None, out=probe)
+        torch.cuda.synchronize()
+
     def attach_exchange(self, process_group=None, single_rank=False, wire_dtype=None):
         """(Re)build the gradient exchange on the engine's update stream for a process group initialised AFTER the engine —
         the recommended order: create the engine and run one step (every stream has been used, i.e. has its hardware queue)
