@@ -67,6 +67,12 @@ typedef struct osd_conv_desc {
   int32_t relu_in;        /* 1: apply ReLU to x while staging (P7 = conv(relu(P6)), fpn.py:98) */
   int32_t algo;           /* 0 = library heuristic; otherwise 1 + impl*32 + variant*8 + tile (see osd_conv_algo_count /
                              DESIGN.md 4.1): lets the host autotune per layer shape by measurement */
+  int32_t reserved0;      /* (keeps the pointer below 8-byte aligned; set to 0) */
+  void* ordered_ws;       /* weight-gradient entries only (ABI 3): NULL = partial tiles are added with fp32 atomics; otherwise
+                             a caller-owned scratch buffer of ordered_ws_bytes bytes — the launch STORES its partial tiles
+                             there and sums them in a fixed order (bit-reproducible dW).  Passed per call: the library keeps
+                             no state between calls.  osd_conv2d_wgrad_mixed reads it from descs[0]. */
+  int64_t ordered_ws_bytes;
 } osd_conv_desc;
 
 /* second pixel source of a 1x1 convolution (osd_conv2d_fwd): dense NHWC [n][h][w][cin2]; output pixel (ho, wo) reads
@@ -265,6 +271,13 @@ int osd_sigmoid_focal_bwd(const float* logits, const int32_t* targets, const flo
 /* OIHW fp32 (+ FrozenBN scale) -> [rows >= cin][r][s][cout_pad] with taps flipped: Wd[ci][r'][s'][co] = w[co][ci][R-1-r'][S-1-s'] */
 int osd_pack_conv_weight_dgrad(const float* w, const float* scale, void* dst, int cout, int cin, int r, int s, int rows,
                                int cout_pad, int src_orsi, int dtype, void* stream);
+/* Ordered mode of the weight-gradient launches (osd_conv2d_wgrad and its _grouped / _batched / _mixed / _multi forms):
+ * with osd_conv_desc.ordered_ws set, every workgroup stores its partial tile into that caller-owned scratch buffer and a
+ * second launch sums the tiles in a fixed order — dW (and db) come out bit-identical from run to run, and the partial tiles
+ * travel as plain stores instead of fp32 atomics performed at the memory side.  With NULL (the default) the partial tiles
+ * are added with atomics (ATen's conv backward makes no ordering promise either: engine/trainer.py:92).  A launch that
+ * needs more than ordered_ws_bytes (workgroups x (tile + tile rows) x 4; 1 GiB covers every launch of the training step)
+ * fails with OSD_ERR_WORKSPACE.  The buffer must not be shared by launches that run concurrently. */
 /* dW[cout][r][s][cin] (fp32, ACCUMULATED with atomics: zero it first) += sum over pixels dy[m][co] * x[m@tap][ci].
  * d describes the FORWARD conv (x geometry, strides, pads, cout, out_stride = pixel stride of dy); scale (nullable) is a
  * per-Cout factor applied to the contribution (the folded FrozenBN scale); db (nullable, fp32 [cout], accumulated) also
@@ -305,15 +318,6 @@ int osd_conv2d_wgrad_multi(const osd_conv_desc* d, int n_seg, const void* const*
  * taken from descs[0]; descs is a HOST array of n_seg descriptors. */
 int osd_conv2d_wgrad_mixed(int n_seg, const osd_conv_desc* descs, const void* const* xs, const void* const* dys,
                            const float* const* scales, float* const* dws, float* const* dbs, void* stream);
-/* Ordered mode of the weight-gradient launches (osd_conv2d_wgrad and its _grouped / _batched / _mixed / _multi forms) on
- * one stream: with a scratch buffer registered for the stream, every workgroup stores its partial tile there and a second
- * launch sums the tiles in a fixed order — dW (and db) come out bit-identical from run to run, and the partial tiles
- * travel as plain stores instead of fp32 atomics performed at the memory side.  Without one (the default) the partial
- * tiles are added with atomics (ATen's conv backward makes no ordering promise either: engine/trainer.py:92).  A launch
- * that needs more than `bytes` (workgroups x (tile + tile rows) x 4; 1 GiB covers every launch of the training step)
- * fails with OSD_ERR_WORKSPACE.  workspace == NULL removes the stream's entry.  The buffer must stay alive and must not be
- * shared by streams that run concurrently. */
-int osd_conv2d_wgrad_set_workspace(void* stream, void* workspace, int64_t bytes);
 /* packed fp32 dW [cout][r][s][cin] -> OIHW fp32 gradient, multiplied by the folded FrozenBN scale (nullable);
  * accumulate != 0 adds to grad_oihw (weights shared over FPN levels) */
 int osd_unpack_wgrad(const float* dw_packed, const float* scale, float* grad_oihw, int cout, int cin, int r, int s,

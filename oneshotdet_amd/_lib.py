@@ -20,7 +20,8 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "n", "h", "w", "cin", "in_stride_n", "in_stride_h", "in_stride_w", "ho", "wo", "cout", "r", "s",
         "stride_h", "stride_w", "pad_h", "pad_w", "w_rows", "out_stride", "res_mode", "res_h", "res_w", "res_stride",
-        "act")] + [("act_scale", C.c_float), ("relu_in", C.c_int32), ("algo", C.c_int32)]
+        "act")] + [("act_scale", C.c_float), ("relu_in", C.c_int32), ("algo", C.c_int32), ("reserved0", C.c_int32),
+                   ("ordered_ws", C.c_void_p), ("ordered_ws_bytes", C.c_int64)]
 
 
 _p, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -99,7 +100,6 @@ SIGNATURES = {
     "osd_roi_pool_levels_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "osd_image_transform": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "osd_image_transform_workspace_bytes": (_i64, [_i, _i, _i, _i]),
-    "osd_conv2d_wgrad_set_workspace": (_i, [_p, _p, _i64]),
     "osd_image_transform_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
 }
 

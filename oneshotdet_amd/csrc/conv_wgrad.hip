@@ -41,7 +41,7 @@ struct WgradParams {
   WgradSeg seg[kMaxSeg];
   int n_seg;
   int n_blocks;       // logical workgroups of the launch (= partial tiles in ordered mode)
-  float* partials;    // ordered mode (osd_conv2d_wgrad_set_workspace): every workgroup STORES its partial tile into slot
+  float* partials;    // ordered mode (osd_conv_desc.ordered_ws): every workgroup STORES its partial tile into slot
                       // [logical id][TCO * TCI + TCO] instead of adding it atomically; wgrad_reduce_kernel sums the slots
                       // in a fixed order: bit-reproducible dW, plain stores instead of memory-side atomics
 };
@@ -926,37 +926,6 @@ __global__ void __launch_bounds__(256) bias_grad_kernel(const T* __restrict__ dy
 
 extern "C" int osd_bias_grad(const void* dy, float* db, int m, int c, int stride, int dtype, void* stream);
 
-// ---- ordered mode: a scratch buffer per stream (osd_conv2d_wgrad_set_workspace) ----
-#include <mutex>
-namespace {
-struct WgradWs { hipStream_t stream; void* ptr; long long bytes; };
-WgradWs g_wgrad_ws[16];
-int g_wgrad_ws_n = 0;
-std::mutex g_wgrad_ws_mu;
-bool wgrad_ws_lookup(hipStream_t s, void** ptr, long long* bytes) {
-  std::lock_guard<std::mutex> lock(g_wgrad_ws_mu);
-  for (int i = 0; i < g_wgrad_ws_n; ++i)
-    if (g_wgrad_ws[i].stream == s) { *ptr = g_wgrad_ws[i].ptr; *bytes = g_wgrad_ws[i].bytes; return true; }
-  return false;
-}
-}  // namespace
-
-extern "C" int osd_conv2d_wgrad_set_workspace(void* stream, void* workspace, int64_t bytes) {
-  std::lock_guard<std::mutex> lock(g_wgrad_ws_mu);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  for (int i = 0; i < g_wgrad_ws_n; ++i)
-    if (g_wgrad_ws[i].stream == s) {
-      if (workspace) { g_wgrad_ws[i].ptr = workspace; g_wgrad_ws[i].bytes = bytes; }
-      else g_wgrad_ws[i] = g_wgrad_ws[--g_wgrad_ws_n];
-      return OSD_OK;
-    }
-  if (!workspace) return OSD_OK;
-  if (bytes <= 0) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_set_workspace: bad size");
-  if (g_wgrad_ws_n == 16) return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad_set_workspace: more than 16 streams with a workspace");
-  g_wgrad_ws[g_wgrad_ws_n++] = WgradWs{s, workspace, (long long)bytes};
-  return OSD_OK;
-}
-
 struct WgradProblem {      // host-side description of one segment
   const osd_conv_desc* d;    // geometry: n, h, w, cin, cout, r, s, strides, pads, out_stride
   int n, h, w;
@@ -1098,16 +1067,12 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   p.n_blocks = (int)nblocks;
   p.partials = nullptr;
   const int tco = tw * sub_co, tci = tw * sub_ci;
-  {
-    void* wsp = nullptr;
-    long long wsb = 0;
-    if (wgrad_ws_lookup(s, &wsp, &wsb)) {
-      const long long need = nblocks * ((long long)tco * tci + tco) * 4;
-      if (need > wsb)
-        return osd_fail(OSD_ERR_WORKSPACE, "wgrad (ordered mode): the launch needs %lld bytes of partial tiles, the stream's workspace has %lld",
-                        need, wsb);
-      p.partials = static_cast<float*>(wsp);
-    }
+  if (d0->ordered_ws != nullptr) {     // ordered mode: the caller's scratch buffer, passed with this call
+    const long long need = nblocks * ((long long)tco * tci + tco) * 4;
+    if (need > (long long)d0->ordered_ws_bytes)
+      return osd_fail(OSD_ERR_WORKSPACE, "wgrad (ordered mode): the launch needs %lld bytes of partial tiles, ordered_ws_bytes is %lld",
+                      need, (long long)d0->ordered_ws_bytes);
+    p.partials = static_cast<float*>(d0->ordered_ws);
   }
   const osd_conv_desc* d = d0;
   // variant: 0 = 32 px x 3 stages, 1 = 64 px x 2, 2 = 32 px x 4, 3 = 64 px x 3 (bf16; fp32 always 32 x 3)

@@ -620,7 +620,7 @@ def _conv_desc(x_shape, dtype_code, cout_store, r, s, stride, pad, out_stride):
     d.stride_h = d.stride_w = stride
     d.pad_h = d.pad_w = pad
     d.out_stride = out_stride
-    return d
+    return _wgrad_ws(d)            # (only the weight-gradient entries read these fields)
 
 
 def pack_conv_master(w_orsi, scale, dtype, w_rows=None):
@@ -654,18 +654,23 @@ _WGRAD_WS = {}      # stream handle -> the tensor registered as its ordered-mode
 
 
 def wgrad_set_workspace(stream=None, nbytes=1 << 30):
-    """Ordered mode of the weight-gradient launches on `stream` (default: the current one): partial tiles as plain stores
-    into a scratch buffer + a fixed-order reduction pass = bit-reproducible dW (osd_conv2d_wgrad_set_workspace).
-    nbytes = 0 switches back to atomics.  Tuner results are cached per mode."""
+    """Ordered mode of the weight-gradient launches made on `stream` (default: the current one): partial tiles as plain stores
+    into a scratch buffer + a fixed-order reduction pass = bit-reproducible dW.  The buffer is kept HERE, on the host side, and
+    handed to the library with every call (osd_conv_desc.ordered_ws): the library has no per-stream state.  nbytes = 0 switches
+    back to atomics.  Tuner results are cached per mode."""
     st = stream if stream is not None else torch.cuda.current_stream()
-    handle = C.c_void_p(st.cuda_stream)
     if nbytes:
-        buf = torch.empty((nbytes // 4,), device=st.device, dtype=torch.float32)
-        _lib.call("osd_conv2d_wgrad_set_workspace", handle, _ptr(buf), int(nbytes))
-        _WGRAD_WS[st.cuda_stream] = buf
+        _WGRAD_WS[st.cuda_stream] = torch.empty((nbytes // 4,), device=st.device, dtype=torch.float32)
     else:
-        _lib.call("osd_conv2d_wgrad_set_workspace", handle, C.c_void_p(0), 0)
         _WGRAD_WS.pop(st.cuda_stream, None)
+
+
+def _wgrad_ws(d):
+    """Fill the descriptor's ordered-mode fields from the current stream's registered scratch buffer (if any)."""
+    buf = _WGRAD_WS.get(torch.cuda.current_stream().cuda_stream)
+    if buf is not None:
+        d.ordered_ws, d.ordered_ws_bytes = buf.data_ptr(), buf.numel() * 4
+    return d
 
 
 def _wgrad_mode():
