@@ -987,7 +987,7 @@ def test_engine_with_ordered_weight_gradients_matches_default_engine():
 def test_ordered_weight_gradients_cover_the_second_stage_stream():
     """TrainEngine(second_stage=True, ordered_wgrad=True): the box head's weight gradients run on the proposal stream, which
     now has its own scratch buffer — two runs of the same step (same sampler keys) give BIT-IDENTICAL gradients for every
-    roi_heads.box conv weight and for the FCOS head.  The backbone gradients also receive the second stage's ROI-pool backward,
+    roi_heads.box conv / linear weight.  The backbone gradients also receive the second stage's ROI-pool backward,
     which scatters with fp32 atomics: equal to rounding only (the engine warns about exactly that)."""
     import warnings
     from oneshotdet_amd import ops, train
@@ -1013,8 +1013,8 @@ def test_ordered_weight_gradients_cover_the_second_stage_stream():
             torch.cuda.synchronize()
             runs.append({k: v.clone() for k, v in eng.named_grads().items()})
         for k in runs[0]:
-            if k.endswith(".weight") and runs[0][k].dim() >= 2 and (k.startswith("roi_heads.box.") or k.startswith("rpn.head.")) \
-                    and "tower" not in k.split(".")[2] + "x" and not k.endswith((".1.weight", ".4.weight")):
+            # (the FCOS head's gradients pass through the loss kernel's atomically summed normalisers: last-bit differences)
+            if k.startswith("roi_heads.box.") and k.endswith(".weight") and runs[0][k].dim() >= 2:
                 assert torch.equal(runs[0][k], runs[1][k]), k
         for k in runs[0]:
             a, b = runs[0][k].float(), runs[1][k].float()
