@@ -97,6 +97,9 @@ class TrainEngine(object):
         self.corr_levels = os.environ.get("OSD_CORR_LEVELS", "1") != "0"
         self.skip_unused_c2 = os.environ.get("OSD_FULL_C2", "0") == "0"
         self.towers_merged = os.environ.get("OSD_TOWERS_MERGED", "0") != "0"
+        # A/B: P3+P4 and P5-P7 of a tower as separate forward chains on the (then idle) weight-gradient streams.  Measured SLOWER
+        # (12.05 vs 11.90 ms per step, same box): like lockstep / merged towers, more concurrency buys nothing here
+        self.split_levels = os.environ.get("OSD_SPLIT_LEVELS", "0") != "0"
         sd = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state_dict.items()}
         self._frozen_sd = sd
         self.convs = {}          # name -> TConv
@@ -547,6 +550,29 @@ class TrainEngine(object):
         # one stream per tower: the HBM-bound GroupNorm passes of one tower run beside the MFMA-bound convs of the other
         main = torch.cuda.current_stream()
         side = self.s1 if self.s1 is not None else main
+        if self.split_levels and len(feats) == 5 and None not in (self.s1, self.wstream, self.wstream2):
+            # ... and one CHAIN per level group: the levels of a tower never meet before the loss, so P5-P7 (34 pixel tiles,
+            # latency-sized launches: 27 us per layer) run as their own conv -> GroupNorm chain on the weight-gradient streams
+            # (idle during the forward pass) inside the HBM-bound GroupNorm windows of the P3+P4 chain, instead of in line
+            big, small = [0, 1], [2, 3, 4]
+            for st in (self.s1, self.wstream, self.wstream2):
+                st.wait_stream(main)
+            with torch.cuda.stream(self.wstream):
+                ocs, ccs = self._towers_forward(feats, ("cls_tower",), small)
+            with torch.cuda.stream(self.wstream2):
+                obs, cbs = self._towers_forward(feats, ("bbox_tower",), small)
+            with torch.cuda.stream(self.s1):
+                obb, cbb = self._towers_forward(feats, ("bbox_tower",), big)
+            ocb, ccb = self._towers_forward(feats, ("cls_tower",), big)
+            for st in (self.s1, self.wstream, self.wstream2):
+                main.wait_stream(st)
+
+            def merge(cb_, cs_, tw):
+                lb, tb = cb_[tw]
+                ls, ts = cs_[tw]
+                return ([(a[0] + b[0], a[1] + b[1], [a[2], b[2]]) for a, b in zip(lb, ls)], tb + ts)
+            ctx = {"cls_tower": merge(ccb, ccs, "cls_tower"), "bbox_tower": merge(cbb, cbs, "bbox_tower")}
+            return list(zip(ocb["cls_tower"] + ocs["cls_tower"], obb["bbox_tower"] + obs["bbox_tower"])), ctx
         side.wait_stream(main)
         with torch.cuda.stream(side):
             ob, cb = self._towers_forward(feats, ("bbox_tower",))
@@ -555,10 +581,12 @@ class TrainEngine(object):
         cc.update(cb)
         return list(zip(oc["cls_tower"], ob["bbox_tower"])), cc
 
-    def _towers_forward(self, feats, towers):
+    def _towers_forward(self, feats, towers, lv=None):
         cv = self.convs
         h = "rpn.head."
         scales = self.extra[h + "scales"][0]
+        lv = list(range(len(feats))) if lv is None else list(lv)        # FPN levels handled by this call
+        feats = [feats[l] for l in lv]
         nl, nt = len(feats), len(towers)
         t = {tw: list(feats) for tw in towers}
         layers = {tw: [] for tw in towers}
@@ -577,7 +605,7 @@ class TrainEngine(object):
             outs["cls_tower"] = ops.conv2d_grouped(t["cls_tower"], cv[h + "cls_ctr"].pc, pad=1)
         if "bbox_tower" in towers:
             outs["bbox_tower"] = ops.conv2d_grouped(t["bbox_tower"], cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE,
-                                                    act_scale_devs=[scales[l:l + 1] for l in range(nl)])
+                                                    act_scale_devs=[scales[l:l + 1] for l in lv])
         return outs, {tw: (layers[tw], t[tw]) for tw in towers}
 
     # ------------------------------------------------------------------------------------------------ loss
@@ -729,7 +757,14 @@ class TrainEngine(object):
                 (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tw, 3 * i + 1))
                 c = cv["%s%s.%d" % (h, tw, 3 * i)]
                 t_in, u, ab = ctxs[tw][0][i]
-                dus[tw] = ops.groupnorm_relu_bwd_levels(u, d_t[tw], ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
+                if isinstance(ab, list):        # forward ran one chain per level group: one saved-statistics block each
+                    dus[tw], lo = [], 0
+                    for ab_g in ab:
+                        k = ab_g.shape[0]
+                        dus[tw] += ops.groupnorm_relu_bwd_levels(u[lo:lo + k], d_t[tw][lo:lo + k], ab_g, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
+                        lo += k
+                else:
+                    dus[tw] = ops.groupnorm_relu_bwd_levels(u, d_t[tw], ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
                 items[tw] += [(t_in[l], dus[tw][l], c.gw, c.bn_scale, c.gb if c.has_bias else None) for l in range(nl)]
             dys = [dus[tw][l] for l in range(nl) for tw in towers]
             c0 = cv["%s%s.%d" % (h, towers[0], 3 * i)]
