@@ -1171,6 +1171,60 @@ static int pred_blocks(int n_seg, const int32_t* ns, const int32_t* hs, const in
   return (int)b;
 }
 
+// ---- the prediction convs' weight gradient as a 1x1 GEMM (default) ----
+// dW[co][r][s][ci] = sum over input pixels q of x[q][ci] * dy[q - (r - 1, s - 1)][co]: with the nine shifted dy vectors of a
+// pixel laid side by side, G[q][tap * 4 + co] (36 of 40 columns; zero outside the map), this is the weight gradient of a 1x1
+// conv with 36 output channels — the MFMA kernel above with ONE output row-tile, x read once — whose result T[tap * 4 + co][ci]
+// a last tiny launch adds into dw[co][tap][ci] (and the centre tap's column sums into db).  The gather moves 8 + 80 bytes per
+// pixel (a sixth of x's bytes): a thread owns one 16-byte chunk = two taps x four channels, 5 lanes cover a pixel's row.
+constexpr int kPredG = 40;             // columns of G
+struct PredGatherLevels { const void* dy[kPredLevels]; int H[kPredLevels], W[kPredLevels], npix[kPredLevels], begin[kPredLevels]; int n_levels; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) pred_dy_gather_kernel(PredGatherLevels L, T* __restrict__ g, int dy_stride) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;          // (pixel over all levels, chunk)
+  const int c8 = (int)(idx % 5);
+  const int q_all = (int)(idx / 5);
+  int lvl = -1;
+#pragma unroll
+  for (int i = 0; i < kPredLevels; ++i)
+    if (i < L.n_levels && q_all >= L.begin[i] && q_all < L.begin[i] + L.npix[i]) lvl = i;
+  if (lvl < 0) return;
+  const void* dyv = L.dy[0];
+  int H = L.H[0], W = L.W[0], beg = L.begin[0];
+#pragma unroll
+  for (int i = 1; i < kPredLevels; ++i)
+    if (lvl == i) { dyv = L.dy[i]; H = L.H[i]; W = L.W[i]; beg = L.begin[i]; }
+  const T* __restrict__ dy = reinterpret_cast<const T*>(dyv);
+  const int q = q_all - beg, HW = H * W;
+  const int img = q / HW, rem = q - img * HW, qy = rem / W, qx = rem - qy * W;
+  T out[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int t = 2 * c8 + h;
+    const int py = qy - t / 3 + 1, px = qx - t % 3 + 1;
+    const bool ok = t < 9 && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
+    const T* dp = dy + ((size_t)(img * H + (ok ? py : qy)) * W + (ok ? px : qx)) * dy_stride;
+#pragma unroll
+    for (int co = 0; co < 4; ++co) out[h * 4 + co] = ok ? dp[co] : from_f32<T>(0.f);
+  }
+  T* o = g + (size_t)q_all * kPredG + c8 * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = out[j];
+}
+
+// dw[co][tap][ci] += T[tap * 4 + co][ci]; db[co] += column sums of the centre tap (tap 4 reads dy[q][co] itself)
+__global__ void __launch_bounds__(256) pred_wgrad_scatter_kernel(const float* __restrict__ t, const float* __restrict__ dbg, float* __restrict__ dw,
+                                                                float* __restrict__ db, int cout, int cin) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = cout * 9 * cin;
+  if (i < n) {
+    const int ci = i % cin, tap = (i / cin) % 9, co = i / (9 * cin);
+    dw[i] += t[(size_t)(tap * 4 + co) * cin + ci];
+  }
+  if (db != nullptr && i < cout) db[i] += dbg[4 * 4 + i];
+}
+
 // pixels per workgroup: a multiple of the 32 pixels a workgroup reads per iteration, at least 256, and large enough that
 // all workgroups are resident at once (2 per CU: the kernel is VALU bound, a second round of a few workgroups costs a
 // whole round's time)
@@ -1187,7 +1241,11 @@ extern "C" int64_t osd_conv2d_wgrad_pred_workspace_bytes(int n_seg, const int32_
                                                          int cin) {
   if (n_seg < 1 || !ns || !hs || !ws || cin <= 0) return 0;
   const long long blocks = pred_blocks(n_seg, ns, hs, ws, pred_ppb(n_seg, ns, hs, ws));
-  return (int64_t)(blocks * ((cin + 255) / 256) * 36 * 256 * 4 + blocks * 16 * 4 + 256);
+  long long tot = 0;
+  for (int i = 0; i < n_seg; ++i) tot += (long long)ns[i] * hs[i] * ws[i];
+  const long long readonce = blocks * ((cin + 255) / 256) * 36 * 256 * 4 + blocks * 16 * 4 + 256;
+  const long long gather = tot * kPredG * 4 + (long long)kPredG * cin * 4 + 1024;      // G [pixels][40] (widest dtype) + T [40][cin] + column sums
+  return (int64_t)(readonce > gather ? readonce : gather);
 }
 
 // The prediction convs' weight + bias gradient (3x3 / stride 1 / pad 1, Cout <= 4, Cin a multiple of 256) over n_seg FPN
@@ -1201,10 +1259,55 @@ extern "C" int osd_conv2d_wgrad_pred(const osd_conv_desc* d, int n_seg, const vo
   if (d->cout < 1 || d->cout > 4 || d->r != 3 || d->s != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 ||
       d->pad_w != 1 || d->cin % 256 != 0 || d->out_stride % 4 != 0)
     return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad_pred: 3x3 / stride 1 / pad 1, cout <= 4, cin %% 256 == 0, dy rows of >= 4 channels");
+  for (int i = 0; i < n_seg; ++i)
+    if (ns[i] <= 0 || hs[i] <= 0 || ws[i] <= 0 || !xs[i] || !dys[i]) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred: bad segment %d", i);
+  static int use_gemm = -1;     // OSD_PRED_WGRAD_READONCE=1: the first-generation read-once kernel (A/B)
+  if (use_gemm < 0) { const char* e = getenv("OSD_PRED_WGRAD_READONCE"); use_gemm = (e && e[0] == '1') ? 0 : 1; }
+  if (use_gemm) {
+    hipStream_t st = OSD_STREAM(stream);
+    const size_t esz = d->dtype == OSD_BF16 ? 2 : 4;
+    // workspace: [column sums: 256 B][T: 40 x cin fp32][G: pixels x 40]
+    float* dbg = static_cast<float*>(workspace);
+    float* tbuf = dbg + 64;
+    char* gbase = reinterpret_cast<char*>(tbuf + (size_t)kPredG * d->cin);
+    if (hipMemsetAsync(workspace, 0, 256 + (size_t)kPredG * d->cin * 4, st) != hipSuccess)
+      return osd_fail(OSD_ERR_LAUNCH, "wgrad_pred: memset failed");
+    PredGatherLevels L;
+    L.n_levels = n_seg;
+    osd_conv_desc d1[kPredLevels];
+    WgradProblem pr[kPredLevels];
+    long long tot = 0;
+    for (int i = 0; i < kPredLevels; ++i) {
+      const int j = i < n_seg ? i : 0;
+      const long long npix = (long long)ns[j] * hs[j] * ws[j];
+      if (npix > 0x7fffffffLL / d->cin) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred: bad segment %d", j);
+      L.dy[i] = dys[j]; L.H[i] = hs[j]; L.W[i] = ws[j]; L.npix[i] = i < n_seg ? (int)npix : 0; L.begin[i] = (int)tot;
+      if (i < n_seg) {
+        d1[i] = *d;
+        d1[i].cout = 36; d1[i].r = 1; d1[i].s = 1; d1[i].pad_h = 0; d1[i].pad_w = 0; d1[i].out_stride = kPredG;
+        static int code = -1;                    // split-target code (OSD_PRED_WGRAD_CODE: A/B); 512 workgroups measured best (65 us; 128: 102, 1,024: 90)
+        if (code < 0) { const char* e = getenv("OSD_PRED_WGRAD_CODE"); code = e ? atoi(e) & 7 : 0; }
+        d1[i].algo = 1 + 0 + 16 * code;          // 128 x 128 tile, 32-pixel stages
+        pr[i] = WgradProblem{&d1[i], ns[i], hs[i], ws[i], xs[i], gbase + (size_t)tot * kPredG * esz, nullptr, tbuf, db ? dbg : nullptr};
+        tot += npix;
+      }
+    }
+    if (tot * 5 > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred: too many pixels");
+    const unsigned gblocks = (unsigned)((tot * 5 + 255) / 256);
+    if (d->dtype == OSD_F32)
+      hipLaunchKernelGGL(pred_dy_gather_kernel<float>, dim3(gblocks), dim3(256), 0, st, L, (float*)gbase, d->out_stride);
+    else
+      hipLaunchKernelGGL(pred_dy_gather_kernel<__bf16>, dim3(gblocks), dim3(256), 0, st, L, (__bf16*)gbase, d->out_stride);
+    int rc = osd_check_launch("pred_dy_gather");
+    if (rc) return rc;
+    rc = wgrad_launch(n_seg, pr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pred_wgrad_scatter_kernel, dim3(cdiv(d->cout * 9 * d->cin, 256)), dim3(256), 0, st, (const float*)tbuf, (const float*)dbg,
+                       dw, db, d->cout, d->cin);
+    return osd_check_launch("pred_wgrad_scatter");
+  }
   PredWgradLevels L;
   L.n_levels = 0;
-  for (int i = 0; i < n_seg; ++i)
-    if (ns[i] <= 0 || hs[i] <= 0 || ws[i] <= 0) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred: bad segment %d", i);
   const int ppb = pred_ppb(n_seg, ns, hs, ws);
   int blocks = 0;
   for (int i = 0; i < n_seg; ++i) {
