@@ -132,7 +132,9 @@ def load():
 def check(rc, what=""):
     if rc != 0:
         msg = load().osd_last_error_string()
-        raise OsdError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+        err = OsdError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+        err.code = rc
+        raise err
 
 
 def call(name, *args):

@@ -12,48 +12,11 @@
 // Pixels are split over `splits` workgroups per output tile (the reduction is 1e5..1e6 long while there are only
 // tens of output tiles); partial tiles are accumulated with fp32 atomics (no-return global_atomic_add_f32).
 // A 3-deep LDS ring with counted vmcnt and one raw barrier per stage, as in conv_igemm_dma.hip.
-#include "osd_common.h"
-#include <cstddef>
+#include "wgrad_params.h"
 
 namespace {
 
 __device__ __attribute__((aligned(256))) unsigned g_wzero[64];
-
-constexpr int kMaxSeg = 24;
-
-// One launch can reduce over several (x, dy) pairs that share the weights (the FPN levels of the FCOS towers): the
-// pixel splits are distributed over the segments, every workgroup works inside one segment, and all of them add into
-// the same dW, so the atomic traffic is paid once instead of once per level.
-struct WgradSeg {
-  const void* x;
-  const void* dy;
-  float* dw;
-  const float* scale;   // optional per-Cout factor (folded FrozenBN scale: d/dw of conv(x, w*scale))
-  float* db;            // optional bias gradient: db[co] += sum over pixels of dy (done by the tap-0 / ci-tile-0 blocks)
-  int H, W, Ho, Wo, M, rows_per_split;
-  int Cin, Cout, R, S, sh, sw, ph, pw, dy_stride, tilesCo, tilesCi, Ktot;
-  int block_begin;      // first (logical) workgroup of this segment; its workgroups: tilesCo x R*S*tilesCi x splits
-};
-
-// Every segment is a complete problem (its own tensors, geometry and outputs; segments that share a dW simply repeat the
-// pointer): the FPN levels of one conv, the repeated blocks of a stage, or all weight gradients of a stage at once.
-struct WgradParams {
-  WgradSeg seg[kMaxSeg];
-  int n_seg;
-  int n_blocks;       // logical workgroups of the launch (= partial tiles in ordered mode)
-  float* partials;    // ordered mode (osd_conv_desc.ordered_ws): every workgroup STORES its partial tile into slot
-                      // [logical id][TCO * TCI + TCO] instead of adding it atomically; wgrad_reduce_kernel sums the slots
-                      // in a fixed order: bit-reproducible dW, plain stores instead of memory-side atomics
-};
-
-// fp32 add into GLOBAL memory.  The dW / db pointers come out of the kernarg table as integers, so plain atomicAdd sees a
-// generic pointer and emits flat_atomic_add_f32 (aperture check, counted on both lgkmcnt and vmcnt)
-typedef __attribute__((address_space(1))) float wg_gfloat;
-__device__ __forceinline__ void wg_atomic_add(float* ptr, float v) {
-  (void)__hip_atomic_fetch_add((wg_gfloat*)ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ void wg_dma16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -62,11 +25,6 @@ __device__ __forceinline__ void wg_dma16(const void* gsrc, unsigned lds_dst) {
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
-}
-
-template <typename T> __device__ __forceinline__ int wg_swz(int row) {
-  if constexpr (sizeof(T) == 2) return 2 * (row & 7);
-  else return 4 * (row & 3);
 }
 
 // Output tile = (WCO x WCI) sub-tiles of TWS channels (TWS = one 256-byte row: 128 bf16 / 64 fp32): 1 x 1 on 4 waves
@@ -994,8 +952,8 @@ static int wgrad_xr_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
 }
 
 // dtype and algo (0 = default, else 1 + variant + 16 * target_code) come from the first problem's descriptor.
-// variant 0..3: 128 x 128 channel tile on 4 waves, pixels per stage x ring depth = 32x3 / 64x2 / 32x4 / 64x3 (bf16;
-// fp32 always 32x3); variants 4..7: 256-wide tiles on 8 waves; 8, 9: 256 x 256 with a 5- / 4-deep ring of 32-pixel stages
+// variant 0..2: 128 x 128 channel tile on 4 waves, pixels per stage x ring depth = 32x3 / 64x2 / 32x4 (bf16; fp32 always 32x3);
+// 13, 3: the software-pipelined 256 x 256 kernel of conv_wgrad_sk.hip with this launcher's splits / in team mode; 12: retired; variants 4..7: 256-wide tiles on 8 waves; 8, 9: 256 x 256 with a 5- / 4-deep ring of 32-pixel stages
 // (the whole 160 KB / 128 KB of LDS as prefetch distance: one workgroup per CU has nothing else to hide the operand
 // latency behind); 10..12: 128 x 256 / 256 x 128 tiles on FOUR waves (64 x 128 per wave, 72 KB: two workgroups per CU)
 static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
@@ -1009,12 +967,13 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   // tower 857 -> 796 us — but the training step does not: 639.6 / 642.9 vs 638.3 / 634.9 images/s in one-box A/B, the
   // extra workgroups compete with the main chain they run beside)
   static const int kTargets[8] = {512, 256, 128, 64, 1024, 768, 1536, 2048};
-  int target = env_target, variant = env_variant;
+  int target = env_target, variant = env_variant, code = 0;
   if (d0->algo > 0) {
     const int a = d0->algo - 1;
     if (a >= 128) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d0->algo);
     variant = a & 15;
-    target = kTargets[a >> 4];
+    code = a >> 4;
+    target = kTargets[code];
   }
   // exact-fp32 MFMA runs at 1/16 of the bf16 rate and its channel tile is 64 wide (4x the output tiles): a workgroup's
   // fixed costs and its atomic epilogue weigh 16x less, so the same codes mean 8x the workgroups (finer pixel splits
@@ -1023,8 +982,8 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   // channel tile (co x ci) in 256-byte sub-tiles: variants 4 / 5 = 2 x 2, 6 = 1 x 2, 7 = 2 x 1 (bf16, 8 waves); else 1 x 1
   const bool bf = d0->dtype == OSD_BF16;
   if (!bf && variant != 0) variant = 0;
-  const int sub_co = bf && (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 9 || variant == 11 || variant == 13 || variant == 14) ? 2 : 1;
-  const int sub_ci = bf && (variant == 4 || variant == 5 || variant == 6 || variant == 8 || variant == 9 || variant == 10 || variant == 12 || variant == 13) ? 2 : 1;
+  const int sub_co = bf && (variant == 3 || variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 9 || variant == 11 || variant == 13 || variant == 14) ? 2 : 1;
+  const int sub_ci = bf && (variant == 3 || variant == 4 || variant == 5 || variant == 6 || variant == 8 || variant == 9 || variant == 10 || variant == 13) ? 2 : 1;
   const int tw = bf ? 128 : 64;
   const int epc = d0->dtype == OSD_BF16 ? 8 : 4;
   WgradParams p;
@@ -1063,6 +1022,35 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
     nblocks += (long long)g.tilesCo * g.tilesCi * g.R * g.S * splits;
     if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
   }
+  p.sk_units = p.sk_teams = p.sk_total = 0;
+  if (bf && variant == 3) {
+    // team mode (conv_wgrad_sk.hip): all segments are instances of ONE conv shape (the FPN levels of a conv, the convs of a
+    // tower), so every pixel range has the same `units` output tiles x taps; teams of `units` workgroups share the launch's
+    // concatenated 64-pixel stages equally.  The target code is the number of rounds: (code + 1) workgroups per CU.
+    if (d0->ordered_ws != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: team mode adds its partial tiles atomically (not for ordered mode)");
+    if (code > 3) return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: team mode knows target codes 0..3 (rounds)");
+    const WgradSeg& g0 = p.seg[0];
+    long long total = 0;
+    for (int i = 0; i < n_seg; ++i) {
+      WgradSeg& g = p.seg[i];
+      if (g.Cout != g0.Cout || g.Cin != g0.Cin || g.R != g0.R || g.S != g0.S)
+        return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: team mode needs segments of one conv shape (segment %d differs)", i);
+      g.stage_begin = (int)total;
+      total += cdiv(g.M, 64);
+    }
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    }
+    const int units = g0.tilesCo * g0.tilesCi * g0.R * g0.S;
+    long long teams = (long long)cus * (code + 1) / units;
+    if (teams < 1) return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: team mode needs at most one output tile x tap per CU (%d)", units);
+    if (teams > total) teams = total;
+    if (total > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
+    p.sk_units = units; p.sk_teams = (int)teams; p.sk_total = (int)total;
+    nblocks = teams * units;
+  }
   for (int i = n_seg; i < kMaxSeg; ++i) p.seg[i] = p.seg[0];
   p.n_blocks = (int)nblocks;
   p.partials = nullptr;
@@ -1075,7 +1063,7 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
     p.partials = static_cast<float*>(d0->ordered_ws);
   }
   const osd_conv_desc* d = d0;
-  // variant: 0 = 32 px x 3 stages, 1 = 64 px x 2, 2 = 32 px x 4, 3 = 64 px x 3 (bf16; fp32 always 32 x 3)
+  // variant: 0 = 32 px x 3 stages, 1 = 64 px x 2, 2 = 32 px x 4 (bf16; fp32 always 32 x 3)
 #define OSD_WG_LAUNCH(TT, BK, NS, WC, WMM, WNN) OSD_WG_LAUNCH3(TT, BK, NS, WC, WC, WMM, WNN, false)
 #define OSD_WG_LAUNCH2(TT, BK, NS, WCOO, WCII, WMM, WNN) OSD_WG_LAUNCH3(TT, BK, NS, WCOO, WCII, WMM, WNN, false)
 #define OSD_WG_LAUNCH3(TT, BK, NS, WCOO, WCII, WMM, WNN, IL)                                                        \
@@ -1092,7 +1080,6 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
     switch (variant) {
       case 1: OSD_WG_LAUNCH(__bf16, 64, 2, 1, 2, 2); break;
       case 2: OSD_WG_LAUNCH(__bf16, 32, 4, 1, 2, 2); break;
-      case 3: OSD_WG_LAUNCH(__bf16, 64, 3, 1, 2, 2); break;
       case 4: OSD_WG_LAUNCH(__bf16, 32, 3, 2, 2, 4); break;
       // long stages on 8 waves (64 MFMAs per wave between barriers, as the forward kernel's 256 x 256 tile): 2-deep ring
       case 5: OSD_WG_LAUNCH(__bf16, 64, 2, 2, 2, 4); break;          // 256 co x 256 ci
@@ -1102,9 +1089,20 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
       case 9: OSD_WG_LAUNCH(__bf16, 32, 4, 2, 2, 4); break;          // 256 x 256, 4 x 32 KB
       case 10: OSD_WG_LAUNCH2(__bf16, 32, 3, 1, 2, 2, 2); break;     // 128 co x 256 ci on 4 waves, 3 x 24 KB
       case 11: OSD_WG_LAUNCH2(__bf16, 32, 3, 2, 1, 2, 2); break;     // 256 co x 128 ci on 4 waves
-      case 12: OSD_WG_LAUNCH2(__bf16, 32, 6, 1, 2, 2, 2); break;     // 128 co x 256 ci on 4 waves, 6 x 24 KB
-      // 13..15: variants 5, 11 and 0 with the DMA pieces issued between the MFMA rows
-      case 13: OSD_WG_LAUNCH3(__bf16, 64, 2, 2, 2, 2, 4, true); break;
+      // 14, 15: variants 11 and 0 with the DMA pieces issued between the MFMA rows
+      case 3:       // conv_wgrad_sk.hip in team mode (set up above)
+      case 12: return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: variant 12 is retired");
+      case 13: {    // conv_wgrad_sk.hip, the splits of this launcher: 256 x 256 on eight waves, software-pipelined loop
+        for (int i = 0; i < n_seg; ++i) {      // the index arithmetic of its DMA is exact (and fits 32-bit byte offsets) below these bounds
+          const WgradSeg& g = p.seg[i];
+          if (g.Wo < 2 || g.Ho < 2 || (long long)g.M * g.Wo >= 0xffffffffLL || (long long)g.M * g.dy_stride * 2 >= 0x7fffffffLL ||
+              (long long)(g.M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin * 2 >= 0x7fffffffLL)
+            return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: the pipelined variants need output maps of at least 2 x 2 and operands below 2 GiB (segment %d)", i);
+        }
+        const int rc = osd_wgrad_sk_launch(p, s);
+        if (rc) return rc;
+        break;
+      }
       case 14: OSD_WG_LAUNCH3(__bf16, 32, 3, 2, 1, 2, 2, true); break;
       case 15: OSD_WG_LAUNCH3(__bf16, 32, 3, 1, 1, 2, 2, true); break;
       default: OSD_WG_LAUNCH(__bf16, 32, 3, 1, 2, 2); break;

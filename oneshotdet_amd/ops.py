@@ -692,16 +692,29 @@ def wgrad_algo_candidates(dtype, cout=0, cin=0):
     """osd_conv2d_wgrad's algo field = 1 + variant + 16 * split-target code.  Variants 0..3: 128 x 128 channel tile with
     different stage shapes (bf16; fp32 has one); 4..9: 256-wide channel tiles on 8 waves (bf16, wide layers; 8 / 9 with
     the deepest rings the LDS holds); 10..12: 128 x 256 / 256 x 128 on four waves."""
-    variants = [0, 1, 2, 3] if dtype == OSD_BF16 else [0]
+    variants = [0, 1, 2] if dtype == OSD_BF16 else [0]
     if dtype == OSD_BF16:
         variants.append(15)         # variant 0 with the DMA pieces issued between the MFMA rows
     if dtype == OSD_BF16 and cout >= 256 and cin >= 256:
-        variants += [4, 5, 8, 9, 13]
+        variants += [3, 4, 5, 8, 9, 13]     # 13, 3: the software-pipelined kernel, splits / team mode (refused where they do not apply)
     if dtype == OSD_BF16 and cin >= 256:
-        variants += [6, 10, 12]     # 128 co x 256 ci
+        variants += [6, 10]         # 128 co x 256 ci
     if dtype == OSD_BF16 and cout >= 256:
         variants += [7, 11, 14]     # 256 co x 128 ci (14: 11 interleaved)
-    return [1 + v + 16 * t for t in (0, 1, 2, 3, 4, 5, 6, 7) for v in variants]
+    # variant 3 (team mode) reads the code as a round count and knows 0..3
+    return [1 + v + 16 * t for t in (0, 1, 2, 3, 4, 5, 6, 7) for v in variants if not (v == 3 and t > 3)]
+
+
+def _candidate_runs(fn):
+    """A tuner candidate whose kernel does not cover this geometry (OSD_ERR_UNSUPPORTED = -2: e.g. the pipelined weight-gradient
+    variant on a map whose width is not a power of two) is skipped; any other failure is an error."""
+    try:
+        fn()
+        return True
+    except _lib.OsdError as e:
+        if getattr(e, "code", 0) == -2:
+            return False
+        raise
 
 
 def _tune_wgrad(key, d, launch, dw, db, widths=None):
@@ -714,7 +727,8 @@ def _tune_wgrad(key, d, launch, dw, db, widths=None):
         cands = cands + wgrad_xr_candidates(d.dtype, d.cout, d.cin, d.r, d.s, d.stride_h, d.pad_h, widths)
     for algo in cands:
         d.algo = algo
-        launch(sdw, sdb)
+        if not _candidate_runs(lambda: launch(sdw, sdb)):
+            continue
         torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         ev[0].record()
@@ -883,7 +897,8 @@ def conv2d_wgrad_mixed(items, algo=None):
             best, best_t = 0, float("inf")
             for cand in wgrad_algo_candidates(descs[0].dtype, max(d.cout for d in descs), max(d.cin for d in descs)):
                 descs[0].algo = cand
-                launch(sdw, sdb)
+                if not _candidate_runs(lambda: launch(sdw, sdb)):
+                    continue
                 torch.cuda.synchronize()
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
                 ev[0].record()

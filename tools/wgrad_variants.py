@@ -35,15 +35,20 @@ def sweep(name, launch, flops, cout, cin, xr=None):
     cands = ops.wgrad_algo_candidates(ops.OSD_BF16, cout, cin)
     if xr is not None:
         cands = cands + ops.wgrad_xr_candidates(ops.OSD_BF16, cout, cin, 3, 3, 1, 1, xr)
+    only = [int(v) for v in os.environ.get("WG_VARIANTS", "").split(",") if v]      # WG_VARIANTS=5,13: these variants only
     for algo in cands:
         v, t = (algo - 1) & 15, ((algo - 1) >> 4) & 7
         if algo > 128:
             v += 100
+        if only and v not in only:
+            continue
         try:
             us = time_it(lambda: launch(algo))
         except Exception as e:
             print("   variant %d target %d failed: %s" % (v, t, e))
             continue
+        if os.environ.get("WG_ALL"):
+            print("   v%d t%d %7.1f us" % (v, t, us))
         if v not in best or us < best[v][0]:
             best[v] = (us, t)
     print("%-44s %s" % (name, "  ".join("v%d: %6.1f us (t%d) %4.0f TF" % (v, us, t, flops / us / 1e6) for v, (us, t) in sorted(best.items()))))
