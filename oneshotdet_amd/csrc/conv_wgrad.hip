@@ -1090,8 +1090,8 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
       case 10: OSD_WG_LAUNCH2(__bf16, 32, 3, 1, 2, 2, 2); break;     // 128 co x 256 ci on 4 waves, 3 x 24 KB
       case 11: OSD_WG_LAUNCH2(__bf16, 32, 3, 2, 1, 2, 2); break;     // 256 co x 128 ci on 4 waves
       // 14, 15: variants 11 and 0 with the DMA pieces issued between the MFMA rows
-      case 3:       // conv_wgrad_sk.hip in team mode (set up above)
       case 12: return osd_fail(OSD_ERR_UNSUPPORTED, "wgrad: variant 12 is retired");
+      case 3:       // conv_wgrad_sk.hip in team mode (set up above)
       case 13: {    // conv_wgrad_sk.hip, the splits of this launcher: 256 x 256 on eight waves, software-pipelined loop
         for (int i = 0; i < n_seg; ++i) {      // the index arithmetic of its DMA is exact (and fits 32-bit byte offsets) below these bounds
           const WgradSeg& g = p.seg[i];

@@ -702,6 +702,8 @@ def wgrad_algo_candidates(dtype, cout=0, cin=0):
     if dtype == OSD_BF16 and cout >= 256:
         variants += [7, 11, 14]     # 256 co x 128 ci (14: 11 interleaved)
     # variant 3 (team mode) reads the code as a round count and knows 0..3
+    excl = [int(v) for v in os.environ.get("OSD_WGRAD_EXCLUDE", "").split(",") if v]      # A/B timing: leave variants out
+    variants = [v for v in variants if v not in excl]
     return [1 + v + 16 * t for t in (0, 1, 2, 3, 4, 5, 6, 7) for v in variants if not (v == 3 and t > 3)]
 
 

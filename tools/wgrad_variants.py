@@ -80,3 +80,31 @@ if which in ("backbone", "all"):
         dw = torch.zeros(cout, k, k, cin, device="cuda")
         sweep(name, lambda a: ops.conv2d_wgrad(x, dy, dw, k, k, stride, pad, cout, algo=a), 2.0 * n * ho * wo * cout * cin * k * k,
               cout, cin, xr=[w] if (k, stride, pad) == (3, 1, 1) else None)
+
+
+def stage_items(cin0, width, cout, blocks, h, w, n=8):
+    """The weight gradients of one ResNet stage as the engine queues them (train.py:_flush_wgrads): block 0 = conv1 1x1 s2
+    (cin0 -> width), conv2 3x3, conv3 1x1 (width -> cout), downsample 1x1 s2 (cin0 -> cout); later blocks conv1 (cout -> width)."""
+    items, fl = [], 0.0
+    hi, wi = 2 * h, 2 * w
+    def add(x, dy, k, stride, pad, co):
+        nonlocal fl
+        ci = x.shape[-1]
+        items.append((x, dy, torch.zeros(co, k, k, ci, device="cuda"), None, None, k, k, stride, pad, co))
+        fl += 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * ci * k * k
+    for b in range(blocks):
+        if b == 0:
+            add(rnd(n, hi, wi, cin0), rnd(n, h, w, width), 1, 2, 0, width)
+            add(rnd(n, hi, wi, cin0), rnd(n, h, w, cout), 1, 2, 0, cout)
+        else:
+            add(rnd(n, h, w, cout), rnd(n, h, w, width), 1, 1, 0, width)
+        add(rnd(n, h, w, width), rnd(n, h, w, width), 3, 1, 1, width)
+        add(rnd(n, h, w, width), rnd(n, h, w, cout), 1, 1, 0, cout)
+    return items, fl
+
+
+if which in ("stages", "all"):
+    for name, args in (("layer2 (13 convs, 100x128)", (256, 128, 512, 4, 100, 128)), ("layer3 (19 convs, 50x64)", (512, 256, 1024, 6, 50, 64)),
+                       ("layer4 (10 convs, 25x32)", (1024, 512, 2048, 3, 25, 32))):
+        items, fl = stage_items(*args)
+        sweep(name, lambda a: ops.conv2d_wgrad_mixed(items, algo=a), fl, max(i[9] for i in items), max(i[0].shape[-1] for i in items))
