@@ -121,6 +121,23 @@ int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* x
                          const int32_t* ns, const int32_t* hs, const int32_t* ws, const void* const* wts,
                          const float* const* biases, void* stream);
 
+/* osd_conv2d_fwd_multi (no residual, mask or activation) for the data-gradient conv whose outputs dt are the gradients w.r.t.
+ * the outputs of a GroupNorm + ReLU (the FCOS towers, fcos.py:29-39): for every pair with gn_us[i] != NULL the epilogue also
+ * gathers the sums the GroupNorm backward needs, from the values it stores (rounded to the conv's dtype, i.e. what a pass over
+ * the stored dt would read): with z = a u + b, dz = z > 0 ? dt : 0, xhat = xa u + xb per pixel and channel,
+ *   gn_wss[i] [gn_n][OSD_GN_SPLITS][gn_groups][2] += sum dz * gamma, sum dz * gamma * xhat     (per image, slab, group)
+ *   gn_pws[i] [gn_n][OSD_GN_SPLITS][2][cout]      += sum dz * xhat, sum dz                       (d gamma / d beta partials)
+ * by fp32 atomics (the caller zeroes both; the slab is picked per workgroup to spread them).  gn_us[i]: the GroupNorm's INPUT
+ * (the forward conv's output) at this conv's output pixels, same dtype and row stride as ys[i]; gn_abs[i]: level i's
+ * [4][gn_n][cout] block of osd_groupnorm_relu_fwd_levels' ab; gn_gammas[i]: [cout].  These are the two halves of the ws of
+ * osd_groupnorm_relu_bwd_levels_fused, which then skips its own statistics pass for that level.  Only the software-pipelined
+ * 3x3 kernel gathers them (d->algo = 15: bf16, widths 64 / 128 / 256) and only for pairs made of whole 256-pixel tiles
+ * whose images are whole 128-pixel runs; anything else returns OSD_ERR_UNSUPPORTED and the caller uses the plain pair of calls. */
+int osd_conv2d_fwd_multi_gn(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys, const int32_t* ns,
+                            const int32_t* hs, const int32_t* ws, const void* const* wts, const float* const* biases,
+                            const void* const* gn_us, const float* const* gn_abs, const float* const* gn_gammas,
+                            float* const* gn_wss, float* const* gn_pws, int gn_n, int gn_groups, void* stream);
+
 /* OIHW fp32 conv weight (+ optional per-Cout scale = FrozenBN weight*rsqrt(var), layers/batch_norm.py:20) ->
  * packed [w_rows][r][s][cin_pad] rows of `dtype`, zero padded. */
 int osd_pack_conv_weight(const float* w_oihw, const float* scale, void* dst, int cout, int cin, int r, int s,
@@ -370,6 +387,13 @@ int osd_groupnorm_relu_fwd_levels(int n_levels, const void* const* xs, void* con
 int osd_groupnorm_relu_bwd_levels(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
                                   const int32_t* hws, const float* ab, const float* gamma, const float* beta, float* ws,
                                   float* dgamma, float* dbeta, int n, int c, int groups, int dtype, void* stream);
+/* the same when osd_conv2d_fwd_multi_gn has already accumulated the sums of some levels: bit l of fused_mask set = level l's
+ * parts of ws (group sums at ws + l*n*OSD_GN_SPLITS*groups*2, d gamma / d beta partials at
+ * ws + n_levels*n*OSD_GN_SPLITS*groups*2 + l*n*OSD_GN_SPLITS*2*c) are complete; the statistics pass skips those levels */
+int osd_groupnorm_relu_bwd_levels_fused(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
+                                        const int32_t* hws, const float* ab, const float* gamma, const float* beta, float* ws,
+                                        float* dgamma, float* dbeta, int n, int c, int groups, int dtype, uint32_t fused_mask,
+                                        void* stream);
 /* FCOS loss (modeling/rpn/fcos/loss.py:101-276; focal term = csrc/cuda/SigmoidFocalLoss_cuda.cu) for one FPN level.
  * phase 0 accumulates sums[5] = {num_pos, sum_w, sum_focal, sum_w*(1-giou), sum_bce} (zero them before the first
  * level); phase 1 writes d_cls_ctr [n][hw][grad_stride] (d logit, d centerness at +0/+1; the caller zero-fills the

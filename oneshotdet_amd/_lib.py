@@ -34,6 +34,7 @@ SIGNATURES = {
     "osd_conv2d_fwd": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_fwd_grouped": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_fwd_multi": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "osd_conv2d_fwd_multi_gn": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "osd_pack_conv_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "osd_pack_stem_weight": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "osd_pack_image": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "osd_conv2d_wgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
     "osd_groupnorm_relu_fwd_levels": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
     "osd_groupnorm_relu_bwd_levels": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "osd_groupnorm_relu_bwd_levels_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_uint32, _p]),
     "osd_sgd_momentum_multi": (_i, [_p, _p, _i, _p, _p, _p, _f, _f, _i, _p]),
     "osd_pack_multi": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _p]),
     "osd_conv2d_wgrad_grouped": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

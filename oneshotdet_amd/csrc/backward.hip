@@ -3,6 +3,7 @@
 // ROIAlign backward, GroupNorm(+ReLU) backward, naive strided data gradient for the two tiny 3x3/2 convs (P6/P7),
 // weight-gradient unpacking (packed [Cout][R][S][Cin] fp32 -> OIHW, FrozenBN scale applied).
 #include "osd_common.h"
+#include "conv_params.h"
 
 namespace {
 
@@ -457,7 +458,7 @@ template <typename T> __global__ void cast_from_f32_kernel(const float* __restri
 // S1 = sum_g dz*gamma, S2 = sum_g dz*gamma*xhat; dgamma_c = sum dz*xhat, dbeta_c = sum dz.
 // xhat comes from the saved per-(image, channel) normalisation xa = rstd, xb = -mean * rstd (never (z - beta) / gamma:
 // gamma == 0 is a legal parameter value).  The kernels (all FPN levels of a tower layer per launch) follow further down.
-constexpr int kGnSplits = 64;
+constexpr int kGnSplits = kGnSlabs;      // conv_params.h: the conv epilogue that gathers the backward statistics uses the same slabs
 
 // naive data gradient for strided convs (used for the two 3x3/2 convs P6, P7: M <= 1664 pixels):
 // dx[n,hi,wi,ci] = sum_{r,s,co : (hi+pad-r) % stride == 0 ...} dy[n,ho,wo,co] * w[co][r][s][ci]  (forward-packed weights)
@@ -890,9 +891,10 @@ template <typename T>
 __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const float* __restrict__ ab, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ ws,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int n, int c,
-                                                            int groups) {
+                                                            int groups, unsigned fused_mask) {
   constexpr int E = Chunk<T>::N;
   const int lvl = blockIdx.z, img = blockIdx.y, split = blockIdx.x;
+  if ((fused_mask >> lvl) & 1u) return;      // this level's sums were gathered by the conv that wrote dt (conv_params.h: ConvGnb)
   const int hw = L.hw[lvl];
   const T* u = reinterpret_cast<const T*>(L.x[lvl]);
   const T* dt = reinterpret_cast<const T*>(L.dy[lvl]);
@@ -1095,6 +1097,11 @@ extern "C" int osd_groupnorm_relu_fwd_levels(int n_levels, const void* const* xs
   int rc = gn_levels_fill(L, n_levels, xs, nullptr, ys, hws);
   if (rc) return rc;
   dim3 g1(kGnSplits, n, n_levels), g2(gn_apply_blocks(), n, n_levels);
+#ifdef OSD_GN_DIAG      // diagnostic build: OSD_GN_SKIP=1 (forward) / 2 (backward) / 3 leaves the statistics launches out (garbage results)
+  static int skip = -1;
+  if (skip < 0) { const char* e = getenv("OSD_GN_SKIP"); skip = e ? atoi(e) : 0; }
+  if (!(skip & 1))
+#endif
   OSD_DISPATCH_DTYPE(dtype,
       hipLaunchKernelGGL(gnl_stats_kernel<float>, g1, dim3(256), 0, OSD_STREAM(stream), L, ws, n, c, groups),
       hipLaunchKernelGGL(gnl_stats_kernel<__bf16>, g1, dim3(256), 0, OSD_STREAM(stream), L, ws, n, c, groups));
@@ -1106,10 +1113,24 @@ extern "C" int osd_groupnorm_relu_fwd_levels(int n_levels, const void* const* xs
   return osd_check_launch("gnl_apply");
 }
 
+// fused_mask: bit l set = level l's slab sums in ws (both parts) were accumulated by osd_conv2d_fwd_multi_gn into ZEROED memory;
+// the statistics pass skips those levels (and is not launched when every level is fused)
+extern "C" int osd_groupnorm_relu_bwd_levels_fused(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
+                                                   const int32_t* hws, const float* ab, const float* gamma, const float* beta,
+                                                   float* ws, float* dgamma, float* dbeta, int n, int c, int groups, int dtype,
+                                                   uint32_t fused_mask, void* stream);
+
 extern "C" int osd_groupnorm_relu_bwd_levels(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
                                              const int32_t* hws, const float* ab, const float* gamma, const float* beta,
                                              float* ws, float* dgamma, float* dbeta, int n, int c, int groups, int dtype,
                                              void* stream) {
+  return osd_groupnorm_relu_bwd_levels_fused(n_levels, us, dts, dus, hws, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, dtype, 0u, stream);
+}
+
+extern "C" int osd_groupnorm_relu_bwd_levels_fused(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
+                                                   const int32_t* hws, const float* ab, const float* gamma, const float* beta,
+                                                   float* ws, float* dgamma, float* dbeta, int n, int c, int groups, int dtype,
+                                                   uint32_t fused_mask, void* stream) {
   const int e = dtype == OSD_BF16 ? 8 : 4;
   if (!gamma || !beta || !ab || !ws || !dgamma || !dbeta || !dts || c % e != 0 || c > 512 || c / e > 256 ||
       256 % (c / e) != 0 || groups > 64 || c % groups != 0 || (c / groups) % e != 0)
@@ -1118,9 +1139,15 @@ extern "C" int osd_groupnorm_relu_bwd_levels(int n_levels, const void* const* us
   int rc = gn_levels_fill(L, n_levels, us, dts, dus, hws);
   if (rc) return rc;
   dim3 g1(kGnSplits, n, n_levels), g2(gn_apply_blocks(), n, n_levels);
+#ifdef OSD_GN_DIAG
+  static int skip = -1;
+  if (skip < 0) { const char* e = getenv("OSD_GN_SKIP"); skip = e ? atoi(e) : 0; }
+  if (!(skip & 2))
+#endif
+  if ((fused_mask & ((1u << n_levels) - 1u)) != ((1u << n_levels) - 1u))
   OSD_DISPATCH_DTYPE(dtype,
-      hipLaunchKernelGGL(gnl_bwd_stats_kernel<float>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups),
-      hipLaunchKernelGGL(gnl_bwd_stats_kernel<__bf16>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups));
+      hipLaunchKernelGGL(gnl_bwd_stats_kernel<float>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, fused_mask),
+      hipLaunchKernelGGL(gnl_bwd_stats_kernel<__bf16>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, fused_mask));
   rc = osd_check_launch("gnl_bwd_stats");
   if (rc) return rc;
   OSD_DISPATCH_DTYPE(dtype,

@@ -12,6 +12,7 @@ namespace {
 struct ConvView {
   const void* x; void* y; const void* res; const void* mask; const float* scale_dev; const void* w; const float* bias;
   int H, W, Ho, Wo, M, sN, sH, HoWo, res_h, res_w;
+  ConvGnb gn;
 };
 
 // tile_m: global pixel-tile index of this workgroup; on return it is the index inside the selected segment
@@ -20,6 +21,7 @@ __device__ __forceinline__ ConvView conv_select_view(const ConvKParams& p, int& 
   q.x = p.x; q.y = p.y; q.res = p.res; q.mask = p.mask; q.scale_dev = p.act_scale_dev; q.w = p.w; q.bias = p.bias;
   q.H = p.H; q.W = p.W; q.Ho = p.Ho; q.Wo = p.Wo; q.M = p.M; q.sN = p.sN; q.sH = p.sH;
   q.res_h = p.res_h; q.res_w = p.res_w;
+  q.gn.u = nullptr; q.gn.ab = nullptr; q.gn.gamma = nullptr; q.gn.ws = nullptr; q.gn.pw = nullptr;
   if (p.n_seg > 0) {
     int si = 0;
 #pragma unroll
@@ -36,6 +38,10 @@ __device__ __forceinline__ ConvView conv_select_view(const ConvKParams& p, int& 
     q.w = (const void*)OSD_KSEG(u64, w); q.bias = (const float*)OSD_KSEG(u64, bias);
     q.H = OSD_KSEG(int, H); q.W = OSD_KSEG(int, W); q.Ho = OSD_KSEG(int, Ho); q.Wo = OSD_KSEG(int, Wo);
     q.M = OSD_KSEG(int, M); q.sN = OSD_KSEG(int, sN); q.sH = OSD_KSEG(int, sH);
+    if (p.gn_groups > 0) {
+      q.gn.u = (const void*)OSD_KSEG(u64, gn.u); q.gn.ab = (const float*)OSD_KSEG(u64, gn.ab);
+      q.gn.gamma = (const float*)OSD_KSEG(u64, gn.gamma); q.gn.ws = (float*)OSD_KSEG(u64, gn.ws); q.gn.pw = (float*)OSD_KSEG(u64, gn.pw);
+    }
     tile_m -= OSD_KSEG(int, tile_begin);
 #undef OSD_KSEG
     q.res_h = q.Ho >> 1; q.res_w = q.Wo >> 1;     // nearest-2x top-down add: the addend is exactly half size (checked by the host)
@@ -48,10 +54,13 @@ __device__ __forceinline__ ConvView conv_select_view(const ConvKParams& p, int& 
 // pixels (wm*TM+j)*16..) through a private LDS region and writes NHWC runs of TN*16 channels with 16-byte-per-lane
 // accesses; all residual loads of a pass are issued before any arithmetic.  The caller has already made the LDS ring
 // reusable (barrier, no DMA in flight).
-template <typename T, int TM, int TN, bool TWO_REGIONS = false>
+template <typename T, int TM, int TN, bool TWO_REGIONS = false, bool GNB = false>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKParams& p, const ConvView& q, char* smem,
                                               int wave, int wm, int wn, int lane, int m0, int n0,
                                               const float* pre_bias = nullptr) {
+  // GNB: the fast path also gathers the GroupNorm-backward statistics of ConvGnb (conv_params.h) from the values it stores —
+  // AFTER their rounding to T, the numbers a separate pass over the stored tensor would read.  The launcher guarantees that the
+  // segments that ask for it consist of whole tiles and that a wave's rows stay inside one image
   // TWO_REGIONS: the fast path's passes alternate between two private staging regions per wave (the caller's LDS must hold
   // 2 x waves x ROWS x CSW bytes), so the staging writes of pass p + 1 need not wait for the reads of pass p
   // pre_bias (optional): the fast path's EPC bias values of this lane (channels n0 + wn * TN * 16 + (lane % CPR) * EPC ..),
@@ -99,6 +108,38 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
       }
     }
     const float escale = p.act == OSD_ACT_EXP_SCALE ? (q_scale_dev ? *(const OSD_G float*)q_scale_dev : p.act_scale) : 1.f;
+    // GroupNorm-backward statistics: z = a u + b decides dz = z > 0 ? dt : 0; with xhat = xa u + xb per (image, channel) every
+    // sum the backward needs follows from two per-channel sums, S = sum dz and Su = sum dz * u, so only a, b live in the loop
+    [[maybe_unused]] bool gn_on = false;
+    [[maybe_unused]] float ga[EPC], gb[EPC], gS[EPC], gSu[EPC];
+    [[maybe_unused]] const OSD_G T* ug = (const OSD_G T*)(q.gn.u);
+    [[maybe_unused]] int gn_img = 0;
+    typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type VecU;
+    [[maybe_unused]] VecU uu[ITER], uu_next[ITER];
+    if constexpr (GNB) {
+      gn_on = q.gn.u != nullptr;
+      if (gn_on) {
+        gn_img = (m0 + wm * TM * 16) / q_HoWo;
+        const OSD_G float* abg = (const OSD_G float*)(q.gn.ab) + (size_t)gn_img * p.Cout + c;
+        const size_t plane = (size_t)p.gn_n * p.Cout;
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) {
+          const f32x4 a4 = *(const OSD_G f32x4*)(abg + e), b4 = *(const OSD_G f32x4*)(abg + plane + e);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { ga[e + k] = a4[k]; gb[e + k] = b4[k]; gS[e + k] = 0.f; gSu[e + k] = 0.f; }
+        }
+        // u of pass 0; the loads of pass ps + 1 are issued before the stores of pass ps, so that waiting for them (vmcnt counts
+        // loads and stores in order) never waits for a store
+        const int mrow0 = m0 + (wm * TM) * 16 + lane / CPR;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+#ifdef OSD_GNB_NO_ULOAD      // diagnostic: every load reads the first row
+          uu[it] = *(const OSD_G VecU*)(ug + c);
+#else
+          uu[it] = *(const OSD_G VecU*)(ug + (size_t)(mrow0 + it * (64 / CPR)) * p.out_stride + c);
+#endif
+      }
+    }
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       char* stage_p = stage + (TWO_REGIONS ? (ps & 1) * (ROWS * CSW) : 0);
@@ -129,6 +170,17 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
 #pragma unroll
         for (int it = 0; it < ITER; ++it)
           mm[it] = *(const OSD_G Vec*)(mkg + (size_t)(mrow + it * (64 / CPR)) * p.out_stride + c);
+      }
+      if constexpr (GNB) {
+        if (gn_on && ps + 1 < NPASS) {
+#pragma unroll
+          for (int it = 0; it < ITER; ++it)
+#ifdef OSD_GNB_NO_ULOAD
+            uu_next[it] = *(const OSD_G VecU*)(ug + c);
+#else
+            uu_next[it] = *(const OSD_G VecU*)(ug + (size_t)(mrow + ROWS + it * (64 / CPR)) * p.out_stride + c);
+#endif
+        }
       }
       float v[ITER][EPC];
 #pragma unroll
@@ -177,6 +229,58 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
 #else
         *(OSD_G Vec*)(yg + (size_t)(mrow + it * (64 / CPR)) * p.out_stride + c) = o;
 #endif
+        if constexpr (GNB) {
+          if (gn_on) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+              const float uval = (float)uu[it][e];
+              const float dz = fmaf(uval, ga[e], gb[e]) > 0.f ? (float)o[e] : 0.f;
+              gS[e] += dz;
+              gSu[e] = fmaf(dz, uval, gSu[e]);
+            }
+          }
+        }
+      }
+      if constexpr (GNB) {
+        if (gn_on) {
+#pragma unroll
+          for (int it = 0; it < ITER; ++it) uu[it] = uu_next[it];
+        }
+      }
+    }
+    if constexpr (GNB) {
+      if (gn_on) {
+        // lanes cc, cc + CPR, ... hold the same channel chunk: fold them, then lanes 0 .. CPR - 1 turn the wave's S, Su into the
+        // sums of the backward pass and add them to this (image, slab)
+#pragma unroll
+        for (int off = CPR; off < 64; off <<= 1) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) { gS[e] += __shfl_xor(gS[e], off); gSu[e] += __shfl_xor(gSu[e], off); }
+        }
+#ifdef OSD_GNB_NO_ATOMICS      // diagnostic
+        if (lane < CPR && gS[0] == 12345.678f) {
+#else
+        if (lane < CPR) {
+#endif
+          const OSD_G float* abg = (const OSD_G float*)(q.gn.ab) + (size_t)gn_img * p.Cout + c;
+          const size_t plane = (size_t)p.gn_n * p.Cout;
+          const OSD_G float* gmg = (const OSD_G float*)(q.gn.gamma) + c;
+          const int slab = (blockIdx.x * 8 + wave) & (kGnSlabs - 1);
+          const int cpg = p.Cout / p.gn_groups;
+          OSD_G float* wsg = (OSD_G float*)(q.gn.ws) + (((size_t)gn_img * kGnSlabs + slab) * p.gn_groups + c / cpg) * 2;
+          OSD_G float* pwg = (OSD_G float*)(q.gn.pw) + (((size_t)gn_img * kGnSlabs + slab) * 2) * p.Cout + c;
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            const float dg = fmaf(abg[2 * plane + e], gSu[e], abg[3 * plane + e] * gS[e]);     // sum dz * xhat
+            s1 = fmaf(gmg[e], gS[e], s1);
+            s2 = fmaf(gmg[e], dg, s2);
+            (void)__hip_atomic_fetch_add(pwg + e, dg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(pwg + p.Cout + e, gS[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          (void)__hip_atomic_fetch_add(wsg, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          (void)__hip_atomic_fetch_add(wsg + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     return;

@@ -339,7 +339,7 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
   p.act = d->act; p.act_scale = d->act_scale; p.act_scale_dev = act_scale_dev; p.relu_in = d->relu_in;
   const long long M = (long long)d->n * d->ho * d->wo;
   if (M <= 0 || M > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad M");
-  p.M = (int)M; p.tilesM = p.tilesN = p.KT = 0; p.n_seg = 0;
+  p.M = (int)M; p.tilesM = p.tilesN = p.KT = 0; p.n_seg = 0; p.gn_n = p.gn_groups = 0;
   p.x2 = nullptr; p.w2 = nullptr; p.cin1 = p.x2_sN = p.x2_sH = p.x2_sW = p.st2 = 0;
   if (src2 != nullptr) {
     // second pixel source (see osd_conv_src2): K = cin + cin2, the packed weights hold both parts side by side
@@ -400,10 +400,15 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
 // size AND their own weights / bias: the five FPN levels of an FCOS tower conv (fcos.py:83-99 applies the same modules to
 // every level: they repeat one weight pointer), both towers at once, or the same layer of the target and the query backbone
 // (generalized_rcnn.py:270-272: two R-50-FPN with separate parameters walk the same graph).  LDS-DMA kernels only.
-extern "C" int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys,
-                                    const void* const* residuals, const void* const* masks,
-                                    const float* const* act_scale_devs, const int32_t* ns, const int32_t* hs,
-                                    const int32_t* ws, const void* const* wts, const float* const* biases, void* stream) {
+struct ConvGnArgs {      // osd_conv2d_fwd_multi_gn's extra arguments (per segment; a null gn_us[i] leaves segment i out)
+  const void* const* us; const float* const* abs; const float* const* gammas; float* const* wss; float* const* pws;
+  int n, groups;
+};
+
+static int conv_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys,
+                          const void* const* residuals, const void* const* masks,
+                          const float* const* act_scale_devs, const int32_t* ns, const int32_t* hs,
+                          const int32_t* ws, const void* const* wts, const float* const* biases, const ConvGnArgs* gn, void* stream) {
   if (!d || !xs || !ys || !ns || !hs || !ws || !wts || !biases || n_seg < 1 || n_seg > kConvMaxSeg)
     return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad arguments (1..%d segments)", kConvMaxSeg);
   if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad dtype %d", d->dtype);
@@ -427,6 +432,9 @@ extern "C" int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const voi
   p.tilesM = p.tilesN = p.KT = 0;
   p.n_seg = n_seg;
   p.x2 = nullptr; p.w2 = nullptr; p.cin1 = p.x2_sN = p.x2_sH = p.x2_sW = p.st2 = 0;
+  p.gn_n = gn ? gn->n : 0; p.gn_groups = gn ? gn->groups : 0;
+  if (gn && (gn->groups < 1 || gn->n < 1 || !gn->us || !gn->abs || !gn->gammas || !gn->wss || !gn->pws))
+    return osd_fail(OSD_ERR_INVALID_ARG, "conv_multi_gn: bad statistics arguments");
   long long mtot = 0;
   for (int i = 0; i < kConvMaxSeg; ++i) {
     const int j = i < n_seg ? i : 0;
@@ -446,6 +454,12 @@ extern "C" int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const voi
     if (d->res_mode == OSD_RES_UP2X && ((sg.Ho | sg.Wo) & 1))
       return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: the nearest-2x addend needs an even output size (segment %d: %d x %d)", j, sg.Ho, sg.Wo);
     sg.M = (int)M; sg.sH = ws[j] * d->cin; sg.sN = hs[j] * ws[j] * d->cin; sg.tile_begin = 0;
+    sg.gn.u = nullptr; sg.gn.ab = nullptr; sg.gn.gamma = nullptr; sg.gn.ws = nullptr; sg.gn.pw = nullptr;
+    if (gn && gn->us[j]) {
+      if (!gn->abs[j] || !gn->gammas[j] || !gn->wss[j] || !gn->pws[j] || ns[j] != gn->n)
+        return osd_fail(OSD_ERR_INVALID_ARG, "conv_multi_gn: segment %d: null statistics argument or a batch other than gn_n", j);
+      sg.gn.u = gn->us[j]; sg.gn.ab = gn->abs[j]; sg.gn.gamma = gn->gammas[j]; sg.gn.ws = gn->wss[j]; sg.gn.pw = gn->pws[j];
+    }
     if (i < n_seg) mtot += M;
   }
   if (mtot > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: too many pixels");
@@ -463,6 +477,8 @@ extern "C" int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const voi
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d not built", d->algo);
     if (tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: skinny tile on a wide conv");
   }
+  if (gn && !(tile == 6 && variant == 1))
+    return osd_fail(OSD_ERR_UNSUPPORTED, "conv_multi_gn: only the software-pipelined 3x3 kernel (algo 15) gathers GroupNorm statistics");
   if (tile == 5) {
     if (d->dtype != OSD_BF16) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: the ping-pong 256x256 kernel is bf16 only");
     return osd_conv_p8_launch(p, reinterpret_cast<hipStream_t>(stream));
@@ -472,6 +488,25 @@ extern "C" int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const voi
     return variant == 1 ? osd_conv_sp_launch(p, reinterpret_cast<hipStream_t>(stream)) : osd_conv_xr_launch(p, reinterpret_cast<hipStream_t>(stream));
   }
   return osd_conv_dma_dispatch(d->dtype, tile, variant, p, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys,
+                                    const void* const* residuals, const void* const* masks,
+                                    const float* const* act_scale_devs, const int32_t* ns, const int32_t* hs,
+                                    const int32_t* ws, const void* const* wts, const float* const* biases, void* stream) {
+  return conv_fwd_multi(d, n_seg, xs, ys, residuals, masks, act_scale_devs, ns, hs, ws, wts, biases, nullptr, stream);
+}
+
+// osd_conv2d_fwd_multi for a data-gradient conv whose outputs dt feed a GroupNorm + ReLU backward: the epilogue also gathers,
+// for every segment with gn_us[i] != nullptr, the sums osd_groupnorm_relu_bwd_levels_fused reads (conv_params.h: ConvGnb)
+extern "C" int osd_conv2d_fwd_multi_gn(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys, const int32_t* ns,
+                                       const int32_t* hs, const int32_t* ws, const void* const* wts, const float* const* biases,
+                                       const void* const* gn_us, const float* const* gn_abs, const float* const* gn_gammas,
+                                       float* const* gn_wss, float* const* gn_pws, int gn_n, int gn_groups, void* stream) {
+  ConvGnArgs gn{gn_us, gn_abs, gn_gammas, gn_wss, gn_pws, gn_n, gn_groups};
+  if (d && (d->res_mode != OSD_RES_NONE || d->act != OSD_ACT_NONE))
+    return osd_fail(OSD_ERR_UNSUPPORTED, "conv_multi_gn: no residual / activation");
+  return conv_fwd_multi(d, n_seg, xs, ys, nullptr, nullptr, nullptr, ns, hs, ws, wts, biases, &gn, stream);
 }
 
 // the same with ONE weight / bias pointer for all pairs (the FPN levels of one conv)

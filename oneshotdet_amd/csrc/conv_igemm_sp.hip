@@ -61,6 +61,7 @@ constexpr int SP_BBYTES = SP_BN * SP_KB;
 constexpr int SP_LDS = 2 * SP_ABYTES + 2 * SP_BBYTES;
 constexpr unsigned SP_OOB = 0x80000000u;            // beyond any buffer of < 2 GiB: the DMA writes zeros
 
+template <bool GNB>      // GNB: the epilogue also gathers the GroupNorm-backward statistics (ConvGnb, conv_params.h)
 __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   typedef __bf16 T;
   constexpr int TM = SP_TM, TN = SP_TN, KB = SP_KB;
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   return;
 #endif
   const float pre_bias[8] = {bq[0][0], bq[0][1], bq[0][2], bq[0][3], bq[1][0], bq[1][1], bq[1][2], bq[1][3]};
-  conv_epilogue<T, TM, TN, true>(acc, p, q, smem, wave, wm, wn, lane, m0, n0, pre_bias);   // 8 waves x 2 x 8,704 B <= SP_LDS
+  conv_epilogue<T, TM, TN, true, GNB>(acc, p, q, smem, wave, wm, wn, lane, m0, n0, pre_bias);   // 8 waves x 2 x 8,704 B <= SP_LDS
 #ifdef OSD_SP_STAMPS
   if (lane == 0 && p.act_scale_dev != nullptr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -377,11 +378,26 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream) {
   p.KT = p.Ktot / SP_BKE;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
     attr_done = true;
   }
   const long long nblocks = (long long)p.tilesM * p.tilesN;
   if (nblocks <= 0 || nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "conv(sp): bad grid");
-  hipLaunchKernelGGL(conv_sp_kernel, dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+  if (p.gn_groups > 0) {
+    // GroupNorm-backward statistics in the epilogue: whole tiles only (fast path), a wave's 128 rows inside one image, one
+    // 16-byte channel chunk inside one group
+    if (p.n_seg <= 0 || p.Cout % SP_BN != 0 || p.out_stride % 8 != 0 || p.Cout % p.gn_groups != 0 || (p.Cout / p.gn_groups) % 8 != 0 ||
+        p.res_mode != OSD_RES_NONE || p.act != OSD_ACT_NONE)
+      return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): GroupNorm statistics need a plain multi-segment conv with Cout %% 256 == 0 and groups of whole 16-byte chunks");
+    for (int i = 0; i < p.n_seg; ++i) {
+      if (!p.seg[i].gn.u) continue;
+      if (p.seg[i].M % SP_BM != 0 || (p.seg[i].Ho * p.seg[i].Wo) % (SP_BM / 2) != 0 || p.seg[i].M / (p.seg[i].Ho * p.seg[i].Wo) != p.gn_n)
+        return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): GroupNorm statistics need images of whole 128-pixel runs (segment %d)", i);
+    }
+    hipLaunchKernelGGL(conv_sp_kernel<true>, dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+  } else {
+    hipLaunchKernelGGL(conv_sp_kernel<false>, dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+  }
   return osd_check_launch("conv_igemm_sp");
 }

@@ -6,6 +6,20 @@
 // spatial size, and its own weights / bias pointer (the FPN levels of a tower conv repeat one pointer; the two towers, or
 // the target and the query backbone, bring their own)
 constexpr int kConvMaxSeg = 12;
+
+// GroupNorm-backward statistics gathered by the epilogue of the data-gradient conv that PRODUCES dt, the gradient w.r.t. the
+// GroupNorm + ReLU output (conv_igemm_sp.hip only; u == nullptr: off for this segment).  With z = a u + b, dz = z > 0 ? dt : 0 and
+// xhat = xa u + xb, per output pixel and channel, the epilogue adds (fp32 atomics) the sums the backward apply kernel
+// (backward.hip: gnl_bwd_apply_kernel) reads — so that the separate pass over (u, dt) of gnl_bwd_stats_kernel is not needed
+constexpr int kGnSlabs = 64;   // partial sums per (level, image): spreads the atomics; = OSD_GN_SPLITS of the C ABI
+struct ConvGnb {
+  const void* u;            // the GroupNorm's input at this conv's OUTPUT pixels: [M][out_stride], the conv's dtype
+  const float* ab;          // [4][n][Cout]: a, b, xa, xb of this level (osd_groupnorm_relu_fwd_levels' ab block)
+  const float* gamma;       // [Cout]
+  float* ws;                // [n][kGnSlabs][groups][2]: sum dz * gamma, sum dz * gamma * xhat
+  float* pw;                // [n][kGnSlabs][2][Cout]: sum dz * xhat (d gamma), sum dz (d beta)
+};
+
 struct ConvSeg {
   const void* x;
   void* y;
@@ -16,6 +30,7 @@ struct ConvSeg {
   const float* bias;
   int H, W, Ho, Wo, M, sN, sH;
   int tile_begin;     // first pixel tile of this segment (filled by the launcher: depends on the tile height)
+  ConvGnb gn;
 };
 
 struct ConvKParams {
@@ -42,6 +57,7 @@ struct ConvKParams {
   const void* w2;     // optional: the second part's own packed weights [w_rows][Cin - cin1] (w then holds [w_rows][cin1], Ktot =
                       // cin1); nullptr: w holds both parts side by side (Ktot = Cin)
   int cin1, x2_sN, x2_sH, x2_sW, st2;
+  int gn_n, gn_groups;   // ConvSeg.gn: images per level and GroupNorm groups (0: no segment asks for the statistics)
   int n_seg;          // 0 = single problem (fields above); > 0: seg[] overrides x/y/res/mask/act_scale_dev/H/W/Ho/Wo/M/sN/sH
   ConvSeg seg[kConvMaxSeg];
 };

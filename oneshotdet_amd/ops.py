@@ -319,18 +319,43 @@ def conv2d_grouped(xs, pc, pad=0, act=ACT_NONE, residuals=None, masks=None, act_
                         act_scale_devs=act_scale_devs, algo=algo, _whole=_whole)
 
 
+ALGO_SP = 1 + 8 + 6       # tile id 6, variant 1: conv_igemm_sp.hip, the only kernel whose epilogue gathers GroupNorm statistics
+
+
+def gn_bwd_fusable(x, pc, stride=1, pad=1):
+    """Can the data-gradient conv over x (NHWC) gather the GroupNorm-backward statistics of its output pixels
+    (osd_conv2d_fwd_multi_gn)?  The software-pipelined 3x3 kernel's shapes, whole 256-pixel tiles, images of whole 128-pixel runs."""
+    n, h, w, c = x.shape
+    return (x.dtype == torch.bfloat16 and pc.r == 3 and pc.s == 3 and stride == 1 and pad == 1 and w in (64, 128, 256) and c % 64 == 0 and
+            pc.cout_store % 256 == 0 and (h * w) % 128 == 0 and (n * h * w) % 256 == 0)
+
+
 def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mode=None, masks=None, act_scale=1.0,
-                 act_scale_devs=None, algo=None, _whole=False):
+                 act_scale_devs=None, algo=None, _whole=False, gnb=None):
     """ONE launch of the same conv geometry over several NHWC tensors, each with its own batch / spatial size and its own
     packed weights pcs[i] (osd_conv2d_fwd_multi): the FPN levels of a tower conv (one PackedConv repeated), both towers at
     once, or one layer of the target backbone together with the same layer of the query backbone.  Or TWO launches (large
     segments / small segments, in the given order) where the tuner measured that to be faster: 256-pixel tiles on 256 CUs
     quantise badly (P3..P7 at bs=8 are 534 tiles = 2 full rounds plus a third with 22 tiles).
     residuals: addends (res_mode RES_SAME, default, or RES_UP2X: exactly half size); masks: ReLU-backward masks (data
-    gradients); act_scale_devs: one device scalar per segment (the learnable Scale).  Returns the outputs."""
+    gradients); act_scale_devs: one device scalar per segment (the learnable Scale).  Returns the outputs.
+    gnb (data-gradient convs feeding a GroupNorm + ReLU backward): dict(us, abs, gammas, wss, pws: one entry per segment, None
+    where the statistics are not wanted; n, groups) — the leading run of segments with an entry goes out as its own launch of
+    the software-pipelined kernel, whose epilogue gathers the sums (osd_conv2d_fwd_multi_gn); the rest as usual."""
     _chk_dev(*xs)
     k = len(xs)
     pc = pcs[0]
+    if gnb is not None and not _whole:
+        c = 0
+        while c < k and gnb["us"][c] is not None:
+            c += 1
+        assert all(u is None for u in gnb["us"][c:]), "segments that gather GroupNorm statistics must come first"
+        assert residuals is None and masks is None and act == ACT_NONE and act_scale_devs is None
+        if c == 0:
+            return conv2d_multi(xs, pcs, stride, pad, act, algo=algo)
+        head = conv2d_multi(xs[:c], pcs[:c], stride, pad, act, algo=ALGO_SP, _whole=True,
+                            gnb={key: (v[:c] if isinstance(v, list) else v) for key, v in gnb.items()})
+        return head + (conv2d_multi(xs[c:], pcs[c:], stride, pad, act) if c < k else [])
     assert len(pcs) == k and all((q.cout_store, q.w_rows, q.cin_k, q.r, q.s) == (pc.cout_store, pc.w_rows, pc.cin_k, pc.r, pc.s)
                                  and not q.stem for q in pcs), "segments must share the conv geometry"
     if res_mode is None:
@@ -402,6 +427,16 @@ def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mod
 
     def launch():
         _lib.call("osd_conv2d_fwd_multi", C.byref(d), *args)
+    if gnb is not None:
+        d.algo = algo
+        _lib.call("osd_conv2d_fwd_multi_gn", C.byref(d), k, _ptr_array(xs), _ptr_array(outs), ns, hs, ws, _ptr_array([q.w for q in pcs]),
+                  _ptr_array([q.bias for q in pcs]), _ptr_array(gnb["us"]), _ptr_array(gnb["abs"]), _ptr_array(gnb["gammas"]),
+                  _ptr_array(gnb["wss"]), _ptr_array(gnb["pws"]), int(gnb["n"]), int(gnb["groups"]), _stream())
+        for i in range(k):
+            _rec("conv", x=xs[i], w=pcs[i].w, bias=pcs[i].bias, cout=pc.cout_store, r=pc.r, s=pc.s, stem=False, stride=stride, pad=pad,
+                 act=act, res=None, res_mode=res_mode, relu_in=False, act_scale=float(act_scale), act_scale_dev=None, mask=None,
+                 out=outs[i])
+        return outs
     if algo is None:
         key = ("grouped", d.dtype, tuple(tuple(o.shape[:3]) for o in outs), d.cout, d.cin, d.r, d.s, stride, pad, d.res_mode,
                act, masks is not None)
@@ -1050,15 +1085,31 @@ def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5):
     return ys, ab
 
 
-def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32):
+def gn_bwd_ws_numel(k, n, c, groups=32):
+    """floats of osd_groupnorm_relu_bwd_levels' ws for k levels: the group sums, then the d gamma / d beta partials"""
+    return k * n * GN_SPLITS * (groups * 2 + 2 * c)
+
+
+def gn_bwd_ws_parts(ws, k, n, c, groups=32):
+    """-> per level (group-sum block, d gamma / d beta block) views of ws: what osd_conv2d_fwd_multi_gn accumulates into"""
+    a = n * GN_SPLITS * groups * 2
+    b = n * GN_SPLITS * 2 * c
+    return [(ws[l * a:(l + 1) * a], ws[k * a + l * b:k * a + (l + 1) * b]) for l in range(k)]
+
+
+def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32, ws=None, fused_mask=0):
+    """ws / fused_mask: the levels whose bit is set had their sums accumulated into (the zeroed) ws by the conv that wrote dts
+    (conv2d_multi(gnb=...)); their statistics pass is skipped."""
     n, _, _, c = us[0].shape
     k = len(us)
     dev = us[0].device
     dus = [torch.empty_like(u) for u in us]
-    ws = torch.empty((k * n * GN_SPLITS * (groups * 2 + 2 * c),), device=dev, dtype=torch.float32)
+    if ws is None:
+        assert fused_mask == 0
+        ws = torch.empty((gn_bwd_ws_numel(k, n, c, groups),), device=dev, dtype=torch.float32)
     hws = (C.c_int32 * k)(*[u.shape[1] * u.shape[2] for u in us])
-    _lib.call("osd_groupnorm_relu_bwd_levels", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
-              _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), _stream())
+    _lib.call("osd_groupnorm_relu_bwd_levels_fused", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
+              _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), int(fused_mask), _stream())
     _rec("gn_relu_bwd", us=list(us), dts=list(dts), gamma=gamma, beta=beta, groups=groups, dgamma=dgamma, dbeta=dbeta, outs=dus)
     return dus
 

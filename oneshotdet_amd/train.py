@@ -129,6 +129,12 @@ class TrainEngine(object):
         if ordered_wgrad is None:
             ordered_wgrad = os.environ.get("OSD_WGRAD_ORDERED", "0") != "0"
         self.ordered_wgrad = bool(ordered_wgrad)
+        # GroupNorm-backward statistics gathered by the data-gradient convs' epilogues (atomics: not in ordered mode).  Built,
+        # parity-tested and OFF: the epilogue's extra read of u costs the conv more (+65 us per launch over P3 + P4 of both
+        # towers, +130 with the arithmetic and the atomics) than the statistics pass it replaces (2 x 26 us, at the HBM
+        # roofline); 11.70 vs 11.34 ms per step in same-box A/B.  OSD_GN_FUSION=1 turns it on
+        self.fuse_gn_bwd = (not self.ordered_wgrad and self.dtype == torch.bfloat16 and os.environ.get("OSD_GN_FUSION", "0") != "0")
+        self._gnb_ws = {}
         # torch hands out stream handles from a pool, so a handle may carry an earlier engine's registration: set the mode of
         # this engine's weight-gradient streams explicitly either way (close() / __del__ release the scratch buffers)
         # (the second stage's weight gradients run on the proposal stream: box_head_forward_backward)
@@ -751,6 +757,23 @@ class TrainEngine(object):
             dpred = [pred_grads[l][k] for l in range(nl)]
             self._wgrad_grouped(pc, [(t_last[l], dpred[l]) for l in range(nl)], k)
             d_t[tw] = self._dgrad_levels(pc, dpred)
+        # GroupNorm-backward statistics of layer i - 1 are gathered by the epilogue of the data-gradient conv of layer i (the
+        # conv that writes the gradient w.r.t. that GroupNorm's output) where the kernel can (ops.gn_bwd_fusable: the large
+        # levels); the GroupNorm backward of those levels then is one pass over (u, dt) instead of two.  Not in ordered mode:
+        # the sums are added atomically
+        fuse = self.fuse_gn_bwd and not any(isinstance(ctxs[tw][0][0][2], list) for tw in towers)
+        fused = {tw: 0 for tw in towers}        # levels of d_t[tw] whose sums are already in that layer's workspace
+        if fuse:
+            u0 = ctxs[towers[0]][0][0][1]
+            n_img, c_gn = u0[0].shape[0], u0[0].shape[-1]
+            numel = ops.gn_bwd_ws_numel(nl, n_img, c_gn, spec.GN_GROUPS)
+            key = (tuple(towers), nl, n_img, c_gn)
+            if self._gnb_ws.get("key") != key:
+                self._gnb_ws = {"key": key, "buf": torch.empty((len(towers) * spec.NUM_CONVS * numel,), device=self.device, dtype=torch.float32)}
+            buf = self._gnb_ws["buf"]
+            buf.zero_()
+            gws = {(tw, i): buf[(k * spec.NUM_CONVS + i) * numel:(k * spec.NUM_CONVS + i + 1) * numel]
+                   for k, tw in enumerate(towers) for i in range(spec.NUM_CONVS)}
         for i in range(spec.NUM_CONVS - 1, -1, -1):
             dus = {}
             for tw in towers:
@@ -764,12 +787,33 @@ class TrainEngine(object):
                         dus[tw] += ops.groupnorm_relu_bwd_levels(u[lo:lo + k], d_t[tw][lo:lo + k], ab_g, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
                         lo += k
                 else:
-                    dus[tw] = ops.groupnorm_relu_bwd_levels(u, d_t[tw], ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
+                    dus[tw] = ops.groupnorm_relu_bwd_levels(u, d_t[tw], ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS,
+                                                            ws=gws[(tw, i)] if fuse else None, fused_mask=fused[tw])
                 items[tw] += [(t_in[l], dus[tw][l], c.gw, c.bn_scale, c.gb if c.has_bias else None) for l in range(nl)]
             dys = [dus[tw][l] for l in range(nl) for tw in towers]
             c0 = cv["%s%s.%d" % (h, towers[0], 3 * i)]
             pds = [cv["%s%s.%d" % (h, tw, 3 * i)].pd for l in range(nl) for tw in towers]
-            out = ops.conv2d_multi(dys, pds, pad=c0.r - 1 - (c0.r // 2))
+            pad = c0.r - 1 - (c0.r // 2)
+            gnb = None
+            if fuse and i > 0:
+                nf = 0          # leading levels the kernel can gather the sums of
+                while nf < nl and all(ops.gn_bwd_fusable(dus[tw][nf], cv["%s%s.%d" % (h, tw, 3 * i)].pd, 1, pad) for tw in towers):
+                    nf += 1
+                if nf > 0:
+                    gnb = {"us": [], "abs": [], "gammas": [], "wss": [], "pws": [], "n": n_img, "groups": spec.GN_GROUPS}
+                    for l in range(nl):
+                        for tw in towers:
+                            _, u_prev, ab_prev = ctxs[tw][0][i - 1]
+                            (gw_prev, _), _ = self.gn("%s%s.%d" % (h, tw, 3 * (i - 1) + 1))
+                            ws_l, pw_l = ops.gn_bwd_ws_parts(gws[(tw, i - 1)], nl, n_img, c_gn, spec.GN_GROUPS)[l]
+                            on = l < nf
+                            gnb["us"].append(u_prev[l] if on else None)
+                            gnb["abs"].append(ab_prev[l] if on else None)
+                            gnb["gammas"].append(gw_prev if on else None)
+                            gnb["wss"].append(ws_l if on else None)
+                            gnb["pws"].append(pw_l if on else None)
+                fused = {tw: (1 << nf) - 1 for tw in towers}
+            out = ops.conv2d_multi(dys, pds, pad=pad, gnb=gnb)
             for k, tw in enumerate(towers):
                 d_t[tw] = out[k::nt]
         for tw in towers:

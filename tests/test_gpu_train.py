@@ -717,6 +717,74 @@ def test_groupnorm_relu_levels_forward_backward_at_fpn_sizes(n, dt):
     assert (db.cpu() - b.grad).abs().max() <= tol * b.grad.abs().max()
 
 
+@pytest.mark.parametrize("fused_levels", [2, 1])
+def test_groupnorm_backward_statistics_gathered_by_the_data_gradient_conv(fused_levels):
+    """osd_conv2d_fwd_multi_gn + osd_groupnorm_relu_bwd_levels_fused: the 3x3 data-gradient conv that writes dt (the gradient
+    w.r.t. a GroupNorm + ReLU output) also gathers that GroupNorm's backward sums in its epilogue, and the GroupNorm backward
+    then skips its statistics pass for those levels.  Two towers x two levels (4 x 64 and 2 x 64 maps of 2 images: whole
+    256-pixel tiles, whole 128-pixel runs per image) with separate weights and GroupNorm parameters, a zero and a negative
+    gamma, with both levels or only the first one gathered: dt is bit-identical to the plain launch, du equal up to the
+    summation order of the sums (<= 1 bf16 ulp on a few elements), d gamma / d beta to 1e-4 relative."""
+    from oneshotdet_amd import ops
+    n, c, G = 2, 256, 32
+    sizes = [(4, 64), (2, 64)]
+    xs, us, pcs, gammas, betas = [], [], [], [], []
+    for tw in range(2):
+        wt = rnd(c, c, 3, 3, seed=40 + tw) / np.sqrt(c * 9)
+        pcs.append(ops.pack_conv(wt.cuda(), bias=torch.zeros(c).cuda(), dtype=torch.bfloat16))
+        g = rnd(c, seed=50 + tw)
+        g[3], g[100] = 0.0, -0.7
+        gammas.append(g.cuda())
+        betas.append((rnd(c, seed=60 + tw) * 0.3).cuda())
+    seg_x, seg_u, seg_pc, seg_tw = [], [], [], []
+    for l, (h, w) in enumerate(sizes):          # segment order of the engine: level-major, towers inside
+        for tw in range(2):
+            seg_x.append(to_nhwc(rnd(n, c, h, w, seed=70 + 2 * l + tw), torch.bfloat16))
+            seg_u.append(to_nhwc(rnd(n, c, h, w, seed=80 + 2 * l + tw, scale=2) + 0.3, torch.bfloat16))
+            seg_pc.append(pcs[tw]); seg_tw.append(tw)
+    abs_ = []
+    for tw in range(2):
+        _, ab = ops.groupnorm_relu_levels([seg_u[2 * l + tw] for l in range(2)], gammas[tw], betas[tw], G, 1e-5)
+        abs_.append(ab)
+    # plain: conv, then the two-pass GroupNorm backward
+    k = 2 * fused_levels      # the gathering launch covers the leading segments, the rest goes out as a plain launch
+    dts = ops.conv2d_multi(seg_x[:k], seg_pc[:k], pad=1, algo=ops.ALGO_SP, _whole=True)
+    if k < len(seg_x):
+        dts += ops.conv2d_multi(seg_x[k:], seg_pc[k:], pad=1)
+    ref = []
+    for tw in range(2):
+        dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+        dus = ops.groupnorm_relu_bwd_levels([seg_u[2 * l + tw] for l in range(2)], [dts[2 * l + tw] for l in range(2)], abs_[tw],
+                                            gammas[tw], betas[tw], dg, db, G)
+        ref.append((dus, dg, db))
+    # gathered: zeroed workspaces, the conv with the statistics arguments, the GroupNorm backward with the levels' bits set
+    wss = [torch.zeros(ops.gn_bwd_ws_numel(2, n, c, G), device="cuda") for _ in range(2)]
+    gnb = {"us": [], "abs": [], "gammas": [], "wss": [], "pws": [], "n": n, "groups": G}
+    for l in range(2):
+        for tw in range(2):
+            on = l < fused_levels
+            ws_l, pw_l = ops.gn_bwd_ws_parts(wss[tw], 2, n, c, G)[l]
+            gnb["us"].append(seg_u[2 * l + tw] if on else None)
+            gnb["abs"].append(abs_[tw][l] if on else None)
+            gnb["gammas"].append(gammas[tw] if on else None)
+            gnb["wss"].append(ws_l if on else None)
+            gnb["pws"].append(pw_l if on else None)
+    dts2 = ops.conv2d_multi(seg_x, seg_pc, pad=1, gnb=gnb)
+    for a, b in zip(dts, dts2):
+        assert torch.equal(a, b)
+    for tw in range(2):
+        dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+        dus = ops.groupnorm_relu_bwd_levels([seg_u[2 * l + tw] for l in range(2)], [dts2[2 * l + tw] for l in range(2)], abs_[tw],
+                                            gammas[tw], betas[tw], dg, db, G, ws=wss[tw], fused_mask=(1 << fused_levels) - 1)
+        rdus, rdg, rdb = ref[tw]
+        for a, b in zip(dus, rdus):
+            a, b = a.float(), b.float()
+            assert (a - b).abs().max() <= 2 ** -7 * b.abs().max()
+            assert (a != b).float().mean() <= 1e-3
+        torch.testing.assert_close(dg, rdg, rtol=1e-4, atol=1e-4 * float(rdg.abs().max()))
+        torch.testing.assert_close(db, rdb, rtol=1e-4, atol=1e-4 * float(rdb.abs().max()))
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_full_size_batch8_training_step_properties(dt):
     """BASELINE.json configs[2] size (8 x 800x1024 targets, 8 x 127x127 queries).  A batch of 8 identical (image, query,
