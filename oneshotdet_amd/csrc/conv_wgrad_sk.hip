@@ -218,8 +218,15 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_wgrad_sk_kernel(WgradParams g
           sk_dma16(xrs, ok ? off : OOB, st + (unsigned)((WCO + b_sub_d) * OPB + (b_q0 % PPS + i) * 1024));
         }
       };
-      // bias gradient: the workgroups that own (tap 0, ci tile 0) also sum their dY tile over its pixels, one column per thread
-      const bool do_bias = (pdb != nullptr) && (nt == 0) && (tid < TCO);
+      // bias gradient: the workgroups of ci tile 0 also sum their dY tile over its pixels, one column per thread.  The nine taps
+      // of a pixel range see the same dY tile, so they take turns (stage s of the segment belongs to tap s mod 9): a
+      // workgroup that summed every stage ran a third slower than its team, and a team moves in lockstep (tower launch: 812 us
+      // with the bias gradient on tap 0, 606 without it, 669 with turns).  A 16-byte-per-thread form of the sum (all 512 threads,
+      // partial sums in registers or in LDS) needs 8 - 30 more registers and made hipcc spill inside the MFMA loop: 1,035 us.
+      // Ordered mode keeps the sum with tap 0, whose slot the reduction reads
+      const int ntaps = gp.partials != nullptr ? 1 : OSD_KSEG(sidx, int, R) * S;
+      const bool do_bias = (pdb != nullptr) && (ci_tile == 0) && (gp.partials != nullptr ? tap == 0 : true) && (tid < TCO);
+      int bias_turn = (p_lo / BKP + ntaps - (gp.partials != nullptr ? 0 : tap)) % ntaps;      // 0: this stage is mine
       auto bias_stage = [&](int buf) {
         const int sub = tid / TWS, cc = tid % TWS;
         const char* sa = smem + buf * STAGE + sub * OPB;
@@ -287,7 +294,8 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_wgrad_sk_kernel(WgradParams g
       int cur = 0;
       if constexpr (BKP == 64) {
         for (int kt = 0; kt < KT; ++kt) {
-          if (do_bias) bias_stage(cur);
+          if (do_bias && bias_turn == 0) bias_stage(cur);
+          bias_turn = bias_turn + 1 == ntaps ? 0 : bias_turn + 1;
           k_step(bf0, bf1, cur, K1(), std::false_type(), 0);
           k_step(bf1, bf0, cur ^ 1, K0(), std::true_type(), cur);
           cur ^= 1;
@@ -297,14 +305,14 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_wgrad_sk_kernel(WgradParams g
         int kt = 0;
         for (; kt + 1 < KT; kt += 2) {
           const int n1 = cur + 1 == NST ? 0 : cur + 1, n2 = n1 + 1 == NST ? 0 : n1 + 1;
-          if (do_bias) bias_stage(cur);
+          if (do_bias && ntaps == 1) bias_stage(cur);
           k_step(bf0, bf1, n1, K0(), std::true_type(), cur);
-          if (do_bias) bias_stage(n1);
+          if (do_bias && ntaps == 1) bias_stage(n1);
           k_step(bf1, bf0, n2, K0(), std::true_type(), n1);
           cur = n2;
         }
         if (kt < KT) {
-          if (do_bias) bias_stage(cur);
+          if (do_bias && ntaps == 1) bias_stage(cur);
           k_step(bf0, bf1, cur + 1 == NST ? 0 : cur + 1, K0(), std::true_type(), cur);
         }
       }
@@ -318,7 +326,7 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_wgrad_sk_kernel(WgradParams g
               (float*)OSD_KSEG(sidx + 1, u64, db) != pdb;
     }
     if (flush) {
-      const bool do_bias = (pdb != nullptr) && (nt == 0) && (tid < TCO);
+      const bool do_bias = (pdb != nullptr) && (ci_tile == 0) && (gp.partials != nullptr ? tap == 0 : true) && (tid < TCO);
       if (gp.partials != nullptr) {
         // ordered mode (never in team mode): the raw partial tile (and the bias partial of the tap-0 / ci-tile-0 workgroups)
         // goes to this workgroup's slot; channels past Cout / Cin hold zeros (their operands were zero fetches)

@@ -762,9 +762,12 @@ def _tune_wgrad(key, d, launch, dw, db, widths=None):
     cands = wgrad_algo_candidates(d.dtype, d.cout, d.cin)
     if os.environ.get("OSD_WGRAD_XR"):      # the filter-row kernel: correct, never the winner so far — opt-in
         cands = cands + wgrad_xr_candidates(d.dtype, d.cout, d.cin, d.r, d.s, d.stride_h, d.pad_h, widths)
+    verbose = os.environ.get("OSD_TUNE_VERBOSE")
     for algo in cands:
         d.algo = algo
         if not _candidate_runs(lambda: launch(sdw, sdb)):
+            if verbose:
+                print("   wgrad tuner: variant %d code %d refused" % ((algo - 1) & 15, (algo - 1) >> 4))
             continue
         torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -774,6 +777,8 @@ def _tune_wgrad(key, d, launch, dw, db, widths=None):
         ev[1].record()
         torch.cuda.synchronize()
         t = ev[0].elapsed_time(ev[1])
+        if verbose:
+            print("   wgrad tuner: variant %d code %d  %.1f us" % ((algo - 1) & 15, (algo - 1) >> 4, t / 3 * 1e3))
         if t < best_t:
             best, best_t = algo, t
     WGRAD_ALGO_CACHE[key] = best

@@ -57,10 +57,11 @@ def sweep(name, launch, flops, cout, cin, xr=None):
 levels = [(8, 100, 128), (8, 50, 64), (8, 25, 32), (8, 13, 16), (8, 7, 8)]
 if which in ("tower", "all"):
     dws = [torch.zeros(256, 3, 3, 256, device="cuda") for _ in range(4)]
+    dbs = [torch.zeros(256, device="cuda") if os.environ.get("WG_BIAS") else None for _ in range(4)]      # WG_BIAS=1: with the fused bias gradient
     items = []
     for i in range(4):
         for (n, h, w) in levels:
-            items.append((rnd(n, h, w, 256), rnd(n, h, w, 256), dws[i], None, None))
+            items.append((rnd(n, h, w, 256), rnd(n, h, w, 256), dws[i], None, dbs[i]))
     m = sum(n * h * w for n, h, w in levels) * 4
     sweep("tower: 4 convs x 5 levels 3x3 256->256", lambda a: ops.conv2d_wgrad_multi(items, 3, 3, 1, 1, 256, algo=a),
           2.0 * m * 256 * 2304, 256, 256, xr=[w for _, _, w in levels])
