@@ -131,6 +131,10 @@ int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* x
  * (the forward conv's output) at this conv's output pixels, same dtype and row stride as ys[i]; gn_abs[i]: level i's
  * [4][gn_n][cout] block of osd_groupnorm_relu_fwd_levels' ab; gn_gammas[i]: [cout].  These are the two halves of the ws of
  * osd_groupnorm_relu_bwd_levels_fused, which then skips its own statistics pass for that level.  Only the software-pipelined
+ * FORWARD statistics instead (the tower conv whose output feeds the GroupNorm): pairs with gn_us[i] == NULL (or gn_us == NULL)
+ * and gn_wss[i] != NULL add the sum and the sum of squares of the stored outputs to gn_wss[i] [gn_n][OSD_GN_SPLITS][gn_groups][2]
+ * — level i's part of the ws of osd_groupnorm_relu_fwd_levels_fused; gn_abs / gn_gammas / gn_pws are not read.  Only the
+ * software-pipelined
  * 3x3 kernel gathers them (d->algo = 15: bf16, widths 64 / 128 / 256) and only for pairs made of whole 256-pixel tiles
  * whose images are whole 128-pixel runs; anything else returns OSD_ERR_UNSUPPORTED and the caller uses the plain pair of calls. */
 int osd_conv2d_fwd_multi_gn(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys, const int32_t* ns,
@@ -384,6 +388,11 @@ int osd_sgd_momentum_multi(const void* table, const int32_t* block_entry, int n_
 int osd_groupnorm_relu_fwd_levels(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
                                   const float* gamma, const float* beta, float* ab, float* ws, int n, int c, int groups,
                                   float eps, int dtype, void* stream);
+/* osd_groupnorm_relu_fwd_levels when osd_conv2d_fwd_multi_gn (forward statistics) has already accumulated the slab sums of the
+ * levels whose bit is set in fused_mask (ws + l*n*OSD_GN_SPLITS*groups*2, zeroed by the caller before the conv) */
+int osd_groupnorm_relu_fwd_levels_fused(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
+                                        const float* gamma, const float* beta, float* ab, float* ws, int n, int c, int groups,
+                                        float eps, int dtype, uint32_t fused_mask, void* stream);
 int osd_groupnorm_relu_bwd_levels(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
                                   const int32_t* hws, const float* ab, const float* gamma, const float* beta, float* ws,
                                   float* dgamma, float* dbeta, int n, int c, int groups, int dtype, void* stream);

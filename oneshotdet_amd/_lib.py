@@ -63,6 +63,7 @@ SIGNATURES = {
     "osd_pack_conv_weight_ex": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "osd_conv2d_wgrad": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
     "osd_groupnorm_relu_fwd_levels": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
+    "osd_groupnorm_relu_fwd_levels_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, C.c_uint32, _p]),
     "osd_groupnorm_relu_bwd_levels": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "osd_groupnorm_relu_bwd_levels_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_uint32, _p]),
     "osd_sgd_momentum_multi": (_i, [_p, _p, _i, _p, _p, _p, _f, _f, _i, _p]),

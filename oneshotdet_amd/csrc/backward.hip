@@ -772,9 +772,10 @@ struct GnLevels {
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256) gnl_stats_kernel(GnLevels L, float* __restrict__ ws, int n, int c, int groups) {
+__global__ void __launch_bounds__(256) gnl_stats_kernel(GnLevels L, float* __restrict__ ws, int n, int c, int groups, unsigned fused_mask) {
   constexpr int E = Chunk<T>::N;
   const int lvl = blockIdx.z, img = blockIdx.y, split = blockIdx.x;
+  if ((fused_mask >> lvl) & 1u) return;      // this level's sums were gathered by the conv that wrote x (conv_params.h: ConvGnb)
   const int hw = L.hw[lvl];
   const T* x = reinterpret_cast<const T*>(L.x[lvl]);
   const int cch = c / E, lanes = 256 / cch;
@@ -1086,9 +1087,21 @@ int gn_levels_fill(GnLevels& L, int n_levels, const void* const* xs, const void*
 }  // namespace
 
 // ws: n_levels * n * OSD_GN_SPLITS * groups * 2 floats; ab (out): [n_levels][2][n][c] fp32 scale / shift per image, channel
+// fused_mask: bit l set = level l's slab sums in ws were accumulated by osd_conv2d_fwd_multi_gn (forward statistics) into ZEROED
+// memory; the statistics pass skips those levels (and is not launched when every level is fused)
+extern "C" int osd_groupnorm_relu_fwd_levels_fused(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
+                                                   const float* gamma, const float* beta, float* ab, float* ws, int n, int c,
+                                                   int groups, float eps, int dtype, uint32_t fused_mask, void* stream);
+
 extern "C" int osd_groupnorm_relu_fwd_levels(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
                                              const float* gamma, const float* beta, float* ab, float* ws, int n, int c,
                                              int groups, float eps, int dtype, void* stream) {
+  return osd_groupnorm_relu_fwd_levels_fused(n_levels, xs, ys, hws, gamma, beta, ab, ws, n, c, groups, eps, dtype, 0u, stream);
+}
+
+extern "C" int osd_groupnorm_relu_fwd_levels_fused(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
+                                                   const float* gamma, const float* beta, float* ab, float* ws, int n, int c,
+                                                   int groups, float eps, int dtype, uint32_t fused_mask, void* stream) {
   const int e = dtype == OSD_BF16 ? 8 : 4;
   if (!gamma || !beta || !ab || !ws || c % e != 0 || c > 512 || c / e > 256 || 256 % (c / e) != 0 || groups > 64 ||
       c % groups != 0 || (c / groups) % e != 0)
@@ -1102,9 +1115,10 @@ extern "C" int osd_groupnorm_relu_fwd_levels(int n_levels, const void* const* xs
   if (skip < 0) { const char* e = getenv("OSD_GN_SKIP"); skip = e ? atoi(e) : 0; }
   if (!(skip & 1))
 #endif
+  if ((fused_mask & ((1u << n_levels) - 1u)) != ((1u << n_levels) - 1u))
   OSD_DISPATCH_DTYPE(dtype,
-      hipLaunchKernelGGL(gnl_stats_kernel<float>, g1, dim3(256), 0, OSD_STREAM(stream), L, ws, n, c, groups),
-      hipLaunchKernelGGL(gnl_stats_kernel<__bf16>, g1, dim3(256), 0, OSD_STREAM(stream), L, ws, n, c, groups));
+      hipLaunchKernelGGL(gnl_stats_kernel<float>, g1, dim3(256), 0, OSD_STREAM(stream), L, ws, n, c, groups, fused_mask),
+      hipLaunchKernelGGL(gnl_stats_kernel<__bf16>, g1, dim3(256), 0, OSD_STREAM(stream), L, ws, n, c, groups, fused_mask));
   rc = osd_check_launch("gnl_stats");
   if (rc) return rc;
   OSD_DISPATCH_DTYPE(dtype,

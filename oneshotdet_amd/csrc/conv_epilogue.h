@@ -116,8 +116,14 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
     [[maybe_unused]] int gn_img = 0;
     typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type VecU;
     [[maybe_unused]] VecU uu[ITER], uu_next[ITER];
+    // GroupNorm FORWARD statistics (gn.u == nullptr, gn.ws != nullptr): sum and sum of squares of the stored values per (image,
+    // slab, group) — what gnl_stats_kernel computes in its own pass over the conv's output
+    [[maybe_unused]] bool gnf_on = false;
+    [[maybe_unused]] float fs = 0.f, fss = 0.f;
     if constexpr (GNB) {
       gn_on = q.gn.u != nullptr;
+      gnf_on = !gn_on && q.gn.ws != nullptr;
+      if (gnf_on) gn_img = (m0 + wm * TM * 16) / q_HoWo;
       if (gn_on) {
         gn_img = (m0 + wm * TM * 16) / q_HoWo;
         const OSD_G float* abg = (const OSD_G float*)(q.gn.ab) + (size_t)gn_img * p.Cout + c;
@@ -230,6 +236,10 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
         *(OSD_G Vec*)(yg + (size_t)(mrow + it * (64 / CPR)) * p.out_stride + c) = o;
 #endif
         if constexpr (GNB) {
+          if (gnf_on) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { const float x = (float)o[e]; fs += x; fss = fmaf(x, x, fss); }
+          }
           if (gn_on) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
@@ -249,6 +259,17 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
       }
     }
     if constexpr (GNB) {
+      if (gnf_on) {
+#pragma unroll
+        for (int off = CPR; off < 64; off <<= 1) { fs += __shfl_xor(fs, off); fss += __shfl_xor(fss, off); }
+        if (lane < CPR) {
+          const int slab = (blockIdx.x * 8 + wave) & (kGnSlabs - 1);
+          const int cpg = p.Cout / p.gn_groups;
+          OSD_G float* wsg = (OSD_G float*)(q.gn.ws) + (((size_t)gn_img * kGnSlabs + slab) * p.gn_groups + c / cpg) * 2;
+          (void)__hip_atomic_fetch_add(wsg, fs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          (void)__hip_atomic_fetch_add(wsg + 1, fss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
       if (gn_on) {
         // lanes cc, cc + CPR, ... hold the same channel chunk: fold them, then lanes 0 .. CPR - 1 turn the wave's S, Su into the
         // sums of the backward pass and add them to this (image, slab)

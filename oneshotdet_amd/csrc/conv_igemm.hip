@@ -433,7 +433,7 @@ static int conv_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* 
   p.n_seg = n_seg;
   p.x2 = nullptr; p.w2 = nullptr; p.cin1 = p.x2_sN = p.x2_sH = p.x2_sW = p.st2 = 0;
   p.gn_n = gn ? gn->n : 0; p.gn_groups = gn ? gn->groups : 0;
-  if (gn && (gn->groups < 1 || gn->n < 1 || !gn->us || !gn->abs || !gn->gammas || !gn->wss || !gn->pws))
+  if (gn && (gn->groups < 1 || gn->n < 1 || !gn->wss))
     return osd_fail(OSD_ERR_INVALID_ARG, "conv_multi_gn: bad statistics arguments");
   long long mtot = 0;
   for (int i = 0; i < kConvMaxSeg; ++i) {
@@ -455,10 +455,13 @@ static int conv_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* 
       return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: the nearest-2x addend needs an even output size (segment %d: %d x %d)", j, sg.Ho, sg.Wo);
     sg.M = (int)M; sg.sH = ws[j] * d->cin; sg.sN = hs[j] * ws[j] * d->cin; sg.tile_begin = 0;
     sg.gn.u = nullptr; sg.gn.ab = nullptr; sg.gn.gamma = nullptr; sg.gn.ws = nullptr; sg.gn.pw = nullptr;
-    if (gn && gn->us[j]) {
-      if (!gn->abs[j] || !gn->gammas[j] || !gn->wss[j] || !gn->pws[j] || ns[j] != gn->n)
+    if (gn && gn->us && gn->us[j]) {          // backward statistics
+      if (!gn->abs || !gn->gammas || !gn->pws || !gn->abs[j] || !gn->gammas[j] || !gn->wss[j] || !gn->pws[j] || ns[j] != gn->n)
         return osd_fail(OSD_ERR_INVALID_ARG, "conv_multi_gn: segment %d: null statistics argument or a batch other than gn_n", j);
       sg.gn.u = gn->us[j]; sg.gn.ab = gn->abs[j]; sg.gn.gamma = gn->gammas[j]; sg.gn.ws = gn->wss[j]; sg.gn.pw = gn->pws[j];
+    } else if (gn && gn->wss[j]) {            // forward statistics: sums of the outputs and of their squares
+      if (ns[j] != gn->n) return osd_fail(OSD_ERR_INVALID_ARG, "conv_multi_gn: segment %d: a batch other than gn_n", j);
+      sg.gn.ws = gn->wss[j];
     }
     if (i < n_seg) mtot += M;
   }
@@ -506,6 +509,7 @@ extern "C" int osd_conv2d_fwd_multi_gn(const osd_conv_desc* d, int n_seg, const 
   ConvGnArgs gn{gn_us, gn_abs, gn_gammas, gn_wss, gn_pws, gn_n, gn_groups};
   if (d && (d->res_mode != OSD_RES_NONE || d->act != OSD_ACT_NONE))
     return osd_fail(OSD_ERR_UNSUPPORTED, "conv_multi_gn: no residual / activation");
+  if (!gn_wss) return osd_fail(OSD_ERR_INVALID_ARG, "conv_multi_gn: gn_wss is null");
   return conv_fwd_multi(d, n_seg, xs, ys, nullptr, nullptr, nullptr, ns, hs, ws, wts, biases, &gn, stream);
 }
 

@@ -391,7 +391,7 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream) {
         p.res_mode != OSD_RES_NONE || p.act != OSD_ACT_NONE)
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): GroupNorm statistics need a plain multi-segment conv with Cout %% 256 == 0 and groups of whole 16-byte chunks");
     for (int i = 0; i < p.n_seg; ++i) {
-      if (!p.seg[i].gn.u) continue;
+      if (!p.seg[i].gn.u && !p.seg[i].gn.ws) continue;
       if (p.seg[i].M % SP_BM != 0 || (p.seg[i].Ho * p.seg[i].Wo) % (SP_BM / 2) != 0 || p.seg[i].M / (p.seg[i].Ho * p.seg[i].Wo) != p.gn_n)
         return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): GroupNorm statistics need images of whole 128-pixel runs (segment %d)", i);
     }

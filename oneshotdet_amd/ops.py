@@ -339,17 +339,19 @@ def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mod
     quantise badly (P3..P7 at bs=8 are 534 tiles = 2 full rounds plus a third with 22 tiles).
     residuals: addends (res_mode RES_SAME, default, or RES_UP2X: exactly half size); masks: ReLU-backward masks (data
     gradients); act_scale_devs: one device scalar per segment (the learnable Scale).  Returns the outputs.
-    gnb (data-gradient convs feeding a GroupNorm + ReLU backward): dict(us, abs, gammas, wss, pws: one entry per segment, None
-    where the statistics are not wanted; n, groups) — the leading run of segments with an entry goes out as its own launch of
-    the software-pipelined kernel, whose epilogue gathers the sums (osd_conv2d_fwd_multi_gn); the rest as usual."""
+    gnb: GroupNorm statistics gathered by the epilogue (osd_conv2d_fwd_multi_gn).  Backward ones (data-gradient convs feeding a
+    GroupNorm + ReLU backward): dict(us, abs, gammas, wss, pws: one entry per segment, None where not wanted; n, groups); forward
+    ones (the conv whose outputs a GroupNorm normalises): dict(wss; n, groups).  The leading run of segments with an entry goes
+    out as its own launch of the software-pipelined kernel, the rest as usual."""
     _chk_dev(*xs)
     k = len(xs)
     pc = pcs[0]
     if gnb is not None and not _whole:
+        on = [w is not None for w in gnb["wss"]]
         c = 0
-        while c < k and gnb["us"][c] is not None:
+        while c < k and on[c]:
             c += 1
-        assert all(u is None for u in gnb["us"][c:]), "segments that gather GroupNorm statistics must come first"
+        assert not any(on[c:]), "segments that gather GroupNorm statistics must come first"
         assert residuals is None and masks is None and act == ACT_NONE and act_scale_devs is None
         if c == 0:
             return conv2d_multi(xs, pcs, stride, pad, act, algo=algo)
@@ -429,9 +431,11 @@ def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mod
         _lib.call("osd_conv2d_fwd_multi", C.byref(d), *args)
     if gnb is not None:
         d.algo = algo
+        bwd = gnb.get("us") is not None        # backward statistics (u, ab, gamma, pw given) or forward ones (sums of the outputs)
         _lib.call("osd_conv2d_fwd_multi_gn", C.byref(d), k, _ptr_array(xs), _ptr_array(outs), ns, hs, ws, _ptr_array([q.w for q in pcs]),
-                  _ptr_array([q.bias for q in pcs]), _ptr_array(gnb["us"]), _ptr_array(gnb["abs"]), _ptr_array(gnb["gammas"]),
-                  _ptr_array(gnb["wss"]), _ptr_array(gnb["pws"]), int(gnb["n"]), int(gnb["groups"]), _stream())
+                  _ptr_array([q.bias for q in pcs]), _ptr_array(gnb["us"]) if bwd else None, _ptr_array(gnb["abs"]) if bwd else None,
+                  _ptr_array(gnb["gammas"]) if bwd else None, _ptr_array(gnb["wss"]), _ptr_array(gnb["pws"]) if bwd else None,
+                  int(gnb["n"]), int(gnb["groups"]), _stream())
         for i in range(k):
             _rec("conv", x=xs[i], w=pcs[i].w, bias=pcs[i].bias, cout=pc.cout_store, r=pc.r, s=pc.s, stem=False, stride=stride, pad=pad,
                  act=act, res=None, res_mode=res_mode, relu_in=False, act_scale=float(act_scale), act_scale_dev=None, mask=None,
@@ -1073,18 +1077,27 @@ def fcos_loss_levels(phase, head_out, gt_boxes, gt_count, strides, size_ranges, 
          scale_devs=scale_devs, sums=sums, d_cls_ctrs=d_cls_ctrs, d_regs=d_regs, d_scale_raws=d_scale_raws)
 
 
-def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5):
+def gn_fwd_ws_parts(ws, k, n, groups=32):
+    """-> per level views of the forward ws [k][n][GN_SPLITS][groups][2]: what osd_conv2d_fwd_multi_gn (forward) accumulates into"""
+    a = n * GN_SPLITS * groups * 2
+    return [ws[l * a:(l + 1) * a] for l in range(k)]
+
+
+def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5, ws=None, fused_mask=0):
     """relu(GroupNorm(x_l)) for the FPN levels of one tower layer in two launches.  Returns (ys, ab) with
-    ab [L][4][N][C] fp32 (per-image scale/shift a, b and the normalisation xa, xb, kept for the backward pass)."""
+    ab [L][4][N][C] fp32 (per-image scale/shift a, b and the normalisation xa, xb, kept for the backward pass).
+    ws / fused_mask: levels whose sums the conv that wrote xs has already added to the (zeroed) ws skip the statistics pass."""
     n, _, _, c = xs[0].shape
     k = len(xs)
     dev = xs[0].device
     ys = [torch.empty_like(x) for x in xs]
     ab = torch.empty((k, 4, n, c), device=dev, dtype=torch.float32)
-    ws = torch.empty((k * n * GN_SPLITS * groups * 2,), device=dev, dtype=torch.float32)
+    if ws is None:
+        assert fused_mask == 0
+        ws = torch.empty((k * n * GN_SPLITS * groups * 2,), device=dev, dtype=torch.float32)
     hws = (C.c_int32 * k)(*[x.shape[1] * x.shape[2] for x in xs])
-    _lib.call("osd_groupnorm_relu_fwd_levels", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),
-              _ptr(ws), n, c, groups, float(eps), _dt(xs[0]), _stream())
+    _lib.call("osd_groupnorm_relu_fwd_levels_fused", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),
+              _ptr(ws), n, c, groups, float(eps), _dt(xs[0]), int(fused_mask), _stream())
     for x, y in zip(xs, ys):
         _rec("gn_relu", x=x, gamma=gamma, beta=beta, groups=groups, eps=float(eps), out=y)
     return ys, ab

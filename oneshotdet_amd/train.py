@@ -135,6 +135,11 @@ class TrainEngine(object):
         # roofline); 11.70 vs 11.34 ms per step in same-box A/B.  OSD_GN_FUSION=1 turns it on
         self.fuse_gn_bwd = (not self.ordered_wgrad and self.dtype == torch.bfloat16 and os.environ.get("OSD_GN_FUSION", "0") != "0")
         self._gnb_ws = {}
+        # the forward statistics (sum, sum of squares of the tower conv's outputs) in the forward conv's epilogue: no extra operand
+        # there, two atomics per wave and group — and still a loss: the conv over P3 + P4 of both towers 243 -> 275 us to save
+        # 2 x 13 us of statistics pass, 11.85 vs 11.55 ms per step in same-box A/B.  OSD_GN_FWD_FUSION=1 turns it on
+        self.fuse_gn_fwd = (not self.ordered_wgrad and self.dtype == torch.bfloat16 and os.environ.get("OSD_GN_FWD_FUSION", "0") != "0")
+        self._gnf_ws = {}
         # torch hands out stream handles from a pool, so a handle may carry an earlier engine's registration: set the mode of
         # this engine's weight-gradient streams explicitly either way (close() / __del__ release the scratch buffers)
         # (the second stage's weight gradients run on the proposal stream: box_head_forward_backward)
@@ -596,14 +601,36 @@ class TrainEngine(object):
         nl, nt = len(feats), len(towers)
         t = {tw: list(feats) for tw in towers}
         layers = {tw: [] for tw in towers}
+        # GroupNorm forward statistics (sum, sum of squares per image and group) are gathered by the tower conv's epilogue where
+        # the kernel can (ops.gn_bwd_fusable: the large levels); the GroupNorm then skips its statistics pass for those levels.
+        # The sums are atomic adds: not in ordered mode
+        n_img, c_gn = feats[0].shape[0], cv["%s%s.0" % (h, towers[0])].pc.cout_store
+        nf = 0
+        if self.fuse_gn_fwd:
+            while nf < nl and all(ops.gn_bwd_fusable(feats[nf], cv["%s%s.0" % (h, tw)].pc, 1, 1) for tw in towers):
+                nf += 1
+        if nf > 0:
+            per = nl * n_img * ops.GN_SPLITS * spec.GN_GROUPS * 2
+            key = (tuple(towers), nl, n_img)
+            buf = self._gnf_ws.get(key)
+            if buf is None:
+                buf = self._gnf_ws[key] = torch.empty((nt * spec.NUM_CONVS * per,), device=self.device, dtype=torch.float32)
+            buf.zero_()
         for i in range(spec.NUM_CONVS):
             xs = [t[tw][l] for l in range(nl) for tw in towers]
             pcs = [cv["%s%s.%d" % (h, tw, 3 * i)].pc for l in range(nl) for tw in towers]
-            us = ops.conv2d_multi(xs, pcs, pad=1)
+            gnb, wsl = None, {}
+            if nf > 0:
+                for k, tw in enumerate(towers):
+                    wsl[tw] = buf[(k * spec.NUM_CONVS + i) * per:(k * spec.NUM_CONVS + i + 1) * per]
+                parts = {tw: ops.gn_fwd_ws_parts(wsl[tw], nl, n_img, spec.GN_GROUPS) for tw in towers}
+                gnb = {"wss": [parts[tw][l] if l < nf else None for l in range(nl) for tw in towers], "n": n_img, "groups": spec.GN_GROUPS}
+            us = ops.conv2d_multi(xs, pcs, pad=1, gnb=gnb)
             for k, tw in enumerate(towers):
                 (gw, _), (gbeta, _) = self.gn("%s%s.%d" % (h, tw, 3 * i + 1))
                 u = us[k::nt]
-                t2, ab = ops.groupnorm_relu_levels(u, gw, gbeta, spec.GN_GROUPS, spec.GN_EPS)
+                t2, ab = ops.groupnorm_relu_levels(u, gw, gbeta, spec.GN_GROUPS, spec.GN_EPS, ws=wsl.get(tw),
+                                                   fused_mask=(1 << nf) - 1 if nf > 0 else 0)
                 layers[tw].append((t[tw], u, ab))
                 t[tw] = t2
         outs = {}

@@ -785,6 +785,40 @@ def test_groupnorm_backward_statistics_gathered_by_the_data_gradient_conv(fused_
         torch.testing.assert_close(db, rdb, rtol=1e-4, atol=1e-4 * float(rdb.abs().max()))
 
 
+def test_groupnorm_forward_statistics_gathered_by_the_tower_conv():
+    """osd_conv2d_fwd_multi_gn (forward statistics) + osd_groupnorm_relu_fwd_levels_fused: the tower conv's epilogue adds the sum
+    and the sum of squares of the outputs it stores to the GroupNorm's slab sums; the GroupNorm skips its statistics pass for
+    those levels.  Two towers x three levels (the third too small to qualify: it keeps the statistics pass): conv outputs
+    bit-identical, GroupNorm outputs equal up to the summation order of the sums (<= 1 bf16 ulp on a few elements), the saved
+    scale / shift (ab) to 1e-5 relative."""
+    from oneshotdet_amd import ops
+    n, c, G = 2, 256, 32
+    sizes = [(4, 64), (2, 64), (3, 5)]
+    pcs = [ops.pack_conv((rnd(c, c, 3, 3, seed=40 + tw) / np.sqrt(c * 9)).cuda(), bias=(rnd(c, seed=45 + tw) * 0.2).cuda(), dtype=torch.bfloat16)
+           for tw in range(2)]
+    gam = [rnd(c, seed=50 + tw).cuda() for tw in range(2)]
+    bet = [(rnd(c, seed=60 + tw) * 0.3).cuda() for tw in range(2)]
+    seg_x = [to_nhwc(rnd(n, c, h, w, seed=70 + 2 * l + tw), torch.bfloat16) for l, (h, w) in enumerate(sizes) for tw in range(2)]
+    seg_pc = [pcs[tw] for _ in sizes for tw in range(2)]
+    nl, nf = len(sizes), 2
+    us = ops.conv2d_multi(seg_x[:2 * nf], seg_pc[:2 * nf], pad=1, algo=ops.ALGO_SP, _whole=True) + ops.conv2d_multi(seg_x[2 * nf:], seg_pc[2 * nf:], pad=1)
+    ref = [ops.groupnorm_relu_levels(us[tw::2], gam[tw], bet[tw], G, 1e-5) for tw in range(2)]
+    wss = [torch.zeros(nl * n * ops.GN_SPLITS * G * 2, device="cuda") for _ in range(2)]
+    parts = [ops.gn_fwd_ws_parts(wss[tw], nl, n, G) for tw in range(2)]
+    gnb = {"wss": [parts[tw][l] if l < nf else None for l in range(nl) for tw in range(2)], "n": n, "groups": G}
+    us2 = ops.conv2d_multi(seg_x, seg_pc, pad=1, gnb=gnb)
+    for a, b in zip(us, us2):
+        assert torch.equal(a, b)
+    for tw in range(2):
+        ys, ab = ops.groupnorm_relu_levels(us2[tw::2], gam[tw], bet[tw], G, 1e-5, ws=wss[tw], fused_mask=(1 << nf) - 1)
+        rys, rab = ref[tw]
+        torch.testing.assert_close(ab, rab, rtol=1e-5, atol=1e-5)
+        for a, b in zip(ys, rys):
+            a, b = a.float(), b.float()
+            assert (a - b).abs().max() <= 2 ** -7 * b.abs().max()
+            assert (a != b).float().mean() <= 1e-3
+
+
 def test_training_step_with_gathered_groupnorm_statistics_equals_the_two_pass_step():
     """TrainEngine.fuse_gn_bwd (OSD_GN_FUSION=1; off by default): at the BASELINE geometry (800x1024: P3 and P4
     qualify) the tower data-gradient convs of layers 3..1 gather the GroupNorm-backward sums of layers 2..0 for P3 + P4.  The
@@ -795,6 +829,7 @@ def test_training_step_with_gathered_groupnorm_statistics_equals_the_two_pass_st
     e0, img, q, gtb, cnt = _engine_and_inputs("bf16", "config1")
     img, q, gtb, cnt = (t.expand(2, *t.shape[1:]).contiguous() for t in (img, q, gtb, cnt))
     assert not e0.fuse_gn_bwd
+    e0.fuse_gn_fwd = False      # the forward statistics too: both engines then share ONE forward pass bit for bit
     l0 = e0.forward_backward(img, q, gtb, cnt).clone()
     g0 = e0.flat_g.clone()
     e0.fuse_gn_bwd = True

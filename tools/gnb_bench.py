@@ -46,5 +46,12 @@ for r in range(3):
     c0 = t(lambda: ops.groupnorm_relu_bwd_levels([seg_u[0], seg_u[2]], [dts[0], dts[2]], abs_[0], gam[0], bet[0], dg, db, G))
     c1 = t(lambda: ops.groupnorm_relu_bwd_levels([seg_u[0], seg_u[2]], [dts[0], dts[2]], abs_[0], gam[0], bet[0], dg, db, G, ws=wss[0], fused_mask=3))
     z = t(lambda: wss[0].zero_())
+    fw = [torch.zeros(2 * n * ops.GN_SPLITS * G * 2, device="cuda") for _ in range(2)]
+    fparts = [ops.gn_fwd_ws_parts(fw[tw], 2, n, G) for tw in range(2)]
+    gnf = {"wss": [fparts[tw][l] for l in range(2) for tw in range(2)], "n": n, "groups": G}
+    f = t(lambda: ops.conv2d_multi(seg_x, seg_pc, pad=1, gnb=gnf))
+    g0 = t(lambda: ops.groupnorm_relu_levels([dts[0], dts[2]], gam[0], bet[0], G, 1e-5))
+    g1 = t(lambda: ops.groupnorm_relu_levels([dts[0], dts[2]], gam[0], bet[0], G, 1e-5, ws=fw[0], fused_mask=3))
+    print("conv + FORWARD statistics %.1f us   GN forward (one tower) two passes %.1f us   apply only %.1f us" % (f, g0, g1))
     print("conv plain %.1f us   conv + statistics %.1f us   GN backward (one tower) two passes %.1f us   apply only %.1f us   zeroing one workspace %.1f us"
           % (a, b, c0, c1, z))
