@@ -4,8 +4,9 @@ RyanXLi/OneshotDet drive it (both stages, SGD with the reference's parameter gro
     python examples/train.py [--iters 20] [--batch 2] [--dtype bf16|f32] [--first-stage-only] [--out /tmp/osd_run]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train.py ...      # one rank per GPU
 
-  * data: there is no dataset here, so every iteration draws synthetic uint8 "photos" of different sizes, ground-truth boxes
-    and support crops cut out of them (DeviceImage.crop = the dataset's PIL crop) — what `COCODataset.__getitem__` returns;
+  * data: `dataset.FewShotCocoDataset` (= the reference's COCODataset: one item per (category, image), seeded epoch order,
+    targets of the item's category, support crops of OTHER images' largest objects above the area threshold) over a synthetic
+    COCO-format annotation set — there are no datasets here, so the "photos" are random uint8 images of different sizes;
   * input pipeline: `transforms.build_transforms` (Resize / flip / ToTensor / Normalize of the reference, executed by the
     fused device kernels), boxes follow their image; `transforms.collate(..., stem_dtype)` = BatchCollator straight into the
     stem conv's input format;
@@ -22,19 +23,24 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oneshotdet_amd import checkpoint, spec, synth, train, transforms as T  # noqa: E402
-from oneshotdet_amd.modules import BoxList  # noqa: E402
+from oneshotdet_amd import checkpoint, dataset, spec, synth, train, transforms as T  # noqa: E402
 
 
-def synthetic_sample(rng):
-    """One (image, boxes, support crop) triple as the dataset would return it (before its transforms)."""
-    h, w = int(rng.randint(300, 480)), int(rng.randint(400, 640))
-    img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
-    n = int(rng.randint(1, 4))
-    x0 = rng.uniform(0, w * 0.6, n); y0 = rng.uniform(0, h * 0.6, n)
-    bw = rng.uniform(40, w * 0.35, n); bh = rng.uniform(40, h * 0.35, n)
-    boxes = np.stack([x0, y0, np.minimum(x0 + bw, w - 1), np.minimum(y0 + bh, h - 1)], 1).astype(np.float32)
-    return img, boxes, boxes[0]
+def synthetic_coco(rng, n_images=24, n_categories=3):
+    """A COCO-format annotation set over synthetic uint8 "photos" of different sizes (1 - 3 objects each): what the reference
+    reads from instances_*.json, for `dataset.FewShotCocoDataset` = its COCODataset (category catalog, seeded epoch order,
+    per-item category, targets, support crops by area threshold)."""
+    images, anns, pix = [], [], {}
+    for k in range(n_images):
+        h, w = int(rng.randint(300, 480)), int(rng.randint(400, 640))
+        images.append({"id": k + 1, "file_name": "synthetic_%d" % (k + 1), "height": h, "width": w})
+        pix[k + 1] = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        for _ in range(int(rng.randint(1, 4))):
+            x0, y0 = float(rng.uniform(0, w * 0.6)), float(rng.uniform(0, h * 0.6))
+            bw, bh = float(rng.uniform(40, w * 0.35)), float(rng.uniform(40, h * 0.35))
+            anns.append({"id": len(anns) + 1, "image_id": k + 1, "category_id": int(rng.randint(1, n_categories + 1)),
+                         "bbox": [x0, y0, bw, bh], "area": bw * bh, "iscrowd": 0})
+    return {"images": images, "annotations": anns, "categories": [{"id": c + 1, "name": "c%d" % c} for c in range(n_categories)]}, pix
 
 
 def main():
@@ -70,15 +76,15 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
         eng.attach_exchange(dist.group.WORLD)
     tf_img, tf_supp = T.build_transforms(min_size=480, max_size=800, supp_min_size=128, supp_max_size=192, is_train=True)
-    rng = np.random.RandomState(1234 + rank)
+    coco, pix = synthetic_coco(np.random.RandomState(1234))                # the same annotation set on every rank
+    ds = dataset.FewShotCocoDataset(coco, lambda info: pix[info["id"]], is_train=True, shot=1, supp_area_threshold=40 * 40)
     os.makedirs(args.out, exist_ok=True)
     for it in range(start, args.iters):
         imgs, supps, targets = [], [], []
-        for _ in range(args.batch):
-            img, boxes, sbox = synthetic_sample(rng)
-            tgt = BoxList(torch.from_numpy(boxes), (img.shape[1], img.shape[0]), mode="xyxy")
-            dimg = T.DeviceImage(img)
-            supp = dimg.crop(sbox)                                            # the dataset's support crop (coco.py:350)
+        for b in range(args.batch):
+            item = ds[((it * world + rank) * args.batch + b) % len(ds)]       # DistributedSampler's split: every rank its own items
+            dimg, tgt = T.DeviceImage(item["img"]), item["target"]
+            supp = T.DeviceImage(item["img_supp"][0])                          # the support crop (coco.py:341)
             # the Compose's Resize and flip steps (Normalize is fused into the collation below)
             for t in tf_img.transforms[:2]:
                 dimg, tgt = t(dimg, tgt)

@@ -637,6 +637,67 @@ def gen_voc_eval():
     np.savez_compressed(os.path.join(HERE, "voc_eval.npz"), **out)
 
 
+def gen_dataset():
+    """data/datasets/coco.py of the REAL reference (COCODataset.__init__ and __getitem__: category catalog, seeded shuffles,
+    annotation filter, BoxList conversion and clipping, random support selection by area threshold, crop, flip augmentation) on
+    the synthetic annotation set of golden_utils.dataset_inputs, through the index / CocoDetection stand-ins of ref_harness
+    (shim 6).  Items are read in order 0 .. len - 1 right after construction (the support choice consumes the global `random`
+    stream).  Identity transforms: the recorded images are what the transforms would receive."""
+    import json
+    import tempfile
+    import zlib
+    from PIL import Image
+    rh.load_reference()
+    rh.install_coco_shims()
+    from maskrcnn_benchmark.config import cfg as ref_cfg
+    from maskrcnn_benchmark.data.datasets import coco as rc
+    coco, pix = gu.dataset_inputs()
+    tmp = tempfile.mkdtemp(prefix="osd_ds_")
+    for iid, a in pix.items():
+        Image.fromarray(a).save(os.path.join(tmp, "img_%d.png" % iid))
+    ann = os.path.join(tmp, "ann.json")
+    json.dump(coco, open(ann, "w"))
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    open("task1_test_split.txt", "w").write("")      # opened (and, for TASK 2, not used) by the constructor
+    out = {}
+    try:
+        for name, is_train, shot, aug, excl_train, excl_test, thr in gu.DATASET_CONFIGS:
+            c = ref_cfg.clone()
+            c.defrost()
+            c.FEW_SHOT.NUM_SHOT = shot
+            c.FEW_SHOT.SUPP_AUG = bool(aug)
+            c.FEW_SHOT.NUM_SUPP_AUG = 1
+            c.FEW_SHOT.TRAINING_EXCL_CATS = list(excl_train)
+            c.FEW_SHOT.TEST_EXCL_CATS = list(excl_test)
+            c.INPUT.SUPP_AREA_THRESHOLD = thr
+            ident = lambda img, target: (img, target)      # noqa: E731
+            ds = rc.COCODataset(c, ann, tmp, is_train, True, transforms=[ident, ident])
+            out[name + ".ids"] = np.asarray(ds.ids, dtype=np.int64)
+            out[name + ".chosen_cats"] = np.asarray(ds.chosen_cats, dtype=np.int64)
+            out[name + ".json_cat_list"] = np.asarray(ds.json_cat_list, dtype=np.int64)
+            for cat, ids in ds.catalog.items():
+                out["%s.catalog.%d" % (name, cat)] = np.asarray(ids, dtype=np.int64)
+            for idx in range(len(ds)):
+                r = ds[idx]
+                assert r["idx"] == idx and r["img_neg_supp"] is r["img_supp"]
+                out["%s.%d.img_crc" % (name, idx)] = np.int64(zlib.crc32(np.ascontiguousarray(np.asarray(r["img"])).tobytes()))
+                out["%s.%d.img_shape" % (name, idx)] = np.asarray(np.asarray(r["img"]).shape, dtype=np.int64)
+                out["%s.%d.boxes" % (name, idx)] = r["target"].bbox.numpy().astype(np.float32)
+                out["%s.%d.labels" % (name, idx)] = r["target"].get_field("labels").numpy().astype(np.int64)
+                out["%s.%d.size" % (name, idx)] = np.asarray(r["target"].size, dtype=np.int64)
+                out["%s.%d.target_id" % (name, idx)] = np.int64(r["target_id"])
+                out["%s.%d.n_supp" % (name, idx)] = np.int64(len(r["img_supp"]))
+                for k, im in enumerate(r["img_supp"]):
+                    out["%s.%d.supp.%d" % (name, idx, k)] = np.asarray(im)
+                info, cat = ds.get_img_info(idx)
+                assert cat == r["target_id"] and info["id"] == ds.ids[idx]
+            print("dataset fixture %s: %d items, categories %s" % (name, len(ds), ds.json_cat_list))
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, "dataset.npz"), **out)
+
+
 def gen_keys(model):
     import json
     sd = model.state_dict()
@@ -659,11 +720,14 @@ def main():
     ap.add_argument("--boxtrain-cases", default="small,nonsquare,shots5,tall,config1")
     ap.add_argument("--only-boxtrain", action="store_true", help="regenerate only tests/golden/boxtrain_*.npz")
     ap.add_argument("--only-voc", action="store_true", help="regenerate only tests/golden/voc_eval.npz")
+    ap.add_argument("--only-dataset", action="store_true", help="regenerate only tests/golden/dataset.npz")
     ap.add_argument("--only-cases", default="", help="write ONLY case_<name>.npz + train_<name>.npz of the listed cases")
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.only_voc:
         return gen_voc_eval()
+    if args.only_dataset:
+        return gen_dataset()
     model, cfg = rh.build_reference_model()
     if args.only_transforms:
         return gen_transforms(cfg)
@@ -694,6 +758,7 @@ def main():
         gen_ragged(model, np_sd)
         gen_transforms(cfg)
         gen_voc_eval()
+        gen_dataset()
         for name in [c for c in args.cases.split(",") if c]:
             gen_case(model, np_sd, name)
     if not args.skip_train:

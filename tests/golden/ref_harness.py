@@ -17,6 +17,12 @@ The reference cannot be imported as shipped in this image: four
      (INSTALL.md:5) has them: `img.resize(size[::-1], BILINEAR)`, `img.transpose(FLIP_LEFT_RIGHT)`, uint8 HWC -> float CHW
      `.div(255)`, per-channel `t.sub_(m).div_(s)`.  The arithmetic they forward to is PIL's and torch's own; the
      reference's Resize.get_size, Compose order, Normalize (BGR255) and BoxList code run unmodified.
+  6. (dataset fixture only: install_coco_shims) `pycocotools.coco.COCO` and `torchvision.datasets.coco.CocoDetection`, both
+     absent: the index queries the reference's data/datasets/coco.py makes (getCatIds, getImgIds(catIds), getAnnIds(imgIds,
+     catIds, iscrowd), loadAnns / loadImgs / loadCats, .imgs) with pycocotools 2.0's filter order, and torchvision 0.2.1's
+     CocoDetection (`ids = list(coco.imgs.keys())`, `__getitem__` -> (PIL RGB image, loadAnns(getAnnIds(imgIds=id)))).  The
+     category choice, catalog, shuffles (Python's `random`, seed 6666), annotation filter, BoxList conversion / clipping,
+     support selection, crop and augmentation — data/datasets/coco.py:56-547 — run unmodified on top of them.
 """
 import os
 import re
@@ -243,3 +249,84 @@ def build_reference_model(extra_opts=()):
     cfg.freeze()
     model = build_detection_model(cfg)
     return model, cfg
+
+
+class _CocoIndex(object):
+    """pycocotools.coco.COCO, the part data/datasets/coco.py uses (shim 6)."""
+
+    def __init__(self, annotation_file):
+        import json
+        self.dataset = json.load(open(annotation_file))
+        self.anns = {a["id"]: a for a in self.dataset["annotations"]}
+        self.imgs = {i["id"]: i for i in self.dataset["images"]}
+        self.cats = {c["id"]: c for c in self.dataset["categories"]}
+        self.imgToAnns, self.catToImgs = {}, {}
+        for a in self.dataset["annotations"]:
+            self.imgToAnns.setdefault(a["image_id"], []).append(a)
+            self.catToImgs.setdefault(a["category_id"], []).append(a["image_id"])
+
+    @staticmethod
+    def _lst(v):
+        return list(v) if isinstance(v, (list, tuple)) else [v]
+
+    def getCatIds(self):
+        return [c["id"] for c in self.dataset["categories"]]
+
+    def getImgIds(self, imgIds=[], catIds=[]):
+        imgIds, catIds = self._lst(imgIds), self._lst(catIds)
+        if len(imgIds) == len(catIds) == 0:
+            return list(self.imgs.keys())
+        ids = set(imgIds)
+        for i, c in enumerate(catIds):
+            if i == 0 and len(ids) == 0:
+                ids = set(self.catToImgs.get(c, []))
+            else:
+                ids &= set(self.catToImgs.get(c, []))
+        return list(ids)
+
+    def getAnnIds(self, imgIds=[], catIds=[], areaRng=[], iscrowd=None):
+        imgIds, catIds = self._lst(imgIds), self._lst(catIds)
+        if len(imgIds) == len(catIds) == len(areaRng) == 0:
+            anns = self.dataset["annotations"]
+        else:
+            anns = [a for i in imgIds for a in self.imgToAnns.get(i, [])] if len(imgIds) else self.dataset["annotations"]
+            anns = anns if len(catIds) == 0 else [a for a in anns if a["category_id"] in catIds]
+        if iscrowd is not None:
+            return [a["id"] for a in anns if a["iscrowd"] == iscrowd]
+        return [a["id"] for a in anns]
+
+    def loadAnns(self, ids=[]):
+        return [self.anns[i] for i in ids] if isinstance(ids, (list, tuple)) else [self.anns[ids]]
+
+    def loadImgs(self, ids=[]):
+        return [self.imgs[i] for i in ids] if isinstance(ids, (list, tuple)) else [self.imgs[ids]]
+
+    def loadCats(self, ids=[]):
+        return [self.cats[i] for i in ids] if isinstance(ids, (list, tuple)) else [self.cats[ids]]
+
+
+def install_coco_shims():
+    """Shim 6 (after load_reference): give the stub torchvision CocoDetection torchvision 0.2.1's behaviour on top of _CocoIndex."""
+    base = sys.modules["torchvision.datasets.coco"].CocoDetection
+
+    def __init__(self, root, annFile, transform=None, target_transform=None):
+        self.root = root
+        self.coco = _CocoIndex(annFile)
+        self.ids = list(self.coco.imgs.keys())
+        self.transform, self.target_transform = transform, target_transform
+
+    def __getitem__(self, index):
+        from PIL import Image
+        img_id = self.ids[index]
+        target = self.coco.loadAnns(self.coco.getAnnIds(imgIds=img_id))
+        img = Image.open(os.path.join(self.root, self.coco.loadImgs(img_id)[0]["file_name"])).convert("RGB")
+        if self.transform is not None:
+            img = self.transform(img)
+        if self.target_transform is not None:
+            target = self.target_transform(target)
+        return img, target
+
+    def __len__(self):
+        return len(self.ids)
+    base.__init__, base.__getitem__, base.__len__ = __init__, __getitem__, __len__
+    sys.modules["pycocotools.coco"].COCO = _CocoIndex

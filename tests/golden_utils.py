@@ -146,3 +146,39 @@ def voc_eval_inputs(seed=0, n_images=7, max_det=48, max_gt=9, n_classes=3):
         preds.append((pb.astype(np.float32), pl.astype(np.int64), ps))
         gts.append((gb, gl.astype(np.int64), gd))
     return preds, gts
+
+
+def dataset_inputs():
+    """A small synthetic COCO-format annotation set + images for the few-shot dataset fixture (tests/golden/dataset.npz):
+    14 images of 40..120 pixels a side, 4 categories with non-contiguous json ids (1, 3, 7, 9), 2 - 5 annotations per image with
+    crowd flags, boxes that reach past the image, degenerate (width <= 1) boxes, objects below the support-area threshold, and
+    one image whose only object of a category is a crowd.  Returns (coco dict, {image id: uint8 HxWx3})."""
+    rs = np.random.RandomState(20241003)
+    cats = [{"id": 1, "name": "a"}, {"id": 3, "name": "b"}, {"id": 7, "name": "c"}, {"id": 9, "name": "d"}]
+    images, anns, pix = [], [], {}
+    aid = 100
+    for k in range(14):
+        iid = 1000 + 7 * k
+        h, w = int(rs.randint(40, 121)), int(rs.randint(40, 121))
+        images.append({"id": iid, "file_name": "img_%d.png" % iid, "height": h, "width": w})
+        pix[iid] = rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        for j in range(int(rs.randint(2, 6))):
+            cat = [1, 3, 7, 9][int(rs.randint(0, 4))]
+            bw, bh = float(rs.uniform(1.0, w * 0.9)), float(rs.uniform(1.0, h * 0.9))
+            if rs.rand() < 0.12:
+                bw = float(rs.uniform(0.2, 1.0))                    # "close to zero area" (has_valid_annotation: any side <= 1)
+            x, y = float(rs.uniform(-3.0, w - 2.0)), float(rs.uniform(-3.0, h - 2.0))      # may start outside / reach past the image
+            anns.append({"id": aid, "image_id": iid, "category_id": cat, "bbox": [round(x, 2), round(y, 2), round(bw, 2), round(bh, 2)],
+                         "area": round(bw * bh, 2), "iscrowd": int(rs.rand() < 0.15)})
+            aid += 1
+    # an image whose only category-9 object is a crowd: it must not enter category 9's catalog
+    images.append({"id": 5000, "file_name": "img_5000.png", "height": 64, "width": 80})
+    pix[5000] = rs.randint(0, 256, size=(64, 80, 3)).astype(np.uint8)
+    anns.append({"id": aid, "image_id": 5000, "category_id": 9, "bbox": [5.0, 6.0, 40.0, 30.0], "area": 1200.0, "iscrowd": 1})
+    anns.append({"id": aid + 1, "image_id": 5000, "category_id": 1, "bbox": [10.5, 3.5, 33.3, 44.4], "area": 1478.52, "iscrowd": 0})
+    return {"images": images, "annotations": anns, "categories": cats}, pix
+
+
+# dataset fixture configurations: (name, is_train, shots, support augmentation (0 or 1 = + horizontal flip), training-excluded
+# contiguous category ids, test-excluded ones, support-area threshold)
+DATASET_CONFIGS = [("train1", True, 1, 0, [2], [], 150.0), ("train3aug", True, 3, 1, [], [], 60.0), ("test1", False, 1, 0, [2], [3], 150.0)]
