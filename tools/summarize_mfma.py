@@ -28,6 +28,7 @@ def main():
         k["name"] = r["Kernel_Name"]
         k[r["Counter_Name"]] = float(r["Counter_Value"])
         k["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        k["grid"] = int(r.get("Grid_Size", 0) or 0)
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
     for k in per.values():
         if "SQ_VALU_MFMA_BUSY_CYCLES" not in k or "GRBM_GUI_ACTIVE" not in k:
@@ -35,13 +36,18 @@ def main():
         n = short(k["name"])
         if not any(t in n for t in ("conv_", "mfma")):
             continue
-        a = agg[n]
-        a[0] += 1
-        a[1] += k["SQ_VALU_MFMA_BUSY_CYCLES"]
-        a[2] += k["GRBM_GUI_ACTIVE"]
-        a[3] += k["ns"]
+        names = [n]
+        # the step's dominant launch on its own row: the tower 3x3 conv over P3 + P4 of one tower at bs 8 = 500 tiles of 512 threads
+        if "conv_sp_kernel" in n and k["grid"] == 500 * 512:
+            names.append(n + " — 500 tiles: the dominant launch (tower conv over P3 + P4)")
+        for nm in names:
+            a = agg[nm]
+            a[0] += 1
+            a[1] += k["SQ_VALU_MFMA_BUSY_CYCLES"]
+            a[2] += k["GRBM_GUI_ACTIVE"]
+            a[3] += k["ns"]
     rows = sorted(agg.items(), key=lambda kv: -kv[1][3])
-    tot = [sum(v[i] for _, v in rows) for i in range(4)]
+    tot = [sum(v[i] for n_, v in rows if "dominant launch" not in n_) for i in range(4)]
     with open(out, "w") as f:
         f.write("# MFMA-busy counters of the conv kernels, `bench.py` training step (bf16), one rocprofv3 --pmc pass\n\n")
         f.write("busy share = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); effective clock = GRBM_GUI_ACTIVE / 8 / "
@@ -49,7 +55,7 @@ def main():
         f.write("| kernel | dispatches | total ms | MFMA busy share | eff. clock GHz |\n|---|---|---|---|---|\n")
         # the 24 largest by total time, plus — always — the 3x3 forward / data-gradient kernels (the step's dominant launch
         # runs on one of them; in a whole-process table the weight-gradient tuning sweeps outweigh it)
-        top = rows[:24] + [r for r in rows[24:] if any(t in r[0] for t in ("conv_sp_kernel", "conv_xr_kernel", "conv_p8_kernel"))]
+        top = rows[:24] + [r for r in rows[24:] if any(t in r[0] for t in ("conv_sp_kernel", "conv_xr_kernel", "conv_p8_kernel", "conv_wgrad_sk_kernel"))]
         for n, (c, busy, gui, ns) in top:
             f.write("| `%s` | %d | %.2f | %.3f | %.2f |\n" % (n, c, ns / 1e6, busy / (gui / 8 * 1024), gui / 8 / ns))
         f.write("| **all conv kernels** | %d | %.2f | **%.3f** | %.2f |\n" % (tot[0], tot[3] / 1e6, tot[1] / (tot[2] / 8 * 1024), tot[2] / 8 / tot[3]))
