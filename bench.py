@@ -26,6 +26,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 METRIC = "images/sec/GPU fwd+bwd, 800x1024 target + 127x127 query, bs=8; 1->8 GPU scaling"
+# --workload: (target geometries cycled step by step, query shots per image, default batch per GPU)
+WORKLOADS = {"config3": (((800, 1024),), 1), "config5": (((640, 832), (800, 1024), (1024, 1312)), 5)}
+WORKLOAD_BATCH = {"config3": 8, "config5": 4}
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (f32-in MFMA = vector rate)
 
 
@@ -118,57 +121,76 @@ class ConvTimer(object):
         return ConvTimer._overhead
 
 
-def cpu_baseline(dtype_name, seconds_budget=25.0, train=False):
-    """The oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores on a bounded sample of
-    the same workload: single 800x1024 + 127x127 pairs — forward incl. proposals (forward mode), or forward + proposals +
-    FCOS loss + backward through autograd (train mode, the headline metric's step without the optimiser)."""
-    import golden_utils as gu
+def cpu_baseline(dtype_name, seconds_budget=25.0, train=False, shapes=((800, 1024),), shots=1):
+    """The oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores on a bounded sample of the same
+    workload: single (target, `shots` x 127x127 query) pairs, one per shape in `shapes` — forward incl. proposals (forward
+    mode), or forward + training proposals + FCOS loss + backward through autograd (train mode: the headline metric's step
+    without the optimiser).  SURVEY.md 8d's protocol: bs = 1, torch.set_num_threads(n) for n = 8 and n = all cores, median of
+    5 timed passes after one warm-up each; `value` is the faster of the two settings, both are reported."""
+    import statistics
+    import numpy as np
     from oneshotdet_amd import spec, synth
     from oracle import hotpath_ref as orc
     sd = orc.to_torch_state_dict(synth.make_state_dict(spec.hot_path_shapes()))
     if train:
         for k, v in sd.items():
             v.requires_grad_(not spec.is_frozen(k))
-    img, q = gu.case_inputs("config1")
-    img, q = torch.from_numpy(img), torch.from_numpy(q)
-    gts = synth.make_gt_boxes(1, 800, 1024, seed=1000, max_boxes=6)
-    cores = torch.get_num_threads()
-
+    samples = []
+    for i, (h, w) in enumerate(shapes):
+        img = torch.from_numpy(synth.make_images("bench.target", 1, h, w, seed=1000 + i))
+        q = torch.from_numpy(synth.make_images("bench.query", shots, 127, 127, seed=1000 + i))
+        samples.append((img, q, synth.make_gt_boxes(1, h, w, seed=1000 + i, max_boxes=6), (h, w)))
+    all_cores = torch.get_num_threads()
     post_s = [0.0]             # seconds inside the proposal post-processing (score / top-k / decode / NMS: numpy O(n^2) NMS)
 
-    def one():
+    def one(sample):
+        img, q, gts, hw = sample
         if not train:
             with torch.no_grad():
-                o = orc.hot_path_forward(img, q, sd)
+                o = orc.hot_path_forward(img, q, sd, shots=shots)
                 t1 = time.time()
-                orc.fcos_postprocess(o["logits"], o["bbox_reg"], o["centerness"], [(800, 1024)])
+                orc.fcos_postprocess(o["logits"], o["bbox_reg"], o["centerness"], [hw])
                 post_s[0] += time.time() - t1
             return
-        o = orc.hot_path_forward(img, q, sd)
+        o = orc.hot_path_forward(img, q, sd, shots=shots)
         with torch.no_grad():
             t1 = time.time()
-            orc.fcos_postprocess(o["logits"], o["bbox_reg"], o["centerness"], [(800, 1024)], pre_nms_top_n=spec.PRE_NMS_TOP_N_TRAIN,
+            orc.fcos_postprocess(o["logits"], o["bbox_reg"], o["centerness"], [hw], pre_nms_top_n=spec.PRE_NMS_TOP_N_TRAIN,
                                  post_nms_top_n=spec.POST_NMS_TOP_N_TRAIN)
             post_s[0] += time.time() - t1
         c, r, t, _ = orc.fcos_loss(o["logits"], o["bbox_reg"], o["centerness"], gts, focal="cuda")
         (c + r + t).backward()
         for v in sd.values():
             v.grad = None
-    one()                      # warm-up (oneDNN primitive creation)
-    post_s[0] = 0.0
-    t0 = time.time()
-    n = 0
-    while True:
-        one()
-        n += 1
-        if time.time() - t0 > seconds_budget * 0.6 or n >= 8:
-            break
-    dt = time.time() - t0
+
+    def pass_seconds():
+        t0 = time.time()
+        for sm in samples:
+            one(sm)
+        return time.time() - t0
+    results, total_s = {}, 0.0
+    settings = sorted({min(8, all_cores), all_cores})
+    per_setting = seconds_budget / len(settings)
+    for nthreads in settings:
+        torch.set_num_threads(nthreads)
+        pass_seconds()                      # warm-up (oneDNN primitive creation for these shapes at this thread count)
+        post_s[0] = 0.0
+        ts, t_begin = [], time.time()
+        while len(ts) < 5 and (len(ts) < 1 or time.time() - t_begin < per_setting):
+            ts.append(pass_seconds())
+        results[nthreads] = dict(images_per_sec=round(len(samples) / statistics.median(ts), 4), passes=len(ts),
+                                 post_share=round(post_s[0] / max(sum(ts), 1e-9), 3))
+        total_s += sum(ts)
+    torch.set_num_threads(all_cores)
+    best = max(results, key=lambda n: results[n]["images_per_sec"])
     what = "forward + training proposals + FCOS loss + backward (autograd)" if train else "forward incl. proposals"
-    return {"value": round(n / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d x (1x800x1024 target + 1x127x127 query) %s, oracle/hotpath_ref.py (torch CPU fp32, %d threads); "
-                      "%.0f %% of that time is the proposal post-processing (score / top-k / decode / the oracle's numpy NMS)"
-                      % (n, what, cores, 100.0 * post_s[0] / dt)}
+    shp = " / ".join("1x%dx%d" % hw for hw in shapes)
+    return {"value": results[best]["images_per_sec"], "unit": "images/sec", "cores": best, "kind": "port",
+            "by_threads": {str(n): results[n] for n in settings},
+            "sample": "bs = 1: (%s target + %dx127x127 query) %s, oracle/hotpath_ref.py (torch CPU fp32); median of <= 5 passes per "
+                      "thread setting (%s threads), %.0f s of CPU work; post_share = fraction spent in the proposal post-processing "
+                      "(score / top-k / decode / the oracle's numpy NMS)"
+                      % (shp, shots, what, " and ".join(str(n) for n in settings), total_s)}
 
 
 def self_launch(argv, n):
@@ -273,8 +295,14 @@ def dist_setup(backend):
     return rank, local_rank, world
 
 
+STEP_STATS = {}      # filled by timed_steps: per-step durations from HIP events on the main stream, per-rank bracket times
+
+
 def timed_steps(step, steps, warmup, world, device_sync, reduce_device):
-    """W untimed steps, then exactly K steps bracketed by barrier + device sync on both sides; MAX over ranks."""
+    """W untimed steps, then exactly K steps bracketed by barrier + device sync on both sides; MAX over ranks.  Beside the
+    contract's bracket, one HIP event per step boundary on the main stream (recorded, never waited for inside the region)
+    gives the per-step durations -> median / p10 / p90 (SURVEY.md 8d reports the median), and every rank's own bracket time
+    is gathered so a slow rank is visible in the line."""
     def sync():
         device_sync()
         if world > 1:
@@ -283,12 +311,32 @@ def timed_steps(step, steps, warmup, world, device_sync, reduce_device):
     for _ in range(warmup):
         step()
     sync()
+    use_ev = reduce_device != "cpu" and torch.cuda.is_available()
+    evs = []
     t0 = time.perf_counter()
     for _ in range(steps):
+        if use_ev:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
         step()
+    if use_ev:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        evs.append(e)
     sync()
     elapsed = time.perf_counter() - t0
+    STEP_STATS.clear()
+    if use_ev and len(evs) > 1:
+        ms = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
+        STEP_STATS["step_ms"] = {"median": round(ms[len(ms) // 2], 3), "p10": round(ms[len(ms) // 10], 3),
+                                 "p90": round(ms[min(len(ms) - 1, (9 * len(ms)) // 10)], 3), "n": len(ms),
+                                 "source": "HIP events at the step boundaries of rank 0's main stream (not synchronised inside "
+                                           "the timed region); `ms_per_step` is the contract's wall bracket / steps"}
     if world > 1:
+        every = [None] * world
+        dist.all_gather_object(every, float(elapsed))
+        STEP_STATS["rank_ms_per_step"] = [round(t / steps * 1e3, 3) for t in every]
         t = torch.tensor([elapsed], device=reduce_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -314,6 +362,7 @@ def result_line(args, world, batch, elapsed, workload, launch, roofline=None, cp
     }
     if cpu is not None:
         line["cpu_baseline"] = cpu
+    line.update(STEP_STATS)
     return line
 
 
@@ -477,34 +526,63 @@ def main_train(args, rank, world, backend="nccl"):
     eng = train.TrainEngine(synth.make_state_dict(spec.full_model_shapes() if two else spec.hot_path_shapes()), dtype=dtype,
                             second_stage=two)
     B = args.batch
-    images = torch.from_numpy(synth.make_images("bench.target", B, 800, 1024, seed=1000 + rank)).cuda()
-    queries = torch.from_numpy(synth.make_images("bench.query", B, 127, 127, seed=1000 + rank)).cuda()
-    gts = synth.make_gt_boxes(B, 800, 1024, seed=1000 + rank, max_boxes=6)
-    gtb = np.zeros((B, 6, 4), np.float32)
-    for i, g in enumerate(gts):
-        gtb[i, :len(g)] = g
-    gt_boxes = torch.from_numpy(gtb).cuda()
-    gt_count = torch.tensor([len(g) for g in gts], dtype=torch.int32).cuda()
+    # config3 (default, the headline): one geometry.  config5 = BASELINE.json configs[4]'s per-GPU workload: multi-scale
+    # targets (short edge cycling 640 / 800 / 1024, long edge = short x 1.28 rounded up to /32: SURVEY.md 8d) and S = 5 queries
+    # per image, mean-pooled (generalized_rcnn.py:100-104); step i runs geometry i mod 3
+    shapes, S = WORKLOADS[args.workload]
+    batches = []
+    for gi, (H, W) in enumerate(shapes):
+        images = torch.from_numpy(synth.make_images("bench.target", B, H, W, seed=1000 + rank + 97 * gi)).cuda()
+        queries = torch.from_numpy(synth.make_images("bench.query", B * S, 127, 127, seed=1000 + rank + 97 * gi)).cuda()
+        gts = synth.make_gt_boxes(B, H, W, seed=1000 + rank + 97 * gi, max_boxes=6)
+        gtb = np.zeros((B, 6, 4), np.float32)
+        for i, g in enumerate(gts):
+            gtb[i, :len(g)] = g
+        batches.append((images, queries, torch.from_numpy(gtb).cuda(), torch.tensor([len(g) for g in gts], dtype=torch.int32).cuda()))
+    images, queries, gt_boxes, gt_count = batches[0]
+
+    def init_pg():
+        """The process group of this run: N ranks under a launcher, or a ONE-rank RCCL group for --live-exchange."""
+        if args.live_exchange and world == 1:
+            if "WORLD_SIZE" not in os.environ or "MASTER_ADDR" not in os.environ:
+                os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                                  MASTER_PORT=os.environ.get("MASTER_PORT", "29531"))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        else:
+            dist_setup(backend)
     pg_early = os.environ.get("OSD_BENCH_PG_AFTER") == "warm"      # A/B: warm_streams() instead of a whole step before RCCL
     if pg_early:
         eng.warm_streams()
-        if args.live_exchange and "WORLD_SIZE" not in os.environ:
-            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
-                              MASTER_PORT=os.environ.get("MASTER_PORT", "29531"))
-            dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-    with ops.tuning():
-        eng.forward_backward(images, queries, gt_boxes, gt_count)
-    torch.cuda.synchronize()
-    # Process group AFTER the first step: by now every stream of the engine has been used (has its hardware queue).  With
-    # RCCL initialised first the same step measured 12-14 % slower on one GPU (streams land on other queues).
-    if pg_early:
-        pass
-    elif args.live_exchange and "WORLD_SIZE" not in os.environ:
-        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
-                          MASTER_PORT=os.environ.get("MASTER_PORT", "29531"))
-        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        init_pg()
+    # Autotuning: every conv shape met for the first time is timed over its candidate kernels.  With N > 1 ranks the choices
+    # must not depend on each rank's own timing noise (ranks running different kernels = the slowest one sets every step): rank
+    # 0's tuner cache is broadcast and replayed by the other ranks (tune_step below), so all ranks launch identical kernels.
+    def tune_all():
+        for bt in batches:
+            with ops.tuning():
+                eng.forward_backward(*bt)
+            torch.cuda.synchronize()
+    cache_file = os.environ.get("OSD_TUNER_CACHE")      # optional: a tuner-cache file (dist_utils.save_tuner_choices)
+    if cache_file and os.path.exists(cache_file):
+        from oneshotdet_amd import dist_utils
+        dist_utils.load_tuner_choices(ops, cache_file)
+    if rank == 0:
+        tune_all()
+        if cache_file and not os.path.exists(cache_file):
+            from oneshotdet_amd import dist_utils
+            dist_utils.save_tuner_choices(ops, cache_file)
     else:
-        dist_setup(backend)
+        eng.warm_streams()             # every stream gets its hardware queue before RCCL creates its own
+    # Process group AFTER the first use of every stream: with RCCL initialised first the same step measured 12-14 % slower on
+    # one GPU (the engine's streams land on other hardware queues).
+    if not pg_early:
+        init_pg()
+    if world > 1:
+        from oneshotdet_amd import dist_utils
+        dist_utils.broadcast_tuner_choices(ops, src=0)
+        if rank != 0:
+            tune_all()                 # cache hits only: nothing is timed here, every shape runs rank 0's choice
+        assert dist_utils.tuner_choices_agree(ops), "ranks ended with different kernel choices"
     if dist.is_initialized():
         eng.attach_exchange(None, single_rank=bool(args.live_exchange), wire_dtype=wire)
     torch.cuda.synchronize()
@@ -523,7 +601,14 @@ def main_train(args, rank, world, backend="nccl"):
     # the step's tail (last weight gradients, exchange, update, repack) overlaps the next step's frozen layers; an
     # explicit device synchronisation brackets the timed region as always (OSD_NO_DEFER_JOIN=1: A/B switch)
     eng.defer_join = not os.environ.get("OSD_NO_DEFER_JOIN") and not args.graph
-    step = lambda: eng.train_step(images, queries, gt_boxes, gt_count)     # noqa: E731
+    step_no = [0]
+
+    def step():
+        bt = batches[step_no[0] % len(batches)]
+        step_no[0] += 1
+        return eng.train_step(*bt)
+    if args.graph and len(batches) > 1:
+        raise SystemExit("--graph captures one geometry: not with --workload config5")
     if args.graph:
         try:
             eng.capture(images, queries, gt_boxes, gt_count)
@@ -540,12 +625,17 @@ def main_train(args, rank, world, backend="nccl"):
         timer.install(ops)
         torch.cuda.synchronize()
         nst = max(2, min(args.steps, 5))
+        if len(batches) > 1:
+            nst = len(batches) * max(1, nst // len(batches))      # every geometry equally often
         eng.wstream = eng.wstream2 = eng.s1 = None    # one stream: concurrent kernels would stretch each other's durations
         eng._overlap = False                          # and no gradient exchange: this pass only times kernels
-        for _ in range(nst):
+        per_shape = []
+        for it in range(nst):
+            n0 = len(timer.records)
             torch.cuda._sleep(int(150e6))
-            eng.forward_backward(images, queries, gt_boxes, gt_count)
+            eng.forward_backward(*batches[it % len(batches)])
             torch.cuda.synchronize()
+            per_shape.append((it % len(batches), n0, len(timer.records)))
         conv_ms = timer.total_ms()
         tflops = timer.flops / (conv_ms * 1e-3) / 1e12
         corr_roofline = timer.correlation_roofline()
@@ -572,6 +662,29 @@ def main_train(args, rank, world, backend="nccl"):
                 "gflop_per_launch": round(2.0 * top[1] * top[2] * top[3] / 1e9, 1),
                 "achieved": round(top[6], 1), "frac": round(top[6] / PEAK_TFLOPS[args.dtype], 4),
                 "ms_per_step": round(top[7], 3)}
+        if len(batches) > 1:
+            # the dominant launch of every geometry by itself (the tower layer over that geometry's P3 + P4, or P3..P7)
+            roofline["per_geometry"] = []
+            ov = ConvTimer.bracket_overhead_ms()
+            for gi, (H, W) in enumerate(shapes):
+                agg = {}
+                for g2, a, b in per_shape:
+                    if g2 != gi:
+                        continue
+                    for (s_, e_), lab in zip(timer.records[a:b], timer.labels[a:b]):
+                        if lab[0].startswith("conv"):
+                            v = agg.setdefault(lab[:4], [0, 0.0, 0.0])
+                            v[0] += 1
+                            v[1] += s_.elapsed_time(e_) - ov
+                            v[2] += lab[4]
+                k, v = max(agg.items(), key=lambda kv: kv[1][1])
+                fam_ms = sum(v2[1] for v2 in agg.values())
+                fam_fl = sum(v2[2] for v2 in agg.values())
+                roofline["per_geometry"].append({
+                    "target": "%dx%d" % (H, W), "dominant_launch": "%s M=%d Cout=%d K=%d" % k,
+                    "avg_launch_us": round(v[1] * 1e3 / v[0], 1), "achieved": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                    "frac": round(v[2] / (v[1] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+                    "fwd_dgrad_conv_family_tflops": round(fam_fl / (fam_ms * 1e-3) / 1e12, 1)})
         if args.layer_table and rank == 0:
             with open(args.layer_table, "w") as f:
                 f.write("| kind | M (pixels) | Cout | K | launches/step | us/launch | TFLOP/s | ms/step |\n|---|---|---|---|---|---|---|---|\n")
@@ -579,14 +692,21 @@ def main_train(args, rank, world, backend="nccl"):
                     f.write("| %s | %d | %d | %d | %.0f | %.1f | %.0f | %.3f |\n" % r)
         timer.uninstall(ops)
     if rank == 0:
-        workload = ("BASELINE.json configs[2]: bs=%d/GPU, 800x1024 target + 127x127 query, %s MFMA convs, forward "
-                    "(two R-50-FPN backbones, query pooling, correlation, FCOS head, training proposals) + FCOS loss + "
-                    "backward (stem/layer1 frozen) + gradient all-reduce + SGD(momentum) + weight repack" % (B, args.dtype))
+        what = ("%s MFMA convs, forward (two R-50-FPN backbones, query pooling, correlation, FCOS head, training proposals) + FCOS "
+                "loss + backward (stem/layer1 frozen) + gradient all-reduce + SGD(momentum) + weight repack" % args.dtype)
+        if args.workload == "config5":
+            workload = ("BASELINE.json configs[4] (per-GPU workload): bs=%d/GPU, multi-scale targets %s cycling step by step + %d "
+                        "x 127x127 queries per image (mean-pooled correlation), %s"
+                        % (B, " / ".join("%dx%d" % hw for hw in shapes), S, what))
+        else:
+            workload = "BASELINE.json configs[2]: bs=%d/GPU, 800x1024 target + 127x127 query, %s" % (B, what)
         if two:
             workload += (" + second stage (subsample 128 ROIs per image, few-shot ROI box head forward, cross-entropy + "
                          "smooth-L1, backward into both backbones)")
-        cpu = cpu_baseline(args.dtype, train=True) if (world == 1 and not args.no_cpu_baseline) else None
+        cpu = cpu_baseline(args.dtype, train=True, shapes=shapes, shots=S) if (world == 1 and not args.no_cpu_baseline) else None
         line = result_line(args, world, B, elapsed, workload, launch, roofline, cpu)
+        if args.workload == "config5":
+            line["metric"] = "images/sec/GPU fwd+bwd, multi-scale {640,800,1024} short-edge target + 5-shot 127x127 query stack, bs=4"
         # which part of the reference's training step (engine/trainer.py:79-93) the line covers: the north_star hot path is
         # the siamese-FCOS first stage; the reference's trainer also runs roi_heads on its proposals
         line["config"]["stages"] = ("first + second stage: the reference's complete training step" if two else
@@ -624,7 +744,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default=os.environ.get("OSD_BENCH_DTYPE", ""), choices=["f32", "bf16"])
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: 8; 4 for --workload config5)")
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS),
+                    help="train mode: config3 = BASELINE.json configs[2]/[3], the headline (800x1024, 1 shot, bs 8); config5 = "
+                         "configs[4]'s per-GPU workload (multi-scale 640/800/1024 short edge, 5-shot query stack, bs 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-timing", action="store_true")
     ap.add_argument("--layer-table", default="", help="train mode: write the per-shape conv table (markdown) here")
@@ -647,6 +770,8 @@ def main():
                     help="exercise only the multi-process plumbing (gloo, no GPU work): used by tests/test_dist_cpu.py")
     args = ap.parse_args()
 
+    if not args.batch:
+        args.batch = WORKLOAD_BATCH[args.workload]
     rank, local_rank, world = check_world(args)      # may start the ranks and exit; never touches the GPU
     if args.dry_run_cpu:
         dist_setup("gloo")

@@ -121,22 +121,29 @@ int osd_conv2d_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* x
                          const int32_t* ns, const int32_t* hs, const int32_t* ws, const void* const* wts,
                          const float* const* biases, void* stream);
 
-/* osd_conv2d_fwd_multi (no residual, mask or activation) for the data-gradient conv whose outputs dt are the gradients w.r.t.
- * the outputs of a GroupNorm + ReLU (the FCOS towers, fcos.py:29-39): for every pair with gn_us[i] != NULL the epilogue also
- * gathers the sums the GroupNorm backward needs, from the values it stores (rounded to the conv's dtype, i.e. what a pass over
- * the stored dt would read): with z = a u + b, dz = z > 0 ? dt : 0, xhat = xa u + xb per pixel and channel,
+/* osd_conv2d_fwd_multi (no residual, mask or activation) whose epilogue also gathers GroupNorm statistics from the values it
+ * stores (rounded to the conv's dtype: what a separate pass over the stored tensor would read), added by fp32 atomics into
+ * buffers the caller has zeroed (the slab index is picked per workgroup to spread them).  Requirements, stated once: the
+ * software-pipelined 3x3 kernel only (d->algo = 15: bf16, 3x3 / stride 1 / pad 1, map widths 64 / 128 / 256), and only pairs
+ * made of whole 256-pixel tiles whose images are whole 128-pixel runs; anything else returns OSD_ERR_UNSUPPORTED and the caller
+ * uses the plain pair of calls (conv, then the statistics pass).  gn_n = images per pair, gn_groups = GroupNorm groups.
+ *
+ * BACKWARD statistics — pair i with gn_us[i] != NULL: the conv is the data-gradient conv whose outputs dt are the gradients
+ * w.r.t. the outputs of a GroupNorm + ReLU (the FCOS towers, fcos.py:29-39).  With z = a u + b, dz = z > 0 ? dt : 0 and
+ * xhat = xa u + xb per pixel and channel,
  *   gn_wss[i] [gn_n][OSD_GN_SPLITS][gn_groups][2] += sum dz * gamma, sum dz * gamma * xhat     (per image, slab, group)
  *   gn_pws[i] [gn_n][OSD_GN_SPLITS][2][cout]      += sum dz * xhat, sum dz                       (d gamma / d beta partials)
- * by fp32 atomics (the caller zeroes both; the slab is picked per workgroup to spread them).  gn_us[i]: the GroupNorm's INPUT
- * (the forward conv's output) at this conv's output pixels, same dtype and row stride as ys[i]; gn_abs[i]: level i's
- * [4][gn_n][cout] block of osd_groupnorm_relu_fwd_levels' ab; gn_gammas[i]: [cout].  These are the two halves of the ws of
- * osd_groupnorm_relu_bwd_levels_fused, which then skips its own statistics pass for that level.  Only the software-pipelined
- * FORWARD statistics instead (the tower conv whose output feeds the GroupNorm): pairs with gn_us[i] == NULL (or gn_us == NULL)
- * and gn_wss[i] != NULL add the sum and the sum of squares of the stored outputs to gn_wss[i] [gn_n][OSD_GN_SPLITS][gn_groups][2]
- * — level i's part of the ws of osd_groupnorm_relu_fwd_levels_fused; gn_abs / gn_gammas / gn_pws are not read.  Only the
- * software-pipelined
- * 3x3 kernel gathers them (d->algo = 15: bf16, widths 64 / 128 / 256) and only for pairs made of whole 256-pixel tiles
- * whose images are whole 128-pixel runs; anything else returns OSD_ERR_UNSUPPORTED and the caller uses the plain pair of calls. */
+ * i.e. the two halves of the ws of osd_groupnorm_relu_bwd_levels_fused, which then skips its own statistics pass for that
+ * level.  gn_us[i]: the GroupNorm's INPUT (the forward conv's output) at this conv's output pixels, dtype and row stride of
+ * ys[i]; gn_abs[i]: level i's [4][gn_n][cout] block (a, b, xa, xb) of osd_groupnorm_relu_fwd_levels' ab; gn_gammas[i]: [cout].
+ * All of gn_us[i], gn_abs[i], gn_gammas[i], gn_wss[i], gn_pws[i] must be non-NULL for such a pair.
+ *
+ * FORWARD statistics — pair i with gn_us[i] == NULL (or gn_us == NULL) and gn_wss[i] != NULL: the conv is the tower conv whose
+ * output feeds the GroupNorm;
+ *   gn_wss[i] [gn_n][OSD_GN_SPLITS][gn_groups][2] += sum y, sum y * y                             (per image, slab, group)
+ * = level i's part of the ws of osd_groupnorm_relu_fwd_levels_fused.  gn_abs, gn_gammas and gn_pws are not read (may be NULL).
+ *
+ * A pair with gn_wss[i] == NULL gathers nothing.  gn_wss itself must not be NULL. */
 int osd_conv2d_fwd_multi_gn(const osd_conv_desc* d, int n_seg, const void* const* xs, void* const* ys, const int32_t* ns,
                             const int32_t* hs, const int32_t* ws, const void* const* wts, const float* const* biases,
                             const void* const* gn_us, const float* const* gn_abs, const float* const* gn_gammas,
@@ -547,11 +554,25 @@ int osd_image_transform_batch(int n_images, const uint8_t* const* srcs_rgb_hwc, 
  * matched_gt = index of the ground-truth box of its class with the largest IoU ('+1' on x2, y2 of both boxes, then the '+1'
  * areas of boxlist_iou; first maximum; -1 when that IoU < iou_thresh or the image has no box of the class) and
  * match = 1 (the highest-scoring detection matched to a non-difficult box; equal scores: the higher index), 0 (unmatched, or
- * a box already claimed) or -1 (matched to a difficult box: ignored), 0 past det_count.  The precision / recall curves and
- * AP (voc_eval.py:139-216) are host arithmetic on these flags (oneshotdet_amd/evaluation.py). */
+ * a box already claimed) or -1 (matched to a difficult box: ignored), 0 past det_count. */
 int osd_voc_match(const float* det_boxes, const float* det_scores, const int32_t* det_labels, const int32_t* det_count,
                   const float* gt_boxes, const int32_t* gt_labels, const uint8_t* gt_difficult, const int32_t* gt_count,
                   int n, int max_det, int max_gt, float iou_thresh, int8_t* match, int32_t* matched_gt, void* stream);
+
+/* Precision / recall curves of every class in one launch (voc_eval.py:139-158).  flags_sorted: the match flags of the whole
+ * dataset ordered by (class id ascending, score descending); class c owns [class_begin[c], class_begin[c + 1]) (n_classes + 1
+ * entries); n_pos [n_classes] = the class's non-difficult ground-truth boxes.  prec / rec (float64, same indexing):
+ * prec[i] = tp / (tp + fp) over the class's first i + 1 detections (NaN while only ignored ones were seen), rec[i] = tp / n_pos
+ * (NaN for n_pos == 0).  Counts are integers and the divisions IEEE double: the reference's numpy values, bit for bit. */
+int osd_voc_curves(const int8_t* flags_sorted, const int32_t* class_begin, const int32_t* n_pos, int n_classes, double* prec,
+                   double* rec, void* stream);
+
+/* Average precision of every class from its curves (calc_detection_voc_ap, voc_eval.py:161-216): use_07_metric != 0 -> the
+ * 11-point PASCAL VOC 2007 metric (bit-identical to the reference's loop), else the area under the monotone precision envelope
+ * (the same terms as the reference's, summed in a fixed tree order: equal to ~1e-16 relative).  has_prec[c] == 0 (class id never
+ * seen) or has_rec[c] == 0 (no countable ground truth) -> NaN, like the reference.  ap [n_classes] float64. */
+int osd_voc_ap(const double* prec, const double* rec, const int32_t* class_begin, const uint8_t* has_prec, const uint8_t* has_rec,
+               int n_classes, int use_07_metric, double* ap, void* stream);
 
 #ifdef __cplusplus
 }

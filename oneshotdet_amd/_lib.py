@@ -98,6 +98,8 @@ SIGNATURES = {
     "osd_box_match_sample": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_box_loss": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _f, _p, _p, _i, _i, _p]),
     "osd_voc_match": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
+    "osd_voc_curves": (_i, [_p, _p, _p, _i, _p, _p, _p]),
+    "osd_voc_ap": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "osd_groupnorm_act_rois_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i, _p]),
     "osd_rois_sum": (_i, [_p, _p, _i, _i, _i64, _i, _p]),
     "osd_roi_pool_levels_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -17,6 +17,17 @@
 //     border, M tail, Cout tail) presents an out-of-range offset and the hardware writes zeros — no zero page, no 64-bit
 //     per-lane pointers (8 VGPRs and two VALU selects per instruction less).
 // The accumulation order over K is conv_xr_kernel's, so the two kernels' outputs are bit-identical (tested).
+//
+// GENW (round 4): ANY map width.  The padded image above needs tiles that start at x = 0 and hold whole lines (W in 64 / 128 /
+// 256).  The general form keeps the tile's 256 pixels CONSECUTIVE in LDS (row 16 + r <- pixel m0 + r, no pad rows) plus one
+// 8-row halo instruction on either side (rows 8..15 <- pixels m0 - 8 .. m0 - 1, rows 272..279 <- m0 + 256 .. m0 + 263), so tap s
+// of pixel r still reads row 16 + r + s - 1 and every fragment base stays a multiple of 16 (the same conflict-free key table).
+// What the zero pad rows did — x = -1 and x = W read zeros — is done in registers: a lane whose pixel sits at x = 0 (x = W - 1)
+// zeroes its tap-0 (tap-2) fragment right before the MFMAs that consume it (4 v_cndmask per fragment, long after the read has
+// landed, so the software pipelining of the reads is untouched).  Same K order, and a masked value is the same exact zero a pad
+// row held: on the widths both forms accept the outputs are bit-identical (tested).  All lanes' vertical validity, the image
+// borders and the M tail stay hardware bounds checks of the DMA.  Every wave issues FIVE pixel instructions per image (the
+// halo one is all out-of-range lanes — zeros into the unused rows 0..7 — on waves 1..6), so the counted waits are uniform.
 #include "osd_common.h"
 #include "conv_params.h"
 #include "conv_epilogue.h"
@@ -61,7 +72,7 @@ constexpr int SP_BBYTES = SP_BN * SP_KB;
 constexpr int SP_LDS = 2 * SP_ABYTES + 2 * SP_BBYTES;
 constexpr unsigned SP_OOB = 0x80000000u;            // beyond any buffer of < 2 GiB: the DMA writes zeros
 
-template <bool GNB>      // GNB: the epilogue also gathers the GroupNorm-backward statistics (ConvGnb, conv_params.h)
+template <bool GNB, bool GENW>      // GNB: the epilogue also gathers the GroupNorm statistics (ConvGnb, conv_params.h); GENW: any width
 __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   typedef __bf16 T;
   constexpr int TM = SP_TM, TN = SP_TN, KB = SP_KB;
@@ -83,14 +94,15 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   const ConvView q = conv_select_view(p, tile_m);
   const int q_H = q.H, q_W = q.W, q_M = q.M, q_HoWo = q.HoWo;
   const int m0 = tile_m * SP_BM, n0 = tile_n * SP_BN;
-  const int logw = __builtin_ctz((unsigned)q_W);       // W in {64, 128, 256} (checked by the launcher)
+  [[maybe_unused]] const int logw = __builtin_ctz((unsigned)q_W);       // !GENW: W in {64, 128, 256} (checked by the launcher)
   const int Cin = p.Cin;
 
   const i32x4 xrs = sp_make_rsrc(q.x, (unsigned)q_M * (unsigned)Cin * 2u);            // H = Ho, W = Wo: M pixels x Cin
   const i32x4 wrs = sp_make_rsrc(q.w, (unsigned)p.w_rows * (unsigned)p.Ktot * 2u);
 
-  // ---- zero both pixel images once: the pad rows stay zero for the whole K loop ----
-  {
+  // ---- zero both pixel images once: the pad rows stay zero for the whole K loop (GENW: no pad rows; every row that is read
+  // is rewritten by each image's DMA) ----
+  if constexpr (!GENW) {
     uint4 z = {0u, 0u, 0u, 0u};
     for (int i = tid; i < 2 * SP_ABYTES / 16; i += 512) *reinterpret_cast<uint4*>(smem + i * 16) = z;
   }
@@ -102,23 +114,54 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   //            line ho - 1 + kr exists is one bit per (instruction, filter row) in a_valid (M tail: all clear)
   //   weights: b_par[i & 1] + i * 8 * Ktot * 2; rows past w_rows are past the end of the buffer by themselves
   const int lrow = lane >> 3, lpos = lane & 7;
-  unsigned a_par[2], b_par[2], a_valid = 0u;
+  unsigned a_par[2], b_par[2], a_valid = 0u;          // a_valid bit i * 3 + kr; GENW: bits 12..14 = the halo instruction
   unsigned a_dst[4];
+  [[maybe_unused]] unsigned h_off = 0u, h_dst = 0u;   // GENW: the halo instruction's source offset (filter row 0, slab 0), LDS row
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (wave * 4 + i) * 8 + lrow;
     const int m = m0 + row;
-    const int R = 16 + row + 16 * (row >> logw);
-    a_dst[i] = (unsigned)__builtin_amdgcn_readfirstlane((16 + (wave * 4 + i) * 8 + 16 * (((wave * 4 + i) * 8) >> logw)) * KB);
+    int R, ad;
+    if constexpr (GENW) {
+      R = 16 + row;
+      ad = (16 + (wave * 4 + i) * 8) * KB;
+    } else {
+      R = 16 + row + 16 * (row >> logw);
+      ad = (16 + (wave * 4 + i) * 8 + 16 * (((wave * 4 + i) * 8) >> logw)) * KB;
+    }
+    a_dst[i] = (unsigned)__builtin_amdgcn_readfirstlane(ad);
     if (i < 2) {
       a_par[i] = (unsigned)((m - i * 8 - q_W) * Cin + ((lpos ^ sp_key(R)) * SP_EPC)) * 2u;      // instruction 0's row + parity chunk
       b_par[i] = (unsigned)((n0 + row - i * 8) * p.Ktot + ((lpos ^ ((row >> 1) & 7)) * SP_EPC)) * 2u;
     }
     if (m < q_M) {
-      const int ho = (m % q_HoWo) >> logw;
+      int ho;
+      if constexpr (GENW) ho = (int)((unsigned)(m % q_HoWo) / (unsigned)q_W);
+      else ho = (m % q_HoWo) >> logw;
 #pragma unroll
       for (int kr = 0; kr < 3; ++kr)
         if ((unsigned)(ho - 1 + kr) < (unsigned)q_H) a_valid |= 1u << (i * 3 + kr);
+    }
+  }
+  // GENW: which of this lane's 8 fragment pixels (tile row (wm * 8 + j) * 16 + (lane & 15)) sit on the left (bit j) / right
+  // (bit 8 + j) border of their line: the tap-0 / tap-2 fragment of such a pixel is zeroed in registers
+  [[maybe_unused]] unsigned edge = 0u;
+  if constexpr (GENW) {
+    const int hrow = wave == 0 ? -8 + lrow : 256 + lrow;         // halo rows: waves 0 and 7; the other waves fetch nothing
+    const int hm = m0 + hrow;
+    h_dst = (unsigned)__builtin_amdgcn_readfirstlane(wave == 0 ? 8 * KB : (wave == 7 ? 272 * KB : 0));
+    h_off = (unsigned)((hm - q_W) * Cin + ((lpos ^ sp_key(16 + hrow)) * SP_EPC)) * 2u;
+    if ((wave == 0 || wave == 7) && hm >= 0 && hm < q_M) {
+      const int ho = (int)((unsigned)(hm % q_HoWo) / (unsigned)q_W);
+#pragma unroll
+      for (int kr = 0; kr < 3; ++kr)
+        if ((unsigned)(ho - 1 + kr) < (unsigned)q_H) a_valid |= 1u << (12 + kr);
+    }
+#pragma unroll
+    for (int j = 0; j < SP_TM; ++j) {
+      const unsigned x = (unsigned)(m0 + (wm * SP_TM + j) * 16 + (lane & 15)) % (unsigned)q_W;
+      if (x == 0u) edge |= 1u << j;
+      if (x == (unsigned)q_W - 1u) edge |= 1u << (8 + j);
     }
   }
   const int line_bytes = q_W * Cin * 2;
@@ -131,6 +174,12 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
     const unsigned off = ((a_valid >> (i * 3 + kr)) & 1u) ? a_par[i & 1] + (unsigned)(i * 16 * Cin + kr * line_bytes + kc * 2) : SP_OOB;
     sp_dma16(xrs, off, a_lds[buf] + a_dst[i]);
   };
+  // GENW: the halo instruction of group (kr, kc) — issued by every wave AHEAD of its four tile instructions
+  [[maybe_unused]] auto issue_halo = [&](int buf, int kr, int kc) {
+    const unsigned off = ((a_valid >> (12 + kr)) & 1u) ? h_off + (unsigned)(kr * line_bytes + kc * 2) : SP_OOB;
+    sp_dma16(xrs, off, a_lds[buf] + h_dst);
+  };
+  constexpr int NIMG = GENW ? 5 : 4;                    // pixel DMA instructions per wave and image
   // weight instruction i of the stage whose K offset is koff (elements) into weight stage `buf`
   auto issue_b = [&](int buf, int i, int koff) {
     sp_dma16(wrs, b_par[i & 1] + (unsigned)((i * 8 * p.Ktot + koff) * 2), b_lds[buf] + (unsigned)((wave * 4 + i) * 1024));
@@ -156,7 +205,8 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int r0 = (wm * TM + j) * 16;
-    x_frag[j] = (16 + r0 + 16 * (r0 >> logw)) * KB;
+    if constexpr (GENW) x_frag[j] = (16 + r0) * KB;
+    else x_frag[j] = (16 + r0 + 16 * (r0 >> logw)) * KB;
   }
 
   const int nslab = Cin / SP_BKE;
@@ -174,13 +224,15 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   // fragment j into xf[j] right behind the 4 MFMAs that consumed it.  ab_n / s_n / kb_n / bb_n: pixel image, tap, K half and
   // weight stage of the NEXT half stage.  DMA: FB -> the 4 weight instructions of the stage at K offset koff into weight
   // buffer dma_bb; FA -> the 4 pixel instructions of group (nkr, nkc) into image dma_ab; both spread over the MFMA groups.
-  auto half_stage = [&](auto early_tag, auto bar_tag, uint4 (&wcur)[TN], uint4 (&wnxt)[TN], int ab_n, auto sn_tag, auto kbn_tag, int bb_n,
+  auto half_stage = [&](auto cur_tag, auto bar_tag, uint4 (&wcur)[TN], uint4 (&wnxt)[TN], int ab_n, auto sn_tag, auto kbn_tag, int bb_n,
                         auto has_next, auto fb_tag, int dma_bb, int koff, auto fa_tag, int dma_ab, int nkr, int nkc) {
+    // cur_tag: the tap (0 / 1 / 2) of THIS half stage's pixel fragments (GENW: taps 0 and 2 are masked at the line borders)
+    [[maybe_unused]] constexpr int s_cur = decltype(cur_tag)::value;
     // BAR: 0 = no barrier in this half stage; 1 / 2 = the stage's barrier, with `vmcnt(0)` / `vmcnt(4)` before it.  The
     // barrier sits BEHIND the first MFMA group: the last fragment read of the previous half stage was issued just before that
     // group, so the lgkmcnt(0) the barrier needs (all my reads of the buffers it releases are complete) has 4 MFMAs of cover.
     constexpr int BAR = decltype(bar_tag)::value;
-    constexpr bool dma_early = decltype(early_tag)::value;
+    constexpr bool dma_early = true;
     constexpr int s_n = decltype(sn_tag)::value, kb_n = decltype(kbn_tag)::value;
     constexpr bool NEXT = decltype(has_next)::value, FB = decltype(fb_tag)::value, FA = decltype(fa_tag)::value;
     const char* xs = smem + ab_n * SP_ABYTES;
@@ -191,7 +243,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
     constexpr int BAR_AT = OSD_SP_BAR_AT;               // MFMA groups of this half stage issued ahead of its barrier
     if constexpr (BAR != 0 && BAR_AT == 0) {
       sp_wait_lgkm0();
-      if constexpr (BAR == 2) sp_wait_vmcnt<4>(); else sp_wait_vmcnt<0>();
+      if constexpr (BAR == 2) sp_wait_vmcnt<NIMG>(); else sp_wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
     }
     if constexpr (NEXT && (BAR == 0 || BAR_AT == 0)) {
@@ -200,6 +252,10 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
     }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
+      if constexpr (GENW && s_cur != 1) {               // x = -1 / x = W of this pixel's line: the zero a pad row would hold
+        const bool z = (edge >> (j + (s_cur == 2 ? 8 : 0))) & 1u;
+        xf[j].x = z ? 0u : xf[j].x; xf[j].y = z ? 0u : xf[j].y; xf[j].z = z ? 0u : xf[j].z; xf[j].w = z ? 0u : xf[j].w;
+      }
 #pragma unroll
       for (int i = 0; i < TN; ++i)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&wcur[i]),
@@ -211,14 +267,14 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
           const unsigned long long ta = __builtin_amdgcn_s_memtime();
           sp_wait_lgkm0();
           const unsigned long long tb = __builtin_amdgcn_s_memtime();
-          if constexpr (BAR == 2) sp_wait_vmcnt<4>(); else sp_wait_vmcnt<0>();
+          if constexpr (BAR == 2) sp_wait_vmcnt<NIMG>(); else sp_wait_vmcnt<0>();
           const unsigned long long tc = __builtin_amdgcn_s_memtime();
           __builtin_amdgcn_s_barrier();
           const unsigned long long td = __builtin_amdgcn_s_memtime();
           st_lgkm += tb - ta; st_vm += tc - tb; st_bar += td - tc;
 #else
           sp_wait_lgkm0();
-          if constexpr (BAR == 2) sp_wait_vmcnt<4>(); else sp_wait_vmcnt<0>();
+          if constexpr (BAR == 2) sp_wait_vmcnt<NIMG>(); else sp_wait_vmcnt<0>();
           __builtin_amdgcn_s_barrier();
 #endif
           if constexpr (NEXT) {
@@ -235,6 +291,9 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
         if ((j < 4) == dma_early) issue_b(dma_bb, j & 3, koff);
       }
       if constexpr (FA) {
+        if constexpr (GENW) {
+          if (j == (dma_early ? 0 : 4)) issue_halo(dma_ab, nkr, nkc);
+        }
         if ((j < 4) == dma_early) issue_a(dma_ab, j & 3, nkr, nkc);
       }
 #endif
@@ -250,6 +309,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
 
   // ---- prologue: pixel image 0, weight stages 0 and 1; then the first fragments ----
   __syncthreads();                                      // the zero fill is complete before any DMA lands on real rows
+  if constexpr (GENW) issue_halo(0, 0, 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) issue_a(0, i, 0, 0);
 #pragma unroll
@@ -278,7 +338,6 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   using B1 = std::integral_constant<int, 1>;
   using B2 = std::integral_constant<int, 2>;
   {
-    using E = std::true_type;
     for (int g = 0; g + 1 < G; ++g) {                     // every group but the last
       int nkr = kr, nkc = kc + SP_BKE;                    // next group
       if (nkc >= Cin) { nkc = 0; ++nkr; }
@@ -286,18 +345,18 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
       const int knext = nkr * 3 * Cin + nkc;              // ... of the next group
       // tap 0, first half: reads its own second half and fetches the NEXT group's pixel image (its buffer was vacated at the
       // previous group's last barrier)
-      half_stage(E(), B0(), wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, Y(), ab ^ 1, nkr, nkc);
+      half_stage(I0(), B0(), wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, Y(), ab ^ 1, nkr, nkc);
       // second half, barrier B(g, 0) inside (the wait leaves the 4 image DMAs in flight): weight stage (g, 1) visible, buffer bb
       // vacated -> fetch weight stage (g, 2) into it
-      half_stage(E(), B2(), wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
+      half_stage(I0(), B2(), wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
       // tap 1
-      half_stage(E(), B0(), wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+      half_stage(I1(), B0(), wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
       // B(g, 1): weight stage (g, 2) visible, buffer bb ^ 1 vacated -> weight stage (g + 1, 0)
-      half_stage(E(), B1(), wf1, wf0, ab, I2(), I0(), bb, Y(), Y(), bb ^ 1, knext, N_(), 0, 0, 0);
+      half_stage(I1(), B1(), wf1, wf0, ab, I2(), I0(), bb, Y(), Y(), bb ^ 1, knext, N_(), 0, 0, 0);
       // tap 2
-      half_stage(E(), B0(), wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+      half_stage(I2(), B0(), wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
       // B(g, 2): next image + weight stage (g + 1, 0) visible; image ab and weight buffer bb vacated -> weight stage (g + 1, 1)
-      half_stage(E(), B1(), wf1, wf0, ab ^ 1, I0(), I0(), bb ^ 1, Y(), Y(), bb, knext + Cin, N_(), 0, 0, 0);
+      half_stage(I2(), B1(), wf1, wf0, ab ^ 1, I0(), I0(), bb ^ 1, Y(), Y(), bb, knext + Cin, N_(), 0, 0, 0);
       ab ^= 1;
       bb ^= 1;
       kr = nkr;
@@ -306,10 +365,10 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
     {
       // last group: no next image; weight stage (g, 1) is in flight, (g, 2) is fetched below
       const int kbase = kr * 3 * Cin + kc;
-      half_stage(E(), B0(), wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-      half_stage(E(), B1(), wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
-      half_stage(E(), B0(), wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-      half_stage(E(), B1(), wf1, wf0, ab, I2(), I0(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+      half_stage(I0(), B0(), wf0, wf1, ab, I0(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+      half_stage(I0(), B1(), wf1, wf0, ab, I1(), I0(), bb ^ 1, Y(), Y(), bb, kbase + 2 * Cin, N_(), 0, 0, 0);
+      half_stage(I1(), B0(), wf0, wf1, ab, I1(), I1(), bb ^ 1, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+      half_stage(I1(), B1(), wf1, wf0, ab, I2(), I0(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
       // the epilogue's bias values (8 consecutive channels per lane, the same in all of its passes) travel while the last
       // MFMAs run: loaded at the start of the epilogue they cost it a full memory latency
       {
@@ -318,8 +377,8 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(bsrc), b1 = *reinterpret_cast<const f32x4*>(bsrc + 4);
         bq[0] = b0; bq[1] = b1;
       }
-      half_stage(E(), B0(), wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
-      half_stage(E(), B0(), wf1, wf0, ab, I0(), I0(), bb, N_(), N_(), 0, 0, N_(), 0, 0, 0);
+      half_stage(I2(), B0(), wf0, wf1, ab, I2(), I1(), bb, Y(), N_(), 0, 0, N_(), 0, 0, 0);
+      half_stage(I2(), B0(), wf1, wf0, ab, I0(), I0(), bb, N_(), N_(), 0, 0, N_(), 0, 0, 0);
     }
 
   }
@@ -352,34 +411,39 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
 
 }  // namespace
 
-int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream) {
+int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_width) {
   ConvKParams p = pin;
   if (p.R != 3 || p.S != 3 || p.sh != 1 || p.sw != 1 || p.ph != 1 || p.pw != 1)
     return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): 3x3 stride 1 pad 1 only");
   if (p.Cin % SP_BKE != 0 || p.sW != p.Cin) return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): dense NHWC input with cin %% 64 == 0");
   if (p.relu_in) return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): relu_in prologue not supported");
   if ((long long)p.w_rows * p.Ktot * 2 >= 0x7fffffffLL) return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): weights over 2 GiB");
+  // any width: dense maps (Wo == W, Ho == H) under 2 GiB.  The padded-image form needs W in 64 / 128 / 256 (tiles start at x = 0
+  // and hold whole lines); every other width — or all of them with general_width — runs the consecutive-rows form (GENW)
+  bool genw = general_width;
   auto ok = [&](int w, int wo, int h, int ho, int m, int sh) {
-    return (w == 64 || w == 128 || w == 256) && wo == w && ho == h && sh == w * p.Cin && (long long)m * p.Cin * 2 < 0x7fffffffLL;
+    if (!(w == 64 || w == 128 || w == 256)) genw = true;
+    return w >= 1 && wo == w && ho == h && sh == w * p.Cin && (long long)m * p.Cin * 2 < 0x7fffffffLL;
   };
   p.tilesM = cdiv(p.M, SP_BM);
   if (p.n_seg > 0) {
     p.tilesM = 0;
     for (int i = 0; i < p.n_seg; ++i) {
       if (!ok(p.seg[i].W, p.seg[i].Wo, p.seg[i].H, p.seg[i].Ho, p.seg[i].M, p.seg[i].sH))
-        return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): segment %d width %d (needs 64, 128 or 256, < 2 GiB)", i, p.seg[i].W);
+        return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): segment %d (width %d) is not a dense map under 2 GiB", i, p.seg[i].W);
       p.seg[i].tile_begin = p.tilesM;
       p.tilesM += cdiv(p.seg[i].M, SP_BM);
     }
   } else if (!ok(p.W, p.Wo, p.H, p.Ho, p.M, p.sH)) {
-    return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): width %d (needs 64, 128 or 256, < 2 GiB)", p.W);
+    return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): not a dense map under 2 GiB (width %d)", p.W);
   }
   p.tilesN = cdiv(p.Cout, SP_BN);
   p.KT = p.Ktot / SP_BKE;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
     attr_done = true;
   }
   const long long nblocks = (long long)p.tilesM * p.tilesN;
@@ -387,6 +451,7 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream) {
   if (p.gn_groups > 0) {
     // GroupNorm-backward statistics in the epilogue: whole tiles only (fast path), a wave's 128 rows inside one image, one
     // 16-byte channel chunk inside one group
+    if (genw) return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): GroupNorm statistics need map widths 64 / 128 / 256");
     if (p.n_seg <= 0 || p.Cout % SP_BN != 0 || p.out_stride % 8 != 0 || p.Cout % p.gn_groups != 0 || (p.Cout / p.gn_groups) % 8 != 0 ||
         p.res_mode != OSD_RES_NONE || p.act != OSD_ACT_NONE)
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): GroupNorm statistics need a plain multi-segment conv with Cout %% 256 == 0 and groups of whole 16-byte chunks");
@@ -395,9 +460,11 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream) {
       if (p.seg[i].M % SP_BM != 0 || (p.seg[i].Ho * p.seg[i].Wo) % (SP_BM / 2) != 0 || p.seg[i].M / (p.seg[i].Ho * p.seg[i].Wo) != p.gn_n)
         return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): GroupNorm statistics need images of whole 128-pixel runs (segment %d)", i);
     }
-    hipLaunchKernelGGL(conv_sp_kernel<true>, dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    hipLaunchKernelGGL((conv_sp_kernel<true, false>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+  } else if (genw) {
+    hipLaunchKernelGGL((conv_sp_kernel<false, true>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
   } else {
-    hipLaunchKernelGGL(conv_sp_kernel<false>, dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    hipLaunchKernelGGL((conv_sp_kernel<false, false>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
   }
   return osd_check_launch("conv_igemm_sp");
 }

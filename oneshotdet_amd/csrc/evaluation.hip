@@ -81,6 +81,121 @@ __global__ void __launch_bounds__(256) voc_match_kernel(const float* __restrict_
   }
 }
 
+
+// ---- precision / recall curves and average precision, all classes in one launch each (voc_eval.py:139-216) ----
+// Input: the dataset's match flags sorted ONCE by (class ascending, score descending) — class c owns [class_begin[c],
+// class_begin[c + 1]).  One workgroup per class walks its range in 256-element chunks with a carry.
+constexpr int kApThreads = 256;
+
+// inclusive scan of one value per thread over the workgroup (Hillis-Steele in LDS); OP(a, b) associative
+template <typename V, typename OP>
+__device__ __forceinline__ V ap_block_scan(V v, V* sh, OP op, bool reverse) {
+  const int t = threadIdx.x;
+  const int pos = reverse ? kApThreads - 1 - t : t;
+  sh[pos] = v;
+  __syncthreads();
+  for (int off = 1; off < kApThreads; off <<= 1) {
+    V o = sh[pos];
+    if (pos >= off) o = op(sh[pos - off], o);
+    __syncthreads();
+    sh[pos] = o;
+    __syncthreads();
+  }
+  const V r = sh[pos];
+  __syncthreads();
+  return r;
+}
+
+// prec[i] = tp_i / (tp_i + fp_i) (NaN while both are 0: only ignored detections so far), rec[i] = tp_i / n_pos (NaN when the
+// class has no countable ground truth: the host then reports no recall curve), with tp_i / fp_i = number of flags 1 / 0 among
+// the class's first i + 1 detections.  Integer counts, IEEE double division: the values numpy computes.
+__global__ void __launch_bounds__(kApThreads) voc_curves_kernel(const int8_t* __restrict__ flags, const int32_t* __restrict__ class_begin,
+                                                                const int32_t* __restrict__ n_pos, double* __restrict__ prec,
+                                                                double* __restrict__ rec) {
+  __shared__ int2 sh[kApThreads];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int b = class_begin[c], e = class_begin[c + 1];
+  const double np = (double)n_pos[c];
+  int2 carry = make_int2(0, 0);
+  auto add2 = [](int2 a, int2 b2) { return make_int2(a.x + b2.x, a.y + b2.y); };
+  for (int base = b; base < e; base += kApThreads) {
+    const int i = base + t;
+    const int f = i < e ? (int)flags[i] : -1;
+    int2 v = ap_block_scan(make_int2(f == 1, f == 0), sh, add2, false);
+    v = add2(v, carry);
+    if (i < e) {
+      prec[i] = (double)v.x / (double)(v.x + v.y);
+      rec[i] = n_pos[c] > 0 ? (double)v.x / np : __longlong_as_double(0x7ff8000000000000ll);
+    }
+    __shared__ int2 last;
+    if (t == kApThreads - 1) last = v;
+    __syncthreads();
+    carry = last;
+    __syncthreads();
+  }
+}
+
+// AP of every class from its curves.  With P_i = max over j >= i of prec_j (NaN read as 0) — the monotone precision envelope,
+// a suffix maximum — both metrics are sums over the points where recall steps:
+//   area metric:      sum over i with rec_i != rec_{i-1} (rec_{-1} = 0) of (rec_i - rec_{i-1}) * P_i
+//   VOC 2007 metric:  (1 / 11) sum over t in {0, 0.1, .., 1} of P_{first i with rec_i >= t} (0 when recall never reaches t)
+// has_rec[c] == 0 (class without countable ground truth) or has_prec[c] == 0 (class id never seen): NaN.
+__global__ void __launch_bounds__(kApThreads) voc_ap_kernel(const double* __restrict__ prec, const double* __restrict__ rec,
+                                                            const int32_t* __restrict__ class_begin, const uint8_t* __restrict__ has_prec,
+                                                            const uint8_t* __restrict__ has_rec, int use_07, double* __restrict__ ap) {
+  __shared__ double sh[kApThreads];
+  __shared__ double p11[11];
+  __shared__ double carry_sh;
+  const int c = blockIdx.x, t = threadIdx.x;
+  if (!has_prec[c] || !has_rec[c]) {
+    if (t == 0) ap[c] = __longlong_as_double(0x7ff8000000000000ll);
+    return;
+  }
+  const int b = class_begin[c], e = class_begin[c + 1];
+  if (t < 11) p11[t] = 0.0;
+  if (t == 0) carry_sh = 0.0;
+  __syncthreads();
+  double area = 0.0;
+  auto dmax = [](double a, double b2) { return a > b2 ? a : b2; };
+  const int nchunk = (e - b + kApThreads - 1) / kApThreads;
+  for (int ch = nchunk - 1; ch >= 0; --ch) {            // from the class's last detections backwards: the suffix maximum
+    const int i = b + ch * kApThreads + t;
+    double p = 0.0;
+    if (i < e) { p = prec[i]; if (!(p == p)) p = 0.0; }
+    double env = ap_block_scan(p, sh, dmax, true);
+    env = dmax(env, carry_sh);
+    __syncthreads();
+    if (i < e) {
+      const double r = rec[i], rp = i > b ? rec[i - 1] : 0.0;
+      if (r != rp) area += (r - rp) * env;
+      if (use_07) {
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+          const double thr = (double)k * 0.1;          // numpy.arange(0., 1.1, 0.1)[k]
+          if (r >= thr && (i == b || !(rec[i - 1] >= thr))) p11[k] = env;
+        }
+      }
+    }
+    if (t == 0) carry_sh = env;                         // thread 0 holds the chunk's first element = the max of everything after
+    __syncthreads();
+  }
+  if (use_07) {
+    if (t == 0) {
+      double a = 0.0;
+      for (int k = 0; k < 11; ++k) a += p11[k] / 11.0;  // voc_eval.py:185-192 adds p / 11 in this order
+      ap[c] = a;
+    }
+    return;
+  }
+  sh[t] = area;
+  __syncthreads();
+  for (int off = kApThreads / 2; off > 0; off >>= 1) {  // fixed-order tree: the same bits on every run
+    if (t < off) sh[t] += sh[t + off];
+    __syncthreads();
+  }
+  if (t == 0) ap[c] = sh[0];
+}
+
 }  // namespace
 
 extern "C" int osd_voc_match(const float* det_boxes, const float* det_scores, const int32_t* det_labels, const int32_t* det_count,
@@ -95,4 +210,24 @@ extern "C" int osd_voc_match(const float* det_boxes, const float* det_scores, co
   hipLaunchKernelGGL(voc_match_kernel, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), det_boxes, det_scores, det_labels,
                      det_count, gt_boxes, gt_labels, gt_difficult, gt_count, max_det, max_gt, iou_thresh, match, matched_gt);
   return osd_check_launch("voc_match");
+}
+
+extern "C" int osd_voc_curves(const int8_t* flags_sorted, const int32_t* class_begin, const int32_t* n_pos, int n_classes,
+                              double* prec, double* rec, void* stream) {
+  if (n_classes < 0) return osd_fail(OSD_ERR_INVALID_ARG, "voc_curves: negative class count");
+  if (n_classes == 0) return OSD_OK;
+  if (!class_begin || !n_pos || !prec || !rec) return osd_fail(OSD_ERR_INVALID_ARG, "voc_curves: null argument");
+  hipLaunchKernelGGL(voc_curves_kernel, dim3(n_classes), dim3(kApThreads), 0, reinterpret_cast<hipStream_t>(stream), flags_sorted,
+                     class_begin, n_pos, prec, rec);
+  return osd_check_launch("voc_curves");
+}
+
+extern "C" int osd_voc_ap(const double* prec, const double* rec, const int32_t* class_begin, const uint8_t* has_prec,
+                          const uint8_t* has_rec, int n_classes, int use_07_metric, double* ap, void* stream) {
+  if (n_classes < 0) return osd_fail(OSD_ERR_INVALID_ARG, "voc_ap: negative class count");
+  if (n_classes == 0) return OSD_OK;
+  if (!class_begin || !has_prec || !has_rec || !ap) return osd_fail(OSD_ERR_INVALID_ARG, "voc_ap: null argument");
+  hipLaunchKernelGGL(voc_ap_kernel, dim3(n_classes), dim3(kApThreads), 0, reinterpret_cast<hipStream_t>(stream), prec, rec, class_begin,
+                     has_prec, has_rec, use_07_metric, ap);
+  return osd_check_launch("voc_ap");
 }

@@ -64,13 +64,23 @@ def crop_like_pil(image, box_xywh):
 
 
 class FewShotCocoDataset(object):
+    """The reference's COCODataset (data/datasets/coco.py:56-547) on an in-memory annotation index.
+
+    Random stream: epoch order and support choices are drawn from ONE private `random.Random(seed)` in the reference's order
+    of draws.  The reference seeds and consumes Python's GLOBAL `random`, which its transforms (RandomHorizontalFlip of the
+    query and support pipelines, data/transforms/transforms.py:66-75) also draw from between items; the support sequence
+    therefore equals the reference's only when no random transform runs between items — how tests/golden/dataset.npz was
+    recorded (flip probability 0).  To reproduce the interleaving with is_train transforms, pass the SAME generator as `rng`
+    here and to transforms.RandomHorizontalFlip(rng=...); `rng=random` (the module itself, after `random.seed(6666)`) is the
+    reference's arrangement exactly."""
+
     def __init__(self, coco, load_image, is_train=True, shot=1, exclude_contiguous=(), supp_area_threshold=80 * 80,
-                 supp_aug=False, transforms=None, supp_transforms=None, selected_category=-1, seed=6666):
+                 supp_aug=False, transforms=None, supp_transforms=None, selected_category=-1, seed=6666, rng=None):
         self.index = coco if isinstance(coco, CocoIndex) else CocoIndex(coco)
         self.load_image, self.is_train, self.shot = load_image, is_train, int(shot)
         self.supp_area_threshold, self.supp_aug = supp_area_threshold, bool(supp_aug)
         self.transforms, self.supp_transforms = transforms, supp_transforms
-        self.rng = random.Random(seed)
+        self.rng = rng if rng is not None else random.Random(seed)
         self.categories = [c for pos, c in enumerate(self.index.category_ids) if pos + 1 not in set(exclude_contiguous)]
         self.contiguous = {c: pos + 1 for pos, c in enumerate(self.index.category_ids) if c in self.categories}
         self.catalog = {c: [i for i in self.index.images_with(c) if _usable(self.index.objects(i, c, crowd=0))]

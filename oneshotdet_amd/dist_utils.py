@@ -55,6 +55,55 @@ def bucket_ranges(plan, total):
     return out
 
 
+TUNER_CACHES = ("ALGO_CACHE", "SPLIT_CACHE", "WGRAD_ALGO_CACHE")
+
+
+def broadcast_tuner_choices(ops, src=0, group=None):
+    """Make every rank run the kernels rank `src` measured to be fastest.  The autotuner (ops.tuning()) decides by timing on the
+    local GPU; with N ranks deciding independently, timing noise gives ranks different kernels for the same shape and the
+    slowest choice sets the pace of every step (the step ends in a collective).  Here `src`'s caches — conv algorithm per
+    shape, large / small segment cut of the grouped launches, weight-gradient variant — replace every other rank's: shapes met
+    afterwards hit the cache and are never timed on those ranks.  Also usable with an env-named cache file: see
+    save_tuner_choices / load_tuner_choices.  No-op without a process group or with one rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    rank = dist.get_rank(group)
+    payload = [{name: dict(getattr(ops, name)) for name in TUNER_CACHES} if rank == src else None]
+    dist.broadcast_object_list(payload, src=src, group=group)
+    if rank != src:
+        for name in TUNER_CACHES:
+            cache = getattr(ops, name)
+            cache.clear()
+            cache.update(payload[0][name])
+
+
+def tuner_choices_agree(ops, group=None):
+    """True iff every rank holds the same tuner caches (a digest of the sorted entries is all-gathered)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return True
+    import hashlib
+    text = repr([(name, sorted((repr(k), v) for k, v in getattr(ops, name).items())) for name in TUNER_CACHES])
+    mine = hashlib.sha256(text.encode()).hexdigest()
+    every = [None] * dist.get_world_size(group)
+    dist.all_gather_object(every, mine, group=group)
+    return all(d == mine for d in every)
+
+
+def save_tuner_choices(ops, path):
+    """The tuner caches as a file (pickle of plain dicts): tune once, start every later run / rank from it (load_tuner_choices)."""
+    import pickle
+    with open(path, "wb") as f:
+        pickle.dump({name: dict(getattr(ops, name)) for name in TUNER_CACHES}, f)
+
+
+def load_tuner_choices(ops, path):
+    import pickle
+    with open(path, "rb") as f:
+        data = pickle.load(f)
+    for name in TUNER_CACHES:
+        getattr(ops, name).update(data.get(name, {}))
+
+
 class GradExchange(object):
     """Gradient averaging overlapped with backward: each bucket of the flat buffer is all-reduced on a communication
     stream as soon as the streams that produce it have been told everything that writes it (ready()), while the rest of
@@ -70,7 +119,9 @@ class GradExchange(object):
         self.wire_dtype = wire_dtype if (wire_dtype is not None and flat.is_cuda) else None
         self._wire = None
         import os
-        self._skip_collective = os.environ.get("OSD_EXCHANGE_SKIP_COLLECTIVE", "0") != "0"
+        # timing diagnostic for the one-rank live-exchange bench ONLY (events and streams, no collective): the subclass / tool
+        # sets it; it is refused with more than one rank, where skipping the all-reduce would train on un-averaged gradients
+        self._skip_collective = False
         # single_rank_too: run the collectives even with one rank (tests exercise the stream plumbing on one GPU)
         self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or single_rank_too)
         self.world = dist.get_world_size(group) if self.active else 1
@@ -92,6 +143,14 @@ class GradExchange(object):
         self.pending = set()
         self.begin()
 
+    def skip_collective_for_timing(self):
+        """A/B diagnostic: keep the stream waits, drop the all-reduce.  One rank only."""
+        if self.active and self.world > 1:
+            raise RuntimeError("skip_collective_for_timing: %d ranks would train on un-averaged gradients" % self.world)
+        import warnings
+        warnings.warn("GradExchange: collectives are SKIPPED (timing diagnostic)")
+        self._skip_collective = True
+
     def begin(self):
         self.pending = set(self.ranges)
 
@@ -112,7 +171,7 @@ class GradExchange(object):
             ev = torch.cuda.Event()
             ev.record(s)
             self.comm.wait_event(ev)
-        if self._skip_collective:          # A/B diagnostic (OSD_EXCHANGE_SKIP_COLLECTIVE=1): events and streams, no collective
+        if self._skip_collective:          # skip_collective_for_timing(): events and streams, no collective
             return
         with torch.cuda.stream(self.comm):
             if self.wire_dtype is not None and lo % 8 == 0 and (hi - lo) % 8 == 0:

@@ -2,10 +2,13 @@
 functions with the same signatures — eval_detection_voc, calc_detection_voc_prec_rec, calc_detection_voc_ap — on BoxLists
 (modules.BoxList; fields `labels`, `scores` on the predictions, `labels`, `difficult` on the ground truth).
 
-The matching of detections to ground-truth boxes (IoU of every detection against every box of its class, the greedy claim in
-score order) runs on the device, all images in ONE launch (osd_voc_match); the precision / recall curves and the AP integrals —
-cumulative sums over a few thousand flags — are host numpy, the reference's own expressions.
-Equal scores: the reference orders them by an unstable argsort; here equal scores are taken in descending index order."""
+Everything numeric runs on the device, three launches per evaluation: osd_voc_match (IoU of every detection against every box
+of its class and the greedy claim in score order, all images at once), osd_voc_curves (true / false positive prefix counts ->
+precision / recall of every class) and osd_voc_ap (suffix-maximum precision envelope -> both AP metrics of every class).  The
+host's part is bookkeeping: the dataset's detections are ordered ONCE by (class, descending score), class ranges and the
+per-class count of non-difficult ground-truth boxes are integer histograms.
+Equal scores: the reference orders them by an unstable argsort; here the later detection (higher image, then higher index) goes
+first."""
 import numpy as np
 import torch
 
@@ -47,62 +50,84 @@ def voc_match(pred_boxlists, gt_boxlists, iou_thresh=0.5, device="cuda"):
     return [(match[i, :dc[i]], mg[i, :dc[i]]) for i in range(n)]
 
 
+def _as_np(t, dtype):
+    return torch.as_tensor(t).cpu().numpy().astype(dtype, copy=False)
+
+
+class _Curves(object):
+    """Per-class curves of one evaluation: flat float64 arrays + class ranges, as osd_voc_curves writes them."""
+    __slots__ = ("prec", "rec", "begin", "has_prec", "has_rec")
+
+
+def _curves(gt_boxlists, pred_boxlists, iou_thresh, device="cuda"):
+    flags = voc_match(pred_boxlists, gt_boxlists, iou_thresh, device)
+    empty_i, empty_f = np.zeros((0,), np.int64), np.zeros((0,), np.float32)
+    det_cls = np.concatenate([_as_np(p.get_field("labels"), np.int64) if len(p) else empty_i for p in pred_boxlists] + [empty_i])
+    det_score = np.concatenate([_as_np(p.get_field("scores"), np.float32) if len(p) else empty_f for p in pred_boxlists] + [empty_f])
+    det_flag = np.concatenate([f for f, _ in flags] + [np.zeros((0,), np.int8)])
+    gt_cls = np.concatenate([_as_np(g.get_field("labels"), np.int64) if len(g) else empty_i for g in gt_boxlists] + [empty_i])
+    gt_hard = np.concatenate([_as_np(g.get_field("difficult"), bool) if len(g) else np.zeros((0,), bool) for g in gt_boxlists] +
+                             [np.zeros((0,), bool)])
+    n_cls = int(max(det_cls.max(initial=-1), gt_cls.max(initial=-1))) + 1
+    # one ordering pass for the whole dataset: class ascending, score descending, later detections first among equal scores
+    order = np.lexsort((-np.arange(det_cls.size), -det_score, det_cls))
+    begin = np.searchsorted(det_cls[order], np.arange(n_cls + 1)).astype(np.int32)
+    n_pos = np.bincount(gt_cls[~gt_hard], minlength=n_cls).astype(np.int32)
+    cv = _Curves()
+    cv.begin = begin
+    cv.has_prec = ((np.diff(begin) > 0) | (np.bincount(gt_cls, minlength=n_cls) > 0)).astype(np.uint8)
+    cv.has_rec = (cv.has_prec.astype(bool) & (n_pos > 0)).astype(np.uint8)
+    dev = torch.device(device)
+    n = int(det_cls.size)
+    prec = torch.empty((max(n, 1),), device=dev, dtype=torch.float64)
+    rec = torch.empty((max(n, 1),), device=dev, dtype=torch.float64)
+    if n_cls:
+        t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (det_flag[order], begin, n_pos)]
+        _lib.call("osd_voc_curves", ops._ptr(t[0]), ops._ptr(t[1]), ops._ptr(t[2]), n_cls, ops._ptr(prec), ops._ptr(rec), ops._stream())
+    cv.prec, cv.rec = prec[:n], rec[:n]
+    return cv
+
+
+def _ap(cv, use_07_metric):
+    n_cls = len(cv.has_prec)
+    ap = torch.empty((max(n_cls, 1),), device=cv.prec.device, dtype=torch.float64)
+    if n_cls:
+        t = [torch.from_numpy(np.ascontiguousarray(a)).to(cv.prec.device) for a in (cv.begin, cv.has_prec, cv.has_rec)]
+        _lib.call("osd_voc_ap", ops._ptr(cv.prec), ops._ptr(cv.rec), ops._ptr(t[0]), ops._ptr(t[1]), ops._ptr(t[2]), n_cls,
+                  int(bool(use_07_metric)), ops._ptr(ap), ops._stream())
+    return ap[:n_cls].cpu().numpy()
+
+
 def calc_detection_voc_prec_rec(gt_boxlists, pred_boxlists, iou_thresh=0.5):
-    """voc_eval.py:70-158.  -> (prec, rec): lists indexed by class id (None for a class that never occurs)."""
-    flags = voc_match(pred_boxlists, gt_boxlists, iou_thresh)
-    n_pos, score, match = {}, {}, {}
-    for (mt, _), p, g in zip(flags, pred_boxlists, gt_boxlists):
-        pl = torch.as_tensor(p.get_field("labels")).cpu().numpy() if len(p) else np.zeros((0,), np.int64)
-        ps = torch.as_tensor(p.get_field("scores")).float().cpu().numpy() if len(p) else np.zeros((0,), np.float32)
-        gl = torch.as_tensor(g.get_field("labels")).cpu().numpy() if len(g) else np.zeros((0,), np.int64)
-        gdf = torch.as_tensor(g.get_field("difficult")).cpu().numpy().astype(bool) if len(g) else np.zeros((0,), bool)
-        for l in np.unique(np.concatenate((pl, gl)).astype(int)):
-            sel = np.nonzero(pl == l)[0]
-            order = sel[np.argsort(ps[sel], kind="stable")[::-1]]          # descending score; equal scores: higher index first
-            n_pos[l] = n_pos.get(l, 0) + int(np.logical_not(gdf[gl == l]).sum())
-            score.setdefault(l, []).extend(ps[order].tolist())
-            match.setdefault(l, []).extend(mt[order].tolist())
-    n_fg_class = max(n_pos.keys()) + 1
-    prec, rec = [None] * n_fg_class, [None] * n_fg_class
-    for l in n_pos:
-        score_l = np.array(score[l])
-        match_l = np.array(match[l], dtype=np.int8)
-        order = score_l.argsort()[::-1]
-        match_l = match_l[order]
-        tp = np.cumsum(match_l == 1)
-        fp = np.cumsum(match_l == 0)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            prec[l] = tp / (fp + tp)                                     # nan where fp + tp == 0, like the reference
-        if n_pos[l] > 0:
-            rec[l] = tp / n_pos[l]
-    return prec, rec
+    """voc_eval.py:70-158.  -> (prec, rec): lists indexed by class id, float64 arrays over the class's detections in descending
+    score order (None for a class id that never occurs; rec None for a class without non-difficult ground truth)."""
+    cv = _curves(gt_boxlists, pred_boxlists, iou_thresh)
+    prec, rec = cv.prec.cpu().numpy(), cv.rec.cpu().numpy()
+    cut = lambda a, c: a[cv.begin[c]:cv.begin[c + 1]]                    # noqa: E731
+    n_cls = len(cv.has_prec)
+    return ([cut(prec, c) if cv.has_prec[c] else None for c in range(n_cls)],
+            [cut(rec, c) if cv.has_rec[c] else None for c in range(n_cls)])
 
 
-def calc_detection_voc_ap(prec, rec, use_07_metric=False):
-    """voc_eval.py:161-216: the 11-point VOC 2007 metric or the area under the monotone precision envelope."""
-    n_fg_class = len(prec)
-    ap = np.empty(n_fg_class)
-    for l in range(n_fg_class):
-        if prec[l] is None or rec[l] is None:
-            ap[l] = np.nan
-            continue
-        if use_07_metric:
-            ap[l] = 0
-            for t in np.arange(0.0, 1.1, 0.1):
-                p = 0 if np.sum(rec[l] >= t) == 0 else np.max(np.nan_to_num(prec[l])[rec[l] >= t])
-                ap[l] += p / 11
-        else:
-            mpre = np.concatenate(([0], np.nan_to_num(prec[l]), [0]))
-            mrec = np.concatenate(([0], rec[l], [1]))
-            mpre = np.maximum.accumulate(mpre[::-1])[::-1]
-            i = np.where(mrec[1:] != mrec[:-1])[0]
-            ap[l] = np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
-    return ap
+def calc_detection_voc_ap(prec, rec, use_07_metric=False, device="cuda"):
+    """voc_eval.py:161-216 on curves given as lists (the reference's argument format): the 11-point VOC 2007 metric or the area
+    under the monotone precision envelope, every class in one launch (osd_voc_ap); NaN for a class without curves."""
+    n_cls = len(prec)
+    cv = _Curves()
+    cv.has_prec = np.array([p is not None for p in prec], np.uint8)
+    cv.has_rec = np.array([p is not None and r is not None for p, r in zip(prec, rec)], np.uint8)
+    sizes = [len(p) if p is not None else 0 for p in prec]
+    cv.begin = np.concatenate(([0], np.cumsum(sizes))).astype(np.int32)
+    flat = lambda xs: np.concatenate([np.asarray(x if x is not None else np.full((k,), np.nan), np.float64)    # noqa: E731
+                                      for x, k in zip(xs, sizes)] + [np.zeros((1,), np.float64)])
+    dev = torch.device(device)
+    cv.prec, cv.rec = torch.from_numpy(flat(prec)).to(dev), torch.from_numpy(flat(rec)).to(dev)
+    return _ap(cv, use_07_metric) if n_cls else np.zeros((0,), np.float64)
 
 
 def eval_detection_voc(pred_boxlists, gt_boxlists, iou_thresh=0.5, use_07_metric=False):
-    """voc_eval.py:48-67.  -> {"ap": per-class AP (nan for absent classes), "map": their nan-mean}."""
+    """voc_eval.py:48-67.  -> {"ap": per-class AP (nan for absent classes), "map": their nan-mean}.  The curves stay on the device
+    between the two launches; the host receives ap[]."""
     assert len(gt_boxlists) == len(pred_boxlists), "Length of gt and pred lists need to be same."
-    prec, rec = calc_detection_voc_prec_rec(pred_boxlists=pred_boxlists, gt_boxlists=gt_boxlists, iou_thresh=iou_thresh)
-    ap = calc_detection_voc_ap(prec, rec, use_07_metric=use_07_metric)
+    ap = _ap(_curves(gt_boxlists, pred_boxlists, iou_thresh), use_07_metric)
     return {"ap": ap, "map": np.nanmean(ap)}

@@ -132,7 +132,8 @@ def stem_input(images, dtype):
 # ---- per-shape algorithm selection by measurement ("measure, don't guess") ----
 # osd_conv_desc.algo = 1 + impl*32 + variant*8 + tile; impl 0 = LDS-DMA ring kernel (variants: deep / shallow ring /
 # short stages), impl 1 = register-staged kernel; tile 0..4 = 128x128, 128x64, 64x64, 256x16, 256x256/8 waves, 5 = ping-pong
-# 256x256, 6 = row-reuse 3x3, 7 = 256x128/8 waves (pixels x channels).
+# 256x256, 6 = row-reuse 3x3 (variant 0: conv_xr, widths 64/128/256; 1: conv_sp, any width; 2: conv_sp's general-width form forced),
+# 7 = 256x128/8 waves (pixels x channels).
 ALGO_CACHE = {}
 _TUNING = [False]
 
@@ -149,7 +150,7 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
         if not os.environ.get("OSD_NO_XR"):           # (A/B switch for tools and benches)
             cands.append(1 + 0 * 32 + 0 * 8 + 6)      # 3x3/1: pixel rows fetched once per filter row (bf16, W in 64/128/256)
             if not os.environ.get("OSD_NO_SP"):
-                cands.append(1 + 0 * 32 + 1 * 8 + 6)  # the same with software-pipelined fragments + mid-stage barrier
+                cands.append(1 + 0 * 32 + 1 * 8 + 6)  # the same with software-pipelined fragments + mid-stage barrier, ANY width
     if cout_store >= 128 and not relu_in:
         cands += [1 + 0 * 32 + v * 8 + 7 for v in (0, 1, 2, 3)]      # 256x128 tile on 8 waves: deep / shallow ring / short stages
     if not relu_in and not has_mask:
@@ -395,7 +396,7 @@ def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mod
                 if t < best_t:
                     cut, best_t = c, t
             SPLIT_CACHE[skey] = cut
-        if cut:
+        if cut is not None:       # (cut 0 = one launch over all segments: also through run(), so that the launch is a `_whole` call)
             return run(cut)
     c = xs[0].shape[-1]
     assert all(x.shape[-1] == pc.cin_k for x in xs), "input channels %d != packed K per tap %d" % (c, pc.cin_k)

@@ -100,6 +100,8 @@ class TrainEngine(object):
         # A/B: P3+P4 and P5-P7 of a tower as separate forward chains on the (then idle) weight-gradient streams.  Measured SLOWER
         # (12.05 vs 11.90 ms per step, same box): like lockstep / merged towers, more concurrency buys nothing here
         self.split_levels = os.environ.get("OSD_SPLIT_LEVELS", "0") != "0"
+        # the sum of the two towers' input gradients inside the cls tower's last data-gradient conv (A/B: OSD_NO_HEAD_SUM_FUSION=1)
+        self.fuse_head_sum = os.environ.get("OSD_NO_HEAD_SUM_FUSION", "0") == "0"
         sd = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state_dict.items()}
         self._frozen_sd = sd
         self.convs = {}          # name -> TConv
@@ -768,11 +770,20 @@ class TrainEngine(object):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 d_t = self._towers_backward(ctxs, pred_grads, ("bbox_tower",), nl)
+            if self.fuse_head_sum:
+                # d combined = d(cls tower input) + d(bbox tower input): the cls tower's LAST data-gradient conv takes the bbox
+                # tower's as its residual operand (the epilogue's RES_SAME add), so the sum costs neither a launch per level nor
+                # a write + re-read of the five level maps (round 3: 5 x add_mask, 0.67 ms of kernel time inside the step)
+                def bbox_grads():
+                    main.wait_stream(side)
+                    self._keep.append(d_t["bbox_tower"])
+                    return d_t["bbox_tower"]
+                return self._towers_backward(ctxs, pred_grads, ("cls_tower",), nl, last_addends=bbox_grads)["cls_tower"]
             d_t.update(self._towers_backward(ctxs, pred_grads, ("cls_tower",), nl))
             main.wait_stream(side)
         return [ops.add_mask(d_t["cls_tower"][l], d_t["bbox_tower"][l]) for l in range(nl)]
 
-    def _towers_backward(self, ctxs, pred_grads, towers, nl):
+    def _towers_backward(self, ctxs, pred_grads, towers, nl, last_addends=None):
         cv = self.convs
         h = "rpn.head."
         nt = len(towers)
@@ -840,7 +851,8 @@ class TrainEngine(object):
                             gnb["wss"].append(ws_l if on else None)
                             gnb["pws"].append(pw_l if on else None)
                 fused = {tw: (1 << nf) - 1 for tw in towers}
-            out = ops.conv2d_multi(dys, pds, pad=pad, gnb=gnb)
+            addends = last_addends() if (i == 0 and last_addends is not None) else None      # (one tower per call: level order)
+            out = ops.conv2d_multi(dys, pds, pad=pad, gnb=gnb, residuals=addends)
             for k, tw in enumerate(towers):
                 d_t[tw] = out[k::nt]
         for tw in towers:

@@ -145,11 +145,12 @@ class Resize(object):
 
 
 class RandomHorizontalFlip(object):
-    def __init__(self, prob=0.5):
-        self.prob = prob
+    def __init__(self, prob=0.5, rng=None):
+        # rng: the source of randomness (anything with .random()); default = Python's global `random`, like the reference
+        self.prob, self.rng = prob, rng
 
     def __call__(self, image, target=None):
-        if random.random() < self.prob:
+        if (self.rng if self.rng is not None else random).random() < self.prob:
             return image.flipped(), _flip_boxes(target)
         return image, target
 

@@ -73,5 +73,29 @@ for n in ("head", "box_head", "backbone.layer4+fpn", "supp_backbone.layer4+fpn")
 ex3.finish()
 ok2 = ok2 and torch.allclose(flat3, torch.full_like(flat3, sum(r + 1.0 for r in range(world)) / world))
 print("RANK %d EXCHANGE=%s" % (rank, ok2), flush=True)
+
+# kernel choices: every rank tunes by its own timing, so before the timed region rank 0's tuner caches replace everyone's
+# (dist_utils.broadcast_tuner_choices); here the ranks start with DIFFERENT choices for the same shapes and extra private keys
+import types
+from oneshotdet_amd import dist_utils
+fake = types.SimpleNamespace(ALGO_CACHE={(1, 8, 100, 128, 256, 256, 3, 3, 1, 1, 0, 0, 0, False): 15 if rank == 0 else 13,
+                                         ("grouped", 1, ((8, 100, 128), (8, 50, 64)), 256): 15 + rank},
+                             SPLIT_CACHE={("split", 1, ((8, 100, 128, 256),), 256, 3, 1, 1, 0, 0, False): rank},
+                             WGRAD_ALGO_CACHE={("w", 1, 256, 256, 3): 4 + 16 * rank})
+if rank == 1:
+    fake.ALGO_CACHE[("only rank 1 met this shape",)] = 7
+ok3 = not dist_utils.tuner_choices_agree(fake)
+dist_utils.broadcast_tuner_choices(fake, src=0)
+ok3 = ok3 and dist_utils.tuner_choices_agree(fake)
+ok3 = ok3 and fake.ALGO_CACHE[(1, 8, 100, 128, 256, 256, 3, 3, 1, 1, 0, 0, 0, False)] == 15 and len(fake.ALGO_CACHE) == 2
+ok3 = ok3 and list(fake.SPLIT_CACHE.values()) == [0] and list(fake.WGRAD_ALGO_CACHE.values()) == [4]
+import tempfile
+path = os.path.join(tempfile.gettempdir(), "osd_tuner_%d_%d.pkl" % (os.getpid(), rank))
+dist_utils.save_tuner_choices(fake, path)
+fake2 = types.SimpleNamespace(ALGO_CACHE={}, SPLIT_CACHE={}, WGRAD_ALGO_CACHE={})
+dist_utils.load_tuner_choices(fake2, path)
+os.remove(path)
+ok3 = ok3 and fake2.ALGO_CACHE == fake.ALGO_CACHE and fake2.WGRAD_ALGO_CACHE == fake.WGRAD_ALGO_CACHE
+print("RANK %d TUNER=%s" % (rank, ok3), flush=True)
 dist.destroy_process_group()
-sys.exit(0 if (ok and ok2) else 1)
+sys.exit(0 if (ok and ok2 and ok3) else 1)

@@ -32,6 +32,8 @@ def test_bench_two_ranks_gloo():
     # rank 1 sleeps 4 ms per step, rank 0 2 ms: MAX over ranks -> >= 4 ms/step; whole-job value = 16 images / step time
     assert r["ms_per_step"] >= 3.9
     assert abs(r["value"] - 16 * 1e3 / r["ms_per_step"]) / r["value"] < 0.01
+    # every rank's own bracket time travels in the line (a slow rank is visible): rank 1 sleeps twice as long per step
+    assert len(r["rank_ms_per_step"]) == 2 and r["rank_ms_per_step"][1] >= 3.9 and max(r["rank_ms_per_step"]) <= r["ms_per_step"] + 1e-3
 
 
 def test_bench_self_launches_its_ranks():
@@ -77,3 +79,5 @@ def test_gradient_average_two_ranks():
     assert "RANK 0 OK=True" in out.stdout and "RANK 1 OK=True" in out.stdout
     # dist_utils.GradExchange / bucket_ranges: the exchange overlapped with backward (same worker, second half)
     assert "RANK 0 EXCHANGE=True" in out.stdout and "RANK 1 EXCHANGE=True" in out.stdout
+    # dist_utils.broadcast_tuner_choices: both ranks end with rank 0's kernel choices (same worker, third part)
+    assert "RANK 0 TUNER=True" in out.stdout and "RANK 1 TUNER=True" in out.stdout

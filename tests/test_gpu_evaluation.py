@@ -1,5 +1,5 @@
-"""GPU (-m gpu): PASCAL VOC evaluation — the device-side matching + host AP of oneshotdet_amd/evaluation.py
-against tests/golden/voc_eval.npz, recorded through the REAL reference's eval_detection_voc / calc_detection_voc_prec_rec
+"""GPU (-m gpu): PASCAL VOC evaluation — the device-side matching, curves and AP of oneshotdet_amd/evaluation.py
+(osd_voc_match / osd_voc_curves / osd_voc_ap) against tests/golden/voc_eval.npz, recorded through the REAL reference's eval_detection_voc / calc_detection_voc_prec_rec
 (data/datasets/evaluation/voc/voc_eval.py:48-216) on synthetic detections: AP of both metrics and the whole precision / recall
 curves to 1e-6 (they are ratios of integers: in fact exactly), the match flags against the oracle's per-image restatement, and
 edge cases (no detections, no ground truth of a class, difficult boxes, duplicates of one box, an empty dataset entry)."""
@@ -46,6 +46,32 @@ def test_voc_ap_equals_the_reference_fixture():
             assert prec[l] is None
         if "rec.%d" % l in f.files:
             np.testing.assert_array_equal(rec[l], f["rec.%d" % l])
+
+
+def test_voc_ap_from_curve_lists_long_classes_and_missing_curves():
+    """calc_detection_voc_ap on the reference's argument format (lists of per-class arrays, None for absent classes) against the
+    oracle's restatement of voc_eval.py:161-216: classes longer than one 256-element chunk (the carried suffix maximum and prefix
+    counts), NaN precision heads (only ignored detections so far), a class without a recall curve, an empty class."""
+    from oneshotdet_amd import evaluation as ev
+    rng = np.random.RandomState(5)
+    prec, rec = [], []
+    for n, npos in ((1000, 300), (257, 5), (0, 3), (40, 0), (256, 1000)):
+        flags = rng.choice([-1, 0, 1], size=n, p=[0.1, 0.5, 0.4]).astype(np.int8)
+        if n:
+            flags[:3] = -1
+        tp, fp = np.cumsum(flags == 1), np.cumsum(flags == 0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            prec.append(tp / (fp + tp))
+        rec.append(tp / npos if npos > 0 else None)
+    prec.insert(2, None)
+    rec.insert(2, None)
+    for use07 in (True, False):
+        got = ev.calc_detection_voc_ap(prec, rec, use_07_metric=use07)
+        want = ov.calc_detection_voc_ap(prec, rec, use_07_metric=use07)
+        np.testing.assert_allclose(np.nan_to_num(got, nan=-1.0), np.nan_to_num(want, nan=-1.0), rtol=0, atol=1e-12)
+    # 11-point metric: the reference's own order of additions, so the same bits
+    np.testing.assert_array_equal(np.nan_to_num(ev.calc_detection_voc_ap(prec, rec, True), nan=-1.0),
+                                  np.nan_to_num(ov.calc_detection_voc_ap(prec, rec, True), nan=-1.0))
 
 
 def test_voc_match_flags_equal_the_oracle_per_image():

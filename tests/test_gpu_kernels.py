@@ -412,9 +412,65 @@ def test_conv2d_software_pipelined_row_reuse_kernel_is_bit_identical_to_the_row_
     pc = o.pack_conv(wt.cuda(), bias=rnd(256, seed=14).cuda(), dtype=torch.bfloat16)
     for ya, yb in zip(o.conv2d_grouped(xs, pc, pad=1, algo=SP, _whole=True), o.conv2d_grouped(xs, pc, pad=1, algo=XR, _whole=True)):
         assert torch.equal(ya, yb)
+
+
+def test_conv2d_software_pipelined_kernel_on_any_width():
+    """conv_igemm_sp.hip's general-width form (GENW: consecutive pixel rows + two halo instructions in LDS, the line borders
+    masked in registers).  (i) Forced on the widths the padded-image form accepts (algo 23 = tile 6, variant 2) it must be
+    BIT-IDENTICAL to that form (algo 15) — same K order, and a masked fragment is the exact zero a pad row held — on every
+    repeat (race screen).  (ii) Picked by algo 15 itself on every other width — BASELINE.json configs[4]'s 104 / 164 (640 x 832,
+    1024 x 1312 at stride 8), a resized COCO image's 168, the tower's P5-P7 widths 32 / 16 / 8, odd and tiny widths, tiles that
+    straddle lines, images and the M tail — it equals the LDS-DMA kernel to fp32 summation order (bf16 outputs: within one bf16
+    ulp, few elements differing) and itself bit for bit.  (iii) One grouped launch over P3..P7 of a 640 x 832 batch equals the
+    per-level launches bit for bit."""
+    o = ops()
+    SP, GEN, DMA = 1 + 8 + 6, 1 + 16 + 6, 1 + 8 + 4
+    for (n, h, w, cin, cout) in [(2, 50, 64, 256, 256), (3, 13, 128, 128, 256), (1, 5, 256, 64, 320), (2, 7, 64, 64, 260),
+                                 (5, 9, 64, 256, 512)]:
+        x = to_nhwc(rnd(n, cin, h, w, seed=1), torch.bfloat16)
+        wt = rnd(cout, cin, 3, 3, seed=2) / (cin * 9) ** 0.5
+        pc = o.pack_conv(wt.cuda(), bias=rnd(cout, seed=3).cuda(), dtype=torch.bfloat16)
+        res = to_nhwc(rnd(n, pc.cout_store, h, w, seed=4), torch.bfloat16)
+        mask = to_nhwc(rnd(n, pc.cout_store, h, w, seed=5), torch.bfloat16)
+        for kw in (dict(), dict(res=res, res_mode=o.RES_SAME, act=o.ACT_RELU), dict(mask=mask)):
+            ref = o.conv2d(x, pc, pad=1, algo=SP, **kw)
+            for rep in range(4):
+                y = o.conv2d(x, pc, pad=1, algo=GEN, **kw)
+                assert torch.equal(y, ref), (n, h, w, cin, cout, sorted(kw), rep, (y.float() - ref.float()).abs().max().item())
+    for (n, h, w, cin, cout) in [(2, 80, 104, 256, 256), (1, 128, 164, 256, 256), (2, 100, 168, 64, 256), (8, 25, 32, 256, 256),
+                                 (8, 13, 16, 256, 256), (8, 7, 8, 256, 256), (3, 23, 19, 128, 320), (2, 5, 3, 64, 256),
+                                 (4, 4, 1, 64, 256), (1, 1, 300, 64, 256), (1, 3, 257, 192, 512)]:
+        x = to_nhwc(rnd(n, cin, h, w, seed=1), torch.bfloat16)
+        wt = rnd(cout, cin, 3, 3, seed=2) / (cin * 9) ** 0.5
+        pc = o.pack_conv(wt.cuda(), bias=rnd(cout, seed=3).cuda(), dtype=torch.bfloat16)
+        res = to_nhwc(rnd(n, pc.cout_store, h, w, seed=4), torch.bfloat16)
+        mask = to_nhwc(rnd(n, pc.cout_store, h, w, seed=5), torch.bfloat16)
+        for kw in (dict(), dict(res=res, res_mode=o.RES_SAME, act=o.ACT_RELU), dict(mask=mask)):
+            ref = o.conv2d(x, pc, pad=1, algo=DMA, **kw)
+            y = o.conv2d(x, pc, pad=1, algo=SP, **kw)
+            d = (y.float() - ref.float()).abs()
+            assert bool((d <= 2.0 ** -7 * ref.float().abs().clamp(min=1.0)).all()), (n, h, w, cin, cout, sorted(kw), d.max().item())
+            assert (d > 0).float().mean().item() < 0.05
+            for rep in range(3):
+                assert torch.equal(o.conv2d(x, pc, pad=1, algo=SP, **kw), y), (n, h, w, rep)
+    # fp32 reference of the op itself on a width with borders inside every fragment
+    n, h, w, cin, cout = 2, 11, 13, 64, 256
+    xf, wf, bf = rnd(n, cin, h, w, seed=7), rnd(cout, cin, 3, 3, seed=8) / (cin * 9) ** 0.5, rnd(cout, seed=9)
+    pc = o.pack_conv(wf.cuda(), bias=bf.cuda(), dtype=torch.bfloat16)
+    y = o.conv2d(to_nhwc(xf, torch.bfloat16), pc, pad=1, algo=SP)
+    ref = torch.nn.functional.conv2d(xf.bfloat16().float(), wf.bfloat16().float(), bf, padding=1)
+    np.testing.assert_allclose(y.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+    # P3..P7 of a 2 x 640 x 832 batch in ONE launch
+    xs = [to_nhwc(rnd(2, 256, hh, ww, seed=20 + i), torch.bfloat16) for i, (hh, ww) in enumerate([(80, 104), (40, 52), (20, 26), (10, 13), (5, 7)])]
+    wt = rnd(256, 256, 3, 3, seed=13) / (256 * 9) ** 0.5
+    pc = o.pack_conv(wt.cuda(), bias=rnd(256, seed=14).cuda(), dtype=torch.bfloat16)
+    ga = o.conv2d_grouped(xs, pc, pad=1, algo=SP, _whole=True)
+    for xa, ya in zip(xs, ga):
+        assert torch.equal(ya, o.conv2d(xa, pc, pad=1, algo=SP))
+    # still refused: 1x1, stride 2, channel counts that are not whole 64-channel slabs
     from oneshotdet_amd import _lib
     with pytest.raises(_lib.OsdError):
-        o.conv2d(to_nhwc(rnd(1, 256, 8, 100, seed=1), torch.bfloat16), pc, pad=1, algo=SP)
+        o.conv2d(to_nhwc(rnd(1, 256, 8, 100, seed=1), torch.bfloat16), pc, stride=2, pad=1, algo=SP)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
