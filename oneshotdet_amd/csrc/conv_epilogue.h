@@ -8,6 +8,12 @@
 
 namespace {
 
+#ifdef OSD_EPI_NO_PIPE      // diagnostic build (OSD_BUILD_TAG=nopipe OSD_BUILD_FLAGS=-DOSD_EPI_NO_PIPE): same-box A/B of the pipelined epilogue
+constexpr bool kEpiPipe = false;
+#else
+constexpr bool kEpiPipe = true;
+#endif
+
 // everything that differs between the (x, y) pairs of a grouped launch; uniform per workgroup (SGPRs)
 struct ConvView {
   const void* x; void* y; const void* res; const void* mask; const float* scale_dev; const void* w; const float* bias;
@@ -54,10 +60,16 @@ __device__ __forceinline__ ConvView conv_select_view(const ConvKParams& p, int& 
 // pixels (wm*TM+j)*16..) through a private LDS region and writes NHWC runs of TN*16 channels with 16-byte-per-lane
 // accesses; all residual loads of a pass are issued before any arithmetic.  The caller has already made the LDS ring
 // reusable (barrier, no DMA in flight).
-template <typename T, int TM, int TN, bool TWO_REGIONS = false, bool GNB = false>
+template <typename T, int TM, int TN, bool TWO_REGIONS = false, bool GNB = false, bool PIPE = false>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKParams& p, const ConvView& q, char* smem,
                                               int wave, int wm, int wn, int lane, int m0, int n0,
                                               const float* pre_bias = nullptr) {
+  // PIPE (round 4; wave tiles of <= 64 x 64, where the registers are there): the residual / mask operands of pass ps + 1 are
+  // loaded while pass ps is computed and stored (two register sets), and pass 0's are issued before anything else — the
+  // HBM-bound 1x1 convs of the bottlenecks (K = 128 .. 512: a K loop of 2 - 8 stages, then an epilogue that reads as many
+  // bytes as it writes) no longer expose one memory latency per pass.  The pipelined form is compiled per (residual, mask)
+  // combination, WITHOUT branches around its loads: hipcc places `s_waitcnt vmcnt(0)` at a branch merge that follows a load,
+  // which would wait for the prefetch right where it is issued.
   // GNB: the fast path also gathers the GroupNorm-backward statistics of ConvGnb (conv_params.h) from the values it stores —
   // AFTER their rounding to T, the numbers a separate pass over the stored tensor would read.  The launcher guarantees that the
   // segments that ask for it consist of whole tiles and that a wave's rows stay inside one image
@@ -108,6 +120,85 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
       }
     }
     const float escale = p.act == OSD_ACT_EXP_SCALE ? (q_scale_dev ? *(const OSD_G float*)q_scale_dev : p.act_scale) : 1.f;
+    if constexpr (PIPE && kEpiPipe && !GNB) {
+      auto piped = [&](auto res_tag, auto mask_tag) {
+        constexpr bool HR = decltype(res_tag)::value, HM = decltype(mask_tag)::value;
+        Vec rr[2][ITER], mm[2][ITER];
+        auto prefetch = [&](int ps, Vec (&r)[ITER], Vec (&m)[ITER]) {
+          const int mrow = m0 + (wm * TM + ps * TMP) * 16 + lane / CPR;
+#pragma unroll
+          for (int it = 0; it < ITER; ++it) {
+            if constexpr (HR) r[it] = *(const OSD_G Vec*)(rg + (size_t)(mrow + it * (64 / CPR)) * p.res_stride + c);
+            if constexpr (HM) m[it] = *(const OSD_G Vec*)(mkg + (size_t)(mrow + it * (64 / CPR)) * p.out_stride + c);
+          }
+        };
+        prefetch(0, rr[0], mm[0]);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          char* stage_p = stage + (TWO_REGIONS ? (ps & 1) * (ROWS * CSW) : 0);
+#pragma unroll
+          for (int jj = 0; jj < TMP; ++jj) {
+            const int j = ps * TMP + jj;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+              *reinterpret_cast<f32x4*>(stage_p + (jj * 16 + (lane & 15)) * CSW + (i * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
+          }
+          if (ps + 1 < NPASS) prefetch(ps + 1, rr[(ps + 1) & 1], mm[(ps + 1) & 1]);      // (ps is a compile-time constant: unrolled)
+          const int mrow = m0 + (wm * TM + ps * TMP) * 16 + lane / CPR;
+          float v[ITER][EPC];
+#pragma unroll
+          for (int it = 0; it < ITER; ++it) {
+            const char* src = stage_p + (it * (64 / CPR) + lane / CPR) * CSW + cc * EPC * 4;
+#pragma unroll
+            for (int e = 0; e < EPC; e += 4) {
+              const f32x4 a4 = *reinterpret_cast<const f32x4*>(src + e * 4);
+              v[it][e] = a4[0] + bv[e]; v[it][e + 1] = a4[1] + bv[e + 1];
+              v[it][e + 2] = a4[2] + bv[e + 2]; v[it][e + 3] = a4[3] + bv[e + 3];
+            }
+          }
+          if constexpr (HR) {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it)
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) v[it][e] += (float)rr[ps & 1][it][e];
+          }
+          if constexpr (HM) {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it)
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) v[it][e] = (float)mm[ps & 1][it][e] > 0.f ? v[it][e] : 0.f;
+          }
+          if (p.act == OSD_ACT_RELU) {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it)
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) v[it][e] = fmaxf(v[it][e], 0.f);
+          } else if (p.act == OSD_ACT_EXP_SCALE) {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it)
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) v[it][e] = expf(v[it][e] * escale);
+          }
+#pragma unroll
+          for (int it = 0; it < ITER; ++it) {
+            Vec o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+              if constexpr (sizeof(T) == 2) o[e] = (__bf16)v[it][e];
+              else o[e] = v[it][e];
+            }
+            *(OSD_G Vec*)(yg + (size_t)(mrow + it * (64 / CPR)) * p.out_stride + c) = o;
+          }
+        }
+      };
+      const bool hr = p.res_mode == OSD_RES_SAME, hm = q_mask != nullptr;
+      if (p.res_mode != OSD_RES_UP2X && (hr || hm)) {
+        if (hr && hm) piped(std::true_type(), std::true_type());
+        else if (hr) piped(std::true_type(), std::false_type());
+        else piped(std::false_type(), std::true_type());
+        return;
+      }
+    }
     // GroupNorm-backward statistics: z = a u + b decides dz = z > 0 ? dt : 0; with xhat = xa u + xb per (image, channel) every
     // sum the backward needs follows from two per-channel sums, S = sum dz and Su = sum dz * u, so only a, b live in the loop
     [[maybe_unused]] bool gn_on = false;

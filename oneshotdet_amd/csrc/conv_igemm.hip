@@ -371,7 +371,7 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
     impl = a >> 5;                 // 0 = LDS-DMA kernel, 1 = register-staged kernel
     variant = (a >> 3) & 3;
     tile = a & 7;
-    if (tile > 7 || (impl == 1 && (variant != 0 || tile > 3)) || (tile == 5 && variant != 0) || (tile == 6 && variant > 2))
+    if (tile > 7 || (impl == 1 && (variant != 0 || tile > 3)) || (tile == 5 && variant != 0))
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv: algo %d not built", d->algo);
     if (p.Cout > 16 && tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: skinny tile on a wide conv");
   }
@@ -383,7 +383,7 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
   }
   if (impl == 0 && tile == 6) {
     if (d->dtype != OSD_BF16) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the row-reuse 3x3 kernel is bf16 only");
-    return variant >= 1 ? osd_conv_sp_launch(p, s, variant == 2) : osd_conv_xr_launch(p, s);
+    return variant >= 1 ? osd_conv_sp_launch(p, s, variant == 2, variant == 3) : osd_conv_xr_launch(p, s);
   }
   if (impl == 0) return osd_conv_dma_dispatch(d->dtype, tile, variant, p, s);
   if (mask) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: mask epilogue only in the LDS-DMA kernel");
@@ -476,7 +476,7 @@ static int conv_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* 
     if (a >= 32) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d is not an LDS-DMA algorithm", d->algo);
     variant = (a >> 3) & 3;
     tile = a & 7;
-    if (tile > 7 || (tile == 5 && variant != 0) || (tile == 6 && variant > 2))
+    if (tile > 7 || (tile == 5 && variant != 0))
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d not built", d->algo);
     if (tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: skinny tile on a wide conv");
   }
@@ -488,7 +488,7 @@ static int conv_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* 
   }
   if (tile == 6) {
     if (d->dtype != OSD_BF16) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: the row-reuse 3x3 kernel is bf16 only");
-    return variant >= 1 ? osd_conv_sp_launch(p, reinterpret_cast<hipStream_t>(stream), variant == 2)
+    return variant >= 1 ? osd_conv_sp_launch(p, reinterpret_cast<hipStream_t>(stream), variant == 2, variant == 3)
                         : osd_conv_xr_launch(p, reinterpret_cast<hipStream_t>(stream));
   }
   return osd_conv_dma_dispatch(d->dtype, tile, variant, p, reinterpret_cast<hipStream_t>(stream));

@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
 #ifdef OSD_CD_NO_EPI             // diagnostic: no output (keeps the accumulators alive)
   if (acc[0][0][0] != 12345.678f) return;
 #endif
-  conv_epilogue<T, TM, TN>(acc, p, q, smem, wave, wm, wn, lane, m0, n0);
+  conv_epilogue<T, TM, TN, false, false, (TM * TN <= 16)>(acc, p, q, smem, wave, wm, wn, lane, m0, n0);
 }
 
 template <typename T, int BM, int BN, int KB, int WM, int WN, int NST, bool RELU_IN = false, bool SRC2 = false>
@@ -353,6 +353,15 @@ int dispatch_tile_dma(int tile, const ConvKParams& p, hipStream_t s) {
 //          ring's LDS — for the HBM-bound 1x1 convs whose K is 2-4 stages long, where workgroups in flight per CU (latency
 //          of the first operand fetch and of the residual read in the epilogue) matter and the ring depth does not
 int osd_conv_dma_dispatch(int dtype, int tile, int variant, const ConvKParams& p, hipStream_t s) {
+  if (dtype == OSD_F32) {
+      if (tile == 2) return launch_dma<float, 64, 64, 64, 2, 2, 8>(p, s);
+      if (tile == 1) return launch_dma<float, 128, 64, 64, 4, 1, 8>(p, s);
+    } else if (p.Cin % 64 == 0) {
+      if (tile == 2) return launch_dma<__bf16, 64, 64, 128, 2, 2, 8>(p, s);
+      if (tile == 1) return launch_dma<__bf16, 128, 64, 128, 4, 1, 5>(p, s);
+    }
+    return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the deep ring is built for the 64x64 and 128x64 tiles (bf16: cin %% 64 == 0)");
+  }
   if (dtype == OSD_F32) {
     if (variant == 1 || variant == 3) return dispatch_tile_dma<float, 64, 2>(tile, p, s);
     if (variant == 2) return dispatch_tile_dma<float, 64, 3>(tile, p, s);

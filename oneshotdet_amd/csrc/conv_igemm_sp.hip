@@ -28,6 +28,11 @@
 // row held: on the widths both forms accept the outputs are bit-identical (tested).  All lanes' vertical validity, the image
 // borders and the M tail stay hardware bounds checks of the DMA.  Every wave issues FIVE pixel instructions per image (the
 // halo one is all out-of-range lanes — zeros into the unused rows 0..7 — on waves 1..6), so the counted waits are uniform.
+//
+// TMX (round 4): pixel fragments per wave.  8 = the 256-pixel tile above; 4 = a 128-pixel x 256-channel tile on the same eight
+// waves (64 x 64 per wave: 8 instead of 6 LDS fragment reads per 16 MFMAs, half the pixel DMA per workgroup, the same weight
+// stages) for the launches whose pixel count gives the 256-pixel tile 25-100 workgroups on 256 CUs (layer3 / layer4 / P5-P7
+// at bs = 8): twice the workgroups.  Same K order and per-pixel arithmetic: bit-identical outputs (tested).
 #include "osd_common.h"
 #include "conv_params.h"
 #include "conv_epilogue.h"
@@ -72,10 +77,12 @@ constexpr int SP_BBYTES = SP_BN * SP_KB;
 constexpr int SP_LDS = 2 * SP_ABYTES + 2 * SP_BBYTES;
 constexpr unsigned SP_OOB = 0x80000000u;            // beyond any buffer of < 2 GiB: the DMA writes zeros
 
-template <bool GNB, bool GENW>      // GNB: the epilogue also gathers the GroupNorm statistics (ConvGnb, conv_params.h); GENW: any width
+template <bool GNB, bool GENW, int TMX>      // GNB: the epilogue also gathers the GroupNorm statistics (ConvGnb, conv_params.h); GENW: any width
 __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   typedef __bf16 T;
-  constexpr int TM = SP_TM, TN = SP_TN, KB = SP_KB;
+  constexpr int TM = TMX, TN = SP_TN, KB = SP_KB;
+  constexpr int BM = 2 * TM * 16;                       // pixels per tile: two wave rows of TM 16-pixel fragments
+  constexpr int PA = BM / 64;                           // pixel DMA instructions (8 rows each) per wave and image
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(size_t)smem;
   const int tid = threadIdx.x;
@@ -93,7 +100,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   int tile_m = t / p.tilesN;
   const ConvView q = conv_select_view(p, tile_m);
   const int q_H = q.H, q_W = q.W, q_M = q.M, q_HoWo = q.HoWo;
-  const int m0 = tile_m * SP_BM, n0 = tile_n * SP_BN;
+  const int m0 = tile_m * BM, n0 = tile_n * SP_BN;
   [[maybe_unused]] const int logw = __builtin_ctz((unsigned)q_W);       // !GENW: W in {64, 128, 256} (checked by the launcher)
   const int Cin = p.Cin;
 
@@ -118,21 +125,22 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   unsigned a_dst[4];
   [[maybe_unused]] unsigned h_off = 0u, h_dst = 0u;   // GENW: the halo instruction's source offset (filter row 0, slab 0), LDS row
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + lrow;
+  for (int i = 0; i < PA; ++i) {
+    const int row = (wave * PA + i) * 8 + lrow;
     const int m = m0 + row;
     int R, ad;
     if constexpr (GENW) {
       R = 16 + row;
-      ad = (16 + (wave * 4 + i) * 8) * KB;
+      ad = (16 + (wave * PA + i) * 8) * KB;
     } else {
       R = 16 + row + 16 * (row >> logw);
-      ad = (16 + (wave * 4 + i) * 8 + 16 * (((wave * 4 + i) * 8) >> logw)) * KB;
+      ad = (16 + (wave * PA + i) * 8 + 16 * (((wave * PA + i) * 8) >> logw)) * KB;
     }
     a_dst[i] = (unsigned)__builtin_amdgcn_readfirstlane(ad);
     if (i < 2) {
       a_par[i] = (unsigned)((m - i * 8 - q_W) * Cin + ((lpos ^ sp_key(R)) * SP_EPC)) * 2u;      // instruction 0's row + parity chunk
-      b_par[i] = (unsigned)((n0 + row - i * 8) * p.Ktot + ((lpos ^ ((row >> 1) & 7)) * SP_EPC)) * 2u;
+      const int brow = (wave * 4 + i) * 8 + lrow;       // weight instruction i of this wave: 4 per wave whatever the pixel tile
+      b_par[i] = (unsigned)((n0 + brow - i * 8) * p.Ktot + ((lpos ^ ((brow >> 1) & 7)) * SP_EPC)) * 2u;
     }
     if (m < q_M) {
       int ho;
@@ -147,9 +155,9 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   // (bit 8 + j) border of their line: the tap-0 / tap-2 fragment of such a pixel is zeroed in registers
   [[maybe_unused]] unsigned edge = 0u;
   if constexpr (GENW) {
-    const int hrow = wave == 0 ? -8 + lrow : 256 + lrow;         // halo rows: waves 0 and 7; the other waves fetch nothing
+    const int hrow = wave == 0 ? -8 + lrow : BM + lrow;         // halo rows: waves 0 and 7; the other waves fetch nothing
     const int hm = m0 + hrow;
-    h_dst = (unsigned)__builtin_amdgcn_readfirstlane(wave == 0 ? 8 * KB : (wave == 7 ? 272 * KB : 0));
+    h_dst = (unsigned)__builtin_amdgcn_readfirstlane(wave == 0 ? 8 * KB : (wave == 7 ? (16 + BM) * KB : 0));
     h_off = (unsigned)((hm - q_W) * Cin + ((lpos ^ sp_key(16 + hrow)) * SP_EPC)) * 2u;
     if ((wave == 0 || wave == 7) && hm >= 0 && hm < q_M) {
       const int ho = (int)((unsigned)(hm % q_HoWo) / (unsigned)q_W);
@@ -158,8 +166,8 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
         if ((unsigned)(ho - 1 + kr) < (unsigned)q_H) a_valid |= 1u << (12 + kr);
     }
 #pragma unroll
-    for (int j = 0; j < SP_TM; ++j) {
-      const unsigned x = (unsigned)(m0 + (wm * SP_TM + j) * 16 + (lane & 15)) % (unsigned)q_W;
+    for (int j = 0; j < TM; ++j) {
+      const unsigned x = (unsigned)(m0 + (wm * TM + j) * 16 + (lane & 15)) % (unsigned)q_W;
       if (x == 0u) edge |= 1u << j;
       if (x == (unsigned)q_W - 1u) edge |= 1u << (8 + j);
     }
@@ -179,7 +187,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
     const unsigned off = ((a_valid >> (12 + kr)) & 1u) ? h_off + (unsigned)(kr * line_bytes + kc * 2) : SP_OOB;
     sp_dma16(xrs, off, a_lds[buf] + h_dst);
   };
-  constexpr int NIMG = GENW ? 5 : 4;                    // pixel DMA instructions per wave and image
+  constexpr int NIMG = GENW ? PA + 1 : PA;              // pixel DMA instructions per wave and image
   // weight instruction i of the stage whose K offset is koff (elements) into weight stage `buf`
   auto issue_b = [&](int buf, int i, int koff) {
     sp_dma16(wrs, b_par[i & 1] + (unsigned)((i * 8 * p.Ktot + koff) * 2), b_lds[buf] + (unsigned)((wave * 4 + i) * 1024));
@@ -288,13 +296,17 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
       // (measured: the two waves of a SIMD issuing their DMA in opposite halves of the half stage — two copies of the K loop —
       // is 5 % SLOWER than all waves issuing at the same place)
       if constexpr (FB) {
-        if ((j < 4) == dma_early) issue_b(dma_bb, j & 3, koff);
+        if constexpr (TM >= 8) {
+          if ((j < 4) == dma_early) issue_b(dma_bb, j & 3, koff);
+        } else {
+          issue_b(dma_bb, j, koff);                       // TM = 4: one weight instruction per MFMA group
+        }
       }
       if constexpr (FA) {
         if constexpr (GENW) {
-          if (j == (dma_early ? 0 : 4)) issue_halo(dma_ab, nkr, nkc);
+          if (j == 0) issue_halo(dma_ab, nkr, nkc);
         }
-        if ((j < 4) == dma_early) issue_a(dma_ab, j & 3, nkr, nkc);
+        if (j < PA) issue_a(dma_ab, j, nkr, nkc);
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);                // keep the replacement read behind its fragment's last MFMA
@@ -311,7 +323,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   __syncthreads();                                      // the zero fill is complete before any DMA lands on real rows
   if constexpr (GENW) issue_halo(0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) issue_a(0, i, 0, 0);
+  for (int i = 0; i < PA; ++i) issue_a(0, i, 0, 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) issue_b(0, i, 0);
 #pragma unroll
@@ -398,7 +410,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   return;
 #endif
   const float pre_bias[8] = {bq[0][0], bq[0][1], bq[0][2], bq[0][3], bq[1][0], bq[1][1], bq[1][2], bq[1][3]};
-  conv_epilogue<T, TM, TN, true, GNB>(acc, p, q, smem, wave, wm, wn, lane, m0, n0, pre_bias);   // 8 waves x 2 x 8,704 B <= SP_LDS
+  conv_epilogue<T, TM, TN, true, GNB, (TM <= 4)>(acc, p, q, smem, wave, wm, wn, lane, m0, n0, pre_bias);   // 8 waves x 2 x 8,704 B <= SP_LDS
 #ifdef OSD_SP_STAMPS
   if (lane == 0 && p.act_scale_dev != nullptr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -411,7 +423,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
 
 }  // namespace
 
-int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_width) {
+int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_width, bool half_tile) {
   ConvKParams p = pin;
   if (p.R != 3 || p.S != 3 || p.sh != 1 || p.sw != 1 || p.ph != 1 || p.pw != 1)
     return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): 3x3 stride 1 pad 1 only");
@@ -422,17 +434,18 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
   // and hold whole lines); every other width — or all of them with general_width — runs the consecutive-rows form (GENW)
   bool genw = general_width;
   auto ok = [&](int w, int wo, int h, int ho, int m, int sh) {
-    if (!(w == 64 || w == 128 || w == 256)) genw = true;
+    if (!(w == 64 || w == 128 || (w == 256 && !half_tile))) genw = true;      // whole lines per tile, tiles start at x = 0
     return w >= 1 && wo == w && ho == h && sh == w * p.Cin && (long long)m * p.Cin * 2 < 0x7fffffffLL;
   };
-  p.tilesM = cdiv(p.M, SP_BM);
+  const int BMx = half_tile ? SP_BM / 2 : SP_BM;
+  p.tilesM = cdiv(p.M, BMx);
   if (p.n_seg > 0) {
     p.tilesM = 0;
     for (int i = 0; i < p.n_seg; ++i) {
       if (!ok(p.seg[i].W, p.seg[i].Wo, p.seg[i].H, p.seg[i].Ho, p.seg[i].M, p.seg[i].sH))
         return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): segment %d (width %d) is not a dense map under 2 GiB", i, p.seg[i].W);
       p.seg[i].tile_begin = p.tilesM;
-      p.tilesM += cdiv(p.seg[i].M, SP_BM);
+      p.tilesM += cdiv(p.seg[i].M, BMx);
     }
   } else if (!ok(p.W, p.Wo, p.H, p.Ho, p.M, p.sH)) {
     return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): not a dense map under 2 GiB (width %d)", p.W);
@@ -441,9 +454,11 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
   p.KT = p.Ktot / SP_BKE;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<true, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
     attr_done = true;
   }
   const long long nblocks = (long long)p.tilesM * p.tilesN;
@@ -451,7 +466,7 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
   if (p.gn_groups > 0) {
     // GroupNorm-backward statistics in the epilogue: whole tiles only (fast path), a wave's 128 rows inside one image, one
     // 16-byte channel chunk inside one group
-    if (genw) return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): GroupNorm statistics need map widths 64 / 128 / 256");
+    if (genw || half_tile) return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): GroupNorm statistics need map widths 64 / 128 / 256 and the 256-pixel tile");
     if (p.n_seg <= 0 || p.Cout % SP_BN != 0 || p.out_stride % 8 != 0 || p.Cout % p.gn_groups != 0 || (p.Cout / p.gn_groups) % 8 != 0 ||
         p.res_mode != OSD_RES_NONE || p.act != OSD_ACT_NONE)
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): GroupNorm statistics need a plain multi-segment conv with Cout %% 256 == 0 and groups of whole 16-byte chunks");
@@ -460,11 +475,14 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
       if (p.seg[i].M % SP_BM != 0 || (p.seg[i].Ho * p.seg[i].Wo) % (SP_BM / 2) != 0 || p.seg[i].M / (p.seg[i].Ho * p.seg[i].Wo) != p.gn_n)
         return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): GroupNorm statistics need images of whole 128-pixel runs (segment %d)", i);
     }
-    hipLaunchKernelGGL((conv_sp_kernel<true, false>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    hipLaunchKernelGGL((conv_sp_kernel<true, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+  } else if (half_tile) {
+    if (genw) hipLaunchKernelGGL((conv_sp_kernel<false, true, 4>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    else hipLaunchKernelGGL((conv_sp_kernel<false, false, 4>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
   } else if (genw) {
-    hipLaunchKernelGGL((conv_sp_kernel<false, true>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    hipLaunchKernelGGL((conv_sp_kernel<false, true, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
   } else {
-    hipLaunchKernelGGL((conv_sp_kernel<false, false>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    hipLaunchKernelGGL((conv_sp_kernel<false, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
   }
   return osd_check_launch("conv_igemm_sp");
 }

@@ -70,5 +70,5 @@ int osd_conv_p8_launch(const ConvKParams& p, hipStream_t s);
 int osd_conv_xr_launch(const ConvKParams& p, hipStream_t s);
 // conv_igemm_sp.hip: the row-reuse kernel with software-pipelined operand fragments and a mid-stage barrier (tile id 6, variant 1:
 // any map width — the padded-image form where every width is 64 / 128 / 256, else the consecutive-rows form; variant 2 =
-// general_width: the consecutive-rows form on every width, for tests and A/B timing)
-int osd_conv_sp_launch(const ConvKParams& p, hipStream_t s, bool general_width = false);
+// general_width: the consecutive-rows form on every width, for tests and A/B timing; variant 3 = half_tile: 128-pixel tiles)
+int osd_conv_sp_launch(const ConvKParams& p, hipStream_t s, bool general_width = false, bool half_tile = false);

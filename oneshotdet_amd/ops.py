@@ -132,7 +132,7 @@ def stem_input(images, dtype):
 # ---- per-shape algorithm selection by measurement ("measure, don't guess") ----
 # osd_conv_desc.algo = 1 + impl*32 + variant*8 + tile; impl 0 = LDS-DMA ring kernel (variants: deep / shallow ring /
 # short stages), impl 1 = register-staged kernel; tile 0..4 = 128x128, 128x64, 64x64, 256x16, 256x256/8 waves, 5 = ping-pong
-# 256x256, 6 = row-reuse 3x3 (variant 0: conv_xr, widths 64/128/256; 1: conv_sp, any width; 2: conv_sp's general-width form forced),
+# 256x256, 6 = row-reuse 3x3 (variant 0: conv_xr, widths 64/128/256; 1: conv_sp, any width; 2: conv_sp's general-width form forced; 3: conv_sp on 128-pixel tiles),
 # 7 = 256x128/8 waves (pixels x channels).
 ALGO_CACHE = {}
 _TUNING = [False]
@@ -146,11 +146,18 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
     if cout_store >= 256 and not relu_in:
         cands.append(1 + 0 * 32 + 1 * 8 + 4)          # 256x256 tile, shallow ring
         cands.append(1 + 0 * 32 + 2 * 8 + 4)          # 256x256 tile, short stages x 4
-        cands.append(1 + 0 * 32 + 0 * 8 + 5)          # 256x256 tile, two wave groups one barrier apart (bf16 only)
+        # superseded generations stay in the library (tests pin them by algo id) but are no longer timed on every shape:
+        # conv_p8 (ping-pong 256x256, never picked) and conv_xr (row reuse without the software pipeline; conv_sp is the same
+        # arithmetic, faster, and takes any width).  OSD_TUNE_LEGACY=1 puts them back among the candidates
+        legacy = os.environ.get("OSD_TUNE_LEGACY", "0") != "0"
+        if legacy:
+            cands.append(1 + 0 * 32 + 0 * 8 + 5)      # 256x256 tile, two wave groups one barrier apart (bf16 only)
         if not os.environ.get("OSD_NO_XR"):           # (A/B switch for tools and benches)
-            cands.append(1 + 0 * 32 + 0 * 8 + 6)      # 3x3/1: pixel rows fetched once per filter row (bf16, W in 64/128/256)
+            if legacy or os.environ.get("OSD_NO_SP"):
+                cands.append(1 + 0 * 32 + 0 * 8 + 6)  # 3x3/1: pixel rows fetched once per filter row (bf16, W in 64/128/256)
             if not os.environ.get("OSD_NO_SP"):
                 cands.append(1 + 0 * 32 + 1 * 8 + 6)  # the same with software-pipelined fragments + mid-stage barrier, ANY width
+                cands.append(1 + 0 * 32 + 3 * 8 + 6)  # ... on 128-pixel tiles: twice the workgroups where 256-pixel tiles leave CUs idle
     if cout_store >= 128 and not relu_in:
         cands += [1 + 0 * 32 + v * 8 + 7 for v in (0, 1, 2, 3)]      # 256x128 tile on 8 waves: deep / shallow ring / short stages
     if not relu_in and not has_mask:

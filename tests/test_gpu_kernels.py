@@ -254,7 +254,7 @@ def test_conv2d_every_algorithm_gives_the_same_answer(dt):
     pc = ops().pack_conv(wt.cuda(), bias=b.cuda(), dtype=DT[dt])
     xx, rr = to_nhwc(x, DT[dt]), to_nhwc(idn, DT[dt])
     ran = 0
-    for algo in ops().conv_algo_candidates(cout, False):
+    for algo in ops().conv_algo_candidates(cout, False) + [1 + 5, 1 + 6, 1 + 16 + 6]:      # + the retired generations, conv_sp's general-width form forced
         try:
             y = ops().conv2d(xx, pc, pad=1, act=ops().ACT_RELU, res=rr, res_mode=ops().RES_SAME, algo=algo)
         except _lib.OsdError:
@@ -283,7 +283,7 @@ def test_conv2d_grouped_equals_per_level_launches(dt):
     res = [to_nhwc(rnd(n, cout, h, w, seed=20 + i), DT[dt]) for i, (n, h, w) in enumerate(sizes)]
     msk = [to_nhwc(rnd(n, cout, h, w, seed=30 + i), DT[dt]) for i, (n, h, w) in enumerate(sizes)]
     ran = 0
-    for algo in o.conv_algo_candidates(cout, False, has_mask=True):
+    for algo in o.conv_algo_candidates(cout, False, has_mask=True) + [1 + 5, 1 + 6, 1 + 16 + 6]:
         try:
             ys = o.conv2d_grouped(xx, pc, pad=1, residuals=res, masks=msk, algo=algo)
         except _lib.OsdError:
@@ -424,7 +424,7 @@ def test_conv2d_software_pipelined_kernel_on_any_width():
     ulp, few elements differing) and itself bit for bit.  (iii) One grouped launch over P3..P7 of a 640 x 832 batch equals the
     per-level launches bit for bit."""
     o = ops()
-    SP, GEN, DMA = 1 + 8 + 6, 1 + 16 + 6, 1 + 8 + 4
+    SP, GEN, HALF, DMA = 1 + 8 + 6, 1 + 16 + 6, 1 + 24 + 6, 1 + 8 + 4
     for (n, h, w, cin, cout) in [(2, 50, 64, 256, 256), (3, 13, 128, 128, 256), (1, 5, 256, 64, 320), (2, 7, 64, 64, 260),
                                  (5, 9, 64, 256, 512)]:
         x = to_nhwc(rnd(n, cin, h, w, seed=1), torch.bfloat16)
@@ -437,6 +437,9 @@ def test_conv2d_software_pipelined_kernel_on_any_width():
             for rep in range(4):
                 y = o.conv2d(x, pc, pad=1, algo=GEN, **kw)
                 assert torch.equal(y, ref), (n, h, w, cin, cout, sorted(kw), rep, (y.float() - ref.float()).abs().max().item())
+            for rep in range(3):       # the 128-pixel tile (algo 31): same K order, same per-pixel arithmetic
+                y = o.conv2d(x, pc, pad=1, algo=HALF, **kw)
+                assert torch.equal(y, ref), ("half tile", n, h, w, cin, cout, sorted(kw), rep, (y.float() - ref.float()).abs().max().item())
     for (n, h, w, cin, cout) in [(2, 80, 104, 256, 256), (1, 128, 164, 256, 256), (2, 100, 168, 64, 256), (8, 25, 32, 256, 256),
                                  (8, 13, 16, 256, 256), (8, 7, 8, 256, 256), (3, 23, 19, 128, 320), (2, 5, 3, 64, 256),
                                  (4, 4, 1, 64, 256), (1, 1, 300, 64, 256), (1, 3, 257, 192, 512)]:
@@ -453,6 +456,7 @@ def test_conv2d_software_pipelined_kernel_on_any_width():
             assert (d > 0).float().mean().item() < 0.05
             for rep in range(3):
                 assert torch.equal(o.conv2d(x, pc, pad=1, algo=SP, **kw), y), (n, h, w, rep)
+                assert torch.equal(o.conv2d(x, pc, pad=1, algo=HALF, **kw), y), ("half tile", n, h, w, rep)
     # fp32 reference of the op itself on a width with borders inside every fragment
     n, h, w, cin, cout = 2, 11, 13, 64, 256
     xf, wf, bf = rnd(n, cin, h, w, seed=7), rnd(cout, cin, 3, 3, seed=8) / (cin * 9) ** 0.5, rnd(cout, seed=9)
@@ -464,9 +468,10 @@ def test_conv2d_software_pipelined_kernel_on_any_width():
     xs = [to_nhwc(rnd(2, 256, hh, ww, seed=20 + i), torch.bfloat16) for i, (hh, ww) in enumerate([(80, 104), (40, 52), (20, 26), (10, 13), (5, 7)])]
     wt = rnd(256, 256, 3, 3, seed=13) / (256 * 9) ** 0.5
     pc = o.pack_conv(wt.cuda(), bias=rnd(256, seed=14).cuda(), dtype=torch.bfloat16)
-    ga = o.conv2d_grouped(xs, pc, pad=1, algo=SP, _whole=True)
-    for xa, ya in zip(xs, ga):
-        assert torch.equal(ya, o.conv2d(xa, pc, pad=1, algo=SP))
+    for algo in (SP, HALF):
+        ga = o.conv2d_grouped(xs, pc, pad=1, algo=algo, _whole=True)
+        for xa, ya in zip(xs, ga):
+            assert torch.equal(ya, o.conv2d(xa, pc, pad=1, algo=SP))
     # still refused: 1x1, stride 2, channel counts that are not whole 64-channel slabs
     from oneshotdet_amd import _lib
     with pytest.raises(_lib.OsdError):

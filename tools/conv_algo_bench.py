@@ -5,7 +5,12 @@ import torch
 from oneshotdet_amd import ops, _lib
 dt = torch.float32 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else torch.bfloat16
 shapes = [(8, 100, 128, 256, 256, 3, 1, 1), (8, 50, 64, 256, 256, 3, 1, 1), (8, 50, 64, 1024, 256, 1, 1, 0),
-          (8, 50, 64, 256, 1024, 1, 1, 0), (8, 25, 32, 512, 512, 3, 1, 1), (8, 200, 256, 64, 256, 1, 1, 0)]
+          (8, 50, 64, 256, 1024, 1, 1, 0), (8, 25, 32, 512, 512, 3, 1, 1), (8, 200, 256, 64, 256, 1, 1, 0),
+          (8, 25, 32, 256, 256, 3, 1, 1), (4, 128, 164, 256, 256, 3, 1, 1), (4, 80, 104, 256, 256, 3, 1, 1), (8, 100, 128, 128, 128, 3, 1, 1),
+          (8, 100, 128, 128, 512, 1, 1, 0),
+          # the latency-bound launches (query backbone, layer4, P6 / P7; 20 = config5's 4 x 5 queries)
+          (8, 8, 8, 256, 256, 3, 1, 1), (8, 4, 4, 512, 512, 3, 1, 1), (8, 16, 16, 128, 128, 3, 1, 1), (20, 8, 8, 256, 256, 3, 1, 1),
+          (8, 8, 8, 1024, 256, 1, 1, 0), (8, 4, 4, 2048, 512, 1, 1, 0), (8, 13, 16, 256, 256, 3, 1, 1)]
 names = {0: "dma", 1: "reg"}
 for (n, h, w, cin, cout, k, s, p) in shapes:
     x = torch.randn(n, h, w, cin, device="cuda").to(dt)
