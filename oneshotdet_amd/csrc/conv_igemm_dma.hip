@@ -354,15 +354,6 @@ int dispatch_tile_dma(int tile, const ConvKParams& p, hipStream_t s) {
 //          of the first operand fetch and of the residual read in the epilogue) matter and the ring depth does not
 int osd_conv_dma_dispatch(int dtype, int tile, int variant, const ConvKParams& p, hipStream_t s) {
   if (dtype == OSD_F32) {
-      if (tile == 2) return launch_dma<float, 64, 64, 64, 2, 2, 8>(p, s);
-      if (tile == 1) return launch_dma<float, 128, 64, 64, 4, 1, 8>(p, s);
-    } else if (p.Cin % 64 == 0) {
-      if (tile == 2) return launch_dma<__bf16, 64, 64, 128, 2, 2, 8>(p, s);
-      if (tile == 1) return launch_dma<__bf16, 128, 64, 128, 4, 1, 5>(p, s);
-    }
-    return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the deep ring is built for the 64x64 and 128x64 tiles (bf16: cin %% 64 == 0)");
-  }
-  if (dtype == OSD_F32) {
     if (variant == 1 || variant == 3) return dispatch_tile_dma<float, 64, 2>(tile, p, s);
     if (variant == 2) return dispatch_tile_dma<float, 64, 3>(tile, p, s);
     return dispatch_tile_dma<float, 64, 4>(tile, p, s);
