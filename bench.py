@@ -105,6 +105,37 @@ class ConvTimer(object):
         return sum(s.elapsed_time(e) for s, e in self.records) - self.bracket_overhead_ms() * len(self.records)
 
     @staticmethod
+    def launch_bracket_overhead_ms(n=60, burst=16):
+        """What a start/stop event bracket adds to ONE kernel launch inside it (dispatch of the kernel behind the start marker,
+        completion signal ahead of the stop marker): with a tiny kernel K, bracket(K x burst) - bracket(K) = (burst - 1) launches
+        back to back, so one launch costs s = that / (burst - 1) and the bracket's fixed part is bracket(K) - s.  rocprofv3's kernel
+        trace reports durations without it; `roofline.kernel_time` subtracts it so that the figure can be checked against profiles/."""
+        if not hasattr(ConvTimer, "_launch_overhead"):
+            from oneshotdet_amd import ops
+            probe = torch.zeros(64, device="cuda", dtype=torch.float32)
+
+            def bracket(k):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(k):
+                    ops.add_mask(probe, None, None, out=probe)
+                b.record()
+                return a, b
+            for _ in range(5):
+                bracket(burst)
+            torch.cuda.synchronize()
+            one, many = [], []
+            for _ in range(n):
+                torch.cuda._sleep(int(2e6))            # park the stream: the host enqueues the bracket ahead of the GPU
+                one.append(bracket(1))
+                many.append(bracket(burst))
+            torch.cuda.synchronize()
+            t1 = sorted(a.elapsed_time(b) for a, b in one)[n // 2]
+            tn = sorted(a.elapsed_time(b) for a, b in many)[n // 2]
+            ConvTimer._launch_overhead = max(0.0, t1 - (tn - t1) / (burst - 1))
+        return ConvTimer._launch_overhead
+
+    @staticmethod
     def bracket_overhead_ms(n=200):
         """Elapsed time of an EMPTY start/stop event bracket on this stream (two marker packets with nothing between):
         subtracted from every bracketed launch so avg_launch_us is the kernel's own duration, the figure rocprofv3's
@@ -650,6 +681,15 @@ def main_train(args, rank, world, backend="nccl"):
                     "conv_ms_per_step": round(conv_ms / nst, 3),
                     "measured": "HIP events per launch (minus the %.1f us empty-bracket overhead), %d eager steps after "
                                 "the timed region" % (ConvTimer.bracket_overhead_ms() * 1e3, nst)}
+        # the same brackets minus what a bracket adds to a kernel launch (calibrated with a tiny kernel, see
+        # ConvTimer.launch_bracket_overhead_ms): the sum of kernel durations a rocprofv3 kernel trace of these launches reports
+        lov = ConvTimer.launch_bracket_overhead_ms()
+        kt_ms = sum(s_.elapsed_time(e_) for s_, e_ in timer.records) - lov * len(timer.records)
+        roofline["kernel_time"] = {"ms_per_step": round(kt_ms / nst, 3), "achieved": round(timer.flops / (kt_ms * 1e-3) / 1e12, 1),
+                                   "frac": round(timer.flops / (kt_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+                                   "bracket_overhead_us_per_launch": round(lov * 1e3, 2),
+                                   "what": "sum of kernel durations = event brackets minus the bracket's calibrated per-launch cost; "
+                                           "compare with the kernel-trace row of profiles/r*_bench_train_bf16.md"}
         # the single shape that takes the most time per step: the family figures above average 264 launches, most of them
         # small or HBM-bound; this is the dominant kernel launch by itself
         table = timer.layer_table(nst)

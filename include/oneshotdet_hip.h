@@ -386,6 +386,17 @@ int osd_grad_wire_cast(const void* src, void* dst, int64_t numel, int to_wire, v
 int osd_sgd_momentum_multi(const void* table, const int32_t* block_entry, int n_blocks, float* params,
                            const float* grads, float* momentum_buf, float lr, float momentum, int first_step,
                            void* stream);
+/* The same update, which ALSO writes the forward-form packed weights (osd_pack_multi with dgrad = 0: `dtype`, FrozenBN scale
+ * folded, [rows][r*s][kpad] rows) of every conv weight it updates — the thread that holds four updated fp32 values stores them
+ * again as `dtype`; the packed buffer's padding (rows >= cout, k >= cin) must already be zero and is not written.  Replaces
+ * osd_sgd_momentum_multi + the forward half of the per-step repack (solver/build.py:8-26 has no counterpart for the latter: the
+ * reference's convs read the fp32 parameters directly).  table: device array of struct { int64 off, numel; float lr_mult, wd;
+ * int32 first_block, n_blocks; int64 dst_off (elements into `packed`; -1: update only), scale_off (floats into `scales`; -1:
+ * none); int32 cin, rs, kpad, pad; } (64 bytes).  Tensors that start on a 16-byte boundary (and, packed, have cin % 4 == 0) take 16 bytes
+ * per lane, the others one value per lane. */
+int osd_sgd_momentum_pack_multi(const void* table, const int32_t* block_entry, int n_blocks, float* params,
+                                const float* grads, float* momentum_buf, const float* scales, void* packed, int dtype,
+                                float lr, float momentum, int first_step, void* stream);
 /* GroupNorm + ReLU of one tower layer over ALL FPN levels (separate tensors sharing gamma/beta) in two launches, and
  * its backward in two launches: statistics per (level, image, slab), finalised inside the apply kernels.
  * xs/ys/us/dts/dus: HOST arrays of n_levels device pointers to [n][hw_l][c] tensors; hws: HOST array;

@@ -250,6 +250,89 @@ __global__ void __launch_bounds__(256) sgd_multi_kernel(const SgdEntry* __restri
   }
 }
 
+// ---- the same update that ALSO writes the forward-form packed weights of the conv tensors it updates (round 4): the repack
+// of the forward form is a scaled, rounded, K-padded copy in the masters' own [cout][R][S][cin] order, so the thread that holds
+// the four updated fp32 values stores them again as `T`, times the folded FrozenBN scale — the packed buffer's padding rows /
+// columns were zeroed once and are never written.  One launch and one read of the masters less per bucket; the data-gradient
+// form (a per-tap transpose) stays pack_multi_kernel's.  Entries with dst_off < 0 (biases, GroupNorm affine, Scale) only update.
+struct SgdPackEntry {
+  long long off, numel;
+  float lr_mult, wd;
+  int first_block, n_blocks;
+  long long dst_off;     // elements into the flat packed buffer; -1: not a conv weight
+  long long scale_off;   // floats into the flat scale buffer; -1: none
+  int cin, rs, kpad, pad_;   // [cout][rs = R * S][cin] master -> [rows][rs][kpad] packed; cin % 4 == 0, off % 4 == 0 (host-checked)
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) sgd_pack_multi_kernel(const SgdPackEntry* __restrict__ table, const int* __restrict__ block_entry,
+                                                             float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                             const float* __restrict__ scales, T* __restrict__ packed, float lr,
+                                                             float momentum, int first) {
+  const SgdPackEntry e = table[block_entry[blockIdx.x]];
+  const float step = lr * e.lr_mult;
+  const long long stride = (long long)e.n_blocks * blockDim.x;
+  const long long tid = (long long)(blockIdx.x - e.first_block) * blockDim.x + threadIdx.x;
+  const bool pack = e.dst_off >= 0;
+  // four values per thread where the tensor starts on a 16-byte boundary (and, packed, a group of four stays inside one tap's
+  // channel run); otherwise — the 2- and 4-row prediction convs behind an odd-sized bias — one value per thread
+  const long long n4 = ((e.off & 3) == 0 && (!pack || (e.cin & 3) == 0)) ? (e.numel >> 2) : 0;
+  f32x4* p4 = reinterpret_cast<f32x4*>(p + e.off);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g + e.off);
+  f32x4* b4 = reinterpret_cast<f32x4*>(buf + e.off);
+  const float* sc = e.scale_off >= 0 ? scales + e.scale_off : nullptr;
+  const int cin4 = e.cin >> 2;
+  const long long row4 = (long long)e.rs * cin4;            // groups of four per output row (co)
+  for (long long i = tid; i < n4; i += stride) {
+    const f32x4 w = p4[i], gr = g4[i];
+    f32x4 m;
+    if (first) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = gr[k] + e.wd * w[k];
+    } else {
+      const f32x4 bb = b4[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = momentum * bb[k] + (gr[k] + e.wd * w[k]);
+    }
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = w[k] - step * m[k];
+    b4[i] = m;
+    p4[i] = o;
+    if (pack) {
+      const long long co = i / row4;
+      const long long rem = i - co * row4;
+      const int tap = (int)(rem / cin4), ci = ((int)(rem - (long long)tap * cin4)) << 2;
+      const float f = sc ? sc[co] : 1.f;
+      T* d = packed + e.dst_off + ((size_t)co * e.rs + tap) * e.kpad + ci;
+      if constexpr (sizeof(T) == 2) {
+        bf16x4 q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = (__bf16)(o[k] * f);
+        *reinterpret_cast<bf16x4*>(d) = q;
+      } else {
+        *reinterpret_cast<f32x4*>(d) = f32x4{o[0] * f, o[1] * f, o[2] * f, o[3] * f};
+      }
+    }
+  }
+  const long long row1 = (long long)e.rs * e.cin;
+  for (long long i = n4 * 4 + tid; i < e.numel; i += stride) {
+    const long long k = e.off + i;
+    const float w = p[k];
+    const float d = g[k] + e.wd * w;
+    const float m = first ? d : momentum * buf[k] + d;
+    const float o = w - step * m;
+    buf[k] = m;
+    p[k] = o;
+    if (pack) {
+      const long long co = i / row1;
+      const long long rem = i - co * row1;
+      const int tap = (int)(rem / e.cin), ci = (int)(rem - (long long)tap * e.cin);
+      packed[e.dst_off + ((size_t)co * e.rs + tap) * e.kpad + ci] = from_f32<T>(o * (sc ? sc[co] : 1.f));
+    }
+  }
+}
+
 // packed fp32 weight gradient [cout][R][S][cin] -> OIHW, times the folded FrozenBN scale (d/dw of conv(x, w*scale))
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, const float* __restrict__ scale, float* __restrict__ g,
                                     int cout, int cin, int R, int S, int accumulate) {
@@ -533,6 +616,19 @@ extern "C" int osd_sgd_momentum_multi(const void* table, const int32_t* block_en
   hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_blocks), dim3(256), 0, OSD_STREAM(stream), (const SgdEntry*)table, block_entry,
                      params, grads, momentum_buf, lr, momentum, first_step);
   return osd_check_launch("sgd_multi");
+}
+
+extern "C" int osd_sgd_momentum_pack_multi(const void* table, const int32_t* block_entry, int n_blocks, float* params,
+                                           const float* grads, float* momentum_buf, const float* scales, void* packed, int dtype,
+                                           float lr, float momentum, int first_step, void* stream) {
+  if (!table || !block_entry || !params || !grads || !momentum_buf || !packed) return osd_fail(OSD_ERR_INVALID_ARG, "sgd_pack: null argument");
+  if (n_blocks <= 0) return OSD_OK;
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(sgd_pack_multi_kernel<float>, dim3(n_blocks), dim3(256), 0, OSD_STREAM(stream), (const SgdPackEntry*)table, block_entry,
+                         params, grads, momentum_buf, scales, (float*)packed, lr, momentum, first_step),
+      hipLaunchKernelGGL(sgd_pack_multi_kernel<__bf16>, dim3(n_blocks), dim3(256), 0, OSD_STREAM(stream), (const SgdPackEntry*)table, block_entry,
+                         params, grads, momentum_buf, scales, (__bf16*)packed, lr, momentum, first_step));
+  return osd_check_launch("sgd_pack_multi");
 }
 
 extern "C" int osd_unpack_wgrad(const float* dw_packed, const float* scale, float* grad_oihw, int cout, int cin, int r, int s,

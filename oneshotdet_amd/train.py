@@ -427,6 +427,8 @@ class TrainEngine(object):
                 tables[bucket] = dict(table=torch.from_numpy(tab).to(self.device),
                                       blocks=torch.tensor(blocks, dtype=torch.int32, device=self.device), n=len(blocks))
             self._pack[form] = dict(flat=flat, tables=tables)
+            if form == 0:
+                self._pack_fwd_entry = {id(e["c"]): e for e in entries}      # conv -> its forward-form entry (the fused update)
             for e in entries:
                 c = e["c"]
                 view = flat[e["dst"]:e["dst"] + e["numel"]].view(e["rows"], c.r, c.s, e["kpad"])
@@ -447,9 +449,10 @@ class TrainEngine(object):
             if c.has_bias and c.cout % 16 != 0:
                 self._padded_bias.setdefault(self._bucket_of(c.w), []).append(c)
 
-    def repack(self, buckets=None):
+    def repack(self, buckets=None, forms=(0, 1)):
         """fp32 masters -> kernel-layout weights of the compute dtype: per gradient bucket two launches (forward and
-        data-gradient forms).  buckets=None: all of them."""
+        data-gradient forms).  buckets=None: all of them; forms=(1,): the data-gradient form only (the fused update has
+        already written the forward form)."""
         for c in self.convs.values():
             if not c.trainable and c.pc is None:
                 c.pc = ops.pack_conv(self._frozen_sd[c.name + ".weight"], bn=None if c.bn_scale is None else tuple(
@@ -459,7 +462,7 @@ class TrainEngine(object):
         if not hasattr(self, "_pack"):
             self._build_pack_tables()
         for bucket in (self.exchange.ranges if buckets is None else buckets):
-            for form in (0, 1):
+            for form in forms:
                 pk = self._pack[form]
                 tb = pk["tables"].get(bucket)
                 if tb is not None:
@@ -1204,26 +1207,36 @@ class TrainEngine(object):
         self.exchange.finish()        # buckets not announced during backward (graph replay, single stream) go now
 
     def _build_sgd_table(self, weights, biases):
-        """Per gradient bucket the table of osd_sgd_momentum_multi (one launch updates every tensor of the bucket)."""
+        """Per gradient bucket the table of osd_sgd_momentum_pack_multi (one launch updates every tensor of the bucket AND writes
+        the forward-form packed weights of its conv tensors; OSD_NO_FUSED_REPACK=1: osd_sgd_momentum_multi + the two-form repack)."""
         import numpy as np
         base = self.flat_w.data_ptr()
+        conv_of = {c.w.data_ptr(): c for c in self.convs.values() if c.trainable}
         rows = {name: [] for name in self.exchange.ranges}
         for group, lr_mult, wd in ((weights, 1.0, self.weight_decay), (biases, 2.0, 0.0)):
             for t in group:
-                rows[self._bucket_of(t)].append(((t.data_ptr() - base) // 4, t.numel(), lr_mult, wd))
+                rows[self._bucket_of(t)].append(((t.data_ptr() - base) // 4, t.numel(), lr_mult, wd, conv_of.get(t.data_ptr())))
+        fuse = os.environ.get("OSD_NO_FUSED_REPACK", "0") == "0"
         tables = {}
         for name, rs in rows.items():
             if not rs:
                 continue
-            tab = np.zeros((len(rs), 4), dtype=np.int64)         # 32 bytes per entry
+            fused = fuse
+            tab = np.zeros((len(rs), 8 if fused else 4), dtype=np.int64)         # 64 / 32 bytes per entry
             blocks = []
-            for i, (off, n, lm, wd) in enumerate(rs):
+            for i, (off, n, lm, wd, c) in enumerate(rs):
                 nb = max(1, min(64, (n + 256 * 16 - 1) // (256 * 16)))
                 tab[i, 0], tab[i, 1] = off, n
                 tab[i, 2] = np.frombuffer(np.array([lm, wd], dtype=np.float32).tobytes(), dtype=np.int64)[0]
                 tab[i, 3] = np.frombuffer(np.array([len(blocks), nb], dtype=np.int32).tobytes(), dtype=np.int64)[0]
+                if fused:
+                    tab[i, 4] = tab[i, 5] = -1
+                    if c is not None:
+                        e = self._pack_fwd_entry[id(c)]
+                        tab[i, 4], tab[i, 5] = e["dst"], e["scale"]
+                        tab[i, 6:8] = np.frombuffer(np.array([c.cin, c.r * c.s, e["kpad"], 0], dtype=np.int32).tobytes(), dtype=np.int64)
                 blocks += [i] * nb
-            tables[name] = dict(table=torch.from_numpy(tab).to(self.device),
+            tables[name] = dict(table=torch.from_numpy(tab).to(self.device), fused=fused,
                                 blocks=torch.tensor(blocks, dtype=torch.int32, device=self.device), n=len(blocks))
         self._sgd = dict(tables=tables, buf=torch.zeros_like(self.flat_w), steps=0)
 
@@ -1231,11 +1244,17 @@ class TrainEngine(object):
         """SGD(momentum) on the bucket's masters, then its repack, on the current stream."""
         sg = self._sgd
         tb = sg["tables"].get(name)
-        if tb is not None:
+        fused = tb is not None and tb["fused"]
+        if fused:
+            pk = self._pack[0]["flat"]
+            ops._lib.call("osd_sgd_momentum_pack_multi", ops._ptr(tb["table"]), ops._ptr(tb["blocks"]), tb["n"],
+                          ops._ptr(self.flat_w), ops._ptr(self.flat_g), ops._ptr(sg["buf"]), ops._ptr(self._flat_scale), ops._ptr(pk),
+                          ops._dt(pk), float(self.lr), float(self.momentum), int(sg["steps"] == 0), ops._stream())
+        elif tb is not None:
             ops._lib.call("osd_sgd_momentum_multi", ops._ptr(tb["table"]), ops._ptr(tb["blocks"]), tb["n"],
                           ops._ptr(self.flat_w), ops._ptr(self.flat_g), ops._ptr(sg["buf"]), float(self.lr),
                           float(self.momentum), int(sg["steps"] == 0), ops._stream())
-        self.repack([name])
+        self.repack([name], forms=(1,) if fused else (0, 1))      # (the padded copies of the 2 / 4 prediction biases ride along)
         self._updated.add(name)
 
     def optimizer_step(self):

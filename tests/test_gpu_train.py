@@ -280,6 +280,16 @@ def test_fused_sgd_matches_torch_optim():
         a.optimizer_step()
         b.optimizer_step()
     torch.testing.assert_close(a.flat_w, b.flat_w, rtol=1e-6, atol=1e-7)
+    # the fused update also wrote the forward-form packed weights (osd_sgd_momentum_pack_multi): they must be what a repack of
+    # the updated masters writes, bit for bit, padding included, and every bucket must have taken the fused launch
+    assert all(t["fused"] for t in a._sgd["tables"].values())
+    got = [a._pack[f]["flat"].clone() for f in (0, 1)]
+    a.repack()
+    for f in (0, 1):
+        assert torch.equal(got[f].view(torch.int16), a._pack[f]["flat"].view(torch.int16)), "packed form %d" % f
+    for c in a.convs.values():
+        if c.trainable and c.has_bias and c.cout % 16 != 0:
+            assert torch.equal(c.pc.bias[:c.cout], c.b)
 
 
 def test_sgd_step_uses_the_reference_parameter_groups():

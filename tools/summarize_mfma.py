@@ -4,7 +4,13 @@ per conv kernel the share of SIMD-cycles in which the matrix pipe was busy.
   SQ_VALU_MFMA_BUSY_CYCLES  cycles, summed over all SIMDs (16 per v_mfma_f32_16x16x32_bf16: MI355X_MICROARCH.md, cycle constants)
   GRBM_GUI_ACTIVE           active cycles summed over the 8 XCDs -> / 8 = the dispatch's cycles at the clock it ran at
   MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs)
-usage: python tools/summarize_mfma.py gpurun_out/pmcg_mfma profiles/r1_pmc_mfma_busy_train_bf16.md"""
+Round 4: durations are NOT taken from the counter-collection pass (its timestamps are not the kernel trace's: round 3's table
+implied 1.9 PFLOP/s for the dominant launch).  With a third argument — the run_kernel_trace.csv of a plain --kernel-trace run of
+the SAME command with the SAME tuner choices (OSD_TUNER_CACHE, so both runs launch the same kernels in the same order) — the
+k-th dispatch of a kernel in the counter pass is joined with the k-th dispatch of that kernel in the trace: busy share and
+cycles from the counters, duration from the trace, and the dominant launch's row closes arithmetically (MFMA instructions =
+busy cycles / 16; x 16,384 FLOP = the launch's algorithmic FLOP; cycles / trace duration = the clock it ran at).
+usage: python tools/summarize_mfma.py gpurun_out/pmcg_mfma profiles/<name>.md [gpurun_out/prof_<tag>/run_kernel_trace.csv]"""
 import collections
 import csv
 import re
@@ -29,6 +35,22 @@ def main():
         k[r["Counter_Name"]] = float(r["Counter_Value"])
         k["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         k["grid"] = int(r.get("Grid_Size", 0) or 0)
+    # kernel trace of a separate, counter-free run: durations by (kernel, occurrence index)
+    trace = collections.defaultdict(list)
+    if len(sys.argv) > 3:
+        for r in sorted(csv.DictReader(open(sys.argv[3])), key=lambda r: int(r["Dispatch_Id"])):
+            trace[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    occ = collections.defaultdict(int)
+    joined = 0
+    for did in sorted(per, key=int):
+        k = per[did]
+        i = occ[k["name"]]
+        occ[k["name"]] += 1
+        k["ns_pmc"] = k["ns"]
+        if i < len(trace.get(k["name"], ())):
+            k["ns"] = trace[k["name"]][i]
+            joined += 1
+    dom = []
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
     for k in per.values():
         if "SQ_VALU_MFMA_BUSY_CYCLES" not in k or "GRBM_GUI_ACTIVE" not in k:
@@ -40,6 +62,7 @@ def main():
         # the step's dominant launch on its own row: the tower 3x3 conv over P3 + P4 of one tower at bs 8 = 500 tiles of 512 threads
         if "conv_sp_kernel" in n and k["grid"] == 500 * 512:
             names.append(n + " — 500 tiles: the dominant launch (tower conv over P3 + P4)")
+            dom.append(k)
         for nm in names:
             a = agg[nm]
             a[0] += 1
@@ -59,6 +82,22 @@ def main():
         for n, (c, busy, gui, ns) in top:
             f.write("| `%s` | %d | %.2f | %.3f | %.2f |\n" % (n, c, ns / 1e6, busy / (gui / 8 * 1024), gui / 8 / ns))
         f.write("| **all conv kernels** | %d | %.2f | **%.3f** | %.2f |\n" % (tot[0], tot[3] / 1e6, tot[1] / (tot[2] / 8 * 1024), tot[2] / 8 / tot[3]))
+        if trace:
+            f.write("\nDurations: kernel trace of a separate counter-free run with the same tuner choices, joined by (kernel, occurrence "
+                    "index): %d of %d dispatches joined.\n" % (joined, len(per)))
+        if dom:
+            n = len(dom)
+            busy = sum(k["SQ_VALU_MFMA_BUSY_CYCLES"] for k in dom) / n
+            cyc = sum(k["GRBM_GUI_ACTIVE"] for k in dom) / n / 8
+            ns, ns_pmc = sum(k["ns"] for k in dom) / n, sum(k["ns_pmc"] for k in dom) / n
+            gflop = busy / 16 * 16384 / 1e9
+            f.write("\n## The dominant launch, closed arithmetically (tower 3x3 conv over P3 + P4 of one tower: 500 tiles, 151.0 GFLOP algorithmic)\n\n"
+                    "| dispatches | SQ_VALU_MFMA_BUSY_CYCLES per dispatch | = MFMA instructions x 16 -> GFLOP issued | cycles per dispatch (GRBM_GUI_ACTIVE / 8) | busy share | "
+                    "duration us: kernel trace | duration us: counter pass | clock GHz = cycles / trace duration | TFLOP/s = issued GFLOP / trace duration |\n|---|---|---|---|---|---|---|---|---|\n")
+            f.write("| %d | %.4g | %.1f | %.4g | %.3f | %.1f | %.1f | %.2f | %.0f |\n"
+                    % (n, busy, gflop, cyc, busy / (cyc * 1024), ns / 1e3, ns_pmc / 1e3, cyc / ns, gflop / (ns * 1e-9) / 1e3))
+            f.write("\nbusy share x 1,024 SIMDs x 1,024 FLOP per SIMD-cycle x clock = the TFLOP/s column; the issued GFLOP exceed the "
+                    "algorithmic 151.0 by the tiles' padding (500 tiles x 256 pixels = 128,000: none here) only.\n")
     print(open(out).read())
 
 
