@@ -393,10 +393,11 @@ int osd_sgd_momentum_multi(const void* table, const int32_t* block_entry, int n_
  * reference's convs read the fp32 parameters directly).  table: device array of struct { int64 off, numel; float lr_mult, wd;
  * int32 first_block, n_blocks; int64 dst_off (elements into `packed`; -1: update only), scale_off (floats into `scales`; -1:
  * none); int32 cin, rs, kpad, pad; } (64 bytes).  Tensors that start on a 16-byte boundary (and, packed, have cin % 4 == 0) take 16 bytes
- * per lane, the others one value per lane. */
+ * per lane, the others one value per lane.  zero_grads != 0: the gradients are consumed — every element read is overwritten with
+ * zero (optimizer.zero_grad() of engine/trainer.py:89 folded into the update: the weight-gradient kernels accumulate). */
 int osd_sgd_momentum_pack_multi(const void* table, const int32_t* block_entry, int n_blocks, float* params,
-                                const float* grads, float* momentum_buf, const float* scales, void* packed, int dtype,
-                                float lr, float momentum, int first_step, void* stream);
+                                float* grads, float* momentum_buf, const float* scales, void* packed, int dtype,
+                                float lr, float momentum, int first_step, int zero_grads, void* stream);
 /* GroupNorm + ReLU of one tower layer over ALL FPN levels (separate tensors sharing gamma/beta) in two launches, and
  * its backward in two launches: statistics per (level, image, slab), finalised inside the apply kernels.
  * xs/ys/us/dts/dus: HOST arrays of n_levels device pointers to [n][hw_l][c] tensors; hws: HOST array;

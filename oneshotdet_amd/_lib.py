@@ -67,7 +67,7 @@ SIGNATURES = {
     "osd_groupnorm_relu_bwd_levels": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "osd_groupnorm_relu_bwd_levels_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_uint32, _p]),
     "osd_sgd_momentum_multi": (_i, [_p, _p, _i, _p, _p, _p, _f, _f, _i, _p]),
-    "osd_sgd_momentum_pack_multi": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _f, _i, _p]),
+    "osd_sgd_momentum_pack_multi": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _f, _i, _i, _p]),
     "osd_pack_multi": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _p]),
     "osd_conv2d_wgrad_grouped": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_wgrad_pred": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -266,9 +266,11 @@ struct SgdPackEntry {
 
 template <typename T>
 __global__ void __launch_bounds__(256) sgd_pack_multi_kernel(const SgdPackEntry* __restrict__ table, const int* __restrict__ block_entry,
-                                                             float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                             float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
                                                              const float* __restrict__ scales, T* __restrict__ packed, float lr,
-                                                             float momentum, int first) {
+                                                             float momentum, int first, int zero_grads) {
+  // zero_grads: the gradient is CONSUMED — zeros are stored behind the read, so the next step's weight-gradient kernels (which
+  // accumulate atomically) find a clean buffer without a 236 MB memset on the critical path of the next forward pass
   const SgdPackEntry e = table[block_entry[blockIdx.x]];
   const float step = lr * e.lr_mult;
   const long long stride = (long long)e.n_blocks * blockDim.x;
@@ -278,7 +280,7 @@ __global__ void __launch_bounds__(256) sgd_pack_multi_kernel(const SgdPackEntry*
   // channel run); otherwise — the 2- and 4-row prediction convs behind an odd-sized bias — one value per thread
   const long long n4 = ((e.off & 3) == 0 && (!pack || (e.cin & 3) == 0)) ? (e.numel >> 2) : 0;
   f32x4* p4 = reinterpret_cast<f32x4*>(p + e.off);
-  const f32x4* g4 = reinterpret_cast<const f32x4*>(g + e.off);
+  f32x4* g4 = reinterpret_cast<f32x4*>(g + e.off);
   f32x4* b4 = reinterpret_cast<f32x4*>(buf + e.off);
   const float* sc = e.scale_off >= 0 ? scales + e.scale_off : nullptr;
   const int cin4 = e.cin >> 2;
@@ -299,6 +301,7 @@ __global__ void __launch_bounds__(256) sgd_pack_multi_kernel(const SgdPackEntry*
     for (int k = 0; k < 4; ++k) o[k] = w[k] - step * m[k];
     b4[i] = m;
     p4[i] = o;
+    if (zero_grads) g4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (pack) {
       const long long co = i / row4;
       const long long rem = i - co * row4;
@@ -324,6 +327,7 @@ __global__ void __launch_bounds__(256) sgd_pack_multi_kernel(const SgdPackEntry*
     const float o = w - step * m;
     buf[k] = m;
     p[k] = o;
+    if (zero_grads) g[k] = 0.f;
     if (pack) {
       const long long co = i / row1;
       const long long rem = i - co * row1;
@@ -619,15 +623,15 @@ extern "C" int osd_sgd_momentum_multi(const void* table, const int32_t* block_en
 }
 
 extern "C" int osd_sgd_momentum_pack_multi(const void* table, const int32_t* block_entry, int n_blocks, float* params,
-                                           const float* grads, float* momentum_buf, const float* scales, void* packed, int dtype,
-                                           float lr, float momentum, int first_step, void* stream) {
+                                           float* grads, float* momentum_buf, const float* scales, void* packed, int dtype,
+                                           float lr, float momentum, int first_step, int zero_grads, void* stream) {
   if (!table || !block_entry || !params || !grads || !momentum_buf || !packed) return osd_fail(OSD_ERR_INVALID_ARG, "sgd_pack: null argument");
   if (n_blocks <= 0) return OSD_OK;
   OSD_DISPATCH_DTYPE(dtype,
       hipLaunchKernelGGL(sgd_pack_multi_kernel<float>, dim3(n_blocks), dim3(256), 0, OSD_STREAM(stream), (const SgdPackEntry*)table, block_entry,
-                         params, grads, momentum_buf, scales, (float*)packed, lr, momentum, first_step),
+                         params, grads, momentum_buf, scales, (float*)packed, lr, momentum, first_step, zero_grads),
       hipLaunchKernelGGL(sgd_pack_multi_kernel<__bf16>, dim3(n_blocks), dim3(256), 0, OSD_STREAM(stream), (const SgdPackEntry*)table, block_entry,
-                         params, grads, momentum_buf, scales, (__bf16*)packed, lr, momentum, first_step));
+                         params, grads, momentum_buf, scales, (__bf16*)packed, lr, momentum, first_step, zero_grads));
   return osd_check_launch("sgd_pack_multi");
 }
 

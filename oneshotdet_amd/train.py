@@ -124,6 +124,11 @@ class TrainEngine(object):
         self.exchange = GradExchange(self.flat_g, bucket_ranges(self._plan, self.flat_g.numel()), self.pg,
                                      single_rank_too=exchange_single_rank, wire_dtype=grad_wire_dtype, comm_stream=self.ustream)
         self._overlap, self._fuse_update, self._updated = True, False, set()
+        # consume_grads: the fused update overwrites the gradients it has read with zeros, so train_step() leaves flat_g clean
+        # for the next step instead of the next forward pass memset-ing 236 MB on its critical path.  named_grads() after a
+        # train_step() then reads zeros: tests that inspect gradients use forward_backward(), or switch this off
+        self.consume_grads = os.environ.get("OSD_NO_CONSUME_GRADS", "0") == "0"
+        self._grads_clean, self._zeroed = False, set()
         self._wqs = None
         self._pred_grad_bufs = {}
         # ordered weight gradients (bit-reproducible dW of every conv_wgrad launch; measured 6 % slower on the tower launch,
@@ -1073,7 +1078,11 @@ class TrainEngine(object):
             if deferred is not None:
                 for ev in deferred["events"]:       # events recorded when the previous step returned
                     main.wait_event(ev)
-            self.flat_g.zero_()
+            # optimizer.zero_grad() (engine/trainer.py:89): the weight-gradient kernels accumulate.  A step whose every bucket went
+            # through the fused update has had its gradients zeroed by that kernel, behind its read (consume_grads)
+            if not self._grads_clean:
+                self.flat_g.zero_()
+            self._grads_clean = False
             self.exchange.begin()
         if deferred is None:
             join_previous()
@@ -1249,7 +1258,9 @@ class TrainEngine(object):
             pk = self._pack[0]["flat"]
             ops._lib.call("osd_sgd_momentum_pack_multi", ops._ptr(tb["table"]), ops._ptr(tb["blocks"]), tb["n"],
                           ops._ptr(self.flat_w), ops._ptr(self.flat_g), ops._ptr(sg["buf"]), ops._ptr(self._flat_scale), ops._ptr(pk),
-                          ops._dt(pk), float(self.lr), float(self.momentum), int(sg["steps"] == 0), ops._stream())
+                          ops._dt(pk), float(self.lr), float(self.momentum), int(sg["steps"] == 0), int(self.consume_grads), ops._stream())
+            if self.consume_grads:
+                self._zeroed.add(name)
         elif tb is not None:
             ops._lib.call("osd_sgd_momentum_multi", ops._ptr(tb["table"]), ops._ptr(tb["blocks"]), tb["n"],
                           ops._ptr(self.flat_w), ops._ptr(self.flat_g), ops._ptr(sg["buf"]), float(self.lr),
@@ -1271,8 +1282,13 @@ class TrainEngine(object):
         for name in self.exchange.ranges:
             if name not in self._updated:
                 self._update_bucket(name)
-        self._updated = set()
+        self._end_of_update()
         self._sgd["steps"] += 1
+
+    def _end_of_update(self):
+        self._updated = set()
+        self._grads_clean = bool(self.consume_grads and self._zeroed >= set(self._sgd["tables"]))      # every bucket consumed
+        self._zeroed = set()
 
     def train_step(self, images, queries, gt_boxes, gt_count):
         """forward + loss + backward + gradient averaging + SGD + repack.  With the fused optimiser each bucket's exchange,
@@ -1288,7 +1304,7 @@ class TrainEngine(object):
             self._fuse_update = False
             deferred_step, self._defer_now = self._defer_now, False
         if deferred_step and all(name in self._updated for name in self.exchange.ranges):
-            self._updated = set()
+            self._end_of_update()
             self._sgd["steps"] += 1
             return losses
         self.join()

@@ -13,5 +13,6 @@ for i in $(seq $R); do
   run "current" . X=1
   run "current, epilogue not pipelined" . OSD_LIB_PATH=$GRAFT_REPO_ROOT/oneshotdet_amd/lib/liboneshotdet_hip_nopipe.so
   run "current, towers' gradient sum as add_mask launches" . OSD_NO_HEAD_SUM_FUSION=1
-  run "current, SGD and forward repack as separate launches" . OSD_NO_FUSED_REPACK=1
+  run "current, SGD and forward repack as separate launches (and a gradient memset per step)" . OSD_NO_FUSED_REPACK=1
+  run "current, gradient memset per step" . OSD_NO_CONSUME_GRADS=1
 done
