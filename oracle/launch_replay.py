@@ -5,7 +5,7 @@ end to end in fp32, this file restates what ONE launch of the HIP library comput
 in plain PyTorch-CPU fp32, so that the bf16 engines — whose end-to-end difference to an fp32 reference is dominated by their
 own 8-bit roundings — can be checked launch by launch to within ONE bf16 unit in the last place:
 
-    tests/test_gpu_launch_replay.py switches on `oneshotdet_amd.ops.TRACE`, runs a real forward / training step, and for
+    tests/test_gpu_launch_replay.py switches on `oneshotdet_amd.trace.TRACE`, runs a real forward / training step, and for
     every recorded launch calls the function below with the engine's OWN input tensors (teacher forcing) and compares the
     result, rounded once to the output dtype, with what the kernel wrote.
 

@@ -4,7 +4,7 @@ End to end a bf16 pipeline can only be compared loosely with an fp32 reference, 
 on the CPU — just as loosely with ANY other bf16 implementation of itself: a 1e-6 perturbation of the weights moves the
 rounded pipeline's gradients by 0.16-0.25 relative L2, as much as bf16 differs from fp32, because every stored tensor is
 re-rounded to 8 bits ~60 times in a row.  So a kernel bug worth 10 % of a gradient tensor could hide under any honest
-end-to-end bf16 tolerance.  It cannot hide here: `oneshotdet_amd.ops.TRACE` records every launch of a REAL forward / training
+end-to-end bf16 tolerance.  It cannot hide here: `oneshotdet_amd.trace.TRACE` records every launch of a REAL forward / training
 step (same engines, same streams), and each one is recomputed on the CPU by oracle/launch_replay.py FROM THE ENGINE'S OWN
 INPUT TENSORS (teacher forcing) in fp32 and rounded once.  Bars, per launch:
   bf16 outputs   every element within ONE bf16 unit in the last place of the restatement (+ 1e-5 x the tensor's absmax for
@@ -169,13 +169,14 @@ def _train_engine(dt, name):
 
 def _traced(fn):
     from oneshotdet_amd import ops
-    ops.TRACE = []
+    from oneshotdet_amd import trace
+    trace.TRACE = []
     try:
         out = fn()
         torch.cuda.synchronize()
-        return out, ops.TRACE
+        return out, trace.TRACE
     finally:
-        ops.TRACE = None
+        trace.TRACE = None
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])

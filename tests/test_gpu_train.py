@@ -444,7 +444,7 @@ def test_train_step_with_updates_behind_backward_equals_the_sequential_step():
     final (while the rest of backward still runs).  Three steps of it against three steps of the sequential
     forward_backward -> reduce_gradients -> optimizer_step on an identical engine: same masters, same packed weights,
     same losses.  fp32 engines: in bf16 a single rounding flip of a repacked weight makes two runs of the SAME code
-    differ by 1 % after three steps at this learning rate (tools/race_probe.py), which would hide a real ordering bug."""
+    differ by 1 % after three steps at this learning rate, which would hide a real ordering bug."""
     from oneshotdet_amd import train
     a, img, q, gtb, cnt = _engine_and_inputs("f32")
     b = train.TrainEngine(synth.make_state_dict(spec.hot_path_shapes()), dtype=torch.float32)
