@@ -586,6 +586,22 @@ int osd_voc_curves(const int8_t* flags_sorted, const int32_t* class_begin, const
 int osd_voc_ap(const double* prec, const double* rec, const int32_t* class_begin, const uint8_t* has_prec, const uint8_t* has_rec,
                int n_classes, int use_07_metric, double* ap, void* stream);
 
+/* COCO-style matching, bbox (the reference's COCO configs: data/datasets/evaluation/coco/coco_eval.py:385-408 hands the
+ * detections to pycocotools' COCOeval — cocodataset/cocoapi, unpinned, INSTALL.md:34-38, absent from this image; the algorithm
+ * restated is its evaluateImg + maskApi.c bbIou: oracle/coco_eval_ref.py, PARITY UNPINNED).  One (image, category) pair per
+ * workgroup: det_boxes_xywh [n_pairs][max_det][4] float64, sorted by descending score and cut at the largest maxDets by the caller,
+ * det_count [n_pairs]; gt_boxes_xywh [n_pairs][max_gt][4], gt_area (the annotation's `area`), gt_crowd (0 / 1), gt_count
+ * (max_gt <= 512).  iou_thrs [n_thrs <= 10] and area_ranges [n_areas <= 4][2] are HOST arrays.  Per (pair, area range, threshold,
+ * detection): dt_match = 1 + the INPUT index of the ground-truth box it takes (0: none) — the still-free box (crowd boxes are
+ * never used up) with the highest IoU >= threshold, non-ignored boxes preferred —, dt_ignore = matched to an ignored box, or
+ * unmatched with w * h outside the range; gt_ignore [n_pairs][n_areas][max_gt] = crowd or `area` outside the range, in the
+ * ignored-last order the accumulation concatenates.  IoU = intersection / union in float64, no '+1'; against a crowd box the union
+ * is the detection's area.  Precision / recall tables and the 12 summary numbers: oneshotdet_amd/evaluation.py. */
+int osd_coco_match(const double* det_boxes_xywh, const int32_t* det_count, const double* gt_boxes_xywh, const double* gt_area,
+                   const uint8_t* gt_crowd, const int32_t* gt_count, int n_pairs, int max_det, int max_gt,
+                   const double* iou_thrs, int n_thrs, const double* area_ranges, int n_areas, int32_t* dt_match,
+                   uint8_t* dt_ignore, uint8_t* gt_ignore, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,7 @@ SIGNATURES = {
     "osd_voc_match": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "osd_voc_curves": (_i, [_p, _p, _p, _i, _p, _p, _p]),
     "osd_voc_ap": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p]),
+    "osd_coco_match": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
     "osd_groupnorm_act_rois_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i, _p]),
     "osd_rois_sum": (_i, [_p, _p, _i, _i, _i64, _i, _p]),
     "osd_roi_pool_levels_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -82,6 +82,96 @@ __global__ void __launch_bounds__(256) voc_match_kernel(const float* __restrict_
 }
 
 
+// ---- COCO-style matching (the reference's COCO configs evaluate through pycocotools' COCOeval, coco_eval.py:385-408; the
+// package is not in the image: this follows its published algorithm, cocoeval.py evaluateImg + maskApi.c bbIou — see
+// oracle/coco_eval_ref.py, "parity unpinned") ----
+// One workgroup per (image, category) pair; thread (a, t) = (area range, IoU threshold) walks the pair's detections in descending
+// score order (the host sorted and cut them at the largest maxDets) and, for each, the ground-truth boxes with the non-ignored
+// ones first: the box with the highest IoU >= t that is still free (a crowd box is never used up), preferring non-ignored boxes.
+// Boxes are [x, y, w, h] doubles; IoU without '+1', against a crowd box the union is the detection's area.
+constexpr int kCocoMaxGt = 512, kCocoMaxT = 10, kCocoMaxA = 4;
+struct CocoParams {
+  double iou_thr[kCocoMaxT];
+  double area_lo[kCocoMaxA], area_hi[kCocoMaxA];
+  int n_thr, n_area;
+};
+
+__global__ void __launch_bounds__(64) coco_match_kernel(const double* __restrict__ det_boxes, const int32_t* __restrict__ det_count,
+                                                        const double* __restrict__ gt_boxes, const double* __restrict__ gt_area,
+                                                        const uint8_t* __restrict__ gt_crowd, const int32_t* __restrict__ gt_count,
+                                                        int max_det, int max_gt, CocoParams cp, int32_t* __restrict__ dt_match,
+                                                        uint8_t* __restrict__ dt_ignore, uint8_t* __restrict__ gt_ignore) {
+  __shared__ double gb[kCocoMaxGt][4];
+  __shared__ double ga[kCocoMaxGt];
+  __shared__ uint8_t gcrowd[kCocoMaxGt];
+  __shared__ int16_t order[kCocoMaxA][kCocoMaxGt];      // per area range: ground-truth indices, non-ignored first (stable)
+  __shared__ uint8_t gig[kCocoMaxA][kCocoMaxGt];        // ... and the ignore flag of the box at that sorted position
+  __shared__ uint8_t taken[kCocoMaxA * kCocoMaxT][kCocoMaxGt];
+  const int pr = blockIdx.x, t = threadIdx.x;
+  const int nd = min(det_count[pr], max_det), ng = min(gt_count[pr], max_gt);
+  for (int g = t; g < ng; g += 64) {
+    const double* b = gt_boxes + ((size_t)pr * max_gt + g) * 4;
+    gb[g][0] = b[0]; gb[g][1] = b[1]; gb[g][2] = b[2]; gb[g][3] = b[3];
+    ga[g] = gt_area[(size_t)pr * max_gt + g];
+    gcrowd[g] = gt_crowd[(size_t)pr * max_gt + g];
+  }
+  __syncthreads();
+  if (t < cp.n_area) {                                  // stable partition of the boxes by their ignore flag for this range
+    int n = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int g = 0; g < ng; ++g) {
+        const bool ig = gcrowd[g] || ga[g] < cp.area_lo[t] || ga[g] > cp.area_hi[t];
+        if ((int)ig == pass) { order[t][n] = (int16_t)g; gig[t][n] = (uint8_t)ig; ++n; }
+      }
+    for (int n2 = 0; n2 < ng; ++n2) gt_ignore[((size_t)pr * cp.n_area + t) * max_gt + n2] = gig[t][n2];
+    for (int n2 = ng; n2 < max_gt; ++n2) gt_ignore[((size_t)pr * cp.n_area + t) * max_gt + n2] = 0;
+  }
+  for (int i = t; i < cp.n_area * cp.n_thr * kCocoMaxGt; i += 64) (&taken[0][0])[i] = 0;
+  __syncthreads();
+  if (t >= cp.n_area * cp.n_thr) return;
+  const int a = t / cp.n_thr, ti = t - a * cp.n_thr;
+  const double thr = cp.iou_thr[ti];
+  int32_t* dm = dt_match + (((size_t)pr * cp.n_area + a) * cp.n_thr + ti) * max_det;
+  uint8_t* di = dt_ignore + (((size_t)pr * cp.n_area + a) * cp.n_thr + ti) * max_det;
+  for (int d = 0; d < max_det; ++d) {
+    int32_t match = 0;
+    uint8_t ign = 0;
+    if (d < nd) {
+      const double* b = det_boxes + ((size_t)pr * max_det + d) * 4;
+      const double dx = b[0], dy = b[1], dw = b[2], dh = b[3];
+      const double darea = dw * dh;
+      double iou = fmin(thr, 1.0 - 1e-10);
+      int m = -1;
+      for (int n = 0; n < ng; ++n) {
+        const int g = order[a][n];
+        if (taken[t][n] && !gcrowd[g]) continue;
+        if (m > -1 && !gig[a][m] && gig[a][n]) break;
+        double o = 0.0;
+        const double w = fmin(dw + dx, gb[g][2] + gb[g][0]) - fmax(dx, gb[g][0]);
+        if (w > 0) {
+          const double h = fmin(dh + dy, gb[g][3] + gb[g][1]) - fmax(dy, gb[g][1]);
+          if (h > 0) {
+            const double inter = w * h;
+            o = inter / (gcrowd[g] ? darea : darea + gb[g][2] * gb[g][3] - inter);
+          }
+        }
+        if (o < iou) continue;
+        iou = o;
+        m = n;
+      }
+      if (m > -1) {
+        ign = gig[a][m];
+        match = order[a][m] + 1;                          // the matched box, as its index in the INPUT order + 1
+        taken[t][m] = 1;
+      } else {
+        ign = (darea < cp.area_lo[a] || darea > cp.area_hi[a]) ? 1 : 0;
+      }
+    }
+    dm[d] = match;
+    di[d] = ign;
+  }
+}
+
 // ---- precision / recall curves and average precision, all classes in one launch each (voc_eval.py:139-216) ----
 // Input: the dataset's match flags sorted ONCE by (class ascending, score descending) — class c owns [class_begin[c],
 // class_begin[c + 1]).  One workgroup per class walks its range in 256-element chunks with a carry.
@@ -230,4 +320,25 @@ extern "C" int osd_voc_ap(const double* prec, const double* rec, const int32_t* 
   hipLaunchKernelGGL(voc_ap_kernel, dim3(n_classes), dim3(kApThreads), 0, reinterpret_cast<hipStream_t>(stream), prec, rec, class_begin,
                      has_prec, has_rec, use_07_metric, ap);
   return osd_check_launch("voc_ap");
+}
+
+extern "C" int osd_coco_match(const double* det_boxes_xywh, const int32_t* det_count, const double* gt_boxes_xywh, const double* gt_area,
+                              const uint8_t* gt_crowd, const int32_t* gt_count, int n_pairs, int max_det, int max_gt,
+                              const double* iou_thrs, int n_thrs, const double* area_ranges, int n_areas, int32_t* dt_match,
+                              uint8_t* dt_ignore, uint8_t* gt_ignore, void* stream) {
+  if (n_pairs < 0 || max_det < 0 || max_gt < 0) return osd_fail(OSD_ERR_INVALID_ARG, "coco_match: negative size");
+  if (n_thrs < 1 || n_thrs > kCocoMaxT || n_areas < 1 || n_areas > kCocoMaxA || !iou_thrs || !area_ranges)
+    return osd_fail(OSD_ERR_INVALID_ARG, "coco_match: 1..%d IoU thresholds and 1..%d area ranges (host arrays)", kCocoMaxT, kCocoMaxA);
+  if (n_pairs == 0) return OSD_OK;
+  if (!det_count || !gt_count || !dt_match || !dt_ignore || !gt_ignore || (max_det > 0 && !det_boxes_xywh) ||
+      (max_gt > 0 && (!gt_boxes_xywh || !gt_area || !gt_crowd)))
+    return osd_fail(OSD_ERR_INVALID_ARG, "coco_match: null argument");
+  if (max_gt > kCocoMaxGt) return osd_fail(OSD_ERR_UNSUPPORTED, "coco_match: at most %d ground-truth boxes per (image, category) (got %d)", kCocoMaxGt, max_gt);
+  CocoParams cp;
+  cp.n_thr = n_thrs; cp.n_area = n_areas;
+  for (int i = 0; i < kCocoMaxT; ++i) cp.iou_thr[i] = i < n_thrs ? iou_thrs[i] : 2.0;
+  for (int i = 0; i < kCocoMaxA; ++i) { cp.area_lo[i] = i < n_areas ? area_ranges[2 * i] : 0.0; cp.area_hi[i] = i < n_areas ? area_ranges[2 * i + 1] : 0.0; }
+  hipLaunchKernelGGL(coco_match_kernel, dim3(n_pairs), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), det_boxes_xywh, det_count,
+                     gt_boxes_xywh, gt_area, gt_crowd, gt_count, max_det, max_gt, cp, dt_match, dt_ignore, gt_ignore);
+  return osd_check_launch("coco_match");
 }

@@ -131,3 +131,153 @@ def eval_detection_voc(pred_boxlists, gt_boxlists, iou_thresh=0.5, use_07_metric
     assert len(gt_boxlists) == len(pred_boxlists), "Length of gt and pred lists need to be same."
     ap = _ap(_curves(gt_boxlists, pred_boxlists, iou_thresh), use_07_metric)
     return {"ap": ap, "map": np.nanmean(ap)}
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# COCO-style evaluation, bbox (data/datasets/evaluation/coco/coco_eval.py:385-408: the reference hands its detections to
+# pycocotools' COCOeval and reads `stats`).  pycocotools is a third-party package that is not in this image: the algorithm here is
+# its published one (cocoeval.py evaluate / accumulate / summarize), restated — PARITY UNPINNED, see oracle/coco_eval_ref.py.
+# The per-(image, category) matching at 10 IoU thresholds x 4 area ranges runs on the device in ONE launch (osd_coco_match); the
+# host sorts, concatenates and integrates.
+COCO_IOU_THRS = np.linspace(.5, 0.95, int(np.round((0.95 - .5) / .05)) + 1, endpoint=True)
+COCO_REC_THRS = np.linspace(.0, 1.00, int(np.round((1.00 - .0) / .01)) + 1, endpoint=True)
+COCO_MAX_DETS = (1, 10, 100)
+COCO_AREA_RNG = ((0 ** 2, 1e5 ** 2), (0 ** 2, 32 ** 2), (32 ** 2, 96 ** 2), (96 ** 2, 1e5 ** 2))
+COCO_AREA_LBL = ("all", "small", "medium", "large")
+COCO_BBOX_METRICS = ("AP", "AP50", "AP75", "APs", "APm", "APl")      # COCOResults.METRICS["bbox"], coco_eval.py:441-443
+
+
+class CocoEval(object):
+    """What the reference reads off a pycocotools COCOeval after evaluate() / accumulate() / summarize(): `stats` (12 numbers)
+    and `eval` = {precision [T,R,K,A,M], recall [T,K,A,M], scores [T,R,K,A,M]}; `results()` = COCOResults' bbox metrics."""
+
+    def __init__(self, precision, recall, scores, cat_ids, img_ids):
+        self.eval = dict(precision=precision, recall=recall, scores=scores)
+        self.cat_ids, self.img_ids = cat_ids, img_ids
+        self.stats = self._summarize()
+
+    def _one(self, ap, iou_thr=None, area="all", max_det=100):
+        a, m = COCO_AREA_LBL.index(area), COCO_MAX_DETS.index(max_det)
+        s = self.eval["precision" if ap else "recall"]
+        if iou_thr is not None:
+            s = s[np.where(iou_thr == COCO_IOU_THRS)[0]]
+        s = s[..., a, m]
+        valid = s[s > -1]
+        return -1.0 if valid.size == 0 else float(valid.mean())
+
+    def _summarize(self):
+        one = self._one
+        return np.array([one(1), one(1, iou_thr=.5), one(1, iou_thr=.75), one(1, area="small"), one(1, area="medium"),
+                         one(1, area="large"), one(0, max_det=1), one(0, max_det=10), one(0), one(0, area="small"),
+                         one(0, area="medium"), one(0, area="large")])
+
+    def results(self):
+        return {"bbox": {k: float(v) for k, v in zip(COCO_BBOX_METRICS, self.stats[:6])}}
+
+
+def coco_match(pairs, device="cuda"):
+    """pairs: list of (det_boxes [d, 4] xywh float64 sorted by descending score, gt_boxes [g, 4] xywh, gt_area [g], gt_crowd [g]).
+    -> per pair (dt_match int32 [A, T, d], dt_ignore bool [A, T, d], gt_ignore bool [A, g]) from ONE launch of osd_coco_match."""
+    import ctypes as C
+    n = len(pairs)
+    A, T = len(COCO_AREA_RNG), len(COCO_IOU_THRS)
+    if n == 0:
+        return []
+    max_det = max([len(p[0]) for p in pairs] + [1])
+    max_gt = max([len(p[1]) for p in pairs] + [1])
+    db, dc = np.zeros((n, max_det, 4), np.float64), np.zeros((n,), np.int32)
+    gb, ga = np.zeros((n, max_gt, 4), np.float64), np.zeros((n, max_gt), np.float64)
+    gc, gn = np.zeros((n, max_gt), np.uint8), np.zeros((n,), np.int32)
+    for i, (d, g, area, crowd) in enumerate(pairs):
+        dc[i], gn[i] = len(d), len(g)
+        if len(d):
+            db[i, :len(d)] = d
+        if len(g):
+            gb[i, :len(g)], ga[i, :len(g)], gc[i, :len(g)] = g, area, crowd
+    dev = torch.device(device)
+    t = [torch.from_numpy(x).to(dev) for x in (db, dc, gb, ga, gc, gn)]
+    dm = torch.empty((n, A, T, max_det), device=dev, dtype=torch.int32)
+    di = torch.empty((n, A, T, max_det), device=dev, dtype=torch.uint8)
+    gi = torch.empty((n, A, max_gt), device=dev, dtype=torch.uint8)
+    thr = (C.c_double * T)(*COCO_IOU_THRS.tolist())
+    rng = (C.c_double * (2 * A))(*[float(v) for r in COCO_AREA_RNG for v in r])
+    _lib.call("osd_coco_match", *[ops._ptr(x) for x in t], n, max_det, max_gt, thr, T, rng, A, ops._ptr(dm), ops._ptr(di), ops._ptr(gi),
+              ops._stream())
+    dm, di, gi = dm.cpu().numpy(), di.cpu().numpy().astype(bool), gi.cpu().numpy().astype(bool)
+    return [(dm[i, :, :, :dc[i]], di[i, :, :, :dc[i]], gi[i, :, :gn[i]]) for i in range(n)]
+
+
+def evaluate_predictions_on_coco(coco_gt, coco_results, iou_type="bbox", img_ids=None, cat_ids=None, device="cuda"):
+    """coco_eval.py:385-408 without the files: coco_gt = the COCO-format ground truth (a dict with "annotations" — image_id,
+    category_id, bbox [x, y, w, h], area, iscrowd — and optionally "images" / "categories", or the annotation list itself),
+    coco_results = the detection list prepare_for_coco_detection builds (image_id, category_id, bbox, score).  -> CocoEval."""
+    if iou_type != "bbox":
+        raise NotImplementedError("iou_type %r: only the box metric is built (the hot path has no mask / keypoint head)" % iou_type)
+    anns = coco_gt["annotations"] if isinstance(coco_gt, dict) else list(coco_gt)
+    if img_ids is None:
+        img_ids = [im["id"] for im in coco_gt["images"]] if isinstance(coco_gt, dict) and coco_gt.get("images") else \
+            list({a["image_id"] for a in anns} | {d["image_id"] for d in coco_results})
+    if cat_ids is None:
+        cat_ids = [c["id"] for c in coco_gt["categories"]] if isinstance(coco_gt, dict) and coco_gt.get("categories") else \
+            list({a["category_id"] for a in anns})
+    img_ids, cat_ids = sorted(img_ids), sorted(cat_ids)
+    by_g, by_d = {}, {}
+    for a in anns:
+        by_g.setdefault((a["image_id"], a["category_id"]), []).append(a)
+    for d in coco_results:
+        by_d.setdefault((d["image_id"], d["category_id"]), []).append(d)
+    # one row per (category, image) that has anything to evaluate, detections in descending score order (stable), cut at 100
+    keys, pairs, scores = [], [], []
+    for cat in cat_ids:
+        for img in img_ids:
+            g, d = by_g.get((img, cat), []), by_d.get((img, cat), [])
+            if not g and not d:
+                continue
+            sc = np.array([x["score"] for x in d], np.float64)
+            order = np.argsort(-sc, kind="mergesort")[:COCO_MAX_DETS[-1]]
+            keys.append((cat, img))
+            scores.append(sc[order])
+            pairs.append((np.array([d[i]["bbox"] for i in order], np.float64).reshape(-1, 4),
+                          np.array([x["bbox"] for x in g], np.float64).reshape(-1, 4),
+                          np.array([x["area"] for x in g], np.float64), np.array([int(x.get("iscrowd", 0)) for x in g], np.uint8)))
+    matched = coco_match(pairs, device)
+    T, R, K, A, M = len(COCO_IOU_THRS), len(COCO_REC_THRS), len(cat_ids), len(COCO_AREA_RNG), len(COCO_MAX_DETS)
+    precision, recall, pscores = -np.ones((T, R, K, A, M)), -np.ones((T, K, A, M)), -np.ones((T, R, K, A, M))
+    rows_of = {}
+    for i, (cat, _) in enumerate(keys):
+        rows_of.setdefault(cat, []).append(i)
+    eps = np.spacing(1)
+    for k, cat in enumerate(cat_ids):
+        rows = rows_of.get(cat, [])
+        if not rows:
+            continue
+        for a in range(A):
+            gt_ig = np.concatenate([matched[i][2][a] for i in rows])
+            npig = int(np.count_nonzero(~gt_ig))
+            if npig == 0:
+                continue
+            for m, max_det in enumerate(COCO_MAX_DETS):
+                sc = np.concatenate([scores[i][:max_det] for i in rows])
+                order = np.argsort(-sc, kind="mergesort")
+                hit = np.concatenate([matched[i][0][a][:, :max_det] for i in rows], axis=1)[:, order] > 0
+                ign = np.concatenate([matched[i][1][a][:, :max_det] for i in rows], axis=1)[:, order]
+                tp = np.cumsum(hit & ~ign, axis=1).astype(np.float64)          # [T, nd]
+                fp = np.cumsum(~hit & ~ign, axis=1).astype(np.float64)
+                nd = tp.shape[1]
+                if nd == 0:
+                    recall[:, k, a, m] = 0
+                    precision[:, :, k, a, m] = 0
+                    pscores[:, :, k, a, m] = 0
+                    continue
+                rc = tp / npig
+                pr = tp / (fp + tp + eps)
+                recall[:, k, a, m] = rc[:, -1]
+                env = np.maximum.accumulate(pr[:, ::-1], axis=1)[:, ::-1]     # precision made monotone from the right
+                ssc = sc[order]
+                for t in range(T):
+                    pos = np.searchsorted(rc[t], COCO_REC_THRS, side="left")
+                    ok = pos < nd
+                    q, s_ = np.zeros((R,)), np.zeros((R,))
+                    q[ok], s_[ok] = env[t][pos[ok]], ssc[pos[ok]]
+                    precision[t, :, k, a, m], pscores[t, :, k, a, m] = q, s_
+    return CocoEval(precision, recall, pscores, cat_ids, img_ids)

@@ -120,3 +120,84 @@ def test_voc_edge_cases():
     big = (np.zeros((600, 4), np.float32), np.ones(600, np.int64), np.zeros(600, np.uint8))
     with pytest.raises(_lib.OsdError):
         ev.voc_match(*boxlists([preds[0]], [big]), 0.5)
+
+
+# ---- COCO-style evaluation (oneshotdet_amd.evaluation.evaluate_predictions_on_coco) against oracle/coco_eval_ref.py.  PARITY
+# UNPINNED: pycocotools is absent; the oracle restates its published algorithm and is pinned by hand-computed cases
+# (tests/test_oracle_coco_eval.py).  What is checked here is that the device matching + host integration reproduce the oracle
+# exactly: every entry of the precision / recall tables and the 12 summary numbers.
+def _coco_dataset(seed, n_images=12, n_cats=3, max_gt=9, max_det=130):
+    rng = np.random.RandomState(seed)
+    gts, dts = [], []
+    for img in range(1, n_images + 1):
+        for cat in range(1, n_cats + 1):
+            ng = rng.randint(0, max_gt + 1) if rng.rand() > 0.2 else 0
+            boxes = []
+            for _ in range(ng):
+                w, h = rng.choice([12.0, 40.0, 150.0]) * (0.5 + rng.rand()), rng.choice([12.0, 40.0, 150.0]) * (0.5 + rng.rand())
+                x, y = rng.rand() * 600, rng.rand() * 400
+                boxes.append([x, y, w, h])
+                crowd = int(rng.rand() < 0.15)
+                # the annotation's area is not always w * h (segment areas): keep some near the range borders
+                area = w * h * (1.0 if rng.rand() < 0.7 else 0.6)
+                gts.append(dict(image_id=img, category_id=cat, bbox=[x, y, w, h], area=area, iscrowd=crowd))
+            nd = rng.randint(0, max_det + 1) if rng.rand() > 0.15 else 0
+            for _ in range(nd):
+                if boxes and rng.rand() < 0.6:          # a jittered copy of a ground-truth box
+                    b = np.array(boxes[rng.randint(len(boxes))]) + rng.randn(4) * np.array([4, 4, 6, 6])
+                    b[2:] = np.maximum(b[2:], 1.0)
+                else:
+                    b = np.array([rng.rand() * 600, rng.rand() * 400, 5 + rng.rand() * 200, 5 + rng.rand() * 200])
+                score = float(np.round(rng.rand(), 2)) if rng.rand() < 0.3 else float(rng.rand())      # some tied scores
+                dts.append(dict(image_id=img, category_id=cat, bbox=b.tolist(), score=score))
+    return gts, dts
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_coco_eval_equals_the_oracle(seed):
+    from oneshotdet_amd import evaluation as ev
+    from oracle import coco_eval_ref as oc
+    gts, dts = _coco_dataset(seed)
+    img_ids, cat_ids = list(range(1, 13)), [1, 2, 3, 4]                  # category 4: no ground truth, no detections
+    want = oc.evaluate(gts, dts, img_ids=img_ids, cat_ids=cat_ids)
+    got = ev.evaluate_predictions_on_coco({"annotations": gts, "images": [{"id": i} for i in img_ids],
+                                           "categories": [{"id": c} for c in cat_ids]}, dts)
+    np.testing.assert_array_equal(got.eval["precision"], want["precision"])
+    np.testing.assert_array_equal(got.eval["recall"], want["recall"])
+    np.testing.assert_array_equal(got.stats, want["stats"])
+    assert (want["precision"][:, :, 3] == -1).all() and 0 < want["stats"][0] < 1
+    assert set(got.results()["bbox"]) == {"AP", "AP50", "AP75", "APs", "APm", "APl"}
+
+
+def test_coco_match_flags_equal_the_oracle_per_pair_and_edge_cases():
+    from oneshotdet_amd import _lib, evaluation as ev
+    from oracle import coco_eval_ref as oc
+    gts, dts = _coco_dataset(7, n_images=4, n_cats=2)
+    by_g, by_d = {}, {}
+    for g in gts:
+        by_g.setdefault((g["image_id"], g["category_id"]), []).append(g)
+    for d in dts:
+        by_d.setdefault((d["image_id"], d["category_id"]), []).append(d)
+    keys = sorted(set(by_g) | set(by_d))
+    pairs = []
+    for k in keys:
+        g, d = by_g.get(k, []), by_d.get(k, [])
+        order = np.argsort([-x["score"] for x in d], kind="mergesort")[:100]
+        pairs.append((np.array([d[i]["bbox"] for i in order], np.float64).reshape(-1, 4), np.array([x["bbox"] for x in g], np.float64).reshape(-1, 4),
+                      np.array([x["area"] for x in g], np.float64), np.array([x["iscrowd"] for x in g], np.uint8)))
+    out = ev.coco_match(pairs)
+    for k, (dm, di, gi) in zip(keys, out):
+        for a, rng_ in enumerate(oc.AREA_RNG):
+            e = oc.evaluate_img(by_g.get(k, []), by_d.get(k, []), rng_, 100)
+            np.testing.assert_array_equal(dm[a] > 0, e["dt_matches"] > 0)
+            np.testing.assert_array_equal(di[a], e["dt_ignore"])
+            np.testing.assert_array_equal(gi[a], e["gt_ignore"])
+    # no detections at all; no ground truth at all; nothing at all
+    g1 = [dict(image_id=1, category_id=1, bbox=[0.0, 0.0, 50.0, 50.0], area=2500.0, iscrowd=0)]
+    for g, d in ((g1, []), ([], [dict(image_id=1, category_id=1, bbox=[0.0, 0.0, 50.0, 50.0], score=0.5)]), ([], [])):
+        want = oc.evaluate(g, d, img_ids=[1], cat_ids=[1])
+        got = ev.evaluate_predictions_on_coco({"annotations": g, "images": [{"id": 1}], "categories": [{"id": 1}]}, d)
+        np.testing.assert_array_equal(got.stats, want["stats"])
+    big = (np.zeros((1, 4)), np.zeros((600, 4)), np.zeros((600,)), np.zeros((600,), np.uint8))
+    with pytest.raises(_lib.OsdError):
+        ev.coco_match([big])
