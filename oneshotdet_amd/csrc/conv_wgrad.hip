@@ -956,7 +956,18 @@ static int wgrad_xr_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
 // 13, 3: the software-pipelined 256 x 256 kernel of conv_wgrad_sk.hip with this launcher's splits / in team mode; 12: retired; variants 4..7: 256-wide tiles on 8 waves; 8, 9: 256 x 256 with a 5- / 4-deep ring of 32-pixel stages
 // (the whole 160 KB / 128 KB of LDS as prefetch distance: one workgroup per CU has nothing else to hide the operand
 // latency behind); 10..12: 128 x 256 / 256 x 128 tiles on FOUR waves (64 x 128 per wave, 72 KB: two workgroups per CU)
+// Variant ids are NOT stable across rounds (round 3 re-used 3 for team mode and 13 for the software-pipelined kernel, retired 12):
+// ids pinned from outside through OSD_WGRAD_VARIANT (the untuned algo-0 default) or an old OSD_DUMP_ALGOS dump may name a kernel
+// that does not cover a launch.  On the algo-0 path such a launch falls back to variant 0, which covers everything; an explicit
+// `algo` keeps returning OSD_ERR_UNSUPPORTED (the tuner skips it).
+static int wgrad_launch_v(int n_seg, const WgradProblem* pr, hipStream_t s, int variant_override);
 static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
+  int rc = wgrad_launch_v(n_seg, pr, s, -1);
+  if (rc == OSD_ERR_UNSUPPORTED && n_seg >= 1 && pr[0].d->algo == 0) rc = wgrad_launch_v(n_seg, pr, s, 0);
+  return rc;
+}
+
+static int wgrad_launch_v(int n_seg, const WgradProblem* pr, hipStream_t s, int variant_override) {
   if (n_seg < 1 || n_seg > kMaxSeg) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: 1..%d segments", kMaxSeg);
   const osd_conv_desc* d0 = pr[0].d;
   if (d0->algo > 128) return wgrad_xr_launch(n_seg, pr, s);
@@ -967,7 +978,7 @@ static int wgrad_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
   // tower 857 -> 796 us — but the training step does not: 639.6 / 642.9 vs 638.3 / 634.9 images/s in one-box A/B, the
   // extra workgroups compete with the main chain they run beside)
   static const int kTargets[8] = {512, 256, 128, 64, 1024, 768, 1536, 2048};
-  int target = env_target, variant = env_variant, code = 0;
+  int target = env_target, variant = variant_override >= 0 ? variant_override : env_variant, code = 0;
   if (d0->algo > 0) {
     const int a = d0->algo - 1;
     if (a >= 128) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: unknown algo %d", d0->algo);

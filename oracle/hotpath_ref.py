@@ -232,6 +232,53 @@ def roi_align(inp, rois, spatial_scale, ph, pw, sampling_ratio):
     return torch.stack(out, dim=0)
 
 
+def roi_align_backward_cuda(grad, rois, spatial_scale, ph, pw, batch, channels, height, width, sampling_ratio):
+    """The reference's ROIAlign BACKWARD, which exists on CUDA only (csrc/ROIAlign.h:27-46 raises on the CPU): a restatement of
+    RoIAlignBackwardFeature, csrc/cuda/ROIAlign_cuda.cu:178-254, with its bilinear_interpolate_gradient (:125-176), in float32 —
+    per pooled cell and sample point g_k = top_diff * w_k / count scattered into the four taps.  It cannot be run against the
+    kernel here (no CUDA); tests/test_oracle_golden.py checks that autograd through `roi_align` above — what the query-branch
+    gradient fixtures were recorded with — equals this statement of the kernel's arithmetic.
+    grad [R, C, ph, pw] float32 numpy; rois [R, 5]; -> bottom_diff [batch, C, H, W] float32."""
+    f32 = np.float32
+    out = np.zeros((batch, channels, height, width), np.float32)
+    for n, r in enumerate(np.asarray(rois, np.float32)):
+        bi = int(r[0])
+        scale = f32(spatial_scale)
+        rsw, rsh, rew, reh = r[1] * scale, r[2] * scale, r[3] * scale, r[4] * scale          # :196-199 (no rounding)
+        roi_w, roi_h = max(rew - rsw, f32(1.0)), max(reh - rsh, f32(1.0))                      # :206-207
+        bin_h, bin_w = f32(roi_h) / f32(ph), f32(roi_w) / f32(pw)
+        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(roi_h / ph))              # :218-219
+        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(roi_w / pw))
+        count = f32(gh * gw)
+        for i in range(ph):
+            for j in range(pw):
+                top = grad[n, :, i, j].astype(np.float32)
+                for iy in range(gh):
+                    y = rsh + f32(i) * bin_h + f32(iy + 0.5) * bin_h / f32(gh)                 # :226
+                    for ix in range(gw):
+                        x = rsw + f32(j) * bin_w + f32(ix + 0.5) * bin_w / f32(gw)             # :229
+                        y_, x_ = f32(y), f32(x)
+                        if y_ < -1.0 or y_ > height or x_ < -1.0 or x_ > width:                # :134-139: no contribution
+                            continue
+                        y_, x_ = max(y_, f32(0.0)), max(x_, f32(0.0))
+                        y_low, x_low = int(y_), int(x_)
+                        if y_low >= height - 1:
+                            y_high = y_low = height - 1
+                            y_ = f32(y_low)
+                        else:
+                            y_high = y_low + 1
+                        if x_low >= width - 1:
+                            x_high = x_low = width - 1
+                            x_ = f32(x_low)
+                        else:
+                            x_high = x_low + 1
+                        ly, lx = f32(y_) - f32(y_low), f32(x_) - f32(x_low)
+                        hy, hx = f32(1.0) - ly, f32(1.0) - lx
+                        for (ty, tx, w) in ((y_low, x_low, hy * hx), (y_low, x_high, hy * lx), (y_high, x_low, ly * hx), (y_high, x_high, ly * lx)):
+                            out[bi, :, ty, tx] += top * f32(w) / count                          # :238-248 (atomicAdd of g_k)
+    return out
+
+
 def query_boxes(image_sizes):
     """modeling/detector/generalized_rcnn.py:257 + SuppAlignLayer.convert_to_roi_format :33-45.
     Quirk: the box is [0, 0, h, w] built from image_sizes = (h, w) but consumed as (x1, y1, x2, y2)."""

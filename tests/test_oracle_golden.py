@@ -154,6 +154,35 @@ def test_box_head_keys_match_reference():
     assert len(spec.full_model_shapes()) == ref["num_all_keys"]
 
 
+def test_roi_align_autograd_equals_the_cuda_backward_kernel_restated():
+    """The query-branch gradients (supp_backbone.*) of every training fixture were recorded through autograd of the oracle's
+    ROIAlign (the reference has no CPU backward, csrc/ROIAlign.h:44).  This closes the loop on the ARITHMETIC: that autograd equals
+    a direct restatement of the reference's CUDA backward kernel (csrc/cuda/ROIAlign_cuda.cu:125-254: g_k = top_diff * w_k / count
+    scattered into the four taps) — on the reference's own ROIAlign vectors (roialign.npz: rois and scales recorded with
+    `_C.roi_align_forward`), on the whole-image query boxes incl. the (h, w)-as-(x2, y2) quirk, on ROIs hanging over the border,
+    malformed (empty) ROIs and adaptive sampling (sampling_ratio 0)."""
+    f = gu.load("roialign.npz")
+    cases = []
+    for i in range(int(f["n"])):
+        scale, ph, pw, sr = f["args.%d" % i]
+        cases.append((f["x.%d" % i], f["rois.%d" % i], float(scale), int(ph), int(pw), int(sr)))
+    rng = np.random.RandomState(3)
+    x = rng.randn(2, 5, 9, 12).astype(np.float32)
+    cases.append((x, orc.query_boxes([(9 * 8, 12 * 8), (5 * 8, 12 * 8)]).numpy(), 1.0 / 8, 1, 1, 2))        # whole-image query boxes
+    cases.append((x, np.array([[0, -6.0, -4.0, 30.0, 20.0], [1, 50.0, 30.0, 200.0, 100.0], [0, 10.0, 10.0, 10.0, 10.0],
+                               [1, 3.3, 2.2, 70.7, 41.9]], np.float32), 0.125, 3, 2, 2))                    # over the border, empty
+    cases.append((x, np.array([[1, 0.0, 0.0, 95.0, 71.0], [0, 7.5, 3.25, 60.0, 50.0]], np.float32), 0.125, 2, 3, 0))   # adaptive sampling
+    for (xi, rois, scale, ph, pw, sr) in cases:
+        xt = torch.from_numpy(np.asarray(xi, np.float32)).requires_grad_(True)
+        y = orc.roi_align(xt, torch.from_numpy(np.asarray(rois, np.float32)), scale, ph, pw, sr)
+        g = torch.from_numpy(rng.randn(*y.shape).astype(np.float32))
+        y.backward(g)
+        want = orc.roi_align_backward_cuda(g.numpy(), rois, scale, ph, pw, *xt.shape, sr)
+        scale_ = max(float(np.abs(want).max()), 1e-6)
+        np.testing.assert_allclose(xt.grad.numpy(), want, rtol=0, atol=2e-6 * scale_)
+        assert np.abs(want).sum() > 0 or len(rois) == 0
+
+
 def test_roi_align_vectorised_equals_per_roi_restatement():
     """roi_align_vec (all ROIs at once) == hotpath_ref.roi_align (one ROI at a time, itself pinned by the reference
     vectors above), incl. boxes that leave the map and degenerate boxes."""
