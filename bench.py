@@ -702,6 +702,16 @@ def main_train(args, rank, world, backend="nccl"):
                 "gflop_per_launch": round(2.0 * top[1] * top[2] * top[3] / 1e9, 1),
                 "achieved": round(top[6], 1), "frac": round(top[6] / PEAK_TFLOPS[args.dtype], 4),
                 "ms_per_step": round(top[7], 3)}
+        # the rows north_star's 0.6 target names — the target backbone's and FPN's forward / data-gradient convs (single launches
+        # with more than 2,048 pixels; the towers are the grouped rows, the query branch the small ones) — as one figure
+        bb = [r for r in table if r[0].startswith("conv") and "grouped" not in r[0] and r[1] > 2048 and r[3] > 0]
+        if bb:
+            gf = sum(2.0 * r[1] * r[2] * r[3] * r[4] / 1e9 for r in bb)
+            ms = sum(r[7] for r in bb)
+            roofline["backbone_convs"] = {"gflop_per_step": round(gf, 1), "ms_per_step": round(ms, 3), "achieved": round(gf / ms, 1),
+                                          "frac": round(gf / ms / PEAK_TFLOPS[args.dtype], 4),
+                                          "what": "forward + data-gradient launches of the backbones / FPN with M > 2048 (--layer-table rows "
+                                                  "conv1x1 / conv3x3 / conv7x1, not grouped)"}
         if len(batches) > 1:
             # the dominant launch of every geometry by itself (the tower layer over that geometry's P3 + P4, or P3..P7)
             roofline["per_geometry"] = []
