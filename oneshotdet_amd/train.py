@@ -162,6 +162,9 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
                           "feeds into both backbones are reproducible only up to the order of those adds")
         for st in self._wgrad_streams:
             ops.wgrad_set_workspace(st, (1 << 30) if self.ordered_wgrad else 0)
+        # which streams share a hardware queue is decided by the order of their first use: fix it now (see warm_streams)
+        if self.wstream is not None:
+            self.warm_streams()
         self.defer_join = False       # opt-in: train_step leaves its tail on the side streams (see train_step / join)
         self._deferred, self._defer_now, self._joined_refs = None, False, None
         self.repack()
@@ -281,12 +284,23 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
                 self.extra[name] = (wv, gv)
 
     def warm_streams(self):
-        """Use every stream of the engine once, in the order they were created: a stream gets its hardware queue at first use,
-        and which queue decides what can overtake what.  Call before anything else in the process creates streams of its own
-        (torch.distributed / RCCL initialisation); see attach_exchange."""
+        """Use every stream of the engine once, in a chosen order: ROCm multiplexes a process's streams onto 4 hardware queues, a
+        queue executes its packets in order, and which two of the six streams end up sharing one is decided at first use.  Measured
+        (rocprofv3 queue ids, tools/queue_map.py): main, the two weight-gradient streams and s1 (query branch + bbox tower) always
+        get queues 1 / 3 / 2 / 4; of the proposal stream and the update stream, the one used FIRST shares queue 4 with s1, the other
+        queue 3 with a weight-gradient stream.  In the natural order of a first step the proposals come first — and then the bbox
+        tower's backward chain (s1) sits behind the 0.75 ms NMS pipeline launched at the loss, the main stream idles ~0.8 ms at the
+        point where it needs the bbox tower's gradient, and the GroupNorm-under-conv overlap of the two towers is lost.  With the
+        update stream used before the proposal stream (default order below) the proposals share a queue with weight gradients,
+        which have slack: +1.2 % .. +3.5 % images/s on three boxes (profiles/r4_stream_order_ab.txt).  OSD_WARM_ORDER=main,w,s1,w2,p,u
+        restores the old pairing.  The engine calls this at construction; call it again before anything else in the process
+        creates streams of its own only if the engine was built without it (torch.distributed / RCCL: see attach_exchange)."""
         cur = torch.cuda.current_stream()
         probe = torch.zeros(64, device=self.device, dtype=torch.float32)
-        for st in (cur, self.wstream, self.s1, self.wstream2, self.pstream, self.ustream):
+        by_name = {"main": cur, "w": self.wstream, "s1": self.s1, "w2": self.wstream2, "p": self.pstream, "u": self.ustream}
+        order = [n for n in os.environ.get("OSD_WARM_ORDER", "main,s1,u,w,w2,p").split(",") if n in by_name]
+        for name in order:
+            st = by_name[name]
             if st is None:
                 continue
             with torch.cuda.stream(st):

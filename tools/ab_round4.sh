@@ -15,4 +15,5 @@ for i in $(seq $R); do
   run "current, towers' gradient sum as add_mask launches" . OSD_NO_HEAD_SUM_FUSION=1
   run "current, SGD and forward repack as separate launches (and a gradient memset per step)" . OSD_NO_FUSED_REPACK=1
   run "current, gradient memset per step" . OSD_NO_CONSUME_GRADS=1
+  run "current, proposals on the bbox tower's hardware queue (the natural first-use order)" . OSD_WARM_ORDER=main,w,s1,w2,p,u
 done
