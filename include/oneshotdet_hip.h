@@ -66,7 +66,10 @@ typedef struct osd_conv_desc {
   float act_scale;
   int32_t relu_in;        /* 1: apply ReLU to x while staging (P7 = conv(relu(P6)), fpn.py:98) */
   int32_t algo;           /* 0 = library heuristic; otherwise 1 + impl*32 + variant*8 + tile (see osd_conv_algo_count /
-                             DESIGN.md 4.1): lets the host autotune per layer shape by measurement */
+                             DESIGN.md 4.1): lets the host autotune per layer shape by measurement.  41 (impl 1, variant 1,
+                             tile 0) = the persistent pointwise kernel: bf16, plain 1x1 / stride 1 conv of one dense NHWC
+                             tensor, cin in 64s, cout in 128s, residual OSD_RES_SAME or none, activation none / ReLU
+                             (osd_conv2d_fwd only) */
   int32_t reserved0;      /* (keeps the pointer below 8-byte aligned; set to 0) */
   void* ordered_ws;       /* weight-gradient entries only (ABI 3): NULL = partial tiles are added with fp32 atomics; otherwise
                              a caller-owned scratch buffer of ordered_ws_bytes bytes — the launch STORES its partial tiles

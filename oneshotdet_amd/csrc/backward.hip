@@ -764,10 +764,18 @@ extern "C" int osd_correlate_bwd_query_levels(int n_levels, const void* const* g
   CorrQLevels L;
   L.n_levels = 0;
   int blocks = 0;
-  for (int i = 0; i < n_levels; ++i) {
+  for (int i = 0; i < n_levels; ++i)
     if (!dqs[i]) return osd_fail(OSD_ERR_INVALID_ARG, "correlate_bwd_query_levels: null dq at level %d", i);
-    hipError_t er = hipMemsetAsync(dqs[i], 0, sizeof(float) * (size_t)n * c, OSD_STREAM(stream));
+  // the sums are accumulated atomically: clear them first — one fill per run of adjacent level buffers (the host side
+  // hands over the rows of ONE [levels, n, c] tensor: a single fill launch instead of five on the step's main chain)
+  for (int i = 0; i < n_levels;) {
+    int j = i + 1;
+    while (j < n_levels && dqs[j] == dqs[j - 1] + (size_t)n * c) ++j;
+    hipError_t er = hipMemsetAsync(dqs[i], 0, sizeof(float) * (size_t)n * c * (j - i), OSD_STREAM(stream));
     if (er != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "correlate_bwd_query_levels: memset failed");
+    i = j;
+  }
+  for (int i = 0; i < n_levels; ++i) {
     if (hws[i] <= 0) continue;
     if (!gs[i] || !feats[i]) return osd_fail(OSD_ERR_INVALID_ARG, "correlate_bwd_query_levels: null tensor at level %d", i);
     int slabs = (hws[i] + 63) / 64;

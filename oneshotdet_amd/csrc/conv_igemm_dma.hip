@@ -252,6 +252,10 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
 
   // ---- main loop: NST-1 stages in flight, one barrier per stage ----
   const int KT = p.KT;
+#ifdef OSD_CD_STAMPS      // diagnostic build: per-wave cycle stamps into the buffer passed as act_scale_dev (tools/cd_stamps.py)
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long st_t1 = 0;
+#endif
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (s < KT) issue_stage(s);
@@ -260,6 +264,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
   for (; kt + NST - 1 < KT; ++kt) {                        // steady state: fetch stage kt+NST-1 while computing stage kt
     wait_vmcnt<LPS * (NST - 2)>();                         // stage kt has landed; later stages stay in flight
     __builtin_amdgcn_s_barrier();                          // every wave's part of stage kt is visible; buffer `nxt` is free
+#ifdef OSD_CD_STAMPS
+    if (kt == 0) st_t1 = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef OSD_CD_NO_DMA             // diagnostic: the loop without its operand fetch
     compute_stage(cur, nxt, std::false_type());
 #else
@@ -271,16 +278,34 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
   for (; kt < KT; ++kt) {                                  // drain: nothing left to fetch
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+#ifdef OSD_CD_STAMPS
+    if (st_t1 == 0) st_t1 = __builtin_amdgcn_s_memtime();
+#endif
     compute_stage(cur, nxt, std::false_type());
     cur = cur + 1 == NST ? 0 : cur + 1;
   }
 
   // ---- epilogue (conv_epilogue.h): LDS-staged, 16-byte-per-lane NHWC stores with bias / residual / mask / activation
+#ifdef OSD_CD_STAMPS
+  const unsigned long long st_t2 = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
 #ifdef OSD_CD_NO_EPI             // diagnostic: no output (keeps the accumulators alive)
   if (acc[0][0][0] != 12345.678f) return;
 #endif
   conv_epilogue<T, TM, TN, false, false, (TM * TN <= 16)>(acc, p, q, smem, wave, wm, wn, lane, m0, n0);
+#ifdef OSD_CD_STAMPS
+  if (p.act != OSD_ACT_EXP_SCALE && p.act_scale_dev != nullptr) {
+    const unsigned long long st_t3 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st_t4 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.act_scale_dev)) + ((size_t)blockIdx.x * NWV + wave) * 8;
+      o[0] = st_t0; o[1] = st_t1 - st_t0; o[2] = st_t2 - st_t1; o[3] = st_t3 - st_t2; o[4] = st_t4 - st_t3;
+      o[5] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (8 << 6) | 20);      // HW_ID: cu id bits [11:8]
+    }
+  }
+#endif
 }
 
 template <typename T, int BM, int BN, int KB, int WM, int WN, int NST, bool RELU_IN = false, bool SRC2 = false>

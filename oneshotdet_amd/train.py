@@ -124,6 +124,12 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         # exchange_single_rank: run the collectives with ONE rank too (the step as it runs under RCCL, measurable on a one-GPU
         # box); grad_wire_dtype=torch.bfloat16: half-width buckets on the wire (dist_utils.GradExchange)
         self.ustream = torch.cuda.Stream(device=self.device)
+        # A/B only (OSD_STREAM_ALIAS="u=w,p=w2"): let one role run on another role's stream — fewer streams for the 4 hardware queues
+        for pair in [a for a in os.environ.get("OSD_STREAM_ALIAS", "").split(",") if "=" in a]:
+            names = {"w": "wstream", "w2": "wstream2", "s1": "s1", "p": "pstream", "u": "ustream"}
+            dst, src = pair.split("=")
+            if getattr(self, names[src]) is not None:
+                setattr(self, names[dst], getattr(self, names[src]))
         self.exchange = GradExchange(self.flat_g, bucket_ranges(self._plan, self.flat_g.numel()), self.pg,
                                      single_rank_too=exchange_single_rank, wire_dtype=grad_wire_dtype, comm_stream=self.ustream)
         self._overlap, self._fuse_update, self._updated = True, False, set()

@@ -20,6 +20,9 @@ ALGO_CACHE = {}
 _TUNING = [False]
 
 
+CONV_ALGO_PW = 1 + 1 * 32 + 1 * 8 + 0      # conv_pw.hip
+
+
 def conv_algo_candidates(cout_store, relu_in, has_mask=False):
     tiles = [3] if cout_store <= 16 else [0, 1, 2]
     if cout_store <= 16:
@@ -44,6 +47,11 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
         cands += [1 + 0 * 32 + v * 8 + 7 for v in (0, 1, 2, 3)]      # 256x128 tile on 8 waves: deep / shallow ring / short stages
     if not relu_in and not has_mask:
         cands += [1 + 1 * 32 + t for t in tiles]
+    if cout_store >= 128 and not relu_in and os.environ.get("OSD_PW"):
+        # persistent pointwise kernel (bf16 1x1 / stride 1 convs; refused elsewhere).  Opt-in: timed alone it wins 3 - 6 % on the
+        # reducing bottleneck convs and the tuner picks it there, but inside the step its 512 long-lived workgroups share the
+        # chip worse with the other streams' kernels: 735 - 737 vs 739.5 - 740.7 images/s in a same-box A/B
+        cands.append(CONV_ALGO_PW)
     return cands
 
 
