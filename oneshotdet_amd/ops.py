@@ -121,7 +121,7 @@ def stem_input(images, dtype):
     return pack_image(images, dtype, hp, wp), (ho, wo)
 
 
-from .tuner import (ALGO_CACHE, CONV_ALGO_PW, SPLIT_CACHE, WGRAD_ALGO_CACHE, _TUNING, _candidate_runs, _tune, _tune_wgrad,      # noqa: E402,F401
+from .tuner import (ALGO_CACHE, CONV_ALGO_PW, SPLIT_CACHE, WGRAD_ALGO_CACHE, _TUNING, _candidate_runs, _time_launches, _tune, _tune_wgrad,      # noqa: E402,F401
                     conv_algo_candidates, tuning, wgrad_algo_candidates, wgrad_xr_candidates)
 
 
@@ -308,14 +308,7 @@ def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mod
             best_t = float("inf")
             for c in range(0, k - 1):
                 run(c)                                  # tunes the algorithms of the parts
-                torch.cuda.synchronize()
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-                ev[0].record()
-                for _ in range(3):
-                    run(c)
-                ev[1].record()
-                torch.cuda.synchronize()
-                t = ev[0].elapsed_time(ev[1])
+                t = _time_launches(lambda: run(c))
                 if t < best_t:
                     cut, best_t = c, t
             SPLIT_CACHE[skey] = cut
@@ -796,14 +789,7 @@ def conv2d_wgrad_mixed(items, algo=None):
                 descs[0].algo = cand
                 if not _candidate_runs(lambda: launch(sdw, sdb)):
                     continue
-                torch.cuda.synchronize()
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-                ev[0].record()
-                for _ in range(3):
-                    launch(sdw, sdb)
-                ev[1].record()
-                torch.cuda.synchronize()
-                t = ev[0].elapsed_time(ev[1])
+                t = _time_launches(lambda: launch(sdw, sdb))
                 if t < best_t:
                     best, best_t = cand, t
             WGRAD_ALGO_CACHE[key] = algo = best

@@ -65,6 +65,23 @@ class tuning(object):
         _TUNING[0] = False
 
 
+def _time_launches(fn):
+    """Milliseconds per launch of `fn`, back to back on the current stream: OSD_TUNE_REPS launches per bracket (default 3), the
+    fastest of OSD_TUNE_ROUNDS brackets (default 1)."""
+    reps, rounds = int(os.environ.get("OSD_TUNE_REPS", "3")), int(os.environ.get("OSD_TUNE_ROUNDS", "1"))
+    best = float("inf")
+    for _ in range(rounds):
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(reps):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        best = min(best, ev[0].elapsed_time(ev[1]) / reps)
+    return best
+
+
 def _tune(key, d, launch, cands=None):
     """Time every candidate algorithm for this conv shape (launch() reads d.algo) and cache the fastest."""
     best, best_t = 0, float("inf")
@@ -84,14 +101,7 @@ def _tune(key, d, launch, cands=None):
             launch()
         except _lib.OsdError:
             continue
-        torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        ev[0].record()
-        for _ in range(3):
-            launch()
-        ev[1].record()
-        torch.cuda.synchronize()
-        t = ev[0].elapsed_time(ev[1])
+        t = _time_launches(launch)
         if t < best_t:
             best, best_t = algo, t
     ALGO_CACHE[key] = best
@@ -154,16 +164,9 @@ def _tune_wgrad(key, d, launch, dw, db, widths=None):
             if verbose:
                 print("   wgrad tuner: variant %d code %d refused" % ((algo - 1) & 15, (algo - 1) >> 4))
             continue
-        torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        ev[0].record()
-        for _ in range(3):
-            launch(sdw, sdb)
-        ev[1].record()
-        torch.cuda.synchronize()
-        t = ev[0].elapsed_time(ev[1])
+        t = _time_launches(lambda: launch(sdw, sdb))
         if verbose:
-            print("   wgrad tuner: variant %d code %d  %.1f us" % ((algo - 1) & 15, (algo - 1) >> 4, t / 3 * 1e3))
+            print("   wgrad tuner: variant %d code %d  %.1f us" % ((algo - 1) & 15, (algo - 1) >> 4, t * 1e3))
         if t < best_t:
             best, best_t = algo, t
     WGRAD_ALGO_CACHE[key] = best
