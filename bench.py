@@ -623,6 +623,8 @@ def main_train(args, rank, world, backend="nccl"):
                 f.write("wgrad %s -> variant %d target_code %d\n" % (k, (a - 1) & 15, (a - 1) >> 4))
             for k, a in ops.ALGO_CACHE.items():
                 f.write("conv %s -> %d\n" % (k, a))
+            for k, a in ops.SPLIT_CACHE.items():
+                f.write("split %s -> %s\n" % (k, a))
 
     launch = ("eager, 7 streams (target backbone + head chain; query backbone; 2 x weight gradients; proposals%s; "
               "pooled-query gradient chain; exchange + update)%s%s"

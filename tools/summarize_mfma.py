@@ -60,7 +60,9 @@ def main():
             continue
         names = [n]
         # the step's dominant launch on its own row: the tower 3x3 conv over P3 + P4 of one tower at bs 8 = 500 tiles of 512 threads
-        if "conv_sp_kernel" in n and k["grid"] == 500 * 512:
+        # (the prediction convs' data gradient over P3 + P4 has the same grid with K = 576 instead of 2,304: told apart by the
+        # MFMAs issued, 38 instead of 151 GFLOP)
+        if "conv_sp_kernel" in n and k["grid"] == 500 * 512 and k["SQ_VALU_MFMA_BUSY_CYCLES"] / 16 * 16384 > 100e9:
             names.append(n + " — 500 tiles: the dominant launch (tower conv over P3 + P4)")
             dom.append(k)
         for nm in names:
