@@ -111,6 +111,9 @@ for j, which, q in captured:
             "wide/rest": [launch_mixed(g) for g in partition(part, lambda it: it[1].shape[-1] >= 256 and it[0].cout >= 256)],
             "3x3/1x1": [launch_mixed(g) for g in partition(part, lambda it: it[0].r)],
             "by-channels": [launch_mixed(g) for g in partition(part, lambda it: (min(it[1].shape[-1], 256), min(it[0].cout, 256)))],
+            "backbone/fpn": [launch_mixed(g) for g in partition(part, lambda it: "fpn" in it[0].name)],
+            "backbone/fpn3x3/fpn1x1": [(launch_group(g) if ("fpn" in g[0][0].name and g[0][0].r == 3 and all(x[0].cout == g[0][0].cout and x[3] == g[0][3] for x in g)) else launch_mixed(g))
+                                       for g in partition(part, lambda it: ("fpn" in it[0].name, it[0].r if "fpn" in it[0].name else 0, it[3] if "fpn" in it[0].name else 0))],
         }
         for name, fns in plans.items():
             try:
