@@ -1053,6 +1053,8 @@ static int wgrad_launch_v(int n_seg, const WgradProblem* pr, hipStream_t s, int 
     if (cus == 0) {
       int dev = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+      const char* e = getenv("OSD_WGRAD_TEAM_CUS");      // A/B: teams sized for fewer CUs (leave some to the other streams' kernels)
+      if (e && atoi(e) > 0) cus = atoi(e);
     }
     const int units = g0.tilesCo * g0.tilesCi * g0.R * g0.S;
     long long teams = (long long)cus * (code + 1) / units;
