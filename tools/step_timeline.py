@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=2, help="instrumented consecutive steps")
+    ap.add_argument("--dump", action="store_true", help="list every launch of the main stream (start, duration) and what ran beside it")
     args = ap.parse_args()
     from oneshotdet_amd import _lib, ops, spec, synth, train
     eng = train.TrainEngine(synth.make_state_dict(spec.hot_path_shapes()), dtype=torch.bfloat16)
@@ -97,6 +98,13 @@ def main():
     print("main stream %d: %d launches, busy %.2f ms, own gaps %.2f ms" % (main, len(ms), per[main] / 1e3, sum(g[0] for g in g2) / 1e3))
     for g, a, b, at in sorted(g2, reverse=True)[:15]:
         print("  gap %7.1f us at +%.2f ms between %s and %s" % (g, (at - t0) / 1e3, a, b))
+    if args.dump:
+        for a, b, n in ms:
+            beside = collections.Counter()
+            for n2, s2, a2, b2 in ev:
+                if streams[s2] != main and b2 > a and a2 < b:
+                    beside["%s@%d" % (n2.replace("osd_", ""), streams[s2])] += min(b, b2) - max(a, a2)
+            print("   +%8.1f us  %7.1f us  %-38s | %s" % (a - t0, b - a, n, ", ".join("%s %.0f" % kv for kv in beside.most_common(4))))
     by = collections.defaultdict(lambda: [0, 0.0])
     for a, b, n in ms:
         by[n][0] += 1
