@@ -383,7 +383,10 @@ int osd_conv_dma_dispatch(int dtype, int tile, int variant, const ConvKParams& p
     if (variant == 2) return dispatch_tile_dma<float, 64, 3>(tile, p, s);
     return dispatch_tile_dma<float, 64, 4>(tile, p, s);
   }
-  if (variant == 3) return dispatch_tile_dma<__bf16, 64, 2>(tile, p, s);
+  // variant 3: short stages (32 K elements), three deep: 48 KB for the 128 x 128 tile = three workgroups per CU.  (Two deep
+  // until round 4: the third stage costs no occupancy on any tile and is faster on every 1x1 shape of the step, 1 - 8 %:
+  // tools/pw_bench.py)
+  if (variant == 3) return dispatch_tile_dma<__bf16, 64, 3>(tile, p, s);
   if (p.Cin % 64 != 0 || variant == 2) return dispatch_tile_dma<__bf16, 64, 4>(tile, p, s);
   if (variant == 1) return dispatch_tile_dma<__bf16, 128, 2>(tile, p, s);
   return dispatch_tile_dma<__bf16, 128, 3>(tile, p, s);

@@ -27,7 +27,7 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
     tiles = [3] if cout_store <= 16 else [0, 1, 2]
     if cout_store <= 16:
         tiles = [3, 2]
-    cands = [1 + 0 * 32 + v * 8 + t for v in (0, 1, 2, 3) for t in tiles]      # v 3: two short stages (many workgroups per CU)
+    cands = [1 + 0 * 32 + v * 8 + t for v in (0, 1, 2, 3) for t in tiles]      # v 3: three short stages (many workgroups per CU)
     if cout_store >= 256 and not relu_in:
         cands.append(1 + 0 * 32 + 1 * 8 + 4)          # 256x256 tile, shallow ring
         cands.append(1 + 0 * 32 + 2 * 8 + 4)          # 256x256 tile, short stages x 4
