@@ -319,10 +319,14 @@ def dist_setup(backend):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
+        # generous timeout: rank 0 autotunes (every candidate kernel of every geometry) BEFORE it joins, the other ranks wait in
+        # the rendezvous meanwhile (config5's three geometries or --second-stage take minutes on a cold box)
+        import datetime
+        tmo = datetime.timedelta(minutes=int(os.environ.get("OSD_PG_TIMEOUT_MIN", "60")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     return rank, local_rank, world
 
 
@@ -611,8 +615,11 @@ def main_train(args, rank, world, backend="nccl"):
     if world > 1:
         from oneshotdet_amd import dist_utils
         dist_utils.broadcast_tuner_choices(ops, src=0)
-        if rank != 0:
-            tune_all()                 # cache hits only: nothing is timed here, every shape runs rank 0's choice
+        if rank != 0:                  # cache hits only: nothing is timed here, a miss raises (ops.replaying)
+            for bt in batches:
+                with ops.replaying():
+                    eng.forward_backward(*bt)
+                torch.cuda.synchronize()
         assert dist_utils.tuner_choices_agree(ops), "ranks ended with different kernel choices"
     if dist.is_initialized():
         eng.attach_exchange(None, single_rank=bool(args.live_exchange), wire_dtype=wire)

@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, "lib")
 # object dir) for A/B timing through OSD_LIB_PATH; the default build is untouched
 TAG = os.environ.get("OSD_BUILD_TAG", "")
 LIB = os.path.join(LIBDIR, "liboneshotdet_hip%s.so" % ("_" + TAG if TAG else ""))
-SOURCES = ["osd_error.hip", "conv_igemm.hip", "conv_igemm_dma.hip", "conv_igemm_p8.hip", "conv_igemm_xr.hip", "conv_igemm_sp.hip", "conv_pw.hip", "conv_wgrad.hip", "conv_wgrad_sk.hip", "backward.hip", "loss.hip", "elementwise.hip", "proposals.hip", "box_head.hip", "transforms.hip", "box_train.hip", "evaluation.hip"]
+SOURCES = ["osd_error.hip", "conv_igemm.hip", "conv_igemm_dma.hip", "conv_igemm_sp.hip", "conv_pw.hip", "conv_wgrad.hip", "conv_wgrad_sk.hip", "backward.hip", "loss.hip", "elementwise.hip", "proposals.hip", "box_head.hip", "transforms.hip", "box_train.hip", "evaluation.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"] + os.environ.get("OSD_BUILD_FLAGS", "").split()
 
@@ -29,7 +29,8 @@ def build_library(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj" + ("_" + TAG if TAG else ""))
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "osd_common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(CSRC, "conv_epilogue.h"), os.path.join(os.path.dirname(HERE), "include", "oneshotdet_hip.h")]
+    # every header under csrc/ is a dependency of every object (a handful of small files: a finer map is not worth a stale build)
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(os.path.dirname(HERE), "include", "oneshotdet_hip.h")]
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

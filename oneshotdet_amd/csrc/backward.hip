@@ -261,7 +261,10 @@ struct SgdPackEntry {
   int first_block, n_blocks;
   long long dst_off;     // elements into the flat packed buffer; -1: not a conv weight
   long long scale_off;   // floats into the flat scale buffer; -1: none
-  int cin, rs, kpad, pad_;   // [cout][rs = R * S][cin] master -> [rows][rs][kpad] packed; cin % 4 == 0, off % 4 == 0 (host-checked)
+  int cin, rs, kpad, pad_;   // [cout][rs = R * S][cin] master -> [rows][rs][kpad] packed.  cin % 4 == 0 and off % 4 == 0 take the
+                             // 16-byte path; anything else falls back to one value per lane IN THE KERNEL (n4 = 0).  The host
+                             // (train_update._build_sgd_table) checks kpad >= cin and that the packed rows end inside the buffer;
+                             // the packed buffer's padding is zero from the initial pack and is never written here
 };
 
 template <typename T>

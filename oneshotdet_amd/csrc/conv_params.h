@@ -64,11 +64,8 @@ struct ConvKParams {
 
 // conv_igemm_dma.hip
 int osd_conv_dma_dispatch(int dtype, int tile, int variant, const ConvKParams& p, hipStream_t s);
-// conv_igemm_p8.hip: bf16, 256 x 256 tile, two wave groups one barrier apart (tile id 5)
-int osd_conv_p8_launch(const ConvKParams& p, hipStream_t s);
-// conv_igemm_xr.hip: bf16, 3x3 / stride 1 / pad 1, 256 x 256 tile, pixel rows fetched once per filter row (tile id 6)
-int osd_conv_xr_launch(const ConvKParams& p, hipStream_t s);
-// conv_igemm_sp.hip: the row-reuse kernel with software-pipelined operand fragments and a mid-stage barrier (tile id 6, variant 1:
+// conv_igemm_sp.hip: bf16, 3x3 / stride 1 / pad 1, pixel rows fetched once per filter row, software-pipelined operand
+// fragments and a mid-stage barrier (tile id 6, variant 1:
 // any map width — the padded-image form where every width is 64 / 128 / 256, else the consecutive-rows form; variant 2 =
 // general_width: the consecutive-rows form on every width, for tests and A/B timing; variant 3 = half_tile: 128-pixel tiles)
 int osd_conv_sp_launch(const ConvKParams& p, hipStream_t s, bool general_width = false, bool half_tile = false);

@@ -1,6 +1,8 @@
 """Data-parallel gradient exchange: the ONE collective of the training step (tools/train_net.py:83-88 uses
 DistributedDataParallel; here the gradients already live in one flat fp32 buffer, so the exchange is a few large
 contiguous all-reduces — RCCL over xGMI with backend "nccl", gloo in the CPU tests)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -89,19 +91,43 @@ def tuner_choices_agree(ops, group=None):
     return all(d == mine for d in every)
 
 
+def _plain_key(k):
+    """A tuner cache key is a (nested) tuple of ints / bools / strings / None; anything else does not belong in the file."""
+    if isinstance(k, tuple):
+        return tuple(_plain_key(e) for e in k)
+    if k is None or isinstance(k, (bool, int, str)):
+        return k
+    if isinstance(k, float) and k == int(k):
+        return int(k)
+    raise ValueError("tuner cache key holds %r" % (k,))
+
+
 def save_tuner_choices(ops, path):
-    """The tuner caches as a file (pickle of plain dicts): tune once, start every later run / rank from it (load_tuner_choices)."""
-    import pickle
-    with open(path, "wb") as f:
-        pickle.dump({name: dict(getattr(ops, name)) for name in TUNER_CACHES}, f)
+    """The tuner caches as a JSON text file: {cache name: [[repr(key), int choice], ...]}; tune once, start every later run / rank
+    from it (load_tuner_choices).  Plain data only — the caches map tuples of ints to ints, so nothing needs pickle (a pickle
+    read back from a predictable path would run whatever a planted file holds)."""
+    import json
+    data = {name: sorted([repr(_plain_key(k)), int(v)] for k, v in getattr(ops, name).items()) for name in TUNER_CACHES}
+    tmp = "%s.tmp.%d" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        json.dump(data, f)
+    os.replace(tmp, path)
 
 
 def load_tuner_choices(ops, path):
-    import pickle
-    with open(path, "rb") as f:
-        data = pickle.load(f)
+    """Read a file written by save_tuner_choices: keys through ast.literal_eval (literals only), every value checked to be an int."""
+    import ast
+    import json
+    with open(path, "r") as f:
+        data = json.load(f)
+    if not isinstance(data, dict):
+        raise ValueError("%s: not a tuner cache file" % path)
     for name in TUNER_CACHES:
-        getattr(ops, name).update(data.get(name, {}))
+        for entry in data.get(name, []):
+            if not (isinstance(entry, list) and len(entry) == 2 and isinstance(entry[0], str) and isinstance(entry[1], int)
+                    and not isinstance(entry[1], bool)):
+                raise ValueError("%s: bad entry %r in %s" % (path, entry, name))
+            getattr(ops, name)[_plain_key(ast.literal_eval(entry[0]))] = entry[1]
 
 
 class GradExchange(object):

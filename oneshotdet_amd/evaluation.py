@@ -152,8 +152,13 @@ class CocoEval(object):
     and `eval` = {precision [T,R,K,A,M], recall [T,K,A,M], scores [T,R,K,A,M]}; `results()` = COCOResults' bbox metrics."""
 
     def __init__(self, precision, recall, scores, cat_ids, img_ids):
+        import types
         self.eval = dict(precision=precision, recall=recall, scores=scores)
         self.cat_ids, self.img_ids = cat_ids, img_ids
+        # what the reference's consumers read off COCOeval.params (coco_eval.py: compute_thresholds_for_classes, COCOResults)
+        self.params = types.SimpleNamespace(iouType="bbox", iouThrs=COCO_IOU_THRS.copy(), recThrs=COCO_REC_THRS.copy(),
+                                            maxDets=list(COCO_MAX_DETS), areaRng=[list(r) for r in COCO_AREA_RNG],
+                                            areaRngLbl=list(COCO_AREA_LBL), catIds=list(cat_ids), imgIds=list(img_ids), useCats=1)
         self.stats = self._summarize()
 
     def _one(self, ap, iou_thr=None, area="all", max_det=100):
@@ -207,10 +212,16 @@ def coco_match(pairs, device="cuda"):
     return [(dm[i, :, :, :dc[i]], di[i, :, :, :dc[i]], gi[i, :, :gn[i]]) for i in range(n)]
 
 
-def evaluate_predictions_on_coco(coco_gt, coco_results, iou_type="bbox", img_ids=None, cat_ids=None, device="cuda"):
-    """coco_eval.py:385-408 without the files: coco_gt = the COCO-format ground truth (a dict with "annotations" — image_id,
-    category_id, bbox [x, y, w, h], area, iscrowd — and optionally "images" / "categories", or the annotation list itself),
-    coco_results = the detection list prepare_for_coco_detection builds (image_id, category_id, bbox, score).  -> CocoEval."""
+def evaluate_predictions_on_coco(coco_gt, coco_results, json_result_file=None, iou_type="bbox", img_ids=None, cat_ids=None, device="cuda"):
+    """coco_eval.py:385-408, the reference's positional order (coco_gt, coco_results, json_result_file, iou_type='bbox'): coco_gt =
+    the COCO-format ground truth (a dict with "annotations" — image_id, category_id, bbox [x, y, w, h], area, iscrowd — and
+    optionally "images" / "categories", or the annotation list itself), coco_results = the detection list
+    prepare_for_coco_detection builds (image_id, category_id, bbox, score); json_result_file: where the reference dumps
+    coco_results before handing the file to pycocotools — written here too when given (nothing reads it back).  -> CocoEval."""
+    if json_result_file is not None:
+        import json
+        with open(json_result_file, "w") as f:
+            json.dump(list(coco_results), f)
     if iou_type != "bbox":
         raise NotImplementedError("iou_type %r: only the box metric is built (the hot path has no mask / keypoint head)" % iou_type)
     anns = coco_gt["annotations"] if isinstance(coco_gt, dict) else list(coco_gt)

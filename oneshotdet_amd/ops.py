@@ -122,7 +122,7 @@ def stem_input(images, dtype):
 
 
 from .tuner import (ALGO_CACHE, CONV_ALGO_PW, SPLIT_CACHE, WGRAD_ALGO_CACHE, _TUNING, _candidate_runs, _time_launches, _tune, _tune_wgrad,      # noqa: E402,F401
-                    conv_algo_candidates, tuning, wgrad_algo_candidates, wgrad_xr_candidates)
+                    conv_algo_candidates, replaying, tuning, wgrad_algo_candidates, wgrad_xr_candidates)
 
 
 class ConvSrc2(C.Structure):

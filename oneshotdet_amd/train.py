@@ -558,6 +558,10 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
                 self.train_step(*self._static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # the captured forward + backward owns its own zeroing of the gradient buffer: `_grads_clean` is a HOST flag, and a graph
+        # captured while it was set would hold no memset — correct only while every replay follows a consuming update.  An eager
+        # forward_backward() between two replays, or a test writing flat_g, would then be accumulated on top of
+        self._grads_clean = False
         self._g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_fb):
             self._static_losses = self.forward_backward(*self._static)
@@ -573,4 +577,7 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         self._g_fb.replay()
         self.reduce_gradients()
         self._g_opt.replay()
+        # what the host flags say after a replay is what they said at capture time; be conservative for whatever eager call
+        # follows: it zeroes the buffer itself (one memset), and the next replay zeroes inside its graph
+        self._grads_clean, self._zeroed, self._updated = False, set(), set()
         return self._static_losses

@@ -127,6 +127,11 @@ class Update(object):
                     tab[i, 4] = tab[i, 5] = -1
                     if c is not None:
                         e = self._pack_fwd_entry[id(c)]
+                        # the kernel trusts this layout (backward.hip: SgdPackEntry): a change in _build_pack_tables must fail here,
+                        # not write out of range there
+                        cout = n // (c.cin * c.r * c.s)
+                        assert e["kpad"] >= c.cin and cout * c.cin * c.r * c.s == n, (name, i, e["kpad"], c.cin, n)
+                        assert 0 <= e["dst"] and e["dst"] + cout * c.r * c.s * e["kpad"] <= self._pack[0]["flat"].numel(), (name, i)
                         tab[i, 4], tab[i, 5] = e["dst"], e["scale"]
                         tab[i, 6:8] = np.frombuffer(np.array([c.cin, c.r * c.s, e["kpad"], 0], dtype=np.int32).tobytes(), dtype=np.int64)
                 blocks += [i] * nb

@@ -13,9 +13,9 @@ SPLIT_CACHE = {}          # grouped launches: where to cut the segment list into
 WGRAD_ALGO_CACHE = {}     # weight-gradient launches: 1 + variant + 16 * split-target code
 
 # osd_conv_desc.algo = 1 + impl*32 + variant*8 + tile; impl 0 = LDS-DMA ring kernel (variants: deep / shallow ring /
-# short stages), impl 1 = register-staged kernel; tile 0..4 = 128x128, 128x64, 64x64, 256x16, 256x256/8 waves, 5 = ping-pong
-# 256x256, 6 = row-reuse 3x3 (variant 0: conv_xr, widths 64/128/256; 1: conv_sp, any width; 2: conv_sp's general-width form forced; 3: conv_sp on 128-pixel tiles),
-# 7 = 256x128/8 waves (pixels x channels).
+# short stages), impl 1 = register-staged kernel; tile 0..4 = 128x128, 128x64, 64x64, 256x16, 256x256/8 waves, 5 = retired
+# (ping-pong 256x256, rounds 1-4), 6 = row-reuse 3x3 conv_sp (variant 0: retired conv_xr; 1: any width; 2: the general-width form
+# forced; 3: 128-pixel tiles), 7 = 256x128/8 waves (pixels x channels).
 ALGO_CACHE = {}
 _TUNING = [False]
 
@@ -31,18 +31,9 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
     if cout_store >= 256 and not relu_in:
         cands.append(1 + 0 * 32 + 1 * 8 + 4)          # 256x256 tile, shallow ring
         cands.append(1 + 0 * 32 + 2 * 8 + 4)          # 256x256 tile, short stages x 4
-        # superseded generations stay in the library (tests pin them by algo id) but are no longer timed on every shape:
-        # conv_p8 (ping-pong 256x256, never picked) and conv_xr (row reuse without the software pipeline; conv_sp is the same
-        # arithmetic, faster, and takes any width).  OSD_TUNE_LEGACY=1 puts them back among the candidates
-        legacy = os.environ.get("OSD_TUNE_LEGACY", "0") != "0"
-        if legacy:
-            cands.append(1 + 0 * 32 + 0 * 8 + 5)      # 256x256 tile, two wave groups one barrier apart (bf16 only)
-        if not os.environ.get("OSD_NO_XR"):           # (A/B switch for tools and benches)
-            if legacy or os.environ.get("OSD_NO_SP"):
-                cands.append(1 + 0 * 32 + 0 * 8 + 6)  # 3x3/1: pixel rows fetched once per filter row (bf16, W in 64/128/256)
-            if not os.environ.get("OSD_NO_SP"):
-                cands.append(1 + 0 * 32 + 1 * 8 + 6)  # the same with software-pipelined fragments + mid-stage barrier, ANY width
-                cands.append(1 + 0 * 32 + 3 * 8 + 6)  # ... on 128-pixel tiles: twice the workgroups where 256-pixel tiles leave CUs idle
+        if not os.environ.get("OSD_NO_SP"):           # (A/B switch for tools and benches)
+            cands.append(1 + 0 * 32 + 1 * 8 + 6)      # 3x3/1: pixel rows fetched once per filter row, software-pipelined fragments + mid-stage barrier, ANY width (bf16)
+            cands.append(1 + 0 * 32 + 3 * 8 + 6)      # ... on 128-pixel tiles: twice the workgroups where 256-pixel tiles leave CUs idle
     if cout_store >= 128 and not relu_in:
         cands += [1 + 0 * 32 + v * 8 + 7 for v in (0, 1, 2, 3)]      # 256x128 tile on 8 waves: deep / shallow ring / short stages
     if not relu_in and not has_mask:
@@ -65,9 +56,28 @@ class tuning(object):
         _TUNING[0] = False
 
 
+class replaying(object):
+    """with ops.replaying(): ...   the ranks other than the tuning one run a step from the caches they were sent
+    (dist_utils.broadcast_tuner_choices): every shape must hit a cache.  A miss — a shape only this rank meets — raises at the
+    point it occurs instead of being timed silently on this rank alone and noticed later by tuner_choices_agree."""
+
+    def __enter__(self):
+        _TUNING[0] = True
+        _REPLAY[0] = True
+
+    def __exit__(self, *a):
+        _TUNING[0] = False
+        _REPLAY[0] = False
+
+
+_REPLAY = [False]
+
+
 def _time_launches(fn):
     """Milliseconds per launch of `fn`, back to back on the current stream: OSD_TUNE_REPS launches per bracket (default 3), the
     fastest of OSD_TUNE_ROUNDS brackets (default 1)."""
+    if _REPLAY[0]:
+        raise RuntimeError("tuner cache miss while replaying another rank's choices: this rank met a shape the tuning rank did not")
     reps, rounds = int(os.environ.get("OSD_TUNE_REPS", "3")), int(os.environ.get("OSD_TUNE_ROUNDS", "1"))
     best = float("inf")
     for _ in range(rounds):

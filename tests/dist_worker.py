@@ -90,7 +90,7 @@ ok3 = ok3 and dist_utils.tuner_choices_agree(fake)
 ok3 = ok3 and fake.ALGO_CACHE[(1, 8, 100, 128, 256, 256, 3, 3, 1, 1, 0, 0, 0, False)] == 15 and len(fake.ALGO_CACHE) == 2
 ok3 = ok3 and list(fake.SPLIT_CACHE.values()) == [0] and list(fake.WGRAD_ALGO_CACHE.values()) == [4]
 import tempfile
-path = os.path.join(tempfile.gettempdir(), "osd_tuner_%d_%d.pkl" % (os.getpid(), rank))
+path = os.path.join(tempfile.gettempdir(), "osd_tuner_%d_%d.json" % (os.getpid(), rank))
 dist_utils.save_tuner_choices(fake, path)
 fake2 = types.SimpleNamespace(ALGO_CACHE={}, SPLIT_CACHE={}, WGRAD_ALGO_CACHE={})
 dist_utils.load_tuner_choices(fake2, path)

@@ -323,7 +323,7 @@ def test_conv2d_grouped_equals_per_level_launches(dt):
     res = [to_nhwc(rnd(n, cout, h, w, seed=20 + i), DT[dt]) for i, (n, h, w) in enumerate(sizes)]
     msk = [to_nhwc(rnd(n, cout, h, w, seed=30 + i), DT[dt]) for i, (n, h, w) in enumerate(sizes)]
     ran = 0
-    for algo in o.conv_algo_candidates(cout, False, has_mask=True) + [1 + 5, 1 + 6, 1 + 16 + 6]:
+    for algo in o.conv_algo_candidates(cout, False, has_mask=True) + [1 + 16 + 6]:
         try:
             ys = o.conv2d_grouped(xx, pc, pad=1, residuals=res, masks=msk, algo=algo)
         except _lib.OsdError:
@@ -359,81 +359,18 @@ def test_conv2d_grouped_rejects_bad_arguments():
         o.conv2d_grouped(xs[:2], pc, pad=1, algo=40)  # register-staged algorithms cannot run grouped
 
 
-def test_conv2d_pingpong_kernel_is_bit_identical_to_the_dma_kernel():
-    """Race screen for conv_igemm_p8.hip (tile id 5: two wave groups one barrier apart, counted vmcnt): it accumulates in
-    the same order as the LDS-DMA 256x256 kernel, so repeated launches must reproduce that kernel's output bit for bit
-    (a DMA/ds_read race shows up as a changed tile).  Shapes: 3x3 with halo and ragged M, 1x1 deep K, KT = 1."""
-    o = ops()
-    P8, DMA = 1 + 5, 1 + 8 + 4
-    for (n, h, w, cin, cout, k, pad) in [(2, 37, 41, 256, 256, 3, 1), (4, 50, 64, 1024, 256, 1, 0), (1, 9, 7, 64, 320, 3, 1),
-                                         (2, 16, 16, 64, 256, 1, 0)]:
-        x = to_nhwc(rnd(n, cin, h, w, seed=1), torch.bfloat16)
-        wt = rnd(cout, cin, k, k, seed=2) / (cin * k * k) ** 0.5
-        pc = o.pack_conv(wt.cuda(), bias=rnd(cout, seed=3).cuda(), dtype=torch.bfloat16)
-        res = to_nhwc(rnd(n, pc.cout_store, h, w, seed=4), torch.bfloat16)
-        ref = o.conv2d(x, pc, pad=pad, res=res, res_mode=o.RES_SAME, act=o.ACT_RELU, algo=DMA)
-        for _ in range(10):
-            y = o.conv2d(x, pc, pad=pad, res=res, res_mode=o.RES_SAME, act=o.ACT_RELU, algo=P8)
-            assert torch.equal(y, ref), (n, h, w, cin, cout, k)
-
-
-def test_conv2d_row_reuse_kernel_matches_the_dma_kernel():
-    """conv_igemm_xr.hip (tile id 6): 3x3 / stride 1 / pad 1, pixel rows fetched once per filter row into a zero-padded
-    LDS image.  It sums K in (r, c, s) order instead of (r, s, c), so it equals the LDS-DMA kernel to fp32 rounding
-    (bf16 outputs: at most one bf16 ulp apart) and itself bit for bit over repeats (race screen).  Shapes: every
-    supported width, tiles that straddle images (H*W not a multiple of 256), ragged M and Cout tails, residual + ReLU and
-    mask epilogues, a grouped launch over two levels; unsupported widths are refused."""
-    o = ops()
-    XR, DMA = 1 + 6, 1 + 8 + 4
-    for (n, h, w, cin, cout) in [(2, 50, 64, 256, 256), (3, 13, 128, 128, 256), (1, 5, 256, 64, 320), (8, 100, 128, 256, 256),
-                                 (2, 7, 64, 64, 260)]:
-        x = to_nhwc(rnd(n, cin, h, w, seed=1), torch.bfloat16)
-        wt = rnd(cout, cin, 3, 3, seed=2) / (cin * 9) ** 0.5
-        pc = o.pack_conv(wt.cuda(), bias=rnd(cout, seed=3).cuda(), dtype=torch.bfloat16)
-        res = to_nhwc(rnd(n, pc.cout_store, h, w, seed=4), torch.bfloat16)
-        ref = o.conv2d(x, pc, pad=1, res=res, res_mode=o.RES_SAME, act=o.ACT_RELU, algo=DMA)
-        y = o.conv2d(x, pc, pad=1, res=res, res_mode=o.RES_SAME, act=o.ACT_RELU, algo=XR)
-        d = (y.float() - ref.float()).abs()
-        tol = 2.0 ** -7 * ref.float().abs().clamp(min=1.0)
-        assert bool((d <= tol).all()), (n, h, w, cin, cout, d.max().item())
-        assert (d > 0).float().mean().item() < 0.05
-        for _ in range(5):
-            assert torch.equal(o.conv2d(x, pc, pad=1, res=res, res_mode=o.RES_SAME, act=o.ACT_RELU, algo=XR), y)
-        mask = to_nhwc(rnd(n, pc.cout_store, h, w, seed=5), torch.bfloat16)
-        ym = o.conv2d(x, pc, pad=1, mask=mask, algo=XR)
-        rm = o.conv2d(x, pc, pad=1, mask=mask, algo=DMA)
-        assert bool(((ym.float() - rm.float()).abs() <= 2.0 ** -7 * rm.float().abs().clamp(min=1.0)).all())
-        assert bool((ym[mask <= 0] == 0).all())
-    # fp32 reference of the op itself on one shape
-    n, h, w, cin, cout = 2, 20, 64, 64, 256
-    xf, wf, bf = rnd(n, cin, h, w, seed=7), rnd(cout, cin, 3, 3, seed=8) / (cin * 9) ** 0.5, rnd(cout, seed=9)
-    pc = o.pack_conv(wf.cuda(), bias=bf.cuda(), dtype=torch.bfloat16)
-    y = o.conv2d(to_nhwc(xf, torch.bfloat16), pc, pad=1, algo=XR)
-    ref = torch.nn.functional.conv2d(xf.bfloat16().float(), wf.bfloat16().float(), bf, padding=1)
-    np.testing.assert_allclose(y.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
-    # grouped launch over two levels (128- and 64-wide)
-    xs = [to_nhwc(rnd(2, 256, 24, 128, seed=11), torch.bfloat16), to_nhwc(rnd(2, 256, 12, 64, seed=12), torch.bfloat16)]
-    wt = rnd(256, 256, 3, 3, seed=13) / (256 * 9) ** 0.5
-    pc = o.pack_conv(wt.cuda(), bias=rnd(256, seed=14).cuda(), dtype=torch.bfloat16)
-    ga = o.conv2d_grouped(xs, pc, pad=1, algo=XR)
-    for xa, ya in zip(xs, ga):
-        assert torch.equal(ya, o.conv2d(xa, pc, pad=1, algo=XR))
-    # refused: width 100, 1x1, stride 2
+def test_conv2d_software_pipelined_row_reuse_kernel_matches_the_dma_kernel():
+    """conv_igemm_sp.hip (tile id 6, variant 1) on the widths its padded-image form takes (64 / 128 / 256): 3x3 / stride 1 / pad 1,
+    pixel rows fetched once per filter row into a zero-padded LDS image, fragments read one half stage ahead, the barrier in the
+    middle of a stage, LDS-DMA as bounds-checked buffer loads (zero padding by the hardware).  It sums K in (r, c, s) order instead
+    of the LDS-DMA kernel's (r, s, c), so it equals that kernel to fp32 rounding (bf16 outputs: at most one bf16 ulp apart, few
+    elements differing) and ITSELF bit for bit over repeats (race screen: a fragment read before its DMA has landed, or a DMA into
+    a buffer still being read, shows up as a changed tile).  Shapes: every width, tiles straddling images (H*W not a multiple of
+    256), vertical borders inside a tile, ragged M and Cout tails, 1..4 channel slabs, all epilogues, a grouped launch; the
+    retired generations' algorithm ids (ping-pong 256x256, row reuse without the software pipeline) are refused."""
     from oneshotdet_amd import _lib
-    with pytest.raises(_lib.OsdError):
-        o.conv2d(to_nhwc(rnd(1, 64, 8, 100, seed=1), torch.bfloat16), pc if pc.cin_k == 64 else o.pack_conv(
-            (rnd(256, 64, 3, 3, seed=2)).cuda(), dtype=torch.bfloat16), pad=1, algo=XR)
-
-
-def test_conv2d_software_pipelined_row_reuse_kernel_is_bit_identical_to_the_row_reuse_kernel():
-    """conv_igemm_sp.hip (tile id 6, variant 1): conv_xr_kernel's arithmetic in conv_xr_kernel's order — the same MFMAs on the
-    same fragments, K summed in the same (r, c, s) order — with the fragments read one half stage ahead, the barrier in the
-    middle of a stage and the LDS-DMA issued as bounds-checked buffer loads (zero padding by the hardware): outputs must be
-    BIT-IDENTICAL to conv_xr_kernel's, on every repeat (race screen: a fragment read before its DMA has landed, or a DMA into a
-    buffer still being read, shows up as a mismatch).  Shapes: every width, tiles straddling images, vertical borders inside
-    a tile, ragged M and Cout tails, 1..4 channel slabs, all epilogues, a grouped launch."""
     o = ops()
-    XR, SP = 1 + 6, 1 + 8 + 6
+    SP, DMA = 1 + 8 + 6, 1 + 8 + 4
     for (n, h, w, cin, cout) in [(2, 50, 64, 256, 256), (3, 13, 128, 128, 256), (1, 5, 256, 64, 320), (8, 100, 128, 256, 256),
                                  (2, 7, 64, 64, 260), (1, 3, 64, 192, 256), (5, 9, 64, 256, 512)]:
         x = to_nhwc(rnd(n, cin, h, w, seed=1), torch.bfloat16)
@@ -442,16 +379,33 @@ def test_conv2d_software_pipelined_row_reuse_kernel_is_bit_identical_to_the_row_
         res = to_nhwc(rnd(n, pc.cout_store, h, w, seed=4), torch.bfloat16)
         mask = to_nhwc(rnd(n, pc.cout_store, h, w, seed=5), torch.bfloat16)
         for kw in (dict(), dict(res=res, res_mode=o.RES_SAME, act=o.ACT_RELU), dict(mask=mask)):
-            ref = o.conv2d(x, pc, pad=1, algo=XR, **kw)
+            ref = o.conv2d(x, pc, pad=1, algo=DMA, **kw)
+            y = o.conv2d(x, pc, pad=1, algo=SP, **kw)
+            d = (y.float() - ref.float()).abs()
+            assert bool((d <= 2.0 ** -7 * ref.float().abs().clamp(min=1.0)).all()), (n, h, w, cin, cout, sorted(kw), d.max().item())
+            assert (d > 0).float().mean().item() < 0.05
             for rep in range(6):
-                y = o.conv2d(x, pc, pad=1, algo=SP, **kw)
-                assert torch.equal(y, ref), (n, h, w, cin, cout, sorted(kw), rep, (y.float() - ref.float()).abs().max().item())
+                assert torch.equal(o.conv2d(x, pc, pad=1, algo=SP, **kw), y), (n, h, w, cin, cout, sorted(kw), rep)
+        assert bool((o.conv2d(x, pc, pad=1, mask=mask, algo=SP)[mask <= 0] == 0).all())
+    # fp32 reference of the op itself on one shape
+    n, h, w, cin, cout = 2, 20, 64, 64, 256
+    xf, wf, bf = rnd(n, cin, h, w, seed=7), rnd(cout, cin, 3, 3, seed=8) / (cin * 9) ** 0.5, rnd(cout, seed=9)
+    pc = o.pack_conv(wf.cuda(), bias=bf.cuda(), dtype=torch.bfloat16)
+    y = o.conv2d(to_nhwc(xf, torch.bfloat16), pc, pad=1, algo=SP)
+    ref = torch.nn.functional.conv2d(xf.bfloat16().float(), wf.bfloat16().float(), bf, padding=1)
+    np.testing.assert_allclose(y.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+    # grouped launch over three levels
     xs = [to_nhwc(rnd(2, 256, 24, 128, seed=11), torch.bfloat16), to_nhwc(rnd(2, 256, 12, 64, seed=12), torch.bfloat16),
           to_nhwc(rnd(1, 256, 3, 64, seed=13), torch.bfloat16)]
     wt = rnd(256, 256, 3, 3, seed=13) / (256 * 9) ** 0.5
     pc = o.pack_conv(wt.cuda(), bias=rnd(256, seed=14).cuda(), dtype=torch.bfloat16)
-    for ya, yb in zip(o.conv2d_grouped(xs, pc, pad=1, algo=SP, _whole=True), o.conv2d_grouped(xs, pc, pad=1, algo=XR, _whole=True)):
-        assert torch.equal(ya, yb)
+    for xa, ya in zip(xs, o.conv2d_grouped(xs, pc, pad=1, algo=SP, _whole=True)):
+        assert torch.equal(ya, o.conv2d(xa, pc, pad=1, algo=SP))
+    for retired in (1 + 5, 1 + 6):
+        with pytest.raises(_lib.OsdError):
+            o.conv2d(xs[0], pc, pad=1, algo=retired)
+        with pytest.raises(_lib.OsdError):
+            o.conv2d_grouped(xs, pc, pad=1, algo=retired, _whole=True)
 
 
 def test_conv2d_software_pipelined_kernel_on_any_width():

@@ -1274,6 +1274,51 @@ def test_captured_training_step_matches_eager_steps():
     assert float((out[True][1] - out[False][1]).norm() / out[False][1].norm()) < 1e-4
 
 
+def test_replay_then_eager_backward_then_replay_does_not_double_count_gradients():
+    """the per-step zeroing of the flat gradient buffer is a host flag (`_grads_clean`) kept in step with the fused
+    update that zeroes what it has read.  A captured forward + backward must carry its own zeroing: the sequence replay_step ->
+    EAGER forward_backward (gradients left in the buffer, no update) -> replay_step has to give the weights of replay_step ->
+    replay_step on the same data, and gradients written into flat_g by hand before a replay must not be applied."""
+    from oneshotdet_amd import train
+    np_sd = synth.make_state_dict(spec.hot_path_shapes())
+    B, h, w = 2, 128, 160
+    q = torch.from_numpy(synth.make_images("rg.q", B, 63, 63, seed=1)).cuda()
+    batches = []
+    for step in range(3):
+        img = torch.from_numpy(synth.make_images("rg.img.%d" % step, B, h, w, seed=step)).cuda()
+        gts = synth.make_gt_boxes(B, h, w, seed=80 + step, max_boxes=3)
+        gtb = torch.zeros(B, 3, 4)
+        for i, g in enumerate(gts):
+            gtb[i, :len(g)] = torch.from_numpy(g)
+        batches.append((img, gtb.cuda(), torch.tensor([len(g) for g in gts], dtype=torch.int32).cuda()))
+    out = {}
+    for mixed in (False, True):
+        eng = train.TrainEngine(np_sd, dtype=torch.float32, lr=0.002)
+        try:
+            eng.capture(batches[0][0], q, batches[0][1], batches[0][2], warmup=1)
+            w0 = None
+            eng.replay_step(batches[1][0], q, batches[1][1], batches[1][2])
+            if mixed:
+                eng.forward_backward(batches[0][0], q, batches[0][1], batches[0][2])      # gradients stay in flat_g, no update
+                torch.cuda.synchronize()
+                assert float(eng.flat_g.abs().max()) > 0
+            eng.replay_step(batches[2][0], q, batches[2][1], batches[2][2])
+            if mixed:
+                torch.cuda.synchronize()
+                w0 = eng.flat_w.clone()
+                eng.flat_g.fill_(1e3)                                                       # a hand-written gradient before a replay
+                eng.replay_step(batches[2][0], q, batches[2][1], batches[2][2])
+            else:
+                eng.replay_step(batches[2][0], q, batches[2][1], batches[2][2])
+            torch.cuda.synchronize()
+            out[mixed] = eng.flat_w.clone().cpu()
+            if w0 is not None:      # an update from a 1e3-everywhere gradient would move every weight by >= lr * 1e3 = 2
+                assert float((eng.flat_w - w0).abs().max()) < 0.5
+        finally:
+            eng.close()
+    assert float((out[True] - out[False]).norm() / out[False].norm()) < 1e-4
+
+
 def test_deferred_join_matches_joined_steps():
     """train_step(defer_join=True) leaves the step's tail (last weight gradients, update, repack, proposals) on the side
     streams and lets the next step's frozen layers run beside it.  Same data, same steps: the losses of every step and the

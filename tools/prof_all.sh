@@ -8,10 +8,10 @@ TAG=${1:-r2}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rm -rf $O/prof_$TAG $O/pmc_$TAG $O/pmcg_mfma /tmp/osd_tuner_$TAG.pkl
+rm -rf $O/prof_$TAG $O/pmc_$TAG $O/pmcg_mfma $O/osd_tuner_$TAG.json
 # one set of tuner choices for every pass: the first run tunes and writes the cache, the others load it — the same kernels in the
 # same order, so the counter passes can be joined with the kernel trace by (kernel, occurrence index)
-export OSD_TUNER_CACHE=/tmp/osd_tuner_$TAG.pkl
+export OSD_TUNER_CACHE=$O/osd_tuner_$TAG.json      # under the run's own scratch directory, not a fixed /tmp name
 bash $R/tools/prof_bench.sh $TAG --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 python3 $R/tools/summarize_profile.py $O/prof_$TAG $O/${TAG}_bench_train_bf16.md > /dev/null 2>&1
 cp $O/prof_$TAG/run_kernel_stats.csv $O/${TAG}_bench_train_bf16_kernel_stats.csv 2>/dev/null

@@ -24,7 +24,7 @@ def bench(fn, reps=20):
 
 def main():
     g = torch.Generator(device="cuda").manual_seed(0)
-    algos = {"dma256/ring2": 1 + 8 + 4, "xr": 1 + 6, "sp": 1 + 8 + 6}
+    algos = {"dma256/ring2": 1 + 8 + 4, "sp": 1 + 8 + 6}
     if os.environ.get("XR_ALGOS"):
         algos = {a: int(a) for a in os.environ["XR_ALGOS"].split(",")}
     for name, shapes, cin, cout in [("tower P3+P4 (grouped)", [(8, 100, 128), (8, 50, 64)], 256, 256),
