@@ -386,6 +386,11 @@ def result_line(args, world, batch, elapsed, workload, launch, roofline=None, cp
     else:
         par = "dp%d: batch sharded over ranks (weak scaling), process-group world size %d, backend %s" % (
             world, pg_world, dist.get_backend())
+        if dist.get_backend() == "nccl":       # "nccl" IS RCCL on ROCm: say which build moved the gradients
+            try:
+                par += " (RCCL %s over xGMI, %d ranks after init)" % (".".join(str(v) for v in torch.cuda.nccl.version()), pg_world)
+            except Exception:      # noqa: BLE001
+                par += " (RCCL)"
     line = {
         "metric": METRIC, "value": round(batch * world * args.steps / elapsed, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
