@@ -30,6 +30,20 @@ METRIC = "images/sec/GPU fwd+bwd, 800x1024 target + 127x127 query, bs=8; 1->8 GP
 WORKLOADS = {"config3": (((800, 1024),), 1), "config5": (((640, 832), (800, 1024), (1024, 1312)), 5)}
 WORKLOAD_BATCH = {"config3": 8, "config5": 4}
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (f32-in MFMA = vector rate)
+PEAK_HBM_TBS = 8.0                             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 measured by a streaming copy)
+
+
+def conv_bytes(x, y, pc, res=None, mask=None, x2=None):
+    """Algorithmic HBM bytes of one conv launch: every tensor once — the input pixels the taps touch (a strided 1x1 reads a
+    quarter of its map), the packed weights, the output, the residual / mask operands of the epilogue."""
+    m = y.shape[0] * y.shape[1] * y.shape[2]
+    b = min(x.numel(), m * pc.r * pc.s * x.shape[-1]) * x.element_size() + pc.w.numel() * pc.w.element_size() + y.numel() * y.element_size()
+    for t in (res, mask):
+        if t is not None:
+            b += min(t.numel(), y.numel()) * t.element_size()
+    if x2 is not None:
+        b += min(x2.numel(), m * x2.shape[-1]) * x2.element_size()
+    return float(b)
 
 
 class ConvTimer(object):
@@ -55,7 +69,9 @@ class ConvTimer(object):
             m = y.shape[0] * y.shape[1] * y.shape[2]
             k_real = 147 if pc.stem else pc.r * pc.s * getattr(pc, "cin_real", pc.cin_k)
             timer.records.append((s, e))
-            timer.labels.append(("conv%dx%d" % (pc.r, pc.s), m, pc.cout, k_real, 2.0 * m * pc.cout * k_real))
+            timer.labels.append(("conv%dx%d" % (pc.r, pc.s), m, pc.cout, k_real, 2.0 * m * pc.cout * k_real,
+                                 conv_bytes(x, y, pc, kw.get("res", a[3] if len(a) > 3 else None), kw.get("mask", a[10] if len(a) > 10 else None),
+                                            kw.get("x2", a[12] if len(a) > 12 else None))))
             timer.flops += 2.0 * m * pc.cout * k_real
             timer.launches += 1
             return y
@@ -75,7 +91,10 @@ class ConvTimer(object):
             m = sum(y.shape[0] * y.shape[1] * y.shape[2] for y in ys)
             k_real = pc.r * pc.s * getattr(pc, "cin_real", pc.cin_k)
             timer.records.append((s, e))
-            timer.labels.append(("conv%dx%d_grouped" % (pc.r, pc.s), m, pc.cout, k_real, 2.0 * m * pc.cout * k_real))
+            rs_, ms_ = kw.get("residuals", a[3] if len(a) > 3 else None), kw.get("masks", a[5] if len(a) > 5 else None)
+            by = sum(conv_bytes(xi, yi, pc, None if not rs_ else rs_[i], None if not ms_ else ms_[i]) for i, (xi, yi) in enumerate(zip(xs, ys)))
+            by -= (len(xs) - 1) * pc.w.numel() * pc.w.element_size() if all(q is pc for q in pcs) else 0.0      # levels share one weight
+            timer.labels.append(("conv%dx%d_grouped" % (pc.r, pc.s), m, pc.cout, k_real, 2.0 * m * pc.cout * k_real, by))
             timer.flops += 2.0 * m * pc.cout * k_real
             timer.launches += 1
             return ys
@@ -89,17 +108,25 @@ class ConvTimer(object):
         self.records, self.flops, self.launches, self.labels = [], 0.0, 0, []
 
     def layer_table(self, steps):
-        """Per-shape totals of the bracketed launches: rows (kind, M, Cout, K, launches/step, us/launch, TFLOP/s, ms/step)."""
+        """Per-shape totals of the bracketed launches: rows (kind, M, Cout, K, launches/step, us/launch, TFLOP/s, ms/step, MB per
+        launch (algorithmic: conv_bytes; 0 for the weight-gradient rows), bound TFLOP/s = min(MFMA peak, 8 TB/s x FLOP per byte),
+        fraction of that bound)."""
         ov = self.bracket_overhead_ms()
         agg = {}
         for (s, e), lab in zip(self.records, self.labels):
-            a = agg.setdefault(lab[:4], [0, 0.0, 0.0])
+            a = agg.setdefault(lab[:4], [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += s.elapsed_time(e) - ov
             a[2] += lab[4]
-        rows = [(k[0], k[1], k[2], k[3], v[0] / steps, v[1] * 1e3 / v[0], v[2] / (v[1] * 1e-3) / 1e12, v[1] / steps)
-                for k, v in agg.items()]
+            a[3] += lab[5] if len(lab) > 5 else 0.0
+        rows = []
+        for k, v in agg.items():
+            tf = v[2] / (v[1] * 1e-3) / 1e12
+            bound = min(self.peak_tflops, PEAK_HBM_TBS * v[2] / v[3]) if v[3] > 0 else self.peak_tflops
+            rows.append((k[0], k[1], k[2], k[3], v[0] / steps, v[1] * 1e3 / v[0], tf, v[1] / steps, v[3] / v[0] / 1e6, bound, tf / bound))
         return sorted(rows, key=lambda r: -r[7])
+
+    peak_tflops = PEAK_TFLOPS["bf16"]
 
     def total_ms(self):
         return sum(s.elapsed_time(e) for s, e in self.records) - self.bracket_overhead_ms() * len(self.records)
@@ -423,7 +450,7 @@ def measured_peaks(dtype):
             "copy_tb_per_s": j["copy_tb_per_s_read_plus_write"]["1024_workgroups"], "source": "profiles/r1_peak_probe.json"}
 
 
-def measured_traffic(mode, dtype):
+def measured_traffic(mode, dtype, launches_per_step=None):
     """HBM bytes per conv-family launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections).  Counters
     cannot be read from inside the process: they are collected OFFLINE by tools/prof_pmc.sh + tools/summarize_pmc.py in
     separate rocprofv3 --pmc passes of this same command and committed under profiles/ with the commit they were taken
@@ -438,6 +465,15 @@ def measured_traffic(mode, dtype):
             j = json.load(f)
         src = "OFFLINE, not measured by this run: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, at commit %s)" % (
             os.path.basename(files[-1]), j.get("commit") or "unknown")
+        # the counter passes launch the conv family N times per step; a file whose N is not this run's was taken on another tree
+        # state (round 4's line quoted 230 launches against the run's 265): per-launch bytes of another launch list are not this
+        # run's traffic — report null and say why (the per-step total of the file stays in the provenance string)
+        n_file = j["conv_family"].get("launches")
+        if launches_per_step is not None and n_file is not None and int(n_file) != int(launches_per_step):
+            return None, ("STALE, refused: profiles/%s counted %d conv-family launches per step (%.2f GB per step) but this run makes %d; "
+                          "regenerate with tools/prof_all.sh at this commit" % (os.path.basename(files[-1]), n_file,
+                                                                               (j["conv_family"]["hbm_read_bytes"] + j["conv_family"]["hbm_write_bytes"]) / 1e9,
+                                                                               launches_per_step))
         return round(j["conv_family"]["hbm_bytes_per_launch"]), src
     except Exception as e:
         return None, "unreadable PMC profile: %r" % (e,)
@@ -684,11 +720,11 @@ def main_train(args, rank, world, backend="nccl"):
         conv_ms = timer.total_ms()
         tflops = timer.flops / (conv_ms * 1e-3) / 1e12
         corr_roofline = timer.correlation_roofline()
-        traffic, traffic_src = measured_traffic("train", args.dtype)
+        traffic, traffic_src = measured_traffic("train", args.dtype, timer.launches // nst)
         roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
                     "peak_measured": measured_peaks(args.dtype), "traffic_source": traffic_src,
-                    "kernel": "conv_sp_kernel / conv_dma_kernel / conv_xr_kernel / conv_igemm_kernel (forward + data gradient) and conv_wgrad_sk_kernel / conv_wgrad_kernel",
+                    "kernel": "conv_sp_kernel / conv_dma_kernel / conv_igemm_kernel (forward + data gradient) and conv_wgrad_sk_kernel / conv_wgrad_kernel",
                     "avg_launch_us": round(conv_ms * 1e3 / max(timer.launches, 1), 2),
                     "launches_per_step": timer.launches // nst,
                     "gflop_per_step": round(timer.flops / nst / 1e9, 1),
@@ -706,6 +742,7 @@ def main_train(args, rank, world, backend="nccl"):
                                            "compare with the kernel-trace row of profiles/r*_bench_train_bf16.md"}
         # the single shape that takes the most time per step: the family figures above average 264 launches, most of them
         # small or HBM-bound; this is the dominant kernel launch by itself
+        timer.peak_tflops = PEAK_TFLOPS[args.dtype]
         table = timer.layer_table(nst)
         top = next((r for r in table if r[0].startswith("conv")), None)
         if top is not None:
@@ -722,10 +759,23 @@ def main_train(args, rank, world, backend="nccl"):
         if bb:
             gf = sum(2.0 * r[1] * r[2] * r[3] * r[4] / 1e9 for r in bb)
             ms = sum(r[7] for r in bb)
+            # every row against ITS roof, min(MFMA peak, 8 TB/s x FLOP per algorithmic byte): the time the rows would take at their
+            # bounds over the time they took; and how the time splits between MFMA-bound and HBM-bound rows
+            ideal_ms = sum(2.0 * r[1] * r[2] * r[3] * r[4] / 1e9 / r[9] for r in bb)
+            hbm_rows = [r for r in bb if r[9] < PEAK_TFLOPS[args.dtype]]
+            hbm_ms = sum(r[7] for r in hbm_rows)
+            hbm_gb = sum(r[8] * r[4] / 1e3 for r in hbm_rows)
             roofline["backbone_convs"] = {"gflop_per_step": round(gf, 1), "ms_per_step": round(ms, 3), "achieved": round(gf / ms, 1),
                                           "frac": round(gf / ms / PEAK_TFLOPS[args.dtype], 4),
+                                          "frac_of_bound": round(ideal_ms / ms, 4), "ms_at_bound": round(ideal_ms, 3),
+                                          "hbm_bound_rows": {"ms_per_step": round(hbm_ms, 3), "gb_per_step": round(hbm_gb, 2),
+                                                             "achieved_tb_s": round(hbm_gb / max(hbm_ms, 1e-9), 2),
+                                                             "frac_of_8_tb_s": round(hbm_gb / max(hbm_ms, 1e-9) / PEAK_HBM_TBS, 4)},
+                                          "mfma_bound_rows": {"ms_per_step": round(ms - hbm_ms, 3),
+                                                              "achieved": round((gf - sum(2.0 * r[1] * r[2] * r[3] * r[4] / 1e9 for r in hbm_rows)) / max(ms - hbm_ms, 1e-9), 1)},
                                           "what": "forward + data-gradient launches of the backbones / FPN with M > 2048 (--layer-table rows "
-                                                  "conv1x1 / conv3x3 / conv7x1, not grouped)"}
+                                                  "conv1x1 / conv3x3 / conv7x1, not grouped); bound per row = min(MFMA peak, 8 TB/s x FLOP per "
+                                                  "algorithmic byte), frac_of_bound = time at the bounds / time taken"}
         if len(batches) > 1:
             # the dominant launch of every geometry by itself (the tower layer over that geometry's P3 + P4, or P3..P7)
             roofline["per_geometry"] = []
@@ -751,9 +801,11 @@ def main_train(args, rank, world, backend="nccl"):
                     "fwd_dgrad_conv_family_tflops": round(fam_fl / (fam_ms * 1e-3) / 1e12, 1)})
         if args.layer_table and rank == 0:
             with open(args.layer_table, "w") as f:
-                f.write("| kind | M (pixels) | Cout | K | launches/step | us/launch | TFLOP/s | ms/step |\n|---|---|---|---|---|---|---|---|\n")
+                f.write("| kind | M (pixels) | Cout | K | launches/step | us/launch | TFLOP/s | ms/step | MB/launch | TB/s | bound TFLOP/s | frac of bound |\n"
+                        "|---|---|---|---|---|---|---|---|---|---|---|---|\n")
                 for r in table:
-                    f.write("| %s | %d | %d | %d | %.0f | %.1f | %.0f | %.3f |\n" % r)
+                    f.write("| %s | %d | %d | %d | %.0f | %.1f | %.0f | %.3f | %.1f | %.2f | %.0f%s | %.2f |\n"
+                            % (r[:9] + (r[8] / max(r[5], 1e-9), r[9], " (hbm)" if r[9] < PEAK_TFLOPS[args.dtype] else "", r[10])))
         timer.uninstall(ops)
     if rank == 0:
         what = ("%s MFMA convs, forward (two R-50-FPN backbones, query pooling, correlation, FCOS head, training proposals) + FCOS "

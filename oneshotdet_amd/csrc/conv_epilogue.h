@@ -60,7 +60,7 @@ __device__ __forceinline__ ConvView conv_select_view(const ConvKParams& p, int& 
 // pixels (wm*TM+j)*16..) through a private LDS region and writes NHWC runs of TN*16 channels with 16-byte-per-lane
 // accesses; all residual loads of a pass are issued before any arithmetic.  The caller has already made the LDS ring
 // reusable (barrier, no DMA in flight).
-template <typename T, int TM, int TN, bool TWO_REGIONS = false, bool GNB = false, bool PIPE = false>
+template <typename T, int TM, int TN, bool TWO_REGIONS = false, int GNB = 0, bool PIPE = false>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKParams& p, const ConvView& q, char* smem,
                                               int wave, int wm, int wn, int lane, int m0, int n0,
                                               const float* pre_bias = nullptr) {
@@ -70,7 +70,10 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
   // bytes as it writes) no longer expose one memory latency per pass.  The pipelined form is compiled per (residual, mask)
   // combination, WITHOUT branches around its loads: hipcc places `s_waitcnt vmcnt(0)` at a branch merge that follows a load,
   // which would wait for the prefetch right where it is issued.
-  // GNB: the fast path also gathers the GroupNorm-backward statistics of ConvGnb (conv_params.h) from the values it stores —
+  // GNB (0 = off; 1 = backward or forward statistics, chosen per segment at run time; 2 = forward statistics ONLY — round 5: the
+  // backward form's per-lane state (a, b, S, Su, two sets of u chunks: ~48 registers) is then not even allocated, and the
+  // instantiation that gathers sum / sum of squares of the tower convs' outputs no longer spills in its epilogue):
+  // the fast path also gathers the GroupNorm-backward statistics of ConvGnb (conv_params.h) from the values it stores —
   // AFTER their rounding to T, the numbers a separate pass over the stored tensor would read.  The launcher guarantees that the
   // segments that ask for it consist of whole tiles and that a wave's rows stay inside one image
   // TWO_REGIONS: the fast path's passes alternate between two private staging regions per wave (the caller's LDS must hold
@@ -120,7 +123,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
       }
     }
     const float escale = p.act == OSD_ACT_EXP_SCALE ? (q_scale_dev ? *(const OSD_G float*)q_scale_dev : p.act_scale) : 1.f;
-    if constexpr (PIPE && kEpiPipe && !GNB) {
+    if constexpr (PIPE && kEpiPipe && GNB == 0) {
       auto piped = [&](auto res_tag, auto mask_tag) {
         constexpr bool HR = decltype(res_tag)::value, HM = decltype(mask_tag)::value;
         Vec rr[2][ITER], mm[2][ITER];
@@ -211,8 +214,8 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
     // slab, group) — what gnl_stats_kernel computes in its own pass over the conv's output
     [[maybe_unused]] bool gnf_on = false;
     [[maybe_unused]] float fs = 0.f, fss = 0.f;
-    if constexpr (GNB) {
-      gn_on = q.gn.u != nullptr;
+    if constexpr (GNB != 0) {
+      gn_on = (GNB == 1) && q.gn.u != nullptr;      // GNB == 2: constant false, the backward form compiles away
       gnf_on = !gn_on && q.gn.ws != nullptr;
       if (gnf_on) gn_img = (m0 + wm * TM * 16) / q_HoWo;
       if (gn_on) {
@@ -268,7 +271,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
         for (int it = 0; it < ITER; ++it)
           mm[it] = *(const OSD_G Vec*)(mkg + (size_t)(mrow + it * (64 / CPR)) * p.out_stride + c);
       }
-      if constexpr (GNB) {
+      if constexpr (GNB != 0) {
         if (gn_on && ps + 1 < NPASS) {
 #pragma unroll
           for (int it = 0; it < ITER; ++it)
@@ -326,7 +329,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
 #else
         *(OSD_G Vec*)(yg + (size_t)(mrow + it * (64 / CPR)) * p.out_stride + c) = o;
 #endif
-        if constexpr (GNB) {
+        if constexpr (GNB != 0) {
           if (gnf_on) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { const float x = (float)o[e]; fs += x; fss = fmaf(x, x, fss); }
@@ -342,14 +345,14 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
           }
         }
       }
-      if constexpr (GNB) {
+      if constexpr (GNB != 0) {
         if (gn_on) {
 #pragma unroll
           for (int it = 0; it < ITER; ++it) uu[it] = uu_next[it];
         }
       }
     }
-    if constexpr (GNB) {
+    if constexpr (GNB != 0) {
       if (gnf_on) {
 #pragma unroll
         for (int off = CPR; off < 64; off <<= 1) { fs += __shfl_xor(fs, off); fss += __shfl_xor(fss, off); }

@@ -375,8 +375,9 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
       if (d->dtype != OSD_BF16 || src2 != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the persistent 1x1 kernel is bf16 only, one source");
       return osd_conv_pw_launch(p, s);
     }
-    // tile 5 (ping-pong 256x256) and tile 6 / variant 0 (row reuse without the software pipeline) were retired in round 5
-    if (tile > 7 || (impl == 1 && (variant != 0 || tile > 3)) || tile == 5 || (impl == 0 && tile == 6 && variant == 0))
+    // tile 6 / variant 0 (row reuse without the software pipeline) and the ping-pong 256x256 kernel were retired in round 5; tile
+    // id 5 now names the 128-pixel x 256-channel LDS-DMA tile
+    if (tile > 7 || (impl == 1 && (variant != 0 || tile > 3)) || (impl == 0 && tile == 6 && variant == 0))
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv: algo %d not built", d->algo);
     if (p.Cout > 16 && tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: skinny tile on a wide conv");
   }
@@ -477,7 +478,7 @@ static int conv_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* 
     if (a >= 32) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d is not an LDS-DMA algorithm", d->algo);
     variant = (a >> 3) & 3;
     tile = a & 7;
-    if (tile > 7 || tile == 5 || (tile == 6 && variant == 0))
+    if (tile > 7 || (tile == 6 && variant == 0))
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d not built", d->algo);
     if (tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: skinny tile on a wide conv");
   }

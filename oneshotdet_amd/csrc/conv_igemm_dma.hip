@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_dma_kernel(ConvKParams p) {
 #ifdef OSD_CD_NO_EPI             // diagnostic: no output (keeps the accumulators alive)
   if (acc[0][0][0] != 12345.678f) return;
 #endif
-  conv_epilogue<T, TM, TN, false, false, (TM * TN <= 16)>(acc, p, q, smem, wave, wm, wn, lane, m0, n0);
+  conv_epilogue<T, TM, TN, false, 0, (TM * TN <= 16)>(acc, p, q, smem, wave, wm, wn, lane, m0, n0);
 #ifdef OSD_CD_STAMPS
   if (p.act != OSD_ACT_EXP_SCALE && p.act_scale_dev != nullptr) {
     const unsigned long long st_t3 = __builtin_amdgcn_s_memtime();
@@ -363,6 +363,12 @@ int dispatch_tile_dma(int tile, const ConvKParams& p, hipStream_t s) {
     case 4:   // 256 x 256, 8 waves: half the operand bytes per MFMA of the 128 x 128 tile (the L1/TA path is the bound there)
       if constexpr (NST * 512 * KB <= 131072) return launch_dma<T, 256, 256, KB, 2, 4, NST>(p, s);
       else return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the 256x256 tile does not fit LDS with this ring");
+    case 5:   // 128 pixels x 256 channels, 8 waves (2 x 4, 64 x 64 per wave; round 5, the id of the retired ping-pong kernel): the
+              // reducing 1x1 convs of the bottlenecks (K = 4 N: 1024 -> 256, 2048 -> 512) stream the whole pixel operand ONCE per
+              // tile row when one tile spans all of N = 256, where the 256 x 128 tile reads it twice; at M = 25,600 still 200
+              // workgroups.  Operand bytes per 128 pixels: 256 + 512 KB against 2 x (256 + 256) for the 128 x 128 tile
+      if constexpr (NST * 384 * KB <= 155648) return launch_dma<T, 128, 256, KB, 2, 4, NST>(p, s);
+      else return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the 128x256 tile does not fit LDS with this ring");
     case 7:   // 256 pixels x 128 channels, 8 waves (4 x 2, 64 x 64 per wave): twice the workgroups of the 256 x 256 tile for
               // the layers whose pixel count gives that tile only 50-100 workgroups on 256 CUs (layer3 / layer4 at bs = 8)
       if constexpr (NST * 384 * KB <= 155648) return launch_dma<T, 256, 128, KB, 4, 2, NST>(p, s);

@@ -77,7 +77,7 @@ constexpr int SP_BBYTES = SP_BN * SP_KB;
 constexpr int SP_LDS = 2 * SP_ABYTES + 2 * SP_BBYTES;
 constexpr unsigned SP_OOB = 0x80000000u;            // beyond any buffer of < 2 GiB: the DMA writes zeros
 
-template <bool GNB, bool GENW, int TMX>      // GNB: the epilogue also gathers the GroupNorm statistics (ConvGnb, conv_params.h); GENW: any width
+template <int GNB, bool GENW, int TMX>      // GNB: the epilogue also gathers GroupNorm statistics (1: backward or forward per segment, 2: forward only; conv_epilogue.h); GENW: any width
 __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   typedef __bf16 T;
   constexpr int TM = TMX, TN = SP_TN, KB = SP_KB;
@@ -454,11 +454,12 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
   p.KT = p.Ktot / SP_BKE;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<true, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<1, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<2, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
     attr_done = true;
   }
   const long long nblocks = (long long)p.tilesM * p.tilesN;
@@ -475,14 +476,17 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
       if (p.seg[i].M % SP_BM != 0 || (p.seg[i].Ho * p.seg[i].Wo) % (SP_BM / 2) != 0 || p.seg[i].M / (p.seg[i].Ho * p.seg[i].Wo) != p.gn_n)
         return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): GroupNorm statistics need images of whole 128-pixel runs (segment %d)", i);
     }
-    hipLaunchKernelGGL((conv_sp_kernel<true, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    bool backward = false;
+    for (int i = 0; i < p.n_seg; ++i) backward = backward || p.seg[i].gn.u != nullptr;
+    if (backward) hipLaunchKernelGGL((conv_sp_kernel<1, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    else hipLaunchKernelGGL((conv_sp_kernel<2, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
   } else if (half_tile) {
-    if (genw) hipLaunchKernelGGL((conv_sp_kernel<false, true, 4>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
-    else hipLaunchKernelGGL((conv_sp_kernel<false, false, 4>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    if (genw) hipLaunchKernelGGL((conv_sp_kernel<0, true, 4>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    else hipLaunchKernelGGL((conv_sp_kernel<0, false, 4>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
   } else if (genw) {
-    hipLaunchKernelGGL((conv_sp_kernel<false, true, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    hipLaunchKernelGGL((conv_sp_kernel<0, true, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
   } else {
-    hipLaunchKernelGGL((conv_sp_kernel<false, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    hipLaunchKernelGGL((conv_sp_kernel<0, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
   }
   return osd_check_launch("conv_igemm_sp");
 }

@@ -13,8 +13,8 @@ SPLIT_CACHE = {}          # grouped launches: where to cut the segment list into
 WGRAD_ALGO_CACHE = {}     # weight-gradient launches: 1 + variant + 16 * split-target code
 
 # osd_conv_desc.algo = 1 + impl*32 + variant*8 + tile; impl 0 = LDS-DMA ring kernel (variants: deep / shallow ring /
-# short stages), impl 1 = register-staged kernel; tile 0..4 = 128x128, 128x64, 64x64, 256x16, 256x256/8 waves, 5 = retired
-# (ping-pong 256x256, rounds 1-4), 6 = row-reuse 3x3 conv_sp (variant 0: retired conv_xr; 1: any width; 2: the general-width form
+# short stages), impl 1 = register-staged kernel; tile 0..4 = 128x128, 128x64, 64x64, 256x16, 256x256/8 waves, 5 = 128x256/8 waves
+# (round 5; the ping-pong 256x256 kernel of rounds 1-4 is retired), 6 = row-reuse 3x3 conv_sp (variant 0: retired conv_xr; 1: any width; 2: the general-width form
 # forced; 3: 128-pixel tiles), 7 = 256x128/8 waves (pixels x channels).
 ALGO_CACHE = {}
 _TUNING = [False]
@@ -36,6 +36,8 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
             cands.append(1 + 0 * 32 + 3 * 8 + 6)      # ... on 128-pixel tiles: twice the workgroups where 256-pixel tiles leave CUs idle
     if cout_store >= 128 and not relu_in:
         cands += [1 + 0 * 32 + v * 8 + 7 for v in (0, 1, 2, 3)]      # 256x128 tile on 8 waves: deep / shallow ring / short stages
+    if cout_store >= 256 and not relu_in:
+        cands += [1 + 0 * 32 + v * 8 + 5 for v in (0, 1, 2, 3)]      # 128x256 tile on 8 waves: all of N = 256 per pixel tile (reducing 1x1 convs)
     if not relu_in and not has_mask:
         cands += [1 + 1 * 32 + t for t in tiles]
     if cout_store >= 128 and not relu_in and os.environ.get("OSD_PW"):

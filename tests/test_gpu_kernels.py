@@ -254,7 +254,7 @@ def test_conv2d_every_algorithm_gives_the_same_answer(dt):
     pc = ops().pack_conv(wt.cuda(), bias=b.cuda(), dtype=DT[dt])
     xx, rr = to_nhwc(x, DT[dt]), to_nhwc(idn, DT[dt])
     ran = 0
-    for algo in ops().conv_algo_candidates(cout, False) + [1 + 5, 1 + 6, 1 + 16 + 6]:      # + the retired generations, conv_sp's general-width form forced
+    for algo in ops().conv_algo_candidates(cout, False) + [1 + 16 + 6]:      # + conv_sp's general-width form forced
         try:
             y = ops().conv2d(xx, pc, pad=1, act=ops().ACT_RELU, res=rr, res_mode=ops().RES_SAME, algo=algo)
         except _lib.OsdError:
@@ -401,11 +401,11 @@ def test_conv2d_software_pipelined_row_reuse_kernel_matches_the_dma_kernel():
     pc = o.pack_conv(wt.cuda(), bias=rnd(256, seed=14).cuda(), dtype=torch.bfloat16)
     for xa, ya in zip(xs, o.conv2d_grouped(xs, pc, pad=1, algo=SP, _whole=True)):
         assert torch.equal(ya, o.conv2d(xa, pc, pad=1, algo=SP))
-    for retired in (1 + 5, 1 + 6):
-        with pytest.raises(_lib.OsdError):
-            o.conv2d(xs[0], pc, pad=1, algo=retired)
-        with pytest.raises(_lib.OsdError):
-            o.conv2d_grouped(xs, pc, pad=1, algo=retired, _whole=True)
+    retired = 1 + 6      # row reuse without the software pipeline (rounds 2-4)
+    with pytest.raises(_lib.OsdError):
+        o.conv2d(xs[0], pc, pad=1, algo=retired)
+    with pytest.raises(_lib.OsdError):
+        o.conv2d_grouped(xs, pc, pad=1, algo=retired, _whole=True)
 
 
 def test_conv2d_software_pipelined_kernel_on_any_width():
