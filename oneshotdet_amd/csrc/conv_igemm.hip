@@ -371,6 +371,10 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
     impl = a >> 5;                 // 0 = LDS-DMA kernel, 1 = register-staged kernel
     variant = (a >> 3) & 3;
     tile = a & 7;
+    if (impl == 1 && variant == 2 && tile <= 1) {      // algos 49 / 50: the pixel-stationary pointwise kernel (conv_px.hip)
+      if (d->dtype != OSD_BF16 || src2 != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the pixel-stationary 1x1 kernel is bf16 only, one source");
+      return osd_conv_px_launch(p, s, tile == 1);
+    }
     if (impl == 1 && variant == 1 && tile == 0) {      // algo 41: the persistent pointwise kernel (conv_pw.hip)
       if (d->dtype != OSD_BF16 || src2 != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the persistent 1x1 kernel is bf16 only, one source");
       return osd_conv_pw_launch(p, s);

@@ -77,18 +77,27 @@ constexpr int SP_BBYTES = SP_BN * SP_KB;
 constexpr int SP_LDS = 2 * SP_ABYTES + 2 * SP_BBYTES;
 constexpr unsigned SP_OOB = 0x80000000u;            // beyond any buffer of < 2 GiB: the DMA writes zeros
 
-template <int GNB, bool GENW, int TMX>      // GNB: the epilogue also gathers GroupNorm statistics (1: backward or forward per segment, 2: forward only; conv_epilogue.h); GENW: any width
+// GNB: the epilogue also gathers GroupNorm statistics (1: backward or forward per segment, 2: forward only; conv_epilogue.h); GENW: any
+// width; TMX: 16-pixel fragments per wave; WNX (round 5): wave columns — 4 = a 256-channel tile on 2 x 4 waves, 2 = a 128-channel
+// tile on 4 x 2 waves (layer2's 128 -> 128 3x3 convs, resnet.py:295-315: the 256-channel tile would spend half its MFMAs and half
+// its weight stages on channels that do not exist)
+template <int GNB, bool GENW, int TMX, int WNX = 4>
 __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   typedef __bf16 T;
   constexpr int TM = TMX, TN = SP_TN, KB = SP_KB;
-  constexpr int BM = 2 * TM * 16;                       // pixels per tile: two wave rows of TM 16-pixel fragments
+  constexpr int WN = WNX, WM = 8 / WNX;                 // wave grid: WM rows of pixels x WN columns of 64 channels
+  constexpr int BM = WM * TM * 16;                      // pixels per tile
+  constexpr int BN = WN * TN * 16;                      // channels per tile
+  constexpr int NBW = BN / 64;                          // weight DMA instructions (8 rows each) per wave and stage
+  constexpr int BBYTES = BN * KB;                       // one weight stage
+  static_assert(BM <= SP_BM && BN <= SP_BN && BM % 64 == 0, "tile geometry");
   constexpr int PA = BM / 64;                           // pixel DMA instructions (8 rows each) per wave and image
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(size_t)smem;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / SP_WN, wn = wave % SP_WN;
+  const int wm = wave / WN, wn = wave % WN;
 
   int t;
   {
@@ -100,7 +109,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   int tile_m = t / p.tilesN;
   const ConvView q = conv_select_view(p, tile_m);
   const int q_H = q.H, q_W = q.W, q_M = q.M, q_HoWo = q.HoWo;
-  const int m0 = tile_m * BM, n0 = tile_n * SP_BN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   [[maybe_unused]] const int logw = __builtin_ctz((unsigned)q_W);       // !GENW: W in {64, 128, 256} (checked by the launcher)
   const int Cin = p.Cin;
 
@@ -139,7 +148,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
     a_dst[i] = (unsigned)__builtin_amdgcn_readfirstlane(ad);
     if (i < 2) {
       a_par[i] = (unsigned)((m - i * 8 - q_W) * Cin + ((lpos ^ sp_key(R)) * SP_EPC)) * 2u;      // instruction 0's row + parity chunk
-      const int brow = (wave * 4 + i) * 8 + lrow;       // weight instruction i of this wave: 4 per wave whatever the pixel tile
+      const int brow = (wave * NBW + i) * 8 + lrow;     // weight instruction i of this wave: NBW per wave whatever the pixel tile
       b_par[i] = (unsigned)((n0 + brow - i * 8) * p.Ktot + ((lpos ^ ((brow >> 1) & 7)) * SP_EPC)) * 2u;
     }
     if (m < q_M) {
@@ -175,7 +184,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   const int line_bytes = q_W * Cin * 2;
 
   const unsigned a_lds[2] = {lds0, lds0 + (unsigned)SP_ABYTES};
-  const unsigned b_lds[2] = {lds0 + 2u * SP_ABYTES, lds0 + 2u * SP_ABYTES + (unsigned)SP_BBYTES};
+  const unsigned b_lds[2] = {lds0 + 2u * SP_ABYTES, lds0 + 2u * SP_ABYTES + (unsigned)BBYTES};
 
   // pixel instruction i of group (kr, kc) into pixel image `buf`
   auto issue_a = [&](int buf, int i, int kr, int kc) {
@@ -190,7 +199,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   constexpr int NIMG = GENW ? PA + 1 : PA;              // pixel DMA instructions per wave and image
   // weight instruction i of the stage whose K offset is koff (elements) into weight stage `buf`
   auto issue_b = [&](int buf, int i, int koff) {
-    sp_dma16(wrs, b_par[i & 1] + (unsigned)((i * 8 * p.Ktot + koff) * 2), b_lds[buf] + (unsigned)((wave * 4 + i) * 1024));
+    sp_dma16(wrs, b_par[i & 1] + (unsigned)((i * 8 * p.Ktot + koff) * 2), b_lds[buf] + (unsigned)((wave * NBW + i) * 1024));
   };
 
   f32x4 acc[TN][TM];
@@ -244,7 +253,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
     constexpr int s_n = decltype(sn_tag)::value, kb_n = decltype(kbn_tag)::value;
     constexpr bool NEXT = decltype(has_next)::value, FB = decltype(fb_tag)::value, FA = decltype(fa_tag)::value;
     const char* xs = smem + ab_n * SP_ABYTES;
-    const char* ws = smem + 2 * SP_ABYTES + bb_n * SP_BBYTES;
+    const char* ws = smem + 2 * SP_ABYTES + bb_n * BBYTES;
 #ifndef OSD_SP_BAR_AT
 #define OSD_SP_BAR_AT 1
 #endif
@@ -297,9 +306,9 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
       // is 5 % SLOWER than all waves issuing at the same place)
       if constexpr (FB) {
         if constexpr (TM >= 8) {
-          if ((j < 4) == dma_early) issue_b(dma_bb, j & 3, koff);
+          if ((j < 4) == dma_early && (j & 3) < NBW) issue_b(dma_bb, j & 3, koff);
         } else {
-          issue_b(dma_bb, j, koff);                       // TM = 4: one weight instruction per MFMA group
+          if (j < NBW) issue_b(dma_bb, j, koff);          // TM = 4: one weight instruction per MFMA group
         }
       }
       if constexpr (FA) {
@@ -325,10 +334,10 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
 #pragma unroll
   for (int i = 0; i < PA; ++i) issue_a(0, i, 0, 0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) issue_b(0, i, 0);
+  for (int i = 0; i < NBW; ++i) issue_b(0, i, 0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) issue_b(1, i, Cin);       // tap 1 of group 0
-  sp_wait_vmcnt<4>();                                   // image 0 and weight stage 0 have landed (mine)
+  for (int i = 0; i < NBW; ++i) issue_b(1, i, Cin);     // tap 1 of group 0
+  sp_wait_vmcnt<NBW>();                                 // image 0 and weight stage 0 have landed (mine)
   __builtin_amdgcn_s_barrier();                         // ... and everyone's
   {
     const char* xs = smem;
@@ -437,7 +446,12 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
     if (!(w == 64 || w == 128 || (w == 256 && !half_tile))) genw = true;      // whole lines per tile, tiles start at x = 0
     return w >= 1 && wo == w && ho == h && sh == w * p.Cin && (long long)m * p.Cin * 2 < 0x7fffffffLL;
   };
+  // round 5: convs with <= 128 output channels run a 256-pixel x 128-channel tile on 4 x 2 waves (64 x 64 per wave, as the
+  // 128-pixel tile's waves): no MFMAs and no weight stages for channels that do not exist
+  const bool narrow = p.Cout <= 128;
+  if (narrow && half_tile) return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): the 128-pixel tile is built for 256-channel tiles only");
   const int BMx = half_tile ? SP_BM / 2 : SP_BM;
+  const int BNx = narrow ? SP_BN / 2 : SP_BN;
   p.tilesM = cdiv(p.M, BMx);
   if (p.n_seg > 0) {
     p.tilesM = 0;
@@ -450,7 +464,7 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
   } else if (!ok(p.W, p.Wo, p.H, p.Ho, p.M, p.sH)) {
     return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): not a dense map under 2 GiB (width %d)", p.W);
   }
-  p.tilesN = cdiv(p.Cout, SP_BN);
+  p.tilesN = cdiv(p.Cout, BNx);
   p.KT = p.Ktot / SP_BKE;
   static bool attr_done = false;
   if (!attr_done) {
@@ -460,6 +474,8 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
     attr_done = true;
   }
   const long long nblocks = (long long)p.tilesM * p.tilesN;
@@ -480,6 +496,9 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
     for (int i = 0; i < p.n_seg; ++i) backward = backward || p.seg[i].gn.u != nullptr;
     if (backward) hipLaunchKernelGGL((conv_sp_kernel<1, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
     else hipLaunchKernelGGL((conv_sp_kernel<2, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+  } else if (narrow) {
+    if (genw) hipLaunchKernelGGL((conv_sp_kernel<0, true, 4, 2>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    else hipLaunchKernelGGL((conv_sp_kernel<0, false, 4, 2>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
   } else if (half_tile) {
     if (genw) hipLaunchKernelGGL((conv_sp_kernel<0, true, 4>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
     else hipLaunchKernelGGL((conv_sp_kernel<0, false, 4>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);

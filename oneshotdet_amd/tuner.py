@@ -21,6 +21,8 @@ _TUNING = [False]
 
 
 CONV_ALGO_PW = 1 + 1 * 32 + 1 * 8 + 0      # conv_pw.hip
+CONV_ALGO_PX = 1 + 1 * 32 + 2 * 8 + 0      # conv_px.hip, eight waves of 16 pixels
+CONV_ALGO_PX_WIDE = CONV_ALGO_PX + 1       # ... four waves of 32 pixels
 
 
 def conv_algo_candidates(cout_store, relu_in, has_mask=False):
@@ -34,12 +36,17 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
         if not os.environ.get("OSD_NO_SP"):           # (A/B switch for tools and benches)
             cands.append(1 + 0 * 32 + 1 * 8 + 6)      # 3x3/1: pixel rows fetched once per filter row, software-pipelined fragments + mid-stage barrier, ANY width (bf16)
             cands.append(1 + 0 * 32 + 3 * 8 + 6)      # ... on 128-pixel tiles: twice the workgroups where 256-pixel tiles leave CUs idle
+    if 64 < cout_store <= 128 and not relu_in and not os.environ.get("OSD_NO_SP") and not os.environ.get("OSD_NO_SP_NARROW"):
+        cands.append(1 + 0 * 32 + 1 * 8 + 6)          # the same kernel on a 256-pixel x 128-channel tile (4 x 2 waves): layer2's 3x3 convs
     if cout_store >= 128 and not relu_in:
         cands += [1 + 0 * 32 + v * 8 + 7 for v in (0, 1, 2, 3)]      # 256x128 tile on 8 waves: deep / shallow ring / short stages
     if cout_store >= 256 and not relu_in:
         cands += [1 + 0 * 32 + v * 8 + 5 for v in (0, 1, 2, 3)]      # 128x256 tile on 8 waves: all of N = 256 per pixel tile (reducing 1x1 convs)
     if not relu_in and not has_mask:
         cands += [1 + 1 * 32 + t for t in tiles]
+    if cout_store >= 64 and not relu_in and not os.environ.get("OSD_NO_PX"):
+        # pixel-stationary pointwise kernel (round 5; bf16 1x1 / stride 1 convs with cin 64 / 128 / 256: refused elsewhere)
+        cands += [CONV_ALGO_PX, CONV_ALGO_PX_WIDE]
     if cout_store >= 128 and not relu_in and os.environ.get("OSD_PW"):
         # persistent pointwise kernel (bf16 1x1 / stride 1 convs; refused elsewhere).  Opt-in: timed alone it wins 3 - 6 % on the
         # reducing bottleneck convs and the tuner picks it there, but inside the step its 512 long-lived workgroups share the

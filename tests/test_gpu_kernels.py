@@ -304,6 +304,49 @@ def test_conv2d_persistent_pointwise_kernel_is_bit_identical(m_shape, cin, cout)
         o.conv2d(to_nhwc(x, torch.float32), pcf, algo=o.CONV_ALGO_PW)
 
 
+@pytest.mark.parametrize("m_shape,cin,cout", [((2, 16, 24), 64, 256), ((2, 25, 32), 128, 512), ((3, 13, 19), 256, 1024), ((1, 50, 64), 256, 320),
+                                                ((8, 50, 64), 256, 1024), ((4, 100, 128), 128, 512), ((2, 9, 7), 64, 64), ((1, 1, 1), 256, 128),
+                                                ((1, 3, 43), 128, 192)])
+def test_conv2d_pixel_stationary_pointwise_kernel_is_bit_identical(m_shape, cin, cout):
+    """conv_px (algo 49, round 5: every wave keeps its 32 pixels' K values in registers, the workgroups walk (pixel block,
+    64-channel chunk) units and stream only weight chunks; residual / mask / bias requested a unit ahead) against the
+    one-tile-per-workgroup LDS-DMA kernel on the EXPANDING bottleneck 1x1 convs (resnet.py:295-315: conv3 + identity + ReLU) and
+    conv1's data gradient (+ skip gradient + mask): same K order and MFMA roles, so BIT-identical outputs — every epilogue
+    combination, K = 64 / 128 / 256, ragged pixel tails (M = 741, 126, 129, 1), units that straddle pixel blocks inside one
+    workgroup, more units than workgroups and fewer, every launch repeated (race screen: a weight chunk read before its DMA
+    landed, an operand set consumed before its loads returned); plus the torch reference.  Refused: cin 512, stride 2, 3x3, fp32."""
+    from oneshotdet_amd import _lib
+    o = ops()
+    n, h, w = m_shape
+    x, wt, b = rnd(n, cin, h, w, seed=1), rnd(cout, cin, 1, 1, seed=2) / cin ** 0.5, rnd(cout, seed=3)
+    idn, mk = rnd(n, cout, h, w, seed=4), rnd(n, cout, h, w, seed=5)
+    x, wt, idn, mk = x.bfloat16().float(), wt.bfloat16().float(), idn.bfloat16().float(), mk.bfloat16().float()
+    pc = o.pack_conv(wt.cuda(), bias=b.cuda(), dtype=torch.bfloat16)
+    xx, rr, mm = to_nhwc(x, torch.bfloat16), to_nhwc(idn, torch.bfloat16), to_nhwc(mk, torch.bfloat16)
+    lin = F.conv2d(x, wt, b)
+    cases = [(dict(), lin), (dict(act=o.ACT_RELU), F.relu(lin)),
+             (dict(res=rr, res_mode=o.RES_SAME, act=o.ACT_RELU), F.relu(lin + idn)),
+             (dict(mask=mm), torch.where(mk > 0, lin, torch.zeros_like(lin))),
+             (dict(res=rr, res_mode=o.RES_SAME, mask=mm), torch.where(mk > 0, lin + idn, torch.zeros_like(lin)))]
+    for kw, ref in cases:
+        base = o.conv2d(xx, pc, algo=1 + 8 + 0, **kw)          # conv_dma, 128 x 128 tile, shallow ring
+        for rep in range(6):
+            algo = (o.CONV_ALGO_PX, o.CONV_ALGO_PX_WIDE)[rep & 1]      # eight waves of 16 pixels / four waves of 32
+            y = o.conv2d(xx, pc, algo=algo, out=torch.full_like(base, 7.0), **kw)      # every element is written
+            assert torch.equal(y, base), (sorted(kw), rep, (y.float() - base.float()).abs().max().item())
+        torch.testing.assert_close(from_nhwc(y), ref, **TOL["bf16"])
+    pc3 = o.pack_conv((rnd(cout, cin, 3, 3, seed=6) / 48).cuda(), bias=b.cuda(), dtype=torch.bfloat16)
+    with pytest.raises(_lib.OsdError):
+        o.conv2d(xx, pc3, pad=1, algo=o.CONV_ALGO_PX)
+    with pytest.raises(_lib.OsdError):
+        o.conv2d(xx, pc, stride=2, algo=o.CONV_ALGO_PX)
+    with pytest.raises(_lib.OsdError):
+        o.conv2d(to_nhwc(x, torch.float32), o.pack_conv(wt.cuda(), bias=b.cuda(), dtype=torch.float32), algo=o.CONV_ALGO_PX)
+    pc512 = o.pack_conv((rnd(64, 512, 1, 1, seed=7) / 23).cuda(), bias=rnd(64, seed=8).cuda(), dtype=torch.bfloat16)
+    with pytest.raises(_lib.OsdError):
+        o.conv2d(to_nhwc(rnd(1, 512, 4, 4, seed=9), torch.bfloat16), pc512, algo=o.CONV_ALGO_PX)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv2d_grouped_equals_per_level_launches(dt):
     """osd_conv2d_fwd_grouped (one launch over the FPN levels that share a tower conv, fcos.py:83-99) against one
@@ -406,6 +449,46 @@ def test_conv2d_software_pipelined_row_reuse_kernel_matches_the_dma_kernel():
         o.conv2d(xs[0], pc, pad=1, algo=retired)
     with pytest.raises(_lib.OsdError):
         o.conv2d_grouped(xs, pc, pad=1, algo=retired, _whole=True)
+
+
+def test_conv2d_software_pipelined_kernel_on_a_128_channel_tile():
+    """conv_igemm_sp.hip with <= 128 output channels (round 5; layer2's 3x3 convs, resnet.py:295-315 with 128 bottleneck channels):
+    the 256-pixel x 128-channel tile on 4 x 2 waves — two weight DMA instructions per wave and stage instead of four, the same
+    per-wave 64 x 64 tile and K order as the 128-pixel form.  Against the LDS-DMA kernel to fp32 summation order (at most one bf16
+    ulp, few elements differing), itself bit for bit over repeats (race screen), on the padded-image widths and the general-width
+    form, tiles straddling images and the M tail, ragged channel counts, all epilogues, a grouped launch; and the fp32 reference."""
+    from oneshotdet_amd import _lib
+    o = ops()
+    SP, GEN, HALF, DMA = 1 + 8 + 6, 1 + 16 + 6, 1 + 24 + 6, 1 + 8 + 0
+    for (n, h, w, cin, cout) in [(8, 100, 128, 128, 128), (2, 50, 64, 128, 128), (3, 13, 128, 64, 96), (1, 5, 256, 256, 128),
+                                 (2, 80, 104, 128, 128), (3, 23, 19, 128, 72), (8, 13, 16, 64, 128), (1, 3, 257, 192, 100)]:
+        x = to_nhwc(rnd(n, cin, h, w, seed=1), torch.bfloat16)
+        wt = rnd(cout, cin, 3, 3, seed=2) / (cin * 9) ** 0.5
+        pc = o.pack_conv(wt.cuda(), bias=rnd(cout, seed=3).cuda(), dtype=torch.bfloat16)
+        res = to_nhwc(rnd(n, pc.cout_store, h, w, seed=4), torch.bfloat16)
+        mask = to_nhwc(rnd(n, pc.cout_store, h, w, seed=5), torch.bfloat16)
+        for kw in (dict(), dict(res=res, res_mode=o.RES_SAME, act=o.ACT_RELU), dict(mask=mask), dict(res=res, res_mode=o.RES_SAME, mask=mask)):
+            ref = o.conv2d(x, pc, pad=1, algo=DMA, **kw)
+            y = o.conv2d(x, pc, pad=1, algo=SP, **kw)
+            d = (y.float() - ref.float()).abs()
+            assert bool((d <= 2.0 ** -7 * ref.float().abs().clamp(min=1.0)).all()), (n, h, w, cin, cout, sorted(kw), d.max().item())
+            assert (d > 0).float().mean().item() < 0.05
+            for rep in range(5):
+                assert torch.equal(o.conv2d(x, pc, pad=1, algo=SP, **kw), y), (n, h, w, cin, cout, sorted(kw), rep)
+            if w in (64, 128, 256):       # the general-width form forced on a padded-image width: the same K order, bit-identical
+                assert torch.equal(o.conv2d(x, pc, pad=1, algo=GEN, **kw), y), ("general width", n, h, w, cin, cout, sorted(kw))
+        with pytest.raises(_lib.OsdError):
+            o.conv2d(x, pc, pad=1, algo=HALF)      # the 128-pixel tile exists for 256-channel tiles only
+    n, h, w, cin, cout = 2, 20, 64, 128, 128
+    xf, wf, bf = rnd(n, cin, h, w, seed=7), rnd(cout, cin, 3, 3, seed=8) / (cin * 9) ** 0.5, rnd(cout, seed=9)
+    pc = o.pack_conv(wf.cuda(), bias=bf.cuda(), dtype=torch.bfloat16)
+    y = o.conv2d(to_nhwc(xf, torch.bfloat16), pc, pad=1, algo=SP)
+    ref = torch.nn.functional.conv2d(xf.bfloat16().float(), wf.bfloat16().float(), bf, padding=1)
+    np.testing.assert_allclose(y.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+    xs = [to_nhwc(rnd(2, 128, 24, 128, seed=11), torch.bfloat16), to_nhwc(rnd(2, 128, 12, 64, seed=12), torch.bfloat16),
+          to_nhwc(rnd(1, 128, 5, 7, seed=13), torch.bfloat16)]
+    for xa, ya in zip(xs, o.conv2d_grouped(xs, pc, pad=1, algo=SP, _whole=True)):
+        assert torch.equal(ya, o.conv2d(xa, pc, pad=1, algo=SP))
 
 
 def test_conv2d_software_pipelined_kernel_on_any_width():

@@ -45,8 +45,8 @@ def timed(fn):
 def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     tot_old = tot_new = 0.0
-    print("| conv | M | N | K | MB | best one-tile algorithm | us | TB/s | conv_pw us | TB/s | TFLOP/s | launches/step |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| conv | M | N | K | MB | best one-tile algorithm | us | TB/s | conv_pw us | TB/s | TFLOP/s | conv_px us | TB/s | launches/step |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for n, h, w, cin, cout, has_res, has_mask, per_step, what in SHAPES:
         x = torch.relu(torch.randn((n, h, w, cin), device="cuda", generator=g)).bfloat16()
         wt = torch.randn((cout, cin, 1, 1), device="cuda", generator=g) / cin ** 0.5
@@ -59,7 +59,7 @@ def main():
         mb = (m * cin + cout * cin + m * cout * (1 + int(has_res) + int(has_mask))) * 2 / 1e6
         best, best_algo = float("inf"), 0
         for algo in ops.conv_algo_candidates(cout, False, has_mask=has_mask):
-            if algo == ops.CONV_ALGO_PW:
+            if algo in (ops.CONV_ALGO_PW, ops.CONV_ALGO_PX, ops.CONV_ALGO_PX_WIDE):
                 continue
             try:
                 ops.conv2d(x, pc, algo=algo, **kw)
@@ -73,13 +73,21 @@ def main():
             t_pw = timed(lambda: ops.conv2d(x, pc, algo=ops.CONV_ALGO_PW, **kw))
         except _lib.OsdError:
             t_pw = float("nan")
+        t_px = float("nan")
+        for a_px in (ops.CONV_ALGO_PX, ops.CONV_ALGO_PX_WIDE):      # the faster of the two wave shapes
+            try:
+                ops.conv2d(x, pc, algo=a_px, **kw)
+                t1 = timed(lambda: ops.conv2d(x, pc, algo=a_px, **kw))
+                t_px = t1 if not (t_px == t_px) else min(t_px, t1)
+            except _lib.OsdError:
+                pass
         a0 = best_algo - 1
         fl = 2.0 * m * cin * cout
-        print("| %s | %d | %d | %d | %.0f | impl %d variant %d tile %d | %.1f | %.2f | %.1f | %.2f | %.0f | %d |" %
-              (what, m, cout, cin, mb, a0 >> 5, (a0 >> 3) & 3, a0 & 7, best, mb / best, t_pw, mb / t_pw, fl / t_pw / 1e6, per_step), flush=True)
+        print("| %s | %d | %d | %d | %.0f | impl %d variant %d tile %d | %.1f | %.2f | %.1f | %.2f | %.0f | %.1f | %.2f | %d |" %
+              (what, m, cout, cin, mb, a0 >> 5, (a0 >> 3) & 3, a0 & 7, best, mb / best, t_pw, mb / t_pw, fl / t_pw / 1e6, t_px, mb / t_px, per_step), flush=True)
         tot_old += best * per_step
-        tot_new += (min(best, t_pw) if t_pw == t_pw else best) * per_step
-    print("\nper step (one backbone): %.0f us with the one-tile algorithms, %.0f us with conv_pw where it wins" % (tot_old, tot_new))
+        tot_new += min([t for t in (best, t_pw, t_px) if t == t]) * per_step
+    print("\nper step (one backbone): %.0f us with the one-tile algorithms, %.0f us with conv_pw / conv_px where they win" % (tot_old, tot_new))
 
 
 if __name__ == "__main__":
