@@ -379,9 +379,9 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
       if (d->dtype != OSD_BF16 || src2 != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the persistent 1x1 kernel is bf16 only, one source");
       return osd_conv_pw_launch(p, s);
     }
-    // tile 6 / variant 0 (row reuse without the software pipeline) and the ping-pong 256x256 kernel were retired in round 5; tile
-    // id 5 now names the 128-pixel x 256-channel LDS-DMA tile
-    if (tile > 7 || (impl == 1 && (variant != 0 || tile > 3)) || (impl == 0 && tile == 6 && variant == 0))
+    // the ping-pong 256x256 kernel and the row-reuse kernel without the software pipeline were retired in round 5: tile id 5 now
+    // names the 128-pixel x 256-channel LDS-DMA tile, tile 6 / variant 0 conv_sp's 128 x 128 tile
+    if (tile > 7 || (impl == 1 && (variant != 0 || tile > 3)))
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv: algo %d not built", d->algo);
     if (p.Cout > 16 && tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: skinny tile on a wide conv");
   }
@@ -389,7 +389,7 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
     return osd_fail(OSD_ERR_UNSUPPORTED, "conv: a second source runs on the LDS-DMA kernel, tiles 0 / 2 / 7");
   if (impl == 0 && tile == 6) {
     if (d->dtype != OSD_BF16) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the row-reuse 3x3 kernel is bf16 only");
-    return osd_conv_sp_launch(p, s, variant == 2, variant == 3);
+    return osd_conv_sp_launch(p, s, variant == 2, variant == 3, variant == 0);
   }
   if (impl == 0) return osd_conv_dma_dispatch(d->dtype, tile, variant, p, s);
   if (mask) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: mask epilogue only in the LDS-DMA kernel");
@@ -482,15 +482,14 @@ static int conv_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* 
     if (a >= 32) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d is not an LDS-DMA algorithm", d->algo);
     variant = (a >> 3) & 3;
     tile = a & 7;
-    if (tile > 7 || (tile == 6 && variant == 0))
-      return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d not built", d->algo);
+    if (tile > 7) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d not built", d->algo);
     if (tile == 3 && p.Cout > 64) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: skinny tile on a wide conv");
   }
   if (gn && !(tile == 6 && variant == 1))
     return osd_fail(OSD_ERR_UNSUPPORTED, "conv_multi_gn: only the software-pipelined 3x3 kernel (algo 15) gathers GroupNorm statistics");
   if (tile == 6) {
     if (d->dtype != OSD_BF16) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: the row-reuse 3x3 kernel is bf16 only");
-    return osd_conv_sp_launch(p, reinterpret_cast<hipStream_t>(stream), variant == 2, variant == 3);
+    return osd_conv_sp_launch(p, reinterpret_cast<hipStream_t>(stream), variant == 2, variant == 3, variant == 0);
   }
   return osd_conv_dma_dispatch(d->dtype, tile, variant, p, reinterpret_cast<hipStream_t>(stream));
 }

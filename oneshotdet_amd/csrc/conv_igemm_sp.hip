@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
 
 }  // namespace
 
-int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_width, bool half_tile) {
+int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_width, bool half_tile, bool small_tile) {
   ConvKParams p = pin;
   if (p.R != 3 || p.S != 3 || p.sh != 1 || p.sw != 1 || p.ph != 1 || p.pw != 1)
     return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): 3x3 stride 1 pad 1 only");
@@ -443,14 +443,18 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
   // and hold whole lines); every other width — or all of them with general_width — runs the consecutive-rows form (GENW)
   bool genw = general_width;
   auto ok = [&](int w, int wo, int h, int ho, int m, int sh) {
-    if (!(w == 64 || w == 128 || (w == 256 && !half_tile))) genw = true;      // whole lines per tile, tiles start at x = 0
+    if (!(w == 64 || w == 128 || (w == 256 && !half_tile && !small_tile))) genw = true;      // whole lines per tile, tiles start at x = 0
     return w >= 1 && wo == w && ho == h && sh == w * p.Cin && (long long)m * p.Cin * 2 < 0x7fffffffLL;
   };
   // round 5: convs with <= 128 output channels run a 256-pixel x 128-channel tile on 4 x 2 waves (64 x 64 per wave, as the
   // 128-pixel tile's waves): no MFMAs and no weight stages for channels that do not exist
-  const bool narrow = p.Cout <= 128;
+  // small_tile (round 5, algo 7): 128 pixels x 128 channels (4 x 2 waves of 32 x 64) for the launches whose WEIGHT stream bounds a
+  // workgroup — layer4's 3x3 (6,400 pixels, K = 4,608): a 256-channel tile streams 2.4 MB of weights through its CU's texture path
+  // whatever its pixel count, 100 workgroups on 256 CUs; 128-channel tiles halve that per workgroup and double the workgroups
+  const bool narrow = p.Cout <= 128 || small_tile;
   if (narrow && half_tile) return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): the 128-pixel tile is built for 256-channel tiles only");
-  const int BMx = half_tile ? SP_BM / 2 : SP_BM;
+  if (small_tile && p.gn_groups > 0) return osd_fail(OSD_ERR_UNSUPPORTED, "conv(sp): no GroupNorm statistics on the small tile");
+  const int BMx = (half_tile || small_tile) ? SP_BM / 2 : SP_BM;
   const int BNx = narrow ? SP_BN / 2 : SP_BN;
   p.tilesM = cdiv(p.M, BMx);
   if (p.n_seg > 0) {
@@ -476,6 +480,8 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
     attr_done = true;
   }
   const long long nblocks = (long long)p.tilesM * p.tilesN;
@@ -496,6 +502,9 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
     for (int i = 0; i < p.n_seg; ++i) backward = backward || p.seg[i].gn.u != nullptr;
     if (backward) hipLaunchKernelGGL((conv_sp_kernel<1, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
     else hipLaunchKernelGGL((conv_sp_kernel<2, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+  } else if (small_tile) {
+    if (genw) hipLaunchKernelGGL((conv_sp_kernel<0, true, 2, 2>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    else hipLaunchKernelGGL((conv_sp_kernel<0, false, 2, 2>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
   } else if (narrow) {
     if (genw) hipLaunchKernelGGL((conv_sp_kernel<0, true, 4, 2>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
     else hipLaunchKernelGGL((conv_sp_kernel<0, false, 4, 2>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);

@@ -14,8 +14,8 @@ WGRAD_ALGO_CACHE = {}     # weight-gradient launches: 1 + variant + 16 * split-t
 
 # osd_conv_desc.algo = 1 + impl*32 + variant*8 + tile; impl 0 = LDS-DMA ring kernel (variants: deep / shallow ring /
 # short stages), impl 1 = register-staged kernel; tile 0..4 = 128x128, 128x64, 64x64, 256x16, 256x256/8 waves, 5 = 128x256/8 waves
-# (round 5; the ping-pong 256x256 kernel of rounds 1-4 is retired), 6 = row-reuse 3x3 conv_sp (variant 0: retired conv_xr; 1: any width; 2: the general-width form
-# forced; 3: 128-pixel tiles), 7 = 256x128/8 waves (pixels x channels).
+# (round 5; the ping-pong 256x256 kernel of rounds 1-4 is retired), 6 = row-reuse 3x3 conv_sp (variant 0: 128 x 128 tiles, round 5 — the id of the
+# retired conv_xr; 1: any width; 2: the general-width form forced; 3: 128-pixel tiles), 7 = 256x128/8 waves (pixels x channels).
 ALGO_CACHE = {}
 _TUNING = [False]
 
@@ -36,6 +36,7 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
         if not os.environ.get("OSD_NO_SP"):           # (A/B switch for tools and benches)
             cands.append(1 + 0 * 32 + 1 * 8 + 6)      # 3x3/1: pixel rows fetched once per filter row, software-pipelined fragments + mid-stage barrier, ANY width (bf16)
             cands.append(1 + 0 * 32 + 3 * 8 + 6)      # ... on 128-pixel tiles: twice the workgroups where 256-pixel tiles leave CUs idle
+            cands.append(1 + 0 * 32 + 0 * 8 + 6)      # ... on 128 x 128 tiles: half the weight stream per workgroup (layer4's 3x3: K = 4,608 on 6,400 pixels)
     if 64 < cout_store <= 128 and not relu_in and not os.environ.get("OSD_NO_SP") and not os.environ.get("OSD_NO_SP_NARROW"):
         cands.append(1 + 0 * 32 + 1 * 8 + 6)          # the same kernel on a 256-pixel x 128-channel tile (4 x 2 waves): layer2's 3x3 convs
     if cout_store >= 128 and not relu_in:

@@ -410,7 +410,7 @@ def test_conv2d_software_pipelined_row_reuse_kernel_matches_the_dma_kernel():
     elements differing) and ITSELF bit for bit over repeats (race screen: a fragment read before its DMA has landed, or a DMA into
     a buffer still being read, shows up as a changed tile).  Shapes: every width, tiles straddling images (H*W not a multiple of
     256), vertical borders inside a tile, ragged M and Cout tails, 1..4 channel slabs, all epilogues, a grouped launch; the
-    retired generations' algorithm ids (ping-pong 256x256, row reuse without the software pipeline) are refused."""
+    128 x 128 tile (algo 7, the id of the retired row-reuse kernel) gives the same bits."""
     from oneshotdet_amd import _lib
     o = ops()
     SP, DMA = 1 + 8 + 6, 1 + 8 + 4
@@ -444,11 +444,9 @@ def test_conv2d_software_pipelined_row_reuse_kernel_matches_the_dma_kernel():
     pc = o.pack_conv(wt.cuda(), bias=rnd(256, seed=14).cuda(), dtype=torch.bfloat16)
     for xa, ya in zip(xs, o.conv2d_grouped(xs, pc, pad=1, algo=SP, _whole=True)):
         assert torch.equal(ya, o.conv2d(xa, pc, pad=1, algo=SP))
-    retired = 1 + 6      # row reuse without the software pipeline (rounds 2-4)
-    with pytest.raises(_lib.OsdError):
-        o.conv2d(xs[0], pc, pad=1, algo=retired)
-    with pytest.raises(_lib.OsdError):
-        o.conv2d_grouped(xs, pc, pad=1, algo=retired, _whole=True)
+    # algo 7 (the retired row-reuse kernel's id) now names conv_sp's 128 x 128 tile: same K order, bit-identical
+    for xa, ya in zip(xs, o.conv2d_grouped(xs, pc, pad=1, algo=1 + 6, _whole=True)):
+        assert torch.equal(ya, o.conv2d(xa, pc, pad=1, algo=SP))
 
 
 def test_conv2d_software_pipelined_kernel_on_a_128_channel_tile():
@@ -501,7 +499,7 @@ def test_conv2d_software_pipelined_kernel_on_any_width():
     ulp, few elements differing) and itself bit for bit.  (iii) One grouped launch over P3..P7 of a 640 x 832 batch equals the
     per-level launches bit for bit."""
     o = ops()
-    SP, GEN, HALF, DMA = 1 + 8 + 6, 1 + 16 + 6, 1 + 24 + 6, 1 + 8 + 4
+    SP, GEN, HALF, DMA, SMALL = 1 + 8 + 6, 1 + 16 + 6, 1 + 24 + 6, 1 + 8 + 4, 1 + 6
     for (n, h, w, cin, cout) in [(2, 50, 64, 256, 256), (3, 13, 128, 128, 256), (1, 5, 256, 64, 320), (2, 7, 64, 64, 260),
                                  (5, 9, 64, 256, 512)]:
         x = to_nhwc(rnd(n, cin, h, w, seed=1), torch.bfloat16)
@@ -517,6 +515,8 @@ def test_conv2d_software_pipelined_kernel_on_any_width():
             for rep in range(3):       # the 128-pixel tile (algo 31): same K order, same per-pixel arithmetic
                 y = o.conv2d(x, pc, pad=1, algo=HALF, **kw)
                 assert torch.equal(y, ref), ("half tile", n, h, w, cin, cout, sorted(kw), rep, (y.float() - ref.float()).abs().max().item())
+                y = o.conv2d(x, pc, pad=1, algo=SMALL, **kw)      # 128 pixels x 128 channels (algo 7)
+                assert torch.equal(y, ref), ("small tile", n, h, w, cin, cout, sorted(kw), rep, (y.float() - ref.float()).abs().max().item())
     for (n, h, w, cin, cout) in [(2, 80, 104, 256, 256), (1, 128, 164, 256, 256), (2, 100, 168, 64, 256), (8, 25, 32, 256, 256),
                                  (8, 13, 16, 256, 256), (8, 7, 8, 256, 256), (3, 23, 19, 128, 320), (2, 5, 3, 64, 256),
                                  (4, 4, 1, 64, 256), (1, 1, 300, 64, 256), (1, 3, 257, 192, 512)]:
@@ -534,6 +534,7 @@ def test_conv2d_software_pipelined_kernel_on_any_width():
             for rep in range(3):
                 assert torch.equal(o.conv2d(x, pc, pad=1, algo=SP, **kw), y), (n, h, w, rep)
                 assert torch.equal(o.conv2d(x, pc, pad=1, algo=HALF, **kw), y), ("half tile", n, h, w, rep)
+                assert torch.equal(o.conv2d(x, pc, pad=1, algo=SMALL, **kw), y), ("small tile", n, h, w, rep)
     # fp32 reference of the op itself on a width with borders inside every fragment
     n, h, w, cin, cout = 2, 11, 13, 64, 256
     xf, wf, bf = rnd(n, cin, h, w, seed=7), rnd(cout, cin, 3, 3, seed=8) / (cin * 9) ** 0.5, rnd(cout, seed=9)
@@ -545,7 +546,7 @@ def test_conv2d_software_pipelined_kernel_on_any_width():
     xs = [to_nhwc(rnd(2, 256, hh, ww, seed=20 + i), torch.bfloat16) for i, (hh, ww) in enumerate([(80, 104), (40, 52), (20, 26), (10, 13), (5, 7)])]
     wt = rnd(256, 256, 3, 3, seed=13) / (256 * 9) ** 0.5
     pc = o.pack_conv(wt.cuda(), bias=rnd(256, seed=14).cuda(), dtype=torch.bfloat16)
-    for algo in (SP, HALF):
+    for algo in (SP, HALF, SMALL):
         ga = o.conv2d_grouped(xs, pc, pad=1, algo=algo, _whole=True)
         for xa, ya in zip(xs, ga):
             assert torch.equal(ya, o.conv2d(xa, pc, pad=1, algo=SP))
