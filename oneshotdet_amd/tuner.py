@@ -45,8 +45,11 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
         cands += [1 + 0 * 32 + v * 8 + 5 for v in (0, 1, 2, 3)]      # 128x256 tile on 8 waves: all of N = 256 per pixel tile (reducing 1x1 convs)
     if not relu_in and not has_mask:
         cands += [1 + 1 * 32 + t for t in tiles]
-    if cout_store >= 64 and not relu_in and not os.environ.get("OSD_NO_PX"):
-        # pixel-stationary pointwise kernel (round 5; bf16 1x1 / stride 1 convs with cin 64 / 128 / 256: refused elsewhere)
+    if cout_store >= 64 and not relu_in and os.environ.get("OSD_PX"):
+        # pixel-stationary pointwise kernel (round 5; bf16 1x1 / stride 1 convs with cin 64 / 128 / 256: refused elsewhere).  Opt-in
+        # like conv_pw: timed alone it wins layer2's expanding convs by 8 - 10 % and the tuner picks it there, but inside the step
+        # its long-lived workgroups share the chip no better than the tile kernels' short ones: 699 - 715 images/s with it, 711 -
+        # 714 without, 692 - 699 for the round-4 head on the same box (profiles/r5_same_box_ab.txt)
         cands += [CONV_ALGO_PX, CONV_ALGO_PX_WIDE]
     if cout_store >= 128 and not relu_in and os.environ.get("OSD_PW"):
         # persistent pointwise kernel (bf16 1x1 / stride 1 convs; refused elsewhere).  Opt-in: timed alone it wins 3 - 6 % on the
