@@ -514,10 +514,10 @@ class TrainTimer(ConvTimer):
         ops.conv2d_wgrad = timed_wgrad
         self._orig_g = ops.conv2d_wgrad_grouped
 
-        def timed_grouped(pairs, dw, r, s, stride, pad, cout, scale=None, db=None):
+        def timed_grouped(pairs, dw, r, s, stride, pad, cout, scale=None, db=None, **kw):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            timer._orig_g(pairs, dw, r, s, stride, pad, cout, scale=scale, db=db)
+            timer._orig_g(pairs, dw, r, s, stride, pad, cout, scale=scale, db=db, **kw)
             b.record()
             timer.records.append((a, b))
             mm = sum(dy.shape[0] * dy.shape[1] * dy.shape[2] for x, dy in pairs)

@@ -331,6 +331,21 @@ int osd_conv2d_wgrad_grouped(const osd_conv_desc* d, int n_seg, const void* cons
 int osd_conv2d_wgrad_pred(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* const* dys, const int32_t* ns,
                           const int32_t* hs, const int32_t* ws, float* dw, float* db, void* workspace, void* stream);
 int64_t osd_conv2d_wgrad_pred_workspace_bytes(int n_seg, const int32_t* ns, const int32_t* hs, const int32_t* ws, int cin);
+/* The same convs' DATA gradient as a GEMM (round 5; autograd of fcos.py:50-61,91-97 in the reference): with the nine shifted dy vectors
+ * of every input pixel side by side,
+ *   G[q][tap * 4 + co] = dy[q - (tap / 3 - 1, tap % 3 - 1)][co]      (64 columns per pixel, 36 used; zero outside the map),
+ * d x[q][ci] = sum over (tap, co) of G[q][tap * 4 + co] * w[co][tap][ci]: a 1x1 conv with K = 64 over G.
+ *   osd_pred_dy_gather: d = the prediction conv's descriptor (dtype, cout <= 4, out_stride = channels per dy pixel); g receives
+ *     [sum of n * h * w over the levels][64] elements of d->dtype, the levels one after the other;
+ *   osd_pred_dgrad_pack: wd[cin][64] (dtype) <- the fp32 master w[cout][3][3][cin]: the packed weights of that 1x1 conv
+ *     (osd_conv2d_fwd with cin = 64, cout = the prediction conv's cin, w_rows = cin, a zero bias);
+ *   osd_conv2d_wgrad_pred_gathered: osd_conv2d_wgrad_pred from the caller's G (the gather is shared with the data gradient);
+ *     workspace: 256 + 64 * cin * 4 bytes. */
+int osd_pred_dy_gather(const osd_conv_desc* d, int n_seg, const void* const* dys, const int32_t* ns, const int32_t* hs,
+                       const int32_t* ws, void* g, void* stream);
+int osd_pred_dgrad_pack(int dtype, const float* w, int cout, int cin, void* wd, void* stream);
+int osd_conv2d_wgrad_pred_gathered(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* g, const int32_t* ns,
+                                   const int32_t* hs, const int32_t* ws, float* dw, float* db, void* workspace, void* stream);
 /* n_seg <= 24 convs of IDENTICAL geometry (d: the shared forward descriptor incl. n, h, w) but different tensors AND
  * different weights — the repeated bottleneck blocks of a ResNet stage (resnet.py:295-315) — in one launch; xs / dys /
  * scales / dws / dbs: HOST arrays of per-conv device pointers (scales, dbs nullable as a whole or per entry).  The output

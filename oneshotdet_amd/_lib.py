@@ -72,6 +72,9 @@ SIGNATURES = {
     "osd_conv2d_wgrad_grouped": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_wgrad_pred": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_wgrad_pred_workspace_bytes": (_i64, [_i, _p, _p, _p, _i]),
+    "osd_pred_dy_gather": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p]),
+    "osd_pred_dgrad_pack": (_i, [_i, _p, _i, _i, _p, _p]),
+    "osd_conv2d_wgrad_pred_gathered": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_wgrad_batched": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_wgrad_multi": (_i, [C.POINTER(ConvDesc), _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "osd_conv2d_wgrad_mixed": (_i, [_i, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),

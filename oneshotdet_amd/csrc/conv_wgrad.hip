@@ -1187,15 +1187,19 @@ static int pred_blocks(int n_seg, const int32_t* ns, const int32_t* hs, const in
 // pixel laid side by side, G[q][tap * 4 + co] (36 of 40 columns; zero outside the map), this is the weight gradient of a 1x1
 // conv with 36 output channels — the MFMA kernel above with ONE output row-tile, x read once — whose result T[tap * 4 + co][ci]
 // a last tiny launch adds into dw[co][tap][ci] (and the centre tap's column sums into db).  The gather moves 8 + 80 bytes per
-// pixel (a sixth of x's bytes): a thread owns one 16-byte chunk = two taps x four channels, 5 lanes cover a pixel's row.
-constexpr int kPredG = 40;             // columns of G
+// pixel (a sixth of x's bytes): a thread owns one 16-byte chunk = two taps x four channels, 8 lanes cover a pixel's row (chunks 5-7
+// and the second half of chunk 4 are zero columns).
+// Round 5: the same G gives the DATA gradient dX[q][ci] = sum over (tap, co) of G[q][tap * 4 + co] * W[co][tap][ci] — a 1x1 conv
+// with K = 64 over G (osd_pred_dy_gather + osd_pred_dgrad_pack + osd_conv2d_fwd) instead of a 3x3 conv over dy whose 4 input
+// channels are padded to 64 per tap (K = 576 for 36 real: 118 - 132 us on the critical chain for a 70 MB write).
+constexpr int kPredG = 64;             // columns of G (36 used; round 5: 64 instead of 40 so that G is also the input of the DATA gradient as a 1x1 conv with K = 64)
 struct PredGatherLevels { const void* dy[kPredLevels]; int H[kPredLevels], W[kPredLevels], npix[kPredLevels], begin[kPredLevels]; int n_levels; };
 
 template <typename T>
 __global__ void __launch_bounds__(256) pred_dy_gather_kernel(PredGatherLevels L, T* __restrict__ g, int dy_stride) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;          // (pixel over all levels, chunk)
-  const int c8 = (int)(idx % 5);
-  const int q_all = (int)(idx / 5);
+  const int c8 = (int)(idx & 7);
+  const int q_all = (int)(idx >> 3);
   int lvl = -1;
 #pragma unroll
   for (int i = 0; i < kPredLevels; ++i)
@@ -1248,6 +1252,70 @@ static int pred_ppb(int n_seg, const int32_t* ns, const int32_t* hs, const int32
   return ppb;
 }
 
+
+static int pred_gather_launch(int dtype, int n_seg, const void* const* dys, const int32_t* ns, const int32_t* hs, const int32_t* ws,
+                              int dy_stride, void* g, hipStream_t st) {
+  PredGatherLevels L;
+  L.n_levels = n_seg;
+  long long tot = 0;
+  for (int i = 0; i < kPredLevels; ++i) {
+    const int j = i < n_seg ? i : 0;
+    const long long npix = (long long)ns[j] * hs[j] * ws[j];
+    L.dy[i] = dys[j]; L.H[i] = hs[j]; L.W[i] = ws[j]; L.npix[i] = i < n_seg ? (int)npix : 0; L.begin[i] = (int)tot;
+    if (i < n_seg) tot += npix;
+  }
+  if (tot * 8 > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "pred_dy_gather: too many pixels");
+  const unsigned gblocks = (unsigned)((tot * 8 + 255) / 256);
+  if (dtype == OSD_F32)
+    hipLaunchKernelGGL(pred_dy_gather_kernel<float>, dim3(gblocks), dim3(256), 0, st, L, (float*)g, dy_stride);
+  else
+    hipLaunchKernelGGL(pred_dy_gather_kernel<__bf16>, dim3(gblocks), dim3(256), 0, st, L, (__bf16*)g, dy_stride);
+  return osd_check_launch("pred_dy_gather");
+}
+
+// the weight gradient from G [pixels of all levels][64] (gathered by the caller): T[tap * 4 + co][ci] by the MFMA weight-gradient
+// kernel on the 1x1 problem (x, G), then the scatter into dw / db.  workspace: [column sums: 256 B][T: 64 x cin fp32]
+static int pred_wgrad_from_g(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* g, const int32_t* ns, const int32_t* hs,
+                             const int32_t* ws, float* dw, float* db, void* workspace, hipStream_t st) {
+  const size_t esz = d->dtype == OSD_BF16 ? 2 : 4;
+  float* dbg = static_cast<float*>(workspace);
+  float* tbuf = dbg + 64;
+  if (hipMemsetAsync(workspace, 0, 256 + (size_t)kPredG * d->cin * 4, st) != hipSuccess)
+    return osd_fail(OSD_ERR_LAUNCH, "wgrad_pred: memset failed");
+  osd_conv_desc d1[kPredLevels];
+  WgradProblem pr[kPredLevels];
+  long long tot = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    const long long npix = (long long)ns[i] * hs[i] * ws[i];
+    if (npix > 0x7fffffffLL / d->cin) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred: bad segment %d", i);
+    d1[i] = *d;
+    d1[i].cout = 36; d1[i].r = 1; d1[i].s = 1; d1[i].pad_h = 0; d1[i].pad_w = 0; d1[i].out_stride = kPredG;
+    static int code = -1;                    // split-target code (OSD_PRED_WGRAD_CODE: A/B); 512 workgroups measured best (65 us; 128: 102, 1,024: 90)
+    if (code < 0) { const char* e = getenv("OSD_PRED_WGRAD_CODE"); code = e ? atoi(e) & 7 : 0; }
+    d1[i].algo = 1 + 0 + 16 * code;          // 128 x 128 tile, 32-pixel stages
+    pr[i] = WgradProblem{&d1[i], ns[i], hs[i], ws[i], xs[i], static_cast<const char*>(g) + (size_t)tot * kPredG * esz, nullptr, tbuf, db ? dbg : nullptr};
+    tot += npix;
+  }
+  int rc = wgrad_launch(n_seg, pr, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pred_wgrad_scatter_kernel, dim3(cdiv(d->cout * 9 * d->cin, 256)), dim3(256), 0, st, (const float*)tbuf, (const float*)dbg,
+                     dw, db, d->cout, d->cin);
+  return osd_check_launch("pred_wgrad_scatter");
+}
+
+// Wd[ci][tap * 4 + co] = w[co][tap][ci]: the prediction conv's weights as the [cin rows][64] matrix of the 1x1 data-gradient conv
+// over G (columns >= 36, and co >= cout, are zero)
+template <typename T>
+__global__ void __launch_bounds__(256) pred_dgrad_pack_kernel(const float* __restrict__ w, T* __restrict__ wd, int cout, int cin) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cin * kPredG) return;
+  const int ci = i / kPredG, col = i - ci * kPredG;
+  const int tap = col >> 2, co = col & 3;
+  float v = 0.f;
+  if (tap < 9 && co < cout) v = w[((size_t)co * 9 + tap) * cin + ci];
+  wd[i] = from_f32<T>(v);
+}
+
 extern "C" int64_t osd_conv2d_wgrad_pred_workspace_bytes(int n_seg, const int32_t* ns, const int32_t* hs, const int32_t* ws,
                                                          int cin) {
   if (n_seg < 1 || !ns || !hs || !ws || cin <= 0) return 0;
@@ -1255,7 +1323,7 @@ extern "C" int64_t osd_conv2d_wgrad_pred_workspace_bytes(int n_seg, const int32_
   long long tot = 0;
   for (int i = 0; i < n_seg; ++i) tot += (long long)ns[i] * hs[i] * ws[i];
   const long long readonce = blocks * ((cin + 255) / 256) * 36 * 256 * 4 + blocks * 16 * 4 + 256;
-  const long long gather = tot * kPredG * 4 + (long long)kPredG * cin * 4 + 1024;      // G [pixels][40] (widest dtype) + T [40][cin] + column sums
+  const long long gather = tot * kPredG * 4 + (long long)kPredG * cin * 4 + 1024;      // G [pixels][64] (widest dtype) + T [64][cin] + column sums
   return (int64_t)(readonce > gather ? readonce : gather);
 }
 
@@ -1276,46 +1344,11 @@ extern "C" int osd_conv2d_wgrad_pred(const osd_conv_desc* d, int n_seg, const vo
   if (use_gemm < 0) { const char* e = getenv("OSD_PRED_WGRAD_READONCE"); use_gemm = (e && e[0] == '1') ? 0 : 1; }
   if (use_gemm) {
     hipStream_t st = OSD_STREAM(stream);
-    const size_t esz = d->dtype == OSD_BF16 ? 2 : 4;
-    // workspace: [column sums: 256 B][T: 40 x cin fp32][G: pixels x 40]
-    float* dbg = static_cast<float*>(workspace);
-    float* tbuf = dbg + 64;
-    char* gbase = reinterpret_cast<char*>(tbuf + (size_t)kPredG * d->cin);
-    if (hipMemsetAsync(workspace, 0, 256 + (size_t)kPredG * d->cin * 4, st) != hipSuccess)
-      return osd_fail(OSD_ERR_LAUNCH, "wgrad_pred: memset failed");
-    PredGatherLevels L;
-    L.n_levels = n_seg;
-    osd_conv_desc d1[kPredLevels];
-    WgradProblem pr[kPredLevels];
-    long long tot = 0;
-    for (int i = 0; i < kPredLevels; ++i) {
-      const int j = i < n_seg ? i : 0;
-      const long long npix = (long long)ns[j] * hs[j] * ws[j];
-      if (npix > 0x7fffffffLL / d->cin) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred: bad segment %d", j);
-      L.dy[i] = dys[j]; L.H[i] = hs[j]; L.W[i] = ws[j]; L.npix[i] = i < n_seg ? (int)npix : 0; L.begin[i] = (int)tot;
-      if (i < n_seg) {
-        d1[i] = *d;
-        d1[i].cout = 36; d1[i].r = 1; d1[i].s = 1; d1[i].pad_h = 0; d1[i].pad_w = 0; d1[i].out_stride = kPredG;
-        static int code = -1;                    // split-target code (OSD_PRED_WGRAD_CODE: A/B); 512 workgroups measured best (65 us; 128: 102, 1,024: 90)
-        if (code < 0) { const char* e = getenv("OSD_PRED_WGRAD_CODE"); code = e ? atoi(e) & 7 : 0; }
-        d1[i].algo = 1 + 0 + 16 * code;          // 128 x 128 tile, 32-pixel stages
-        pr[i] = WgradProblem{&d1[i], ns[i], hs[i], ws[i], xs[i], gbase + (size_t)tot * kPredG * esz, nullptr, tbuf, db ? dbg : nullptr};
-        tot += npix;
-      }
-    }
-    if (tot * 5 > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred: too many pixels");
-    const unsigned gblocks = (unsigned)((tot * 5 + 255) / 256);
-    if (d->dtype == OSD_F32)
-      hipLaunchKernelGGL(pred_dy_gather_kernel<float>, dim3(gblocks), dim3(256), 0, st, L, (float*)gbase, d->out_stride);
-    else
-      hipLaunchKernelGGL(pred_dy_gather_kernel<__bf16>, dim3(gblocks), dim3(256), 0, st, L, (__bf16*)gbase, d->out_stride);
-    int rc = osd_check_launch("pred_dy_gather");
+    // workspace: [column sums: 256 B][T: 64 x cin fp32][G: pixels x 64]
+    char* gbase = reinterpret_cast<char*>(static_cast<float*>(workspace) + 64 + (size_t)kPredG * d->cin);
+    int rc = pred_gather_launch(d->dtype, n_seg, dys, ns, hs, ws, d->out_stride, gbase, st);
     if (rc) return rc;
-    rc = wgrad_launch(n_seg, pr, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(pred_wgrad_scatter_kernel, dim3(cdiv(d->cout * 9 * d->cin, 256)), dim3(256), 0, st, (const float*)tbuf, (const float*)dbg,
-                       dw, db, d->cout, d->cin);
-    return osd_check_launch("pred_wgrad_scatter");
+    return pred_wgrad_from_g(d, n_seg, xs, gbase, ns, hs, ws, dw, db, workspace, st);
   }
   PredWgradLevels L;
   L.n_levels = 0;
@@ -1345,6 +1378,48 @@ extern "C" int osd_conv2d_wgrad_pred(const osd_conv_desc* d, int n_seg, const vo
   hipLaunchKernelGGL(pred_wgrad_reduce_kernel, dim3(cdiv(n, 256), 16), dim3(256), 0, st, (const float*)part, (const float*)part_b, dw, db,
                      blocks, groups, d->cin, d->cout);
   return osd_check_launch("pred_wgrad(reduce)");
+}
+
+static int pred_check(const char* who, const osd_conv_desc* d, int n_seg, const int32_t* ns, const int32_t* hs, const int32_t* ws) {
+  if (!d || !ns || !hs || !ws || n_seg < 1 || n_seg > kPredLevels) return osd_fail(OSD_ERR_INVALID_ARG, "%s: bad arguments (1..%d levels)", who, kPredLevels);
+  if (d->dtype != OSD_F32 && d->dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "%s: bad dtype", who);
+  if (d->cout < 1 || d->cout > 4 || d->r != 3 || d->s != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1 ||
+      d->cin % 256 != 0 || d->out_stride % 4 != 0)
+    return osd_fail(OSD_ERR_UNSUPPORTED, "%s: 3x3 / stride 1 / pad 1, cout <= 4, cin %% 256 == 0, dy rows of >= 4 channels", who);
+  for (int i = 0; i < n_seg; ++i)
+    if (ns[i] <= 0 || hs[i] <= 0 || ws[i] <= 0) return osd_fail(OSD_ERR_INVALID_ARG, "%s: bad segment %d", who, i);
+  return OSD_OK;
+}
+
+extern "C" int osd_pred_dy_gather(const osd_conv_desc* d, int n_seg, const void* const* dys, const int32_t* ns, const int32_t* hs,
+                                  const int32_t* ws, void* g, void* stream) {
+  if (!dys || !g) return osd_fail(OSD_ERR_INVALID_ARG, "pred_dy_gather: null argument");
+  int rc = pred_check("pred_dy_gather", d, n_seg, ns, hs, ws);
+  if (rc) return rc;
+  for (int i = 0; i < n_seg; ++i)
+    if (!dys[i]) return osd_fail(OSD_ERR_INVALID_ARG, "pred_dy_gather: null segment %d", i);
+  return pred_gather_launch(d->dtype, n_seg, dys, ns, hs, ws, d->out_stride, g, OSD_STREAM(stream));
+}
+
+extern "C" int osd_pred_dgrad_pack(int dtype, const float* w, int cout, int cin, void* wd, void* stream) {
+  if (!w || !wd || cout < 1 || cout > 4 || cin < 1) return osd_fail(OSD_ERR_INVALID_ARG, "pred_dgrad_pack: bad arguments (cout 1..4)");
+  if (dtype != OSD_F32 && dtype != OSD_BF16) return osd_fail(OSD_ERR_INVALID_ARG, "pred_dgrad_pack: bad dtype");
+  const unsigned blocks = (unsigned)cdiv(cin * kPredG, 256);
+  if (dtype == OSD_F32)
+    hipLaunchKernelGGL(pred_dgrad_pack_kernel<float>, dim3(blocks), dim3(256), 0, OSD_STREAM(stream), w, (float*)wd, cout, cin);
+  else
+    hipLaunchKernelGGL(pred_dgrad_pack_kernel<__bf16>, dim3(blocks), dim3(256), 0, OSD_STREAM(stream), w, (__bf16*)wd, cout, cin);
+  return osd_check_launch("pred_dgrad_pack");
+}
+
+extern "C" int osd_conv2d_wgrad_pred_gathered(const osd_conv_desc* d, int n_seg, const void* const* xs, const void* g, const int32_t* ns,
+                                              const int32_t* hs, const int32_t* ws, float* dw, float* db, void* workspace, void* stream) {
+  if (!xs || !g || !dw || !workspace) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred_gathered: null argument");
+  int rc = pred_check("wgrad_pred_gathered", d, n_seg, ns, hs, ws);
+  if (rc) return rc;
+  for (int i = 0; i < n_seg; ++i)
+    if (!xs[i]) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad_pred_gathered: null segment %d", i);
+  return pred_wgrad_from_g(d, n_seg, xs, g, ns, hs, ws, dw, db, workspace, OSD_STREAM(stream));
 }
 
 // n_seg convs of IDENTICAL geometry (same x / dy shapes, different tensors and different weights: the repeated bottleneck

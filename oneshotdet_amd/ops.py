@@ -652,8 +652,43 @@ def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None, db=None,
     _rec("wgrad", items=[dict(x=x, dy=dy, dw=dw_packed, scale=scale, db=db, r=r, s=s, stride=stride, pad=pad, cout=cout)])
 
 
-def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, db=None, algo=None):
-    """One launch over several (x, dy) pairs sharing the weights (FPN levels): dw_packed += sum over pairs."""
+PRED_G = 64      # columns of the prediction convs' gathered dy matrix (osd_pred_dy_gather)
+
+
+def pred_gemm_ok(cout, r, s, stride, pad, cin, n_levels):
+    """Do the prediction convs' GEMM paths (weight gradient and data gradient over the gathered dy matrix G) cover this conv?"""
+    return cout <= 4 and (r, s, stride, pad) == (3, 3, 1, 1) and cin % 256 == 0 and n_levels <= 6
+
+
+def pred_dy_gather(dys, cout, cin):
+    """G[q][tap * 4 + co] = dy[q - (tap / 3 - 1, tap % 3 - 1)][co] for every pixel q of the levels `dys` (NHWC, >= 4 channels stored), the
+    levels one after the other: [sum n h w][64].  Shared by the prediction convs' weight gradient and data gradient."""
+    dy0 = dys[0]
+    d = _conv_desc((dy0.shape[0], dy0.shape[1], dy0.shape[2], cin), _dt(dy0), cout, 3, 3, 1, 1, dy0.shape[-1])
+    k = len(dys)
+    tot = sum(t.shape[0] * t.shape[1] * t.shape[2] for t in dys)
+    g = torch.empty((tot, PRED_G), device=dy0.device, dtype=dy0.dtype)
+    ptrs = (C.c_void_p * k)(*[t.data_ptr() for t in dys])
+    ns = (C.c_int32 * k)(*[t.shape[0] for t in dys])
+    hs = (C.c_int32 * k)(*[t.shape[1] for t in dys])
+    ws = (C.c_int32 * k)(*[t.shape[2] for t in dys])
+    _lib.call("osd_pred_dy_gather", C.byref(d), k, ptrs, ns, hs, ws, _ptr(g), _stream())
+    _rec("pred_gather", dys=list(dys), cout=cout, out=g)
+    return g
+
+
+def pred_dgrad_pack(w_master, cout, cin, dtype, out=None):
+    """The prediction conv's fp32 master [cout][3][3][cin] as the packed weights of the 1x1 data-gradient conv over G: a PackedConv
+    with cin rows of 64 columns (column tap * 4 + co)."""
+    wd = torch.empty((cin, 1, 1, PRED_G), device=w_master.device, dtype=dtype) if out is None else out
+    _lib.call("osd_pred_dgrad_pack", _dt(wd), _ptr(w_master), cout, cin, _ptr(wd), _stream())
+    _rec("pred_dgrad_pack", w=w_master, cout=cout, cin=cin, out=wd)
+    return wd
+
+
+def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, db=None, algo=None, g=None):
+    """One launch over several (x, dy) pairs sharing the weights (FPN levels): dw_packed += sum over pairs.
+    g: the prediction convs' gathered dy matrix (pred_dy_gather) when the caller has built it already (the data gradient shares it)."""
     x0, dy0 = pairs[0]
     d = _conv_desc(x0.shape, _dt(x0), cout, r, s, stride, pad, dy0.shape[-1])
     k = len(pairs)
@@ -666,9 +701,13 @@ def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, 
     if (cout <= 4 and (r, s, stride, pad) == (3, 3, 1, 1) and x0.shape[-1] % 256 == 0 and scale is None and k <= 6
             and not os.environ.get("OSD_NO_PRED_WGRAD")):
         # prediction convs (2 / 4 output channels): the read-once kernel, not a 128-channel MFMA tile
-        need = int(_lib.load().osd_conv2d_wgrad_pred_workspace_bytes(k, ns, hs, ws, x0.shape[-1]))
-        wsp = torch.empty((need // 4 + 1,), device=x0.device, dtype=torch.float32)
-        _lib.call("osd_conv2d_wgrad_pred", C.byref(d), k, xs, dys, ns, hs, ws, _ptr(dw_packed), _ptr(db), _ptr(wsp), st)
+        if g is not None and not os.environ.get("OSD_PRED_WGRAD_READONCE"):
+            wsp = torch.empty((64 + PRED_G * x0.shape[-1] + 64,), device=x0.device, dtype=torch.float32)
+            _lib.call("osd_conv2d_wgrad_pred_gathered", C.byref(d), k, xs, _ptr(g), ns, hs, ws, _ptr(dw_packed), _ptr(db), _ptr(wsp), st)
+        else:
+            need = int(_lib.load().osd_conv2d_wgrad_pred_workspace_bytes(k, ns, hs, ws, x0.shape[-1]))
+            wsp = torch.empty((need // 4 + 1,), device=x0.device, dtype=torch.float32)
+            _lib.call("osd_conv2d_wgrad_pred", C.byref(d), k, xs, dys, ns, hs, ws, _ptr(dw_packed), _ptr(db), _ptr(wsp), st)
         _rec("wgrad", items=[dict(x=x, dy=dy, dw=dw_packed, scale=None, db=db, r=r, s=s, stride=stride, pad=pad, cout=cout)
                              for x, dy in pairs])
         return

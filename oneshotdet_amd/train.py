@@ -140,6 +140,10 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         self._grads_clean, self._zeroed = False, set()
         self._wqs = None
         self._pred_grad_bufs = {}
+        # the prediction convs' data gradient as a 1x1 conv over the gathered dy matrix the weight gradient builds anyway (round 5;
+        # OSD_NO_PRED_DGRAD_GEMM=1: the 3x3 conv over dy, A/B)
+        self.pred_dgrad_gemm = os.environ.get("OSD_NO_PRED_DGRAD_GEMM", "0") == "0"
+        self._pred_dgrad = {}
         # ordered weight gradients (bit-reproducible dW of every conv_wgrad launch; measured 6 % slower on the tower launch,
         # 20-55 % on the short ones: off by default, OSD_WGRAD_ORDERED=1 or ordered_wgrad=True): 1 GiB of scratch per stream
         if ordered_wgrad is None:

@@ -68,9 +68,33 @@ class BackwardPass(object):
                          for c, x, dy, stride, pad in part]
                 self._on_wstream(lambda items=items: ops.conv2d_wgrad_mixed(items), items, which)
 
-    def _wgrad_grouped(self, c, pairs, which=0):
+    def _wgrad_grouped(self, c, pairs, which=0, g=None):
         self._on_wstream(lambda: ops.conv2d_wgrad_grouped(pairs, c.gw, c.r, c.s, 1, c.r // 2, c.cout, scale=c.bn_scale,
-                                                          db=c.gb if c.has_bias else None), pairs, which)
+                                                          db=c.gb if c.has_bias else None, g=g), (pairs, g), which)
+
+    def _pred_backward(self, c, t_last, dpred, which):
+        """Weight AND data gradient of a prediction conv (cls_logits + centerness fused / bbox_pred, fcos.py:50-61,91-97) over the FPN
+        levels from ONE gathered matrix G [pixels][64] (the nine shifted dy vectors of every pixel side by side): the weight
+        gradient as the 1x1 problem (t_last, G) on the side stream, the data gradient as a 1x1 conv with K = 64 over G — one launch
+        that writes all levels (round 5; until then a 3x3 conv over dy with its 2 / 4 input channels padded to 64 per tap:
+        118 - 132 us on the critical chain for a 70 MB write).  -> the per-level d(t_last), views of one buffer."""
+        nl = len(dpred)
+        g = ops.pred_dy_gather(dpred, c.cout, c.cin)
+        self._wgrad_grouped(c, [(t_last[l], dpred[l]) for l in range(nl)], which, g=g)
+        key = ("pred_dgrad", c.name)
+        ent = self._pred_dgrad.get(key)
+        if ent is None:
+            wd = torch.empty((c.cin, 1, 1, ops.PRED_G), device=self.device, dtype=self.dtype)
+            ent = self._pred_dgrad[key] = ops.PackedConv(wd, torch.zeros(ops._round_up(c.cin, 16), device=self.device, dtype=torch.float32),
+                                                         c.cin, c.cin, c.cin, ops.PRED_G, 1, 1, cin_real=9 * c.cout)
+        ops.pred_dgrad_pack(c.w, c.cout, c.cin, self.dtype, out=ent.w)      # (the master changes every step: 256 x 64 values)
+        dx = ops.conv2d(g.view(1, 1, g.shape[0], ops.PRED_G), ent)
+        out, q0 = [], 0
+        for t in dpred:
+            n, hh, ww = t.shape[0], t.shape[1], t.shape[2]
+            out.append(dx.view(-1, c.cin)[q0:q0 + n * hh * ww].view(n, hh, ww, c.cin))
+            q0 += n * hh * ww
+        return out
 
     def _dgrad_levels(self, c, dys):
         """Data gradient of a conv shared by the FPN levels: one grouped launch (forward kernel, flipped weights)."""
@@ -112,8 +136,11 @@ class BackwardPass(object):
             layers, t_last = ctxs[tw]
             pc = cv[h + ("cls_ctr" if tw == "cls_tower" else "bbox_pred")]
             dpred = [pred_grads[l][k] for l in range(nl)]
-            self._wgrad_grouped(pc, [(t_last[l], dpred[l]) for l in range(nl)], k)
-            d_t[tw] = self._dgrad_levels(pc, dpred)
+            if self.pred_dgrad_gemm and ops.pred_gemm_ok(pc.cout, pc.r, pc.s, 1, pc.r // 2, pc.cin, nl):
+                d_t[tw] = self._pred_backward(pc, t_last, dpred, k)
+            else:
+                self._wgrad_grouped(pc, [(t_last[l], dpred[l]) for l in range(nl)], k)
+                d_t[tw] = self._dgrad_levels(pc, dpred)
         # GroupNorm-backward statistics of layer i - 1 are gathered by the epilogue of the data-gradient conv of layer i (the
         # conv that writes the gradient w.r.t. that GroupNorm's output) where the kernel can (ops.gn_bwd_fusable: the large
         # levels); the GroupNorm backward of those levels then is one pass over (u, dt) instead of two.  Not in ordered mode:

@@ -194,6 +194,35 @@ def wgrad_launch(x, dy, r, s, stride, pad, cout, scale=None, want_bias=False):
     return dw.permute(0, 2, 3, 1).contiguous(), db
 
 
+def pred_gather_launch(dys):
+    """osd_pred_dy_gather: G[q][tap * 4 + co] = dy[q - (tap / 3 - 1, tap % 3 - 1)][co] (co < 4, 64 columns, zero outside the map), the levels
+    one after the other — the prediction convs' (fcos.py:50-61) output gradients laid out so that both their weight gradient and
+    their data gradient are 1x1 problems.  A pure copy: exact."""
+    rows = []
+    for dy in dys:
+        n, h, w, _ = dy.shape
+        d = dy[..., :4].float()
+        g = torch.zeros((n, h, w, 64), dtype=torch.float32)
+        for tap in range(9):
+            oy, ox = tap // 3 - 1, tap % 3 - 1
+            y0, y1, x0, x1 = max(0, oy), h + min(0, oy), max(0, ox), w + min(0, ox)       # q with q - (oy, ox) inside the map
+            if y1 > y0 and x1 > x0:
+                g[:, y0:y1, x0:x1, tap * 4:tap * 4 + 4] = d[:, y0 - oy:y1 - oy, x0 - ox:x1 - ox, :]
+        rows.append(g.reshape(-1, 64))
+    return torch.cat(rows, 0)
+
+
+def pred_dgrad_pack_launch(w, cout, cin):
+    """osd_pred_dgrad_pack: the fp32 master [cout][3][3][cin] as the [cin][1][1][64] weights of the 1x1 data-gradient conv over G:
+    column tap * 4 + co of row ci = w[co][tap][ci]; the other columns zero."""
+    w = w.float().reshape(cout, 9, cin)
+    wd = torch.zeros((cin, 64), dtype=torch.float32)
+    for tap in range(9):
+        for co in range(cout):
+            wd[:, tap * 4 + co] = w[co, tap]
+    return wd.view(cin, 1, 1, 64)
+
+
 def fcos_loss_grad_launch(head_out, gt_boxes, gt_count, scales, gamma, alpha):
     """Phase 1 of osd_fcos_loss_levels: d loss / d (logit, centerness) and d loss / d (bbox_pred conv output) from the STORED
     head outputs, by autograd of the loss restated in hotpath_ref.fcos_loss (fcos/loss.py:213-276).  reg = exp(scale * x), so

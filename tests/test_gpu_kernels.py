@@ -348,6 +348,55 @@ def test_conv2d_pixel_stationary_pointwise_kernel_is_bit_identical(m_shape, cin,
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("cout", [2, 4])
+def test_prediction_conv_data_gradient_as_a_gemm_over_the_gathered_dy(dt, cout):
+    """Round 5: the data gradient of the FCOS prediction convs (cls_logits + centerness fused: 2 outputs, bbox_pred: 4; fcos.py:50-61,
+    3x3 / pad 1 over the five FPN levels) as osd_pred_dy_gather -> G [pixels][64] (the nine shifted dy vectors of every pixel side by
+    side) + osd_pred_dgrad_pack (W as [cin][64]) + ONE 1x1 conv with K = 64 over all levels, against autograd of F.conv2d per
+    level, and the weight gradient from the same G (osd_conv2d_wgrad_pred_gathered) against autograd too.  Levels of every
+    size down to 1 x 1 and 1 x 3 (all nine taps cross the border), dy stored with 4 channels."""
+    o = ops()
+    cin = 256
+    sizes = [(2, 25, 32), (2, 13, 16), (2, 7, 8), (1, 1, 3), (3, 1, 1)]
+    w = (rnd(cout, cin, 3, 3, seed=1) / 48)
+    dys = [rnd(n, 4, h, ww, seed=10 + i) for i, (n, h, ww) in enumerate(sizes)]
+    xs = [rnd(n, cin, h, ww, seed=20 + i) for i, (n, h, ww) in enumerate(sizes)]
+    for d in dys:
+        d[:, cout:] = 0.0                      # the channels past cout are stored as zeros by the loss kernel
+    if dt == "bf16":
+        w, dys, xs = w.bfloat16().float(), [d.bfloat16().float() for d in dys], [x.bfloat16().float() for x in xs]
+    dev_dys = [to_nhwc(d, DT[dt]) for d in dys]
+    dev_xs = [to_nhwc(x, DT[dt]) for x in xs]
+    master = w.permute(0, 2, 3, 1).contiguous().cuda()           # [cout][3][3][cin] fp32
+    g = o.pred_dy_gather(dev_dys, cout, cin)
+    assert tuple(g.shape) == (sum(n * h * ww for n, h, ww in sizes), 64)
+    wd = o.pred_dgrad_pack(master, cout, cin, DT[dt])
+    pcd = o.PackedConv(wd, torch.zeros(cin, device="cuda"), cin, cin, cin, 64, 1, 1, cin_real=9 * cout)
+    dx = o.conv2d(g.view(1, 1, g.shape[0], 64), pcd).view(-1, cin)
+    dw = torch.zeros((cout, 3, 3, cin), device="cuda")
+    db = torch.zeros((cout,), device="cuda")
+    o.conv2d_wgrad_grouped(list(zip(dev_xs, dev_dys)), dw, 3, 3, 1, 1, cout, db=db, g=g)
+    q0 = 0
+    ref_dw, ref_db = torch.zeros(cout, cin, 3, 3), torch.zeros(cout)
+    for (n, h, ww), d, x in zip(sizes, dys, xs):
+        xr = x.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        br = torch.zeros(cout, requires_grad=True)
+        F.conv2d(xr, wr, br, padding=1).backward(d[:, :cout])
+        got = dx[q0:q0 + n * h * ww].view(n, h, ww, cin).permute(0, 3, 1, 2).float().cpu()
+        torch.testing.assert_close(got, xr.grad, **TOL[dt])
+        ref_dw += wr.grad
+        ref_db += br.grad
+        q0 += n * h * ww
+    scale = float(ref_dw.abs().max())
+    assert float((dw.permute(0, 3, 1, 2).cpu() - ref_dw).abs().max()) <= (2e-2 if dt == "bf16" else 1e-4) * scale
+    torch.testing.assert_close(db.cpu(), ref_db, rtol=1e-3, atol=1e-3 * float(ref_db.abs().max()))
+    # the gathered matrix itself: every column of every pixel, exactly
+    from oracle import launch_replay as lr
+    assert torch.equal(g.float().cpu(), lr.pred_gather_launch([t.cpu() for t in dev_dys]).to(DT[dt]).float())
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv2d_grouped_equals_per_level_launches(dt):
     """osd_conv2d_fwd_grouped (one launch over the FPN levels that share a tower conv, fcos.py:83-99) against one
     osd_conv2d_fwd launch per level with the same algorithm: the per-tile arithmetic is identical, so the outputs must

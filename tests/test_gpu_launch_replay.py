@@ -127,6 +127,12 @@ class Replayer(object):
             if it["db"] is not None:
                 self._accumulate(it["db"], db)
 
+    def do_pred_gather(self, r):
+        self._check("pred_gather", r["out"], lr.pred_gather_launch([cpu(t) for t in r["dys"]]))
+
+    def do_pred_dgrad_pack(self, r):
+        self._check("pred_dgrad_pack", r["out"], lr.pred_dgrad_pack_launch(cpu(r["w"]), r["cout"], r["cin"]))
+
     def do_fcos_loss(self, r):
         if r["phase"] != 1:
             return
@@ -198,7 +204,7 @@ def test_every_launch_of_a_training_step_matches_its_cpu_restatement(name, dt):
     # coverage: the step's launch kinds are all there ...
     for kind in ("pack_image", "conv1x1", "conv3x3", "conv7x1", "maxpool", "roi_align", "shot_mean", "correlate", "gn_relu",
                  "fcos_loss_grad", "gn_relu_bwd", "correlate_bwd_query", "roi_align_bwd", "shot_mean_bwd", "wgrad", "add_mask",
-                 "scatter2x", "upsample2x_bwd"):
+                 "scatter2x", "upsample2x_bwd", "pred_gather", "pred_dgrad_pack"):
         assert rp.counts.get(kind, 0) > 0, "no %s launch in the trace" % kind
     # ... and every trainable conv weight / bias / GroupNorm affine gradient was produced by replayed launches
     flat_lo, flat_hi = eng.flat_g.data_ptr(), eng.flat_g.data_ptr() + eng.flat_g.numel() * 4

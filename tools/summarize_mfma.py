@@ -80,7 +80,7 @@ def main():
         f.write("| kernel | dispatches | total ms | MFMA busy share | eff. clock GHz |\n|---|---|---|---|---|\n")
         # the 24 largest by total time, plus — always — the 3x3 forward / data-gradient kernels (the step's dominant launch
         # runs on one of them; in a whole-process table the weight-gradient tuning sweeps outweigh it)
-        top = rows[:24] + [r for r in rows[24:] if any(t in r[0] for t in ("conv_sp_kernel", "conv_xr_kernel", "conv_p8_kernel", "conv_wgrad_sk_kernel"))]
+        top = rows[:24] + [r for r in rows[24:] if any(t in r[0] for t in ("conv_sp_kernel", "conv_px_kernel", "conv_wgrad_sk_kernel"))]
         for n, (c, busy, gui, ns) in top:
             f.write("| `%s` | %d | %.2f | %.3f | %.2f |\n" % (n, c, ns / 1e6, busy / (gui / 8 * 1024), gui / 8 / ns))
         f.write("| **all conv kernels** | %d | %.2f | **%.3f** | %.2f |\n" % (tot[0], tot[3] / 1e6, tot[1] / (tot[2] / 8 * 1024), tot[2] / 8 / tot[3]))
