@@ -144,6 +144,9 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         # OSD_NO_PRED_DGRAD_GEMM=1: the 3x3 conv over dy, A/B)
         self.pred_dgrad_gemm = os.environ.get("OSD_NO_PRED_DGRAD_GEMM", "0") == "0"
         self._pred_dgrad = {}
+        # experiment (train_backward._release_held_wgrads): "" = the towers' weight gradients go out where the head backward ends
+        self.tower_wgrad_at = os.environ.get("OSD_TOWER_WGRAD_AT", "")
+        self._held_wgrads = []
         # ordered weight gradients (bit-reproducible dW of every conv_wgrad launch; measured 6 % slower on the tower launch,
         # 20-55 % on the short ones: off by default, OSD_WGRAD_ORDERED=1 or ordered_wgrad=True): 1 GiB of scratch per stream
         if ordered_wgrad is None:
@@ -446,7 +449,8 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         losses, pred_grads = self.loss_and_grads(head_out, gt_boxes, gt_count)
         self.last_head_out, self.last_pred_grads = head_out, pred_grads      # (tests: conditioning of the Scale gradients)
         d_comb = self.head_backward(combined, hctx, pred_grads)
-        self._bucket_ready("head", 0, [st for st in (main, self.wstream, self.wstream2) if st is not None])
+        if not self._held_wgrads:
+            self._bucket_ready("head", 0, [st for st in (main, self.wstream, self.wstream2) if st is not None])
         # correlation backward (generalized_rcnn.py:307-311): d q = sum_hw g * feat, d feat = g * q
         dq = ops.correlate_bwd_query_levels(d_comb, feats) if self.corr_levels else \
             [ops.correlate_bwd_query(g, f) for g, f in zip(d_comb, feats)]

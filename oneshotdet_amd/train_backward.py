@@ -203,9 +203,25 @@ class BackwardPass(object):
                 d_t[tw] = out[k::nt]
         for tw in towers:
             c0 = cv["%s%s.0" % (h, tw)]
-            self._on_wstream(lambda it=items[tw], c0=c0: ops.conv2d_wgrad_multi(it, c0.r, c0.s, 1, c0.r // 2, c0.cout),
-                             items[tw], self.TOWERS.index(tw))
+            job = (lambda it=items[tw], c0=c0: ops.conv2d_wgrad_multi(it, c0.r, c0.s, 1, c0.r // 2, c0.cout), items[tw], self.TOWERS.index(tw))
+            if self.tower_wgrad_at:           # experiment: hold the towers' weight gradients until the backbone backward reaches a stage
+                self._held_wgrads.append(job)
+            else:
+                self._on_wstream(*job)
         return d_t
+
+    def _release_held_wgrads(self, point):
+        """OSD_TOWER_WGRAD_AT=<point> (experiment): the towers' 252-workgroup team-mode weight gradients take every CU for
+        ~0.6 ms each; launched where the head backward ends they stall the full-chip kernels behind them (the last tower data
+        gradient, the correlation backward, FPN P3); launched at `point` of the TARGET backbone's backward they run beside
+        layer4 / layer3 kernels that fill 100 - 200 of the 256 CUs."""
+        if self.tower_wgrad_at != point or not self._held_wgrads:
+            return
+        held, self._held_wgrads = self._held_wgrads, []
+        cur = torch.cuda.current_stream()
+        for job in held:
+            self._on_wstream(*job)
+        self._bucket_ready("head", 0, [st for st in (cur, self.wstream, self.wstream2) if st is not None])
 
     def backbones_backward(self, ctxs, dPs, which0=0):
         """Backward of both backbones in lockstep (the mirror of backbones_forward): every data-gradient conv is ONE launch
@@ -255,6 +271,8 @@ class BackwardPass(object):
         for j in range(nb):
             lateral[id(ctxs[j]["c4"])] = lat4[j]
             lateral[id(ctxs[j]["c3"])] = lat3[j]
+        if which0 == 0:
+            self._release_held_wgrads("fpn")
         # body, last block first.  `g` = gradient w.r.t. the block output, already masked by its ReLU.
         for bi in range(len(ctxs[0]["blocks"]) - 1, -1, -1):
             blks = [c["blocks"][bi] for c in ctxs]
@@ -274,6 +292,8 @@ class BackwardPass(object):
                 for j in range(nb):
                     self._flush_wgrads(j, which0 + j)
                     self._bucket_ready(bbs[j].rstrip(".") + "." + sname, which0 + j)
+                if which0 == 0:
+                    self._release_held_wgrads(stage)
             if blks[0]["first"]:
                 stage_done()
                 break                                   # input of layer2 = frozen layer1 output: no data gradient
@@ -294,4 +314,6 @@ class BackwardPass(object):
         for j in range(nb):             # later reads its packed weights
             self._flush_wgrads(j, which0 + j)
         self._wqs = None
+        if which0 == 0:
+            self._release_held_wgrads(self.tower_wgrad_at)      # whatever was not released on the way
         return None
