@@ -360,8 +360,18 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   using B2 = std::integral_constant<int, 2>;
   {
     for (int g = 0; g + 1 < G; ++g) {                     // every group but the last
-      int nkr = kr, nkc = kc + SP_BKE;                    // next group
+      // next group: the three FILTER ROWS of one 64-channel slab one after the other, then the next slab (round 5; until then
+      // all slabs of a filter row first).  The image of filter row kr + 1 is the image of kr shifted by one map line: two thirds
+      // of its lines were fetched a group ago and are still in the XCD's L2 (~64 KB per workgroup between the two reads; in
+      // the old order a whole pass over the other slabs lay between them, ~6 MB per XCD against 4 MB of L2).  PMC FETCH_SIZE of
+      // the tower launch: 145.5 MB for 67 MB of operands before (profiles/r5_pmc_traffic_by_kernel.txt)
+#ifdef OSD_SP_ROW_MAJOR_K
+      int nkr = kr, nkc = kc + SP_BKE;
       if (nkc >= Cin) { nkc = 0; ++nkr; }
+#else
+      int nkr = kr + 1, nkc = kc;
+      if (nkr >= 3) { nkr = 0; nkc += SP_BKE; }
+#endif
       const int kbase = kr * 3 * Cin + kc;                // K offset of tap 0 of this group; tap s adds s * Cin
       const int knext = nkr * 3 * Cin + nkc;              // ... of the next group
       // tap 0, first half: reads its own second half and fetches the NEXT group's pixel image (its buffer was vacated at the
