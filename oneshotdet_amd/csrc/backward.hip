@@ -491,41 +491,46 @@ __global__ void __launch_bounds__(256) correlate_bwd_q_kernel(const T* __restric
   }
 }
 
-// ROIAlign backward (csrc/cuda/ROIAlign_cuda.cu:125-254) on NHWC, fp32 gradient of the (tiny) query feature map
-__global__ void roialign_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ rois, float* __restrict__ gx, int h,
-                                    int w, int c, int num_rois, float scale, int ph, int pw, int sampling) {
-  const long long total = (long long)num_rois * ph * pw * c;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % c);
-    long long t = i / c;
-    const int px = (int)(t % pw); t /= pw;
-    const int py = (int)(t % ph);
-    const int r = (int)(t / ph);
-    const float* roi = rois + (size_t)r * 5;
-    const int b = (int)roi[0];
-    const float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
-    const float roi_w = fmaxf(rew - rsw, 1.f), roi_h = fmaxf(reh - rsh, 1.f);
-    const float bin_h = roi_h / (float)ph, bin_w = roi_w / (float)pw;
-    const int gh = sampling > 0 ? sampling : (int)ceilf(roi_h / ph);
-    const int gw = sampling > 0 ? sampling : (int)ceilf(roi_w / pw);
-    const float g = gy[i] / (float)(gh * gw);
-    float* base = gx + (size_t)b * h * w * c + ch;
-    for (int iy = 0; iy < gh; ++iy) {
-      const float yy = rsh + py * bin_h + (iy + .5f) * bin_h / (float)gh;
-      for (int ix = 0; ix < gw; ++ix) {
-        const float xx = rsw + px * bin_w + (ix + .5f) * bin_w / (float)gw;
-        float yv = yy, xv = xx;
-        if (yv < -1.0f || yv > (float)h || xv < -1.0f || xv > (float)w) continue;
-        if (yv <= 0.f) yv = 0.f;
-        if (xv <= 0.f) xv = 0.f;
-        int yl = (int)yv, xl = (int)xv, yh, xh;
-        if (yl >= h - 1) { yh = yl = h - 1; yv = (float)yl; } else { yh = yl + 1; }
-        if (xl >= w - 1) { xh = xl = w - 1; xv = (float)xl; } else { xh = xl + 1; }
-        const float ly = yv - yl, lx = xv - xl, hy = 1.f - ly, hx = 1.f - lx;
-        atomicAdd(base + ((size_t)yl * w + xl) * c, g * hy * hx);
-        atomicAdd(base + ((size_t)yl * w + xh) * c, g * hy * lx);
-        atomicAdd(base + ((size_t)yh * w + xl) * c, g * ly * hx);
-        atomicAdd(base + ((size_t)yh * w + xh) * c, g * ly * lx);
+// ROIAlign backward (csrc/cuda/ROIAlign_cuda.cu:125-254) on NHWC, fp32 gradient of the (tiny) query feature map.  Round 5: one
+// WAVEFRONT per output cell (roi, ph, pw) like the forward (elementwise.hip): the sample grid and the four tap pixels / weights of
+// every sample are wave-uniform, lane l adds the gradient of channels l, l + 64, ... — every atomic wave-instruction is one
+// contiguous 256-byte run of a tap pixel's channels (the shape the memory-side atomic unit runs at full rate on; the
+// one-thread-per-output mapping of the reference gives the same addresses but recomputes the geometry per channel).
+__global__ void __launch_bounds__(64) roialign_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ rois, float* __restrict__ gx, int h,
+                                                          int w, int c, int num_rois, float scale, int ph, int pw, int sampling) {
+  const int cell = blockIdx.x;
+  const int px = cell % pw, py = (cell / pw) % ph, r = cell / (pw * ph);
+  const int lane = threadIdx.x;
+  const float* roi = rois + (size_t)r * 5;
+  const int b = (int)roi[0];
+  const float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
+  const float roi_w = fmaxf(rew - rsw, 1.f), roi_h = fmaxf(reh - rsh, 1.f);
+  const float bin_h = roi_h / (float)ph, bin_w = roi_w / (float)pw;
+  const int gh = sampling > 0 ? sampling : (int)ceilf(roi_h / ph);
+  const int gw = sampling > 0 ? sampling : (int)ceilf(roi_w / pw);
+  const float inv = (float)(gh * gw);
+  float* img = gx + (size_t)b * h * w * c;
+  const float* grow = gy + (size_t)cell * c;
+  for (int iy = 0; iy < gh; ++iy) {
+    const float yy = rsh + py * bin_h + (iy + .5f) * bin_h / (float)gh;
+    for (int ix = 0; ix < gw; ++ix) {
+      const float xx = rsw + px * bin_w + (ix + .5f) * bin_w / (float)gw;
+      float yv = yy, xv = xx;
+      if (yv < -1.0f || yv > (float)h || xv < -1.0f || xv > (float)w) continue;      // wave-uniform
+      if (yv <= 0.f) yv = 0.f;
+      if (xv <= 0.f) xv = 0.f;
+      int yl = (int)yv, xl = (int)xv, yh, xh;
+      if (yl >= h - 1) { yh = yl = h - 1; yv = (float)yl; } else { yh = yl + 1; }
+      if (xl >= w - 1) { xh = xl = w - 1; xv = (float)xl; } else { xh = xl + 1; }
+      const float ly = yv - yl, lx = xv - xl, hy = 1.f - ly, hx = 1.f - lx;
+      float* t1 = img + ((size_t)yl * w + xl) * c, *t2 = img + ((size_t)yl * w + xh) * c;
+      float* t3 = img + ((size_t)yh * w + xl) * c, *t4 = img + ((size_t)yh * w + xh) * c;
+      for (int ch = lane; ch < c; ch += 64) {
+        const float g = grow[ch] / inv;
+        atomicAdd(t1 + ch, g * hy * hx);
+        atomicAdd(t2 + ch, g * hy * lx);
+        atomicAdd(t3 + ch, g * ly * hx);
+        atomicAdd(t4 + ch, g * ly * lx);
       }
     }
   }
@@ -801,7 +806,9 @@ extern "C" int osd_roialign_bwd(const float* gy, const float* rois, float* gx, i
   hipError_t er = hipMemsetAsync(gx, 0, sizeof(float) * (size_t)b * h * w * c, OSD_STREAM(stream));
   if (er != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "roialign_bwd: memset failed");
   if (num_rois == 0) return OSD_OK;
-  hipLaunchKernelGGL(roialign_bwd_kernel, dim3(grid_for((long long)num_rois * ph * pw * c, 256)), dim3(256), 0, OSD_STREAM(stream),
+  const long long cells = (long long)num_rois * ph * pw;      // one wavefront per output cell
+  if (cells > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "roialign_bwd: too many cells");
+  hipLaunchKernelGGL(roialign_bwd_kernel, dim3((unsigned)cells), dim3(64), 0, OSD_STREAM(stream),
                      gy, rois, gx, h, w, c, num_rois, spatial_scale, ph, pw, sampling_ratio);
   return osd_check_launch("roialign_bwd");
 }

@@ -242,35 +242,40 @@ __global__ void groupnorm_relu_apply_kernel(const T* __restrict__ x, const float
   }
 }
 
-// ------------------------------------------------------------------------------------------------ ROIAlign forward
-// Semantics of csrc/cuda/ROIAlign_cuda.cu:11-122 (bilinear_interpolate + RoIAlignForward) on an NHWC input.
-// One thread per (roi, ph, pw, channel); channel fastest so the 4 taps are coalesced channel runs.
+// ------------------------------------------------------------------------------------------------ ROIAlign forward (K5)
+// Semantics of csrc/cuda/ROIAlign_cuda.cu:11-122 (bilinear_interpolate + RoIAlignForward) on an NHWC input — restructured for wave64
+// (round 5): ONE WAVEFRONT per output cell (roi, ph, pw).  Everything that depends on the cell only — the sample
+// grid, the four tap pixels and weights of every sample, the border rules — is wave-uniform: it is computed once per wavefront on
+// the scalar unit (the reference's one-thread-per-output mapping recomputes it for every channel), and the 64 lanes stream the
+// channel run of each tap: lane l owns channels 4 l .. 4 l + 3 of every 256-channel slab (8 / 16 bytes per lane and tap: one
+// contiguous 512 / 1,024-byte run per wave-instruction).  The per-channel arithmetic is the reference's expression in its order
+// (out += w1 v1 + w2 v2 + w3 v3 + w4 v4 per sample, / count at the end).
 template <typename T>
-__global__ void roialign_fwd_kernel(const T* __restrict__ x, const float* __restrict__ rois, float* __restrict__ y, int h,
-                                    int w, int c, int num_rois, float scale, int ph, int pw, int sampling) {
-  const long long total = (long long)num_rois * ph * pw * c;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % c);
-    long long t = i / c;
-    const int px = (int)(t % pw); t /= pw;
-    const int py = (int)(t % ph);
-    const int r = (int)(t / ph);
-    const float* roi = rois + (size_t)r * 5;
-    const int b = (int)roi[0];
-    const float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
-    const float roi_w = fmaxf(rew - rsw, 1.f), roi_h = fmaxf(reh - rsh, 1.f);
-    const float bin_h = roi_h / (float)ph, bin_w = roi_w / (float)pw;
-    const int gh = sampling > 0 ? sampling : (int)ceilf(roi_h / ph);
-    const int gw = sampling > 0 ? sampling : (int)ceilf(roi_w / pw);
-    const float count = (float)(gh * gw);
-    const T* base = x + (size_t)b * h * w * c + ch;
-    float out = 0.f;
+__global__ void __launch_bounds__(64) roialign_fwd_kernel(const T* __restrict__ x, const float* __restrict__ rois, float* __restrict__ y, int h,
+                                                          int w, int c, int num_rois, float scale, int ph, int pw, int sampling) {
+  const int cell = blockIdx.x;                            // (roi, py, px)
+  const int px = cell % pw, py = (cell / pw) % ph, r = cell / (pw * ph);
+  const int lane = threadIdx.x;
+  const float* roi = rois + (size_t)r * 5;
+  const int b = (int)roi[0];
+  const float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
+  const float roi_w = fmaxf(rew - rsw, 1.f), roi_h = fmaxf(reh - rsh, 1.f);
+  const float bin_h = roi_h / (float)ph, bin_w = roi_w / (float)pw;
+  const int gh = sampling > 0 ? sampling : (int)ceilf(roi_h / ph);
+  const int gw = sampling > 0 ? sampling : (int)ceilf(roi_w / pw);
+  const float count = (float)(gh * gw);
+  const T* img = x + (size_t)b * h * w * c;
+  float* out_row = y + (size_t)cell * c;
+  const bool vec = (c & 3) == 0;
+  for (int c0 = 0; c0 < c; c0 += 256) {                   // 256-channel slabs (the FPN maps have exactly one)
+    const int ch = c0 + lane * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int iy = 0; iy < gh; ++iy) {
       const float yy = rsh + py * bin_h + (iy + .5f) * bin_h / (float)gh;
       for (int ix = 0; ix < gw; ++ix) {
         const float xx = rsw + px * bin_w + (ix + .5f) * bin_w / (float)gw;
         float yv = yy, xv = xx;
-        if (yv < -1.0f || yv > (float)h || xv < -1.0f || xv > (float)w) continue;
+        if (yv < -1.0f || yv > (float)h || xv < -1.0f || xv > (float)w) continue;      // wave-uniform
         if (yv <= 0.f) yv = 0.f;
         if (xv <= 0.f) xv = 0.f;
         int yl = (int)yv, xl = (int)xv, yh, xh;
@@ -278,12 +283,39 @@ __global__ void roialign_fwd_kernel(const T* __restrict__ x, const float* __rest
         if (xl >= w - 1) { xh = xl = w - 1; xv = (float)xl; } else { xh = xl + 1; }
         const float ly = yv - yl, lx = xv - xl, hy = 1.f - ly, hx = 1.f - lx;
         const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-        const float v1 = to_f32(base[((size_t)yl * w + xl) * c]), v2 = to_f32(base[((size_t)yl * w + xh) * c]);
-        const float v3 = to_f32(base[((size_t)yh * w + xl) * c]), v4 = to_f32(base[((size_t)yh * w + xh) * c]);
-        out += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+        const T* t1 = img + ((size_t)yl * w + xl) * c, *t2 = img + ((size_t)yl * w + xh) * c;
+        const T* t3 = img + ((size_t)yh * w + xl) * c, *t4 = img + ((size_t)yh * w + xh) * c;
+        if (vec) {
+          if (ch < c) {
+            float v1[4], v2[4], v3[4], v4[4];
+            if constexpr (sizeof(T) == 2) {
+              const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(t1 + ch), a2 = *reinterpret_cast<const bf16x4*>(t2 + ch);
+              const bf16x4 a3 = *reinterpret_cast<const bf16x4*>(t3 + ch), a4 = *reinterpret_cast<const bf16x4*>(t4 + ch);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v1[e] = (float)a1[e]; v2[e] = (float)a2[e]; v3[e] = (float)a3[e]; v4[e] = (float)a4[e]; }
+            } else {
+              const f32x4 a1 = *reinterpret_cast<const f32x4*>(t1 + ch), a2 = *reinterpret_cast<const f32x4*>(t2 + ch);
+              const f32x4 a3 = *reinterpret_cast<const f32x4*>(t3 + ch), a4 = *reinterpret_cast<const f32x4*>(t4 + ch);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v1[e] = a1[e]; v2[e] = a2[e]; v3[e] = a3[e]; v4[e] = a4[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+          }
+        } else {                                          // channel counts that are not multiples of 4: one value at a time
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ch + e < c) acc[e] += w1 * to_f32(t1[ch + e]) + w2 * to_f32(t2[ch + e]) + w3 * to_f32(t3[ch + e]) + w4 * to_f32(t4[ch + e]);
+        }
       }
     }
-    y[i] = out / count;
+    if (vec) {
+      if (ch < c) *reinterpret_cast<f32x4*>(out_row + ch) = f32x4{acc[0] / count, acc[1] / count, acc[2] / count, acc[3] / count};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (ch + e < c) out_row[ch + e] = acc[e] / count;
+    }
   }
 }
 
@@ -547,10 +579,12 @@ extern "C" int osd_roialign_fwd(const void* x, const float* rois, float* y, int 
   (void)b;
   if (num_rois == 0) return OSD_OK;
   if (!x || !rois || !y) return osd_fail(OSD_ERR_INVALID_ARG, "roialign: null argument");
-  const int g = grid_for((long long)num_rois * ph * pw * c, 256);
+  const long long cells = (long long)num_rois * ph * pw;      // one wavefront per output cell
+  if (cells <= 0 || cells > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "roialign: bad roi / cell count");
+  const int g = (int)cells;
   OSD_DISPATCH_DTYPE(dtype,
-      hipLaunchKernelGGL(roialign_fwd_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const float*)x, rois, y, h, w, c, num_rois, spatial_scale, ph, pw, sampling_ratio),
-      hipLaunchKernelGGL(roialign_fwd_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), (const __bf16*)x, rois, y, h, w, c, num_rois, spatial_scale, ph, pw, sampling_ratio));
+      hipLaunchKernelGGL(roialign_fwd_kernel<float>, dim3(g), dim3(64), 0, OSD_STREAM(stream), (const float*)x, rois, y, h, w, c, num_rois, spatial_scale, ph, pw, sampling_ratio),
+      hipLaunchKernelGGL(roialign_fwd_kernel<__bf16>, dim3(g), dim3(64), 0, OSD_STREAM(stream), (const __bf16*)x, rois, y, h, w, c, num_rois, spatial_scale, ph, pw, sampling_ratio));
   return osd_check_launch("roialign_fwd");
 }
 

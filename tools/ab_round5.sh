@@ -15,3 +15,11 @@ for i in $(seq $R); do
   run "current + conv_px among the tuner candidates" . OSD_PX=1
   run "current, no 128-channel conv_sp tile" . OSD_NO_SP_NARROW=1
 done
+# config5 (BASELINE.json configs[4]'s per-GPU workload) and forward mode against the base, same box: tools/ab_round5.sh <rounds> config5 | forward
+if [ "$2" = "config5" ] || [ "$2" = "forward" ]; then
+  [ "$2" = "config5" ] && ARGS="--no-cpu-baseline --no-conv-timing --workload config5 --steps 30 --warmup 9" || ARGS="--no-cpu-baseline --no-conv-timing --mode forward --dtype bf16"
+  for i in $(seq $R); do
+    run "base (round-4 head), $2" _ab/base X=1
+    run "current, $2" . X=1
+  done
+fi

@@ -33,8 +33,13 @@ def phases_of(trace, line):
     nst = int(re.search(r"(\d+) eager steps", line["roofline"]["measured"]).group(1))
     assert len(marks) >= 1 + w + k + nst, (len(marks), w, k, nst)
     cut = lambda j: marks[j] + 1            # noqa: E731   first dispatch after step j's loss
+    # the roofline pass: bench.py parks the stream behind a 150 M-cycle spin kernel before each of its nst steps — the pass is
+    # everything from the first of the last nst long spin kernels on.  (Until round 5 it was cut at the previous step's loss
+    # launch and so held the BACKWARD half of the last timed step too: ~5.5 steps of kernels divided by 5.)
+    spins = [i for i, r in enumerate(trace) if "spin_kernel" in r["Kernel_Name"] and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 30e6]
+    roof0 = spins[-nst] if len(spins) >= nst else cut(len(marks) - nst - 1)
     ph = {"tuning": trace[:cut(0)], "warm-up": trace[cut(0):cut(w)], "timed steps": trace[cut(w):cut(w + k)],
-          "roofline pass": trace[cut(len(marks) - nst - 1):]}
+          "roofline pass": [r for r in trace[roof0:] if "spin_kernel" not in r["Kernel_Name"]]}
     return ph, nst
 
 
