@@ -430,6 +430,25 @@ int osd_groupnorm_relu_fwd_levels(int n_levels, const void* const* xs, void* con
 int osd_groupnorm_relu_fwd_levels_fused(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
                                         const float* gamma, const float* beta, float* ab, float* ws, int n, int c, int groups,
                                         float eps, int dtype, uint32_t fused_mask, void* stream);
+/* The same two operations with ONE pass over HBM each (bf16 only; groupnorm_onepass.hip): a workgroup keeps its pixels in registers
+ * between the statistics and the apply step and the workgroups of a (level, image) exchange their partial sums through `ws` behind
+ * an arrival counter in `sync` (deterministic: partials are summed in a fixed order; only d gamma / d beta are atomic adds, one per
+ * channel and (level, image), as in the two-launch form).  Same arguments and results as the two-launch entries (statistics summed in
+ * another order: outputs agree to fp32 rounding of the sums), plus:
+ *   ws:   osd_groupnorm_onepass_workspace_bytes(n_levels, hws, n, c, groups, backward) bytes, no initialisation needed;
+ *   sync: osd_groupnorm_onepass_sync_bytes(n_levels, n) bytes, ZERO before the first launch that uses it; every launch leaves it zero
+ *         again (no memset per launch).  Launches that may overlap in time (different streams) need sync buffers of their own.
+ *         sync[2] != 0 after a launch: a workgroup gave up waiting for its job (~1 s), the results are invalid.
+ * Replaces maskrcnn_benchmark/modeling/rpn/fcos/fcos.py:29-37 (GroupNorm + ReLU of a tower layer; torch.nn.GroupNorm forward and
+ * autograd backward in the reference). */
+int64_t osd_groupnorm_onepass_workspace_bytes(int n_levels, const int32_t* hws, int n, int c, int groups, int backward);
+int64_t osd_groupnorm_onepass_sync_bytes(int n_levels, int n);
+int osd_groupnorm_relu_fwd_levels_onepass(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
+                                          const float* gamma, const float* beta, float* ab, float* ws, int32_t* sync, int n, int c,
+                                          int groups, float eps, int dtype, void* stream);
+int osd_groupnorm_relu_bwd_levels_onepass(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
+                                          const int32_t* hws, const float* ab, const float* gamma, const float* beta, float* ws,
+                                          int32_t* sync, float* dgamma, float* dbeta, int n, int c, int groups, int dtype, void* stream);
 int osd_groupnorm_relu_bwd_levels(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
                                   const int32_t* hws, const float* ab, const float* gamma, const float* beta, float* ws,
                                   float* dgamma, float* dbeta, int n, int c, int groups, int dtype, void* stream);

@@ -27,8 +27,17 @@ def _dt(t):
     raise TypeError("unsupported activation dtype %s" % t.dtype)
 
 
+class _Ptr(C.c_void_p):
+    """a device address that keeps its tensor alive: `_ptr(x.contiguous())` on a non-contiguous x creates a temporary whose block the
+    caching allocator would hand to the NEXT allocation made while the argument list is still being built (before the launch)"""
+
+
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    if t is None:
+        return C.c_void_p(0)
+    p = _Ptr(t.data_ptr())
+    p.keep = t
+    return p
 
 
 def _chk_dev(*ts):
@@ -959,6 +968,43 @@ def gn_fwd_ws_parts(ws, k, n, groups=32):
     return [ws[l * a:(l + 1) * a] for l in range(k)]
 
 
+# ---- one-pass GroupNorm (csrc/groupnorm_onepass.hip): OSD_GN_ONEPASS=0 keeps the two-launch kernels ----
+# OSD_GN_ONEPASS: "f" (default) = the forward kernel only — +0.8 % on the bs = 8 step in same-box A/B, the backward kernel -1 % .. +0.3 %
+# (profiles/r5_gn1p_ab.txt: its 1,160 workgroups are 2.3 rounds of load / hand-off / store, and the two-launch form's second read
+# of (u, dt) comes out of the Infinity Cache, not HBM); "1" = both, "b" = backward only, "0" = the two-launch kernels
+_GN1P_MODE = os.environ.get("OSD_GN_ONEPASS", "f")
+GN_ONEPASS = _GN1P_MODE != "0"
+GN_ONEPASS_FWD = _GN1P_MODE in ("f", "1")
+GN_ONEPASS_BWD = _GN1P_MODE in ("b", "1")
+_GN1P_SYNC = {}      # (device index, stream handle) -> zeroed int32 words: launches on one stream are ordered, streams never share
+
+
+def gn_onepass_ok(x, groups):
+    c = x.shape[-1]
+    return (GN_ONEPASS and x.dtype == torch.bfloat16 and c % 8 == 0 and c <= 512 and 512 % (c // 8) == 0 and c % groups == 0
+            and (c // groups) % 8 == 0 and groups <= 64)
+
+
+def _gn1p_sync(dev, k, n):
+    need = int(_lib.load().osd_groupnorm_onepass_sync_bytes(k, n)) // 4
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    buf = _GN1P_SYNC.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _GN1P_SYNC[key] = torch.zeros((max(need, 32 * 513),), device=dev, dtype=torch.int32)
+    return buf
+
+
+def gn_onepass_errors():
+    """sum of the error words of every one-pass sync buffer (0 = no workgroup ever gave up waiting); synchronises"""
+    return int(sum(int(b[2].item()) for b in _GN1P_SYNC.values()))
+
+
+def _gn1p_ws(dev, k, hws, n, c, groups, backward):
+    nbytes = int(_lib.load().osd_groupnorm_onepass_workspace_bytes(k, hws, n, c, groups, int(backward)))
+    assert nbytes > 0
+    return torch.empty((nbytes // 4,), device=dev, dtype=torch.float32)
+
+
 def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5, ws=None, fused_mask=0):
     """relu(GroupNorm(x_l)) for the FPN levels of one tower layer in two launches.  Returns (ys, ab) with
     ab [L][4][N][C] fp32 (per-image scale/shift a, b and the normalisation xa, xb, kept for the backward pass).
@@ -968,12 +1014,18 @@ def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5, ws=None, fused_m
     dev = xs[0].device
     ys = [torch.empty_like(x) for x in xs]
     ab = torch.empty((k, 4, n, c), device=dev, dtype=torch.float32)
-    if ws is None:
-        assert fused_mask == 0
-        ws = torch.empty((k * n * GN_SPLITS * groups * 2,), device=dev, dtype=torch.float32)
+    assert ws is not None or fused_mask == 0
     hws = (C.c_int32 * k)(*[x.shape[1] * x.shape[2] for x in xs])
-    _lib.call("osd_groupnorm_relu_fwd_levels_fused", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),
-              _ptr(ws), n, c, groups, float(eps), _dt(xs[0]), int(fused_mask), _stream())
+    if fused_mask == 0 and GN_ONEPASS_FWD and gn_onepass_ok(xs[0], groups):
+        sync = _gn1p_sync(dev, k, n)
+        ws1 = _gn1p_ws(dev, k, hws, n, c, groups, False)       # a NAMED tensor: a temporary would be freed (and handed out again) before the launch
+        _lib.call("osd_groupnorm_relu_fwd_levels_onepass", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),
+                  _ptr(ws1), _ptr(sync), n, c, groups, float(eps), _dt(xs[0]), _stream())
+    else:
+        if ws is None:
+            ws = torch.empty((k * n * GN_SPLITS * groups * 2,), device=dev, dtype=torch.float32)
+        _lib.call("osd_groupnorm_relu_fwd_levels_fused", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),
+                  _ptr(ws), n, c, groups, float(eps), _dt(xs[0]), int(fused_mask), _stream())
     for x, y in zip(xs, ys):
         _rec("gn_relu", x=x, gamma=gamma, beta=beta, groups=groups, eps=float(eps), out=y)
     return ys, ab
@@ -998,12 +1050,18 @@ def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32
     k = len(us)
     dev = us[0].device
     dus = [torch.empty_like(u) for u in us]
-    if ws is None:
-        assert fused_mask == 0
-        ws = torch.empty((gn_bwd_ws_numel(k, n, c, groups),), device=dev, dtype=torch.float32)
+    assert ws is not None or fused_mask == 0
     hws = (C.c_int32 * k)(*[u.shape[1] * u.shape[2] for u in us])
-    _lib.call("osd_groupnorm_relu_bwd_levels_fused", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
-              _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), int(fused_mask), _stream())
+    if fused_mask == 0 and GN_ONEPASS_BWD and gn_onepass_ok(us[0], groups):
+        sync = _gn1p_sync(dev, k, n)
+        ws1 = _gn1p_ws(dev, k, hws, n, c, groups, True)
+        _lib.call("osd_groupnorm_relu_bwd_levels_onepass", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
+                  _ptr(beta), _ptr(ws1), _ptr(sync), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), _stream())
+    else:
+        if ws is None:
+            ws = torch.empty((gn_bwd_ws_numel(k, n, c, groups),), device=dev, dtype=torch.float32)
+        _lib.call("osd_groupnorm_relu_bwd_levels_fused", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
+                  _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), int(fused_mask), _stream())
     _rec("gn_relu_bwd", us=list(us), dts=list(dts), gamma=gamma, beta=beta, groups=groups, dgamma=dgamma, dbeta=dbeta, outs=dus)
     return dus
 

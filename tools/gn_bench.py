@@ -32,7 +32,13 @@ beta = torch.zeros(256, device="cuda") + 0.05
 ys, ab = ops.groupnorm_relu_levels(xs, gamma, beta, 32, 1e-5)
 dg, db = torch.zeros(256, device="cuda"), torch.zeros(256, device="cuda")
 mb = sum(x.numel() for x in xs) * 2 / 1e6
-tf = bench(lambda: ops.groupnorm_relu_levels(xs, gamma, beta, 32, 1e-5))
-tb = bench(lambda: ops.groupnorm_relu_bwd_levels(xs, dts, ab, gamma, beta, dg, db, 32))
-print("apply blocks %s: forward (stats + apply) %.1f us = %.2f TB/s; backward (stats + apply) %.1f us = %.2f TB/s"
-      % (os.environ.get("OSD_GN_APPLY_BLOCKS", "64"), tf, 3 * mb / tf, tb, 5 * mb / tb))
+for onepass in (False, True):
+    ops.GN_ONEPASS = ops.GN_ONEPASS_FWD = ops.GN_ONEPASS_BWD = onepass
+    ys, ab = ops.groupnorm_relu_levels(xs, gamma, beta, 32, 1e-5)
+    tf = bench(lambda: ops.groupnorm_relu_levels(xs, gamma, beta, 32, 1e-5))
+    tb = bench(lambda: ops.groupnorm_relu_bwd_levels(xs, dts, ab, gamma, beta, dg, db, 32))
+    # algorithmic bytes: forward reads u and writes t (2 x), backward reads u, dt and writes du (3 x); the two-launch forms move 3 x / 5 x
+    print("%s (OSD_GN_APPLY_BLOCKS %s, OSD_GN1P_U_FWD %s, OSD_GN1P_U_BWD %s): forward %.1f us = %.2f TB/s of tensors; backward %.1f us = %.2f TB/s of tensors"
+          % ("one pass  " if onepass else "two launch", os.environ.get("OSD_GN_APPLY_BLOCKS", "32"), os.environ.get("OSD_GN1P_U_FWD", "auto"),
+             os.environ.get("OSD_GN1P_U_BWD", "8"), tf, 2 * mb / tf, tb, 3 * mb / tb), flush=True)
+print("one-pass error words:", ops.gn_onepass_errors())
