@@ -130,7 +130,7 @@ def stem_input(images, dtype):
     return pack_image(images, dtype, hp, wp), (ho, wo)
 
 
-from .tuner import (ALGO_CACHE, CONV_ALGO_PW, CONV_ALGO_PX, CONV_ALGO_PX_WIDE, SPLIT_CACHE, WGRAD_ALGO_CACHE, _TUNING, _candidate_runs, _time_launches, _tune, _tune_wgrad,      # noqa: E402,F401
+from .tuner import (ALGO_CACHE, CONV_ALGO_PW, CONV_ALGO_PX, CONV_ALGO_PX_WIDE, SPLIT_CACHE, WGRAD_ALGO_CACHE, _TUNING, _candidate_runs, _photo_finish, _time_launches, _tune, _tune_wgrad,      # noqa: E402,F401
                     conv_algo_candidates, replaying, tuning, wgrad_algo_candidates, wgrad_xr_candidates)
 
 
@@ -832,15 +832,17 @@ def conv2d_wgrad_mixed(items, algo=None):
             scratch = {}
             sdw = [scratch.setdefault(id(t), torch.empty_like(t)) for t in real_dws]
             sdb = [None if t is None else scratch.setdefault(id(t), torch.empty_like(t)) for t in real_dbs]
-            best, best_t = 0, float("inf")
+            timed = []
             for cand in wgrad_algo_candidates(descs[0].dtype, max(d.cout for d in descs), max(d.cin for d in descs)):
                 descs[0].algo = cand
                 if not _candidate_runs(lambda: launch(sdw, sdb)):
                     continue
-                t = _time_launches(lambda: launch(sdw, sdb))
-                if t < best_t:
-                    best, best_t = cand, t
-            WGRAD_ALGO_CACHE[key] = algo = best
+                timed.append((_time_launches(lambda: launch(sdw, sdb)), cand))
+
+            def retime(cand):
+                descs[0].algo = cand
+                return _time_launches(lambda: launch(sdw, sdb))
+            WGRAD_ALGO_CACHE[key] = algo = _photo_finish(timed, retime)
         else:
             algo = 0
     descs[0].algo = algo

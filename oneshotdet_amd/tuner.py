@@ -105,9 +105,27 @@ def _time_launches(fn):
     return best
 
 
+def _photo_finish(timed, retime):
+    """timed: [(ms, algo)] of one bracket each.  Candidates within OSD_TUNE_MARGIN (default 5 %) of the fastest — at most three — are
+    timed twice more and the fastest of a candidate's brackets decides: one three-launch bracket carries a few per cent of noise,
+    and a wrong pick on a 0.6 ms weight-gradient launch is a per cent of the step for the whole run."""
+    timed = sorted(timed)
+    if not timed:
+        return 0
+    margin = 1.0 + float(os.environ.get("OSD_TUNE_MARGIN", "0.05"))
+    close = [(t, a) for t, a in timed if t <= timed[0][0] * margin][:3]
+    if len(close) < 2:
+        return timed[0][1]
+    best = {a: t for t, a in close}
+    for _ in range(2):
+        for _, a in close:
+            best[a] = min(best[a], retime(a))
+    return min(best.items(), key=lambda kv: kv[1])[0]
+
+
 def _tune(key, d, launch, cands=None):
     """Time every candidate algorithm for this conv shape (launch() reads d.algo) and cache the fastest."""
-    best, best_t = 0, float("inf")
+    timed = []
     forced = os.environ.get("OSD_FORCE_ALGO_3X3_256")     # experiments: pin the big 3x3 256-channel convs to one algorithm
     if forced and d.cout == 256 and d.r == 3 and d.stride_h == 1:
         d.algo = int(forced)
@@ -124,9 +142,12 @@ def _tune(key, d, launch, cands=None):
             launch()
         except _lib.OsdError:
             continue
-        t = _time_launches(launch)
-        if t < best_t:
-            best, best_t = algo, t
+        timed.append((_time_launches(launch), algo))
+
+    def retime(algo):
+        d.algo = algo
+        return _time_launches(launch)
+    best = _photo_finish(timed, retime)
     ALGO_CACHE[key] = best
     return best
 
@@ -176,7 +197,7 @@ def _tune_wgrad(key, d, launch, dw, db, widths=None):
     """Time every candidate on scratch outputs (the kernel accumulates) and cache the winner for this shape."""
     sdw = torch.empty_like(dw)
     sdb = None if db is None else torch.empty_like(db)
-    best, best_t = 0, float("inf")
+    timed = []
     cands = wgrad_algo_candidates(d.dtype, d.cout, d.cin)
     if os.environ.get("OSD_WGRAD_XR"):      # the filter-row kernel: correct, never the winner so far (DESIGN 6b) — opt-in
         cands = cands + wgrad_xr_candidates(d.dtype, d.cout, d.cin, d.r, d.s, d.stride_h, d.pad_h, widths)
@@ -190,7 +211,11 @@ def _tune_wgrad(key, d, launch, dw, db, widths=None):
         t = _time_launches(lambda: launch(sdw, sdb))
         if verbose:
             print("   wgrad tuner: variant %d code %d  %.1f us" % ((algo - 1) & 15, (algo - 1) >> 4, t * 1e3))
-        if t < best_t:
-            best, best_t = algo, t
+        timed.append((t, algo))
+
+    def retime(algo):
+        d.algo = algo
+        return _time_launches(lambda: launch(sdw, sdb))
+    best = _photo_finish(timed, retime)
     WGRAD_ALGO_CACHE[key] = best
     return best
