@@ -314,13 +314,11 @@ def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mod
                     conv2d_multi(xs[c:], pcs[c:], stride, pad, act, sl(residuals, c, k), res_mode, sl(masks, c, k), act_scale,
                                  sl(act_scale_devs, c, k), _whole=True))
         if cut is None and _TUNING[0]:
-            best_t = float("inf")
+            timed = []
             for c in range(0, k - 1):
                 run(c)                                  # tunes the algorithms of the parts
-                t = _time_launches(lambda: run(c))
-                if t < best_t:
-                    cut, best_t = c, t
-            SPLIT_CACHE[skey] = cut
+                timed.append((_time_launches(lambda: run(c)), c))
+            SPLIT_CACHE[skey] = cut = _photo_finish(timed, lambda c: _time_launches(lambda: run(c)))
         if cut is not None:       # (cut 0 = one launch over all segments: also through run(), so that the launch is a `_whole` call)
             return run(cut)
     c = xs[0].shape[-1]
