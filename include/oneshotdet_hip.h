@@ -459,6 +459,15 @@ int osd_groupnorm_relu_bwd_levels_fused(int n_levels, const void* const* us, con
                                         const int32_t* hws, const float* ab, const float* gamma, const float* beta, float* ws,
                                         float* dgamma, float* dbeta, int n, int c, int groups, int dtype, uint32_t fused_mask,
                                         void* stream);
+/* osd_groupnorm_relu_bwd_levels which ALSO accumulates the bias gradient of the conv that produced us (fcos.py:29-37:
+ * Conv2d(bias=True) -> GroupNorm -> ReLU): conv_dbias[c] += sum over levels, images and pixels of du.  No pass over du: per channel
+ * sum_px du = rstd (gamma sum_px dz - N c1 - c2 sum_px xhat), and the statistics pass gathers sum_px xhat beside its other sums (one more
+ * plane of slab partials: ws holds n_levels*n*OSD_GN_SPLITS*(groups*2 + 3*c) floats here).  One atomic add per channel and
+ * (level, image).  The tower's weight-gradient launch then runs without its fused d-bias column sums (11 % of that launch). */
+int osd_groupnorm_relu_bwd_levels_convbias(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
+                                           const int32_t* hws, const float* ab, const float* gamma, const float* beta, float* ws,
+                                           float* dgamma, float* dbeta, float* conv_dbias, int n, int c, int groups, int dtype,
+                                           void* stream);
 /* FCOS loss (modeling/rpn/fcos/loss.py:101-276; focal term = csrc/cuda/SigmoidFocalLoss_cuda.cu) for one FPN level.
  * phase 0 accumulates sums[5] = {num_pos, sum_w, sum_focal, sum_w*(1-giou), sum_bce} (zero them before the first
  * level); phase 1 writes d_cls_ctr [n][hw][grad_stride] (d logit, d centerness at +0/+1; the caller zero-fills the

@@ -66,6 +66,7 @@ SIGNATURES = {
     "osd_groupnorm_relu_fwd_levels_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, C.c_uint32, _p]),
     "osd_groupnorm_relu_bwd_levels": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "osd_groupnorm_relu_bwd_levels_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_uint32, _p]),
+    "osd_groupnorm_relu_bwd_levels_convbias": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "osd_groupnorm_onepass_workspace_bytes": (_i64, [_i, _p, _i, _i, _i, _i]),
     "osd_groupnorm_onepass_sync_bytes": (_i64, [_i, _i]),
     "osd_groupnorm_relu_fwd_levels_onepass": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),

@@ -1010,7 +1010,9 @@ template <typename T>
 __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const float* __restrict__ ab, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ ws,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int n, int c,
-                                                            int groups, unsigned fused_mask) {
+                                                            int groups, unsigned fused_mask, float* __restrict__ sxw) {
+  // sxw (optional): per-(level, image, slab) partial sums of xhat per channel, [levels][n][kGnSplits][c] — with them the apply
+  // kernel knows sum_px du per channel without a pass over du: the bias gradient of the conv that produced u (see there)
   constexpr int E = Chunk<T>::N;
   const int lvl = blockIdx.z, img = blockIdx.y, split = blockIdx.x;
   if ((fused_mask >> lvl) & 1u) return;      // this level's sums were gathered by the conv that wrote dt (conv_params.h: ConvGnb)
@@ -1021,7 +1023,7 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
   const int cc = threadIdx.x % cch, pl = threadIdx.x / cch;
   const int per = (hw + kGnSplits - 1) / kGnSplits;
   const int p0 = split * per, p1 = min(hw, p0 + per);
-  float av[E], bv[E], gm[E], xa[E], xb[E], s1 = 0.f, s2 = 0.f, dg[E], db[E];
+  float av[E], bv[E], gm[E], xa[E], xb[E], s1 = 0.f, s2 = 0.f, dg[E], db[E], sx[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     av[e] = ab[(((size_t)lvl * 4 + 0) * n + img) * c + cc * E + e];
@@ -1029,7 +1031,7 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
     xa[e] = ab[(((size_t)lvl * 4 + 2) * n + img) * c + cc * E + e];
     xb[e] = ab[(((size_t)lvl * 4 + 3) * n + img) * c + cc * E + e];
     gm[e] = gamma[cc * E + e];
-    dg[e] = 0.f; db[e] = 0.f;
+    dg[e] = 0.f; db[e] = 0.f; sx[e] = 0.f;
   }
   if (pl < lanes) {
     constexpr int U = 4;          // pixels in flight per thread: 2 * U 16-byte loads issued before the arithmetic
@@ -1054,12 +1056,13 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
           s2 += dz * gm[e] * xhat;
           dg[e] += dz * xhat;
           db[e] += dz;
+          sx[e] += xhat;
         }
       }
     }
   }
-  __shared__ float red[2][256];
-  __shared__ float redc[2][512];
+  __shared__ float red[3][256];
+  __shared__ float redc[3][512];
   red[0][threadIdx.x] = s1;
   red[1][threadIdx.x] = s2;
   __syncthreads();
@@ -1080,15 +1083,18 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
     __syncthreads();
     red[0][threadIdx.x] = dg[e];
     red[1][threadIdx.x] = db[e];
+    red[2][threadIdx.x] = sx[e];
     __syncthreads();
     if (threadIdx.x < cch) {
-      float t1 = 0.f, t2 = 0.f;
+      float t1 = 0.f, t2 = 0.f, t3 = 0.f;
       for (int l = 0; l < lanes; ++l) {
         t1 += red[0][l * cch + threadIdx.x];
         t2 += red[1][l * cch + threadIdx.x];
+        t3 += red[2][l * cch + threadIdx.x];
       }
       redc[0][threadIdx.x * E + e] = t1;
       redc[1][threadIdx.x * E + e] = t2;
+      redc[2][threadIdx.x * E + e] = t3;
     }
   }
   __syncthreads();
@@ -1096,9 +1102,11 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
   // 2 x c words ran at the contended-atomic rate and cost more than the whole data pass); summed by the apply kernel
   float* pw = ws + (size_t)gridDim.z * n * kGnSplits * groups * 2 +
               ((((size_t)lvl * n + img) * kGnSplits + split) * 2) * c;
+  float* px = sxw ? sxw + ((((size_t)lvl * n + img) * kGnSplits + split)) * c : nullptr;
   for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
     pw[ch] = redc[0][ch];
     pw[c + ch] = redc[1][ch];
+    if (px) px[ch] = redc[2][ch];
   }
 }
 
@@ -1106,7 +1114,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const float* __restrict__ ab, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ ws,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int n,
-                                                            int c, int groups) {
+                                                            int c, int groups, const float* __restrict__ sxw,
+                                                            float* __restrict__ conv_db) {
   constexpr int E = Chunk<T>::N;
   const int lvl = blockIdx.z, img = blockIdx.y;
   const int hw = L.hw[lvl];
@@ -1122,8 +1131,12 @@ __global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const fl
     ssum[0][g] = s1;
     ssum[1][g] = s2;
   }
+  __syncthreads();
   if (blockIdx.x == 0) {     // one workgroup per (level, image) folds the slabs' d gamma / d beta partials
     const float* pw = ws + (size_t)gridDim.z * n * kGnSplits * groups * 2 + (((size_t)lvl * n + img) * kGnSplits * 2) * c;
+    const float* px = sxw ? sxw + (((size_t)lvl * n + img) * kGnSplits) * c : nullptr;
+    const int cpg0 = c / groups;
+    const float inv_m0 = 1.f / ((float)hw * cpg0);
     for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll 16
@@ -1133,9 +1146,22 @@ __global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const fl
       }
       atomicAdd(dgamma + ch, t1);
       atomicAdd(dbeta + ch, t2);
+      if (conv_db != nullptr) {
+        // The bias gradient of the conv that produced u (fcos.py:29-37: Conv2d(bias=True) -> GroupNorm) is sum_px du, and
+        //   sum_px du = rstd (gamma sum_px dz - N c1 - c2 sum_px xhat)
+        // follows from sums this pass already has (t2 = sum dz; c1, c2 = the group means) plus sum_px xhat per channel from the
+        // statistics pass: one atomic per channel and (level, image) here instead of a d-bias column sum inside the tower's
+        // weight-gradient launch, which cost it 11 % (610 vs 550 us, tools/sk_bias_cost.py).  It is the sum of the fp32 du, not
+        // of their bf16 roundings
+        float t3 = 0.f;
+#pragma unroll 16
+        for (int k = 0; k < kGnSplits; ++k) t3 += px[(size_t)k * c + ch];
+        const int g0 = ch / cpg0;
+        const float rstd = ab[(((size_t)lvl * 4 + 2) * n + img) * c + ch];
+        atomicAdd(conv_db + ch, rstd * (gamma[ch] * t2 - (float)hw * (ssum[0][g0] * inv_m0) - (ssum[1][g0] * inv_m0) * t3));
+      }
     }
   }
-  __syncthreads();
   const T* u = reinterpret_cast<const T*>(L.x[lvl]);
   const T* dt = reinterpret_cast<const T*>(L.dy[lvl]);
   T* du = reinterpret_cast<T*>(L.y[lvl]);
@@ -1247,29 +1273,21 @@ extern "C" int osd_groupnorm_relu_fwd_levels_fused(int n_levels, const void* con
 
 // fused_mask: bit l set = level l's slab sums in ws (both parts) were accumulated by osd_conv2d_fwd_multi_gn into ZEROED memory;
 // the statistics pass skips those levels (and is not launched when every level is fused)
-extern "C" int osd_groupnorm_relu_bwd_levels_fused(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
-                                                   const int32_t* hws, const float* ab, const float* gamma, const float* beta,
-                                                   float* ws, float* dgamma, float* dbeta, int n, int c, int groups, int dtype,
-                                                   uint32_t fused_mask, void* stream);
 
-extern "C" int osd_groupnorm_relu_bwd_levels(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
-                                             const int32_t* hws, const float* ab, const float* gamma, const float* beta,
-                                             float* ws, float* dgamma, float* dbeta, int n, int c, int groups, int dtype,
-                                             void* stream) {
-  return osd_groupnorm_relu_bwd_levels_fused(n_levels, us, dts, dus, hws, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, dtype, 0u, stream);
-}
-
-extern "C" int osd_groupnorm_relu_bwd_levels_fused(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
-                                                   const int32_t* hws, const float* ab, const float* gamma, const float* beta,
-                                                   float* ws, float* dgamma, float* dbeta, int n, int c, int groups, int dtype,
-                                                   uint32_t fused_mask, void* stream) {
+static int gn_bwd_levels_impl(int n_levels, const void* const* us, const void* const* dts, void* const* dus, const int32_t* hws,
+                              const float* ab, const float* gamma, const float* beta, float* ws, float* dgamma, float* dbeta,
+                              float* conv_dbias, int n, int c, int groups, int dtype, uint32_t fused_mask, void* stream) {
   const int e = dtype == OSD_BF16 ? 8 : 4;
   if (!gamma || !beta || !ab || !ws || !dgamma || !dbeta || !dts || c % e != 0 || c > 512 || c / e > 256 ||
       256 % (c / e) != 0 || groups > 64 || c % groups != 0 || (c / groups) % e != 0)
     return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_bwd_levels: unsupported shape c=%d groups=%d", c, groups);
+  if (conv_dbias != nullptr && fused_mask != 0u)
+    return osd_fail(OSD_ERR_UNSUPPORTED, "groupnorm_bwd_levels: the conv bias gradient needs this launch's own statistics pass on every level");
   GnLevels L;
   int rc = gn_levels_fill(L, n_levels, us, dts, dus, hws);
   if (rc) return rc;
+  // the per-slab sums of xhat (for conv_dbias) follow the group sums and the d gamma / d beta partials in ws
+  float* sxw = conv_dbias ? ws + (size_t)n_levels * n * kGnSplits * (groups * 2 + 2 * c) : nullptr;
   dim3 g1(kGnSplits, n, n_levels), g2(gn_apply_blocks(), n, n_levels);
 #ifdef OSD_GN_DIAG
   static int skip = -1;
@@ -1278,12 +1296,34 @@ extern "C" int osd_groupnorm_relu_bwd_levels_fused(int n_levels, const void* con
 #endif
   if ((fused_mask & ((1u << n_levels) - 1u)) != ((1u << n_levels) - 1u))
   OSD_DISPATCH_DTYPE(dtype,
-      hipLaunchKernelGGL(gnl_bwd_stats_kernel<float>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, fused_mask),
-      hipLaunchKernelGGL(gnl_bwd_stats_kernel<__bf16>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, fused_mask));
+      hipLaunchKernelGGL(gnl_bwd_stats_kernel<float>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, fused_mask, sxw),
+      hipLaunchKernelGGL(gnl_bwd_stats_kernel<__bf16>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, fused_mask, sxw));
   rc = osd_check_launch("gnl_bwd_stats");
   if (rc) return rc;
   OSD_DISPATCH_DTYPE(dtype,
-      hipLaunchKernelGGL(gnl_bwd_apply_kernel<float>, g2, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups),
-      hipLaunchKernelGGL(gnl_bwd_apply_kernel<__bf16>, g2, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups));
+      hipLaunchKernelGGL(gnl_bwd_apply_kernel<float>, g2, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, sxw, conv_dbias),
+      hipLaunchKernelGGL(gnl_bwd_apply_kernel<__bf16>, g2, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, sxw, conv_dbias));
   return osd_check_launch("gnl_bwd_apply");
+}
+
+extern "C" int osd_groupnorm_relu_bwd_levels(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
+                                             const int32_t* hws, const float* ab, const float* gamma, const float* beta,
+                                             float* ws, float* dgamma, float* dbeta, int n, int c, int groups, int dtype,
+                                             void* stream) {
+  return gn_bwd_levels_impl(n_levels, us, dts, dus, hws, ab, gamma, beta, ws, dgamma, dbeta, nullptr, n, c, groups, dtype, 0u, stream);
+}
+
+extern "C" int osd_groupnorm_relu_bwd_levels_fused(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
+                                                   const int32_t* hws, const float* ab, const float* gamma, const float* beta,
+                                                   float* ws, float* dgamma, float* dbeta, int n, int c, int groups, int dtype,
+                                                   uint32_t fused_mask, void* stream) {
+  return gn_bwd_levels_impl(n_levels, us, dts, dus, hws, ab, gamma, beta, ws, dgamma, dbeta, nullptr, n, c, groups, dtype, fused_mask, stream);
+}
+
+extern "C" int osd_groupnorm_relu_bwd_levels_convbias(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
+                                                      const int32_t* hws, const float* ab, const float* gamma, const float* beta,
+                                                      float* ws, float* dgamma, float* dbeta, float* conv_dbias, int n, int c,
+                                                      int groups, int dtype, void* stream) {
+  if (!conv_dbias) return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_bwd_levels_convbias: null conv_dbias");
+  return gn_bwd_levels_impl(n_levels, us, dts, dus, hws, ab, gamma, beta, ws, dgamma, dbeta, conv_dbias, n, c, groups, dtype, 0u, stream);
 }

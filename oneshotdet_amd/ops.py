@@ -1043,16 +1043,23 @@ def gn_bwd_ws_parts(ws, k, n, c, groups=32):
     return [(ws[l * a:(l + 1) * a], ws[k * a + l * b:k * a + (l + 1) * b]) for l in range(k)]
 
 
-def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32, ws=None, fused_mask=0):
+def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32, ws=None, fused_mask=0, conv_db=None):
     """ws / fused_mask: the levels whose bit is set had their sums accumulated into (the zeroed) ws by the conv that wrote dts
-    (conv2d_multi(gnb=...)); their statistics pass is skipped."""
+    (conv2d_multi(gnb=...)); their statistics pass is skipped.
+    conv_db [c] fp32 (optional; not with fused_mask): += the bias gradient of the conv that produced us (sum of du over levels,
+    images, pixels), from sums the two passes gather anyway (osd_groupnorm_relu_bwd_levels_convbias)."""
     n, _, _, c = us[0].shape
     k = len(us)
     dev = us[0].device
     dus = [torch.empty_like(u) for u in us]
     assert ws is not None or fused_mask == 0
     hws = (C.c_int32 * k)(*[u.shape[1] * u.shape[2] for u in us])
-    if fused_mask == 0 and GN_ONEPASS_BWD and gn_onepass_ok(us[0], groups):
+    if conv_db is not None:
+        assert fused_mask == 0 and ws is None
+        ws = torch.empty((k * n * GN_SPLITS * (groups * 2 + 3 * c),), device=dev, dtype=torch.float32)
+        _lib.call("osd_groupnorm_relu_bwd_levels_convbias", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab),
+                  _ptr(gamma), _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), _ptr(conv_db), n, c, groups, _dt(us[0]), _stream())
+    elif fused_mask == 0 and GN_ONEPASS_BWD and gn_onepass_ok(us[0], groups):
         sync = _gn1p_sync(dev, k, n)
         ws1 = _gn1p_ws(dev, k, hws, n, c, groups, True)
         _lib.call("osd_groupnorm_relu_bwd_levels_onepass", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
@@ -1062,7 +1069,8 @@ def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32
             ws = torch.empty((gn_bwd_ws_numel(k, n, c, groups),), device=dev, dtype=torch.float32)
         _lib.call("osd_groupnorm_relu_bwd_levels_fused", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
                   _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), int(fused_mask), _stream())
-    _rec("gn_relu_bwd", us=list(us), dts=list(dts), gamma=gamma, beta=beta, groups=groups, dgamma=dgamma, dbeta=dbeta, outs=dus)
+    _rec("gn_relu_bwd", us=list(us), dts=list(dts), gamma=gamma, beta=beta, groups=groups, dgamma=dgamma, dbeta=dbeta, outs=dus,
+         conv_db=conv_db)
     return dus
 
 

@@ -161,6 +161,9 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         # the forward statistics (sum, sum of squares of the tower conv's outputs) in the forward conv's epilogue: no extra operand
         # there, two atomics per wave and group — and still a loss: the conv over P3 + P4 of both towers 243 -> 275 us to save
         # 2 x 13 us of statistics pass, 11.85 vs 11.55 ms per step in same-box A/B.  OSD_GN_FWD_FUSION=1 turns it on
+        # the tower convs' bias gradients from the GroupNorm backward's sums instead of the weight-gradient launch's column sums
+        # (-11 % on that launch); not in ordered mode (its sum order over (level, image) is atomic) and bf16 / fp32 alike
+        self.gn_conv_db = (not self.ordered_wgrad and os.environ.get("OSD_NO_GN_CONV_DB", "0") == "0")
         self.fuse_gn_fwd = (not self.ordered_wgrad and self.dtype == torch.bfloat16 and os.environ.get("OSD_GN_FWD_FUSION", "0") != "0")
         self._gnf_ws = {}
         # torch hands out stream handles from a pool, so a handle may carry an earlier engine's registration: set the mode of

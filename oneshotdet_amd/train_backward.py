@@ -164,16 +164,20 @@ class BackwardPass(object):
                 (gw, ggw), (gbeta, ggb) = self.gn("%s%s.%d" % (h, tw, 3 * i + 1))
                 c = cv["%s%s.%d" % (h, tw, 3 * i)]
                 t_in, u, ab = ctxs[tw][0][i]
+                # the tower conv's bias gradient (sum of du) comes out of the GroupNorm backward's own sums; the weight-gradient
+                # launch then runs without its d-bias column sums (ops.groupnorm_relu_bwd_levels(conv_db=...))
+                gn_db = c.gb if (self.gn_conv_db and c.has_bias and not fuse) else None
                 if isinstance(ab, list):        # forward ran one chain per level group: one saved-statistics block each
                     dus[tw], lo = [], 0
                     for ab_g in ab:
                         k = ab_g.shape[0]
-                        dus[tw] += ops.groupnorm_relu_bwd_levels(u[lo:lo + k], d_t[tw][lo:lo + k], ab_g, gw, gbeta, ggw, ggb, spec.GN_GROUPS)
+                        dus[tw] += ops.groupnorm_relu_bwd_levels(u[lo:lo + k], d_t[tw][lo:lo + k], ab_g, gw, gbeta, ggw, ggb, spec.GN_GROUPS,
+                                                                 conv_db=gn_db)
                         lo += k
                 else:
                     dus[tw] = ops.groupnorm_relu_bwd_levels(u, d_t[tw], ab, gw, gbeta, ggw, ggb, spec.GN_GROUPS,
-                                                            ws=gws[(tw, i)] if fuse else None, fused_mask=fused[tw])
-                items[tw] += [(t_in[l], dus[tw][l], c.gw, c.bn_scale, c.gb if c.has_bias else None) for l in range(nl)]
+                                                            ws=gws[(tw, i)] if fuse else None, fused_mask=fused[tw], conv_db=gn_db)
+                items[tw] += [(t_in[l], dus[tw][l], c.gw, c.bn_scale, c.gb if (c.has_bias and gn_db is None) else None) for l in range(nl)]
             dys = [dus[tw][l] for l in range(nl) for tw in towers]
             c0 = cv["%s%s.%d" % (h, towers[0], 3 * i)]
             pds = [cv["%s%s.%d" % (h, tw, 3 * i)].pd for l in range(nl) for tw in towers]

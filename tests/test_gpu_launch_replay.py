@@ -117,6 +117,8 @@ class Replayer(object):
             self._check("gn_relu_bwd", du, ref)
             self._accumulate(r["dgamma"], dg)
             self._accumulate(r["dbeta"], db)
+            if r.get("conv_db") is not None:      # the producing conv's bias gradient = sum of du over images and pixels
+                self._accumulate(r["conv_db"], ref.double().sum(dim=(0, 1, 2)).float())
 
     def do_wgrad(self, r):
         self.counts["wgrad"] = self.counts.get("wgrad", 0) + 1

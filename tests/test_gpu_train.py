@@ -727,6 +727,55 @@ def test_groupnorm_relu_levels_forward_backward_at_fpn_sizes(n, dt):
     assert (db.cpu() - b.grad).abs().max() <= tol * b.grad.abs().max()
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_groupnorm_backward_also_gives_the_producing_convs_bias_gradient(dt):
+    """osd_groupnorm_relu_bwd_levels_convbias: the bias gradient of the conv in front of the GroupNorm (fcos.py:29-37,
+    Conv2d(bias=True) -> GroupNorm -> ReLU) is sum_px du, which the kernels get from their own sums (gamma sum dz, the group means,
+    sum xhat) without a pass over du.  Against autograd's x.grad summed over images and pixels, and against the du the same call
+    wrote; du / d gamma / d beta are unchanged by the extra output.  gamma == 0 and gamma < 0 channels, five FPN sizes, two images."""
+    from oneshotdet_amd import ops
+    sizes = [(100, 128), (50, 64), (25, 32), (13, 16), (7, 8)]
+    g = rnd(256, seed=3) * 0.7
+    g[::7] = 0.0
+    g[2::13] = -0.4
+    g.requires_grad_(True)
+    b = rnd(256, seed=4).requires_grad_(True)
+    xs, dys = [], []
+    for i, (h, w) in enumerate(sizes):
+        x = rnd(2, 256, h, w, seed=10 + i, scale=2) + 0.3
+        dy = rnd(2, 256, h, w, seed=20 + i) * (10.0 if i == 1 else 1.0)
+        if dt == "bf16":
+            x, dy = x.bfloat16().float(), dy.bfloat16().float()
+        x.requires_grad_(True)
+        (F.relu(F.group_norm(x, 32, g, b, eps=1e-5)) * dy).sum().backward()
+        xs.append(x); dys.append(dy)
+    ref_db = sum(x.grad.sum(dim=(0, 2, 3)) for x in xs)
+    xx = [to_nhwc(x.detach(), DT[dt]) for x in xs]
+    dd = [to_nhwc(d, DT[dt]) for d in dys]
+    gc, bc = g.detach().cuda(), b.detach().cuda()
+    _, ab = ops.groupnorm_relu_levels(xx, gc, bc, 32, 1e-5)
+    dg0, db0 = torch.zeros(256, device="cuda"), torch.zeros(256, device="cuda")
+    du0 = ops.groupnorm_relu_bwd_levels(xx, dd, ab, gc, bc, dg0, db0, 32)
+    dg1, db1, cdb = torch.zeros(256, device="cuda"), torch.zeros(256, device="cuda"), torch.zeros(256, device="cuda")
+    du1 = ops.groupnorm_relu_bwd_levels(xx, dd, ab, gc, bc, dg1, db1, 32, conv_db=cdb)
+    assert all(torch.equal(p, q) for p, q in zip(du0, du1))
+    torch.testing.assert_close(dg1, dg0, rtol=1e-5, atol=1e-5 * float(dg0.abs().max()))
+    torch.testing.assert_close(db1, db0, rtol=1e-5, atol=1e-5 * float(db0.abs().max()))
+    own = sum(d.float().sum(dim=(0, 1, 2)) for d in du1)
+    scale = float(ref_db.abs().max())
+    tol = 2e-4 if dt == "f32" else 5e-3          # bf16: autograd sees fp32 du, `own` their bf16 roundings; the kernel's sum is of the fp32 du
+    assert float((cdb.cpu() - ref_db).abs().max()) <= tol * scale
+    # `own` sums the STORED du: in bf16 each carries a rounding of up to 2^-9 relative, and the roundings of a channel are not
+    # independent (a gamma == 0 channel stores almost the same value at every pixel): bound them by their worst case; the kernel's
+    # value is the sum of the unrounded du, which the autograd comparison above pins
+    worst = sum(d.float().abs().sum(dim=(0, 1, 2)) for d in du1) * 2.0 ** -9
+    bound = 2e-4 * scale + (worst if dt == "bf16" else 0.0)
+    assert bool(((cdb - own).abs() <= bound).all()), float(((cdb - own).abs() / bound).max())
+    # accumulates: a second call adds the same again
+    ops.groupnorm_relu_bwd_levels(xx, dd, ab, gc, bc, dg1, db1, 32, conv_db=cdb)
+    assert float((cdb.cpu() - 2 * ref_db).abs().max()) <= 2 * tol * scale
+
+
 @pytest.mark.parametrize("fused_levels", [2, 1])
 def test_groupnorm_backward_statistics_gathered_by_the_data_gradient_conv(fused_levels):
     """osd_conv2d_fwd_multi_gn + osd_groupnorm_relu_bwd_levels_fused: the 3x3 data-gradient conv that writes dt (the gradient
