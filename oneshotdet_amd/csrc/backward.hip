@@ -1006,7 +1006,7 @@ __global__ void __launch_bounds__(256) gnl_apply_kernel(GnLevels L, const float*
   }
 }
 
-template <typename T>
+template <typename T, bool SX>
 __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const float* __restrict__ ab, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ ws,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int n, int c,
@@ -1056,7 +1056,7 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
           s2 += dz * gm[e] * xhat;
           dg[e] += dz * xhat;
           db[e] += dz;
-          sx[e] += xhat;
+          if constexpr (SX) sx[e] += xhat;
         }
       }
     }
@@ -1083,18 +1083,18 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
     __syncthreads();
     red[0][threadIdx.x] = dg[e];
     red[1][threadIdx.x] = db[e];
-    red[2][threadIdx.x] = sx[e];
+    if constexpr (SX) red[2][threadIdx.x] = sx[e];
     __syncthreads();
     if (threadIdx.x < cch) {
       float t1 = 0.f, t2 = 0.f, t3 = 0.f;
       for (int l = 0; l < lanes; ++l) {
         t1 += red[0][l * cch + threadIdx.x];
         t2 += red[1][l * cch + threadIdx.x];
-        t3 += red[2][l * cch + threadIdx.x];
+        if constexpr (SX) t3 += red[2][l * cch + threadIdx.x];
       }
       redc[0][threadIdx.x * E + e] = t1;
       redc[1][threadIdx.x * E + e] = t2;
-      redc[2][threadIdx.x * E + e] = t3;
+      if constexpr (SX) redc[2][threadIdx.x * E + e] = t3;
     }
   }
   __syncthreads();
@@ -1102,7 +1102,7 @@ __global__ void __launch_bounds__(256) gnl_bwd_stats_kernel(GnLevels L, const fl
   // 2 x c words ran at the contended-atomic rate and cost more than the whole data pass); summed by the apply kernel
   float* pw = ws + (size_t)gridDim.z * n * kGnSplits * groups * 2 +
               ((((size_t)lvl * n + img) * kGnSplits + split) * 2) * c;
-  float* px = sxw ? sxw + ((((size_t)lvl * n + img) * kGnSplits + split)) * c : nullptr;
+  float* px = (SX && sxw) ? sxw + ((((size_t)lvl * n + img) * kGnSplits + split)) * c : nullptr;
   for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
     pw[ch] = redc[0][ch];
     pw[c + ch] = redc[1][ch];
@@ -1131,35 +1131,42 @@ __global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const fl
     ssum[0][g] = s1;
     ssum[1][g] = s2;
   }
-  __syncthreads();
-  if (blockIdx.x == 0) {     // one workgroup per (level, image) folds the slabs' d gamma / d beta partials
+  // one workgroup per (level, image) folds the slabs' d gamma / d beta partials (while the first threads sum the group partials).
+  // The bias gradient of the conv that produced u (fcos.py:29-37: Conv2d(bias=True) -> GroupNorm) is sum_px du, and
+  //   sum_px du = rstd (gamma sum_px dz - N c1 - c2 sum_px xhat)
+  // follows from sums this pass has (sum dz = d beta; c1, c2 = the group means) plus sum_px xhat per channel from the statistics
+  // pass: one atomic per channel and (level, image) instead of a d-bias column sum inside the tower's weight-gradient launch, which
+  // cost it 11 % (610 vs 550 us, tools/sk_bias_cost.py).  It is the sum of the fp32 du, not of their bf16 roundings
+  float f2[2] = {0.f, 0.f}, f3[2] = {0.f, 0.f};          // c <= 512 on 256 threads: two channels per thread
+  if (blockIdx.x == 0) {
     const float* pw = ws + (size_t)gridDim.z * n * kGnSplits * groups * 2 + (((size_t)lvl * n + img) * kGnSplits * 2) * c;
     const float* px = sxw ? sxw + (((size_t)lvl * n + img) * kGnSplits) * c : nullptr;
-    const int cpg0 = c / groups;
-    const float inv_m0 = 1.f / ((float)hw * cpg0);
-    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
-      float t1 = 0.f, t2 = 0.f;
+    int q = 0;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x, ++q) {
+      float t1 = 0.f, t2 = 0.f, t3 = 0.f;
 #pragma unroll 16
       for (int k = 0; k < kGnSplits; ++k) {      // 32 independent loads in flight per thread
         t1 += pw[(size_t)k * 2 * c + ch];
         t2 += pw[(size_t)k * 2 * c + c + ch];
       }
-      atomicAdd(dgamma + ch, t1);
-      atomicAdd(dbeta + ch, t2);
-      if (conv_db != nullptr) {
-        // The bias gradient of the conv that produced u (fcos.py:29-37: Conv2d(bias=True) -> GroupNorm) is sum_px du, and
-        //   sum_px du = rstd (gamma sum_px dz - N c1 - c2 sum_px xhat)
-        // follows from sums this pass already has (t2 = sum dz; c1, c2 = the group means) plus sum_px xhat per channel from the
-        // statistics pass: one atomic per channel and (level, image) here instead of a d-bias column sum inside the tower's
-        // weight-gradient launch, which cost it 11 % (610 vs 550 us, tools/sk_bias_cost.py).  It is the sum of the fp32 du, not
-        // of their bf16 roundings
-        float t3 = 0.f;
+      if (px != nullptr) {
 #pragma unroll 16
         for (int k = 0; k < kGnSplits; ++k) t3 += px[(size_t)k * c + ch];
-        const int g0 = ch / cpg0;
-        const float rstd = ab[(((size_t)lvl * 4 + 2) * n + img) * c + ch];
-        atomicAdd(conv_db + ch, rstd * (gamma[ch] * t2 - (float)hw * (ssum[0][g0] * inv_m0) - (ssum[1][g0] * inv_m0) * t3));
       }
+      atomicAdd(dgamma + ch, t1);
+      atomicAdd(dbeta + ch, t2);
+      f2[q & 1] = t2; f3[q & 1] = t3;
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && conv_db != nullptr) {
+    const int cpg0 = c / groups;
+    const float inv_m0 = 1.f / ((float)hw * cpg0);
+    int q = 0;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x, ++q) {
+      const int g0 = ch / cpg0;
+      const float rstd = ab[(((size_t)lvl * 4 + 2) * n + img) * c + ch];
+      atomicAdd(conv_db + ch, rstd * (gamma[ch] * f2[q & 1] - (float)hw * (ssum[0][g0] * inv_m0) - (ssum[1][g0] * inv_m0) * f3[q & 1]));
     }
   }
   const T* u = reinterpret_cast<const T*>(L.x[lvl]);
@@ -1295,9 +1302,17 @@ static int gn_bwd_levels_impl(int n_levels, const void* const* us, const void* c
   if (!(skip & 2))
 #endif
   if ((fused_mask & ((1u << n_levels) - 1u)) != ((1u << n_levels) - 1u))
-  OSD_DISPATCH_DTYPE(dtype,
-      hipLaunchKernelGGL(gnl_bwd_stats_kernel<float>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, fused_mask, sxw),
-      hipLaunchKernelGGL(gnl_bwd_stats_kernel<__bf16>, g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, fused_mask, sxw));
+  {
+    if (sxw) {
+      OSD_DISPATCH_DTYPE(dtype,
+          hipLaunchKernelGGL((gnl_bwd_stats_kernel<float, true>), g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, fused_mask, sxw),
+          hipLaunchKernelGGL((gnl_bwd_stats_kernel<__bf16, true>), g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, fused_mask, sxw));
+    } else {
+      OSD_DISPATCH_DTYPE(dtype,
+          hipLaunchKernelGGL((gnl_bwd_stats_kernel<float, false>), g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, fused_mask, sxw),
+          hipLaunchKernelGGL((gnl_bwd_stats_kernel<__bf16, false>), g1, dim3(256), 0, OSD_STREAM(stream), L, ab, gamma, beta, ws, dgamma, dbeta, n, c, groups, fused_mask, sxw));
+    }
+  }
   rc = osd_check_launch("gnl_bwd_stats");
   if (rc) return rc;
   OSD_DISPATCH_DTYPE(dtype,
