@@ -1137,36 +1137,47 @@ __global__ void __launch_bounds__(256) gnl_bwd_apply_kernel(GnLevels L, const fl
   // follows from sums this pass has (sum dz = d beta; c1, c2 = the group means) plus sum_px xhat per channel from the statistics
   // pass: one atomic per channel and (level, image) instead of a d-bias column sum inside the tower's weight-gradient launch, which
   // cost it 11 % (610 vs 550 us, tools/sk_bias_cost.py).  It is the sum of the fp32 du, not of their bf16 roundings
-  float f2[2] = {0.f, 0.f}, f3[2] = {0.f, 0.f};          // c <= 512 on 256 threads: two channels per thread
-  if (blockIdx.x == 0) {
+  // The first four workgroups of a (level, image) share the fold in 64-channel chunks: thread (part = t / 64, channel t % 64) adds every
+  // fourth slab (a wave reads 64 consecutive channels: coalesced), LDS adds the four parts.  One workgroup folding all 256 channels x
+  // 64 slabs x 3 planes (192 loads per thread) held the launch ~5 us longer.
+  constexpr int kFoldWgs = 4, kFoldW = 64;              // 64-channel chunks, dealt round-robin to the first four workgroups
+  __shared__ float fold[3][256];
+  __syncthreads();                                      // ssum
+  if ((int)blockIdx.x < kFoldWgs) {
+    const int nfold = min((int)gridDim.x, kFoldWgs);
     const float* pw = ws + (size_t)gridDim.z * n * kGnSplits * groups * 2 + (((size_t)lvl * n + img) * kGnSplits * 2) * c;
     const float* px = sxw ? sxw + (((size_t)lvl * n + img) * kGnSplits) * c : nullptr;
-    int q = 0;
-    for (int ch = threadIdx.x; ch < c; ch += blockDim.x, ++q) {
-      float t1 = 0.f, t2 = 0.f, t3 = 0.f;
-#pragma unroll 16
-      for (int k = 0; k < kGnSplits; ++k) {      // 32 independent loads in flight per thread
-        t1 += pw[(size_t)k * 2 * c + ch];
-        t2 += pw[(size_t)k * 2 * c + c + ch];
-      }
-      if (px != nullptr) {
-#pragma unroll 16
-        for (int k = 0; k < kGnSplits; ++k) t3 += px[(size_t)k * c + ch];
-      }
-      atomicAdd(dgamma + ch, t1);
-      atomicAdd(dbeta + ch, t2);
-      f2[q & 1] = t2; f3[q & 1] = t3;
-    }
-  }
-  __syncthreads();
-  if (blockIdx.x == 0 && conv_db != nullptr) {
     const int cpg0 = c / groups;
     const float inv_m0 = 1.f / ((float)hw * cpg0);
-    int q = 0;
-    for (int ch = threadIdx.x; ch < c; ch += blockDim.x, ++q) {
-      const int g0 = ch / cpg0;
-      const float rstd = ab[(((size_t)lvl * 4 + 2) * n + img) * c + ch];
-      atomicAdd(conv_db + ch, rstd * (gamma[ch] * f2[q & 1] - (float)hw * (ssum[0][g0] * inv_m0) - (ssum[1][g0] * inv_m0) * f3[q & 1]));
+    for (int chunk = blockIdx.x; chunk * kFoldW < c; chunk += nfold) {
+      const int ch = chunk * kFoldW + (threadIdx.x % kFoldW), part = threadIdx.x / kFoldW;      // 4 parts x 16 slabs
+      float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+      if (ch < c) {
+#pragma unroll 8
+        for (int k = part; k < kGnSplits; k += 256 / kFoldW) {
+          t1 += pw[(size_t)k * 2 * c + ch];
+          t2 += pw[(size_t)k * 2 * c + c + ch];
+        }
+        if (px != nullptr) {
+#pragma unroll 8
+          for (int k = part; k < kGnSplits; k += 256 / kFoldW) t3 += px[(size_t)k * c + ch];
+        }
+      }
+      __syncthreads();                                  // the previous chunk's sums have been read
+      fold[0][threadIdx.x] = t1; fold[1][threadIdx.x] = t2; fold[2][threadIdx.x] = t3;
+      __syncthreads();
+      if (threadIdx.x < kFoldW && ch < c) {
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 256 / kFoldW; ++q) { a1 += fold[0][q * kFoldW + threadIdx.x]; a2 += fold[1][q * kFoldW + threadIdx.x]; a3 += fold[2][q * kFoldW + threadIdx.x]; }
+        atomicAdd(dgamma + ch, a1);
+        atomicAdd(dbeta + ch, a2);
+        if (conv_db != nullptr) {
+          const int g0 = ch / cpg0;
+          const float rstd = ab[(((size_t)lvl * 4 + 2) * n + img) * c + ch];
+          atomicAdd(conv_db + ch, rstd * (gamma[ch] * a2 - (float)hw * (ssum[0][g0] * inv_m0) - (ssum[1][g0] * inv_m0) * a3));
+        }
+      }
     }
   }
   const T* u = reinterpret_cast<const T*>(L.x[lvl]);
