@@ -375,10 +375,8 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
       if (d->dtype != OSD_BF16 || src2 != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the pixel-stationary 1x1 kernel is bf16 only, one source");
       return osd_conv_px_launch(p, s, tile == 1);
     }
-    if (impl == 1 && variant == 1 && tile == 0) {      // algo 41: the persistent pointwise kernel (conv_pw.hip)
-      if (d->dtype != OSD_BF16 || src2 != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the persistent 1x1 kernel is bf16 only, one source");
-      return osd_conv_pw_launch(p, s);
-    }
+    if (impl == 1 && variant == 1 && tile == 0)        // algo 41 was the persistent pointwise kernel of round 4 (conv_pw.hip: retired in
+      return osd_fail(OSD_ERR_UNSUPPORTED, "conv: algo 41 (conv_pw) was retired in round 5");      // round 5, never the tuner's pick inside the step; git history)
     // the ping-pong 256x256 kernel and the row-reuse kernel without the software pipeline were retired in round 5: tile id 5 now
     // names the 128-pixel x 256-channel LDS-DMA tile, tile 6 / variant 0 conv_sp's 128 x 128 tile
     if (tile > 7 || (impl == 1 && (variant != 0 || tile > 3)))

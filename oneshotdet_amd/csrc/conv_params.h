@@ -69,9 +69,6 @@ int osd_conv_dma_dispatch(int dtype, int tile, int variant, const ConvKParams& p
 // any map width — the padded-image form where every width is 64 / 128 / 256, else the consecutive-rows form; variant 2 =
 // general_width: the consecutive-rows form on every width, for tests and A/B timing; variant 3 = half_tile: 128-pixel tiles)
 int osd_conv_sp_launch(const ConvKParams& p, hipStream_t s, bool general_width = false, bool half_tile = false, bool small_tile = false);
-// conv_pw.hip: bf16, plain 1x1 / stride 1 conv of one dense NHWC tensor, persistent workgroups with one operand ring across tiles
-// and the tile's residual / mask operand requested under its K loop (algo id 41: the HBM-bound bottleneck convs)
-int osd_conv_pw_launch(const ConvKParams& p, hipStream_t s);
 // conv_px.hip: bf16, plain 1x1 / stride 1 conv with cin 64 / 128 / 256: every wave keeps its 32 pixels' K values in registers and
 // the workgroups stream only weight chunks (algo ids 49 / 50: eight waves of 16 pixels / four of 32; the expanding bottleneck convs
 // and conv1's data gradient)

@@ -130,7 +130,7 @@ def stem_input(images, dtype):
     return pack_image(images, dtype, hp, wp), (ho, wo)
 
 
-from .tuner import (ALGO_CACHE, CONV_ALGO_PW, CONV_ALGO_PX, CONV_ALGO_PX_WIDE, SPLIT_CACHE, WGRAD_ALGO_CACHE, _TUNING, _candidate_runs, _photo_finish, _time_launches, _tune, _tune_wgrad,      # noqa: E402,F401
+from .tuner import (ALGO_CACHE, CONV_ALGO_PX, CONV_ALGO_PX_WIDE, SPLIT_CACHE, WGRAD_ALGO_CACHE, _TUNING, _candidate_runs, _photo_finish, _time_launches, _tune, _tune_wgrad,      # noqa: E402,F401
                     conv_algo_candidates, replaying, tuning, wgrad_algo_candidates, wgrad_xr_candidates)
 
 

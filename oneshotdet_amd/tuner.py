@@ -20,7 +20,6 @@ ALGO_CACHE = {}
 _TUNING = [False]
 
 
-CONV_ALGO_PW = 1 + 1 * 32 + 1 * 8 + 0      # conv_pw.hip
 CONV_ALGO_PX = 1 + 1 * 32 + 2 * 8 + 0      # conv_px.hip, eight waves of 16 pixels
 CONV_ALGO_PX_WIDE = CONV_ALGO_PX + 1       # ... four waves of 32 pixels
 
@@ -46,16 +45,11 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False):
     if not relu_in and not has_mask:
         cands += [1 + 1 * 32 + t for t in tiles]
     if cout_store >= 64 and not relu_in and os.environ.get("OSD_PX"):
-        # pixel-stationary pointwise kernel (round 5; bf16 1x1 / stride 1 convs with cin 64 / 128 / 256: refused elsewhere).  Opt-in
-        # like conv_pw: timed alone it wins layer2's expanding convs by 8 - 10 % and the tuner picks it there, but inside the step
+        # pixel-stationary pointwise kernel (round 5; bf16 1x1 / stride 1 convs with cin 64 / 128 / 256: refused elsewhere).  Opt-in,
+        # like round 4's persistent conv_pw (retired): timed alone it wins layer2's expanding convs by 8 - 10 % and the tuner picks it there, but inside the step
         # its long-lived workgroups share the chip no better than the tile kernels' short ones: 699 - 715 images/s with it, 711 -
         # 714 without, 692 - 699 for the round-4 head on the same box (profiles/r5_same_box_ab.txt)
         cands += [CONV_ALGO_PX, CONV_ALGO_PX_WIDE]
-    if cout_store >= 128 and not relu_in and os.environ.get("OSD_PW"):
-        # persistent pointwise kernel (bf16 1x1 / stride 1 convs; refused elsewhere).  Opt-in: timed alone it wins 3 - 6 % on the
-        # reducing bottleneck convs and the tuner picks it there, but inside the step its 512 long-lived workgroups share the
-        # chip worse with the other streams' kernels: 735 - 737 vs 739.5 - 740.7 images/s in a same-box A/B
-        cands.append(CONV_ALGO_PW)
     return cands
 
 

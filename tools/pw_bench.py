@@ -1,6 +1,7 @@
 """GPU box: the bottleneck 1x1 convs of the bs=8 training step (resnet.py:295-315; forward with residual + ReLU, data gradient with
-the block's residual gradient + ReLU mask) on the persistent pointwise kernel (conv_pw, algo 41) against the best of the
-one-tile-per-workgroup algorithms — time, algorithmic HBM bytes per second, TFLOP/s.   python tools/pw_bench.py [reps]"""
+the block's residual gradient + ReLU mask) on the pixel-stationary pointwise kernel (conv_px, algos 49 / 50) against the best of the
+one-tile-per-workgroup algorithms — time, algorithmic HBM bytes per second.  (Round 4's persistent conv_pw, algo 41, was retired in
+round 5.)   python tools/pw_bench.py [reps]"""
 import os
 import sys
 
@@ -45,7 +46,7 @@ def timed(fn):
 def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     tot_old = tot_new = 0.0
-    print("| conv | M | N | K | MB | best one-tile algorithm | us | TB/s | conv_pw us | TB/s | TFLOP/s | conv_px us | TB/s | launches/step |")
+    print("| conv | M | N | K | MB | best one-tile algorithm | us | TB/s | (conv_pw: retired) | - | - | conv_px us | TB/s | launches/step |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for n, h, w, cin, cout, has_res, has_mask, per_step, what in SHAPES:
         x = torch.relu(torch.randn((n, h, w, cin), device="cuda", generator=g)).bfloat16()
@@ -59,7 +60,7 @@ def main():
         mb = (m * cin + cout * cin + m * cout * (1 + int(has_res) + int(has_mask))) * 2 / 1e6
         best, best_algo = float("inf"), 0
         for algo in ops.conv_algo_candidates(cout, False, has_mask=has_mask):
-            if algo in (ops.CONV_ALGO_PW, ops.CONV_ALGO_PX, ops.CONV_ALGO_PX_WIDE):
+            if algo in (ops.CONV_ALGO_PX, ops.CONV_ALGO_PX_WIDE):
                 continue
             try:
                 ops.conv2d(x, pc, algo=algo, **kw)
@@ -68,11 +69,7 @@ def main():
             t = timed(lambda: ops.conv2d(x, pc, algo=algo, **kw))
             if t < best:
                 best, best_algo = t, algo
-        try:
-            ops.conv2d(x, pc, algo=ops.CONV_ALGO_PW, **kw)
-            t_pw = timed(lambda: ops.conv2d(x, pc, algo=ops.CONV_ALGO_PW, **kw))
-        except _lib.OsdError:
-            t_pw = float("nan")
+        t_pw = float("nan")
         t_px = float("nan")
         for a_px in (ops.CONV_ALGO_PX, ops.CONV_ALGO_PX_WIDE):      # the faster of the two wave shapes
             try:
@@ -87,7 +84,7 @@ def main():
               (what, m, cout, cin, mb, a0 >> 5, (a0 >> 3) & 3, a0 & 7, best, mb / best, t_pw, mb / t_pw, fl / t_pw / 1e6, t_px, mb / t_px, per_step), flush=True)
         tot_old += best * per_step
         tot_new += min([t for t in (best, t_pw, t_px) if t == t]) * per_step
-    print("\nper step (one backbone): %.0f us with the one-tile algorithms, %.0f us with conv_pw / conv_px where they win" % (tot_old, tot_new))
+    print("\nper step (one backbone): %.0f us with the one-tile algorithms, %.0f us with conv_px where it wins" % (tot_old, tot_new))
 
 
 if __name__ == "__main__":
