@@ -28,6 +28,7 @@ constexpr int kL = 8;            // levels per launch
 constexpr int kThreads = 512;
 constexpr int kSyncStride = 32;  // ints per job in `sync` (128 bytes: a line of its own); [0] arrivals, [16] departures
 constexpr int kSpinLimit = 1 << 20;
+constexpr int kMaxParts = 192;   // workgroups of one (level, image): see gn1p_fill
 
 struct Gn1pParams {
   const void* x[kL];       // forward: u (conv output); backward: u
@@ -433,6 +434,10 @@ int gn1p_fill(Gn1pParams& P, const char* who, int n_levels, const void* const* x
     if (hws[j] < 1 || (long long)hws[j] * c * 2 >= 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "%s: level %d is empty or an image of it exceeds 2 GiB", who, j);
     P.x[l] = xs[j]; P.dy[l] = dys ? dys[j] : nullptr; P.y[l] = ys[j]; P.hw[l] = hws[j];
     P.parts[l] = (hws[j] + px - 1) / px;
+    // forward progress: a job's workgroups must be able to be resident together — beside the job of another one-pass launch on
+    // another stream (the two towers) — on 2 x 256 slots; bigger maps take the two-launch kernels (the caller falls back)
+    if (P.parts[l] > kMaxParts)
+      return osd_fail(OSD_ERR_UNSUPPORTED, "%s: level %d needs %d workgroups per image (> %d): use the two-launch form", who, j, P.parts[l], kMaxParts);
     if (2 * c + P.parts[l] > 2 * (kThreads / (c / 8)) * c)
       return osd_fail(OSD_ERR_UNSUPPORTED, "%s: level %d has more pixels per image than the fold's LDS scratch covers", who, j);
     P.ticket_begin[l] = (int)total;

@@ -1016,12 +1016,18 @@ def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5, ws=None, fused_m
     ab = torch.empty((k, 4, n, c), device=dev, dtype=torch.float32)
     assert ws is not None or fused_mask == 0
     hws = (C.c_int32 * k)(*[x.shape[1] * x.shape[2] for x in xs])
-    if fused_mask == 0 and GN_ONEPASS_FWD and gn_onepass_ok(xs[0], groups):
+    onepass = fused_mask == 0 and GN_ONEPASS_FWD and gn_onepass_ok(xs[0], groups)
+    if onepass:
         sync = _gn1p_sync(dev, k, n)
         ws1 = _gn1p_ws(dev, k, hws, n, c, groups, False)       # a NAMED tensor: a temporary would be freed (and handed out again) before the launch
-        _lib.call("osd_groupnorm_relu_fwd_levels_onepass", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),
-                  _ptr(ws1), _ptr(sync), n, c, groups, float(eps), _dt(xs[0]), _stream())
-    else:
+        try:
+            _lib.call("osd_groupnorm_relu_fwd_levels_onepass", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),
+                      _ptr(ws1), _ptr(sync), n, c, groups, float(eps), _dt(xs[0]), _stream())
+        except _lib.OsdError as e:
+            if getattr(e, "code", 0) != -2:       # OSD_ERR_UNSUPPORTED: a map too large for one resident job — the two launches below
+                raise
+            onepass = False
+    if not onepass:
         if ws is None:
             ws = torch.empty((k * n * GN_SPLITS * groups * 2,), device=dev, dtype=torch.float32)
         _lib.call("osd_groupnorm_relu_fwd_levels_fused", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),
@@ -1059,12 +1065,19 @@ def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32
         ws = torch.empty((k * n * GN_SPLITS * (groups * 2 + 3 * c),), device=dev, dtype=torch.float32)
         _lib.call("osd_groupnorm_relu_bwd_levels_convbias", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab),
                   _ptr(gamma), _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), _ptr(conv_db), n, c, groups, _dt(us[0]), _stream())
-    elif fused_mask == 0 and GN_ONEPASS_BWD and gn_onepass_ok(us[0], groups):
-        sync = _gn1p_sync(dev, k, n)
-        ws1 = _gn1p_ws(dev, k, hws, n, c, groups, True)
-        _lib.call("osd_groupnorm_relu_bwd_levels_onepass", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
-                  _ptr(beta), _ptr(ws1), _ptr(sync), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), _stream())
     else:
+        onepass = fused_mask == 0 and GN_ONEPASS_BWD and gn_onepass_ok(us[0], groups)
+        if onepass:
+            sync = _gn1p_sync(dev, k, n)
+            ws1 = _gn1p_ws(dev, k, hws, n, c, groups, True)
+            try:
+                _lib.call("osd_groupnorm_relu_bwd_levels_onepass", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab),
+                          _ptr(gamma), _ptr(beta), _ptr(ws1), _ptr(sync), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), _stream())
+            except _lib.OsdError as e:
+                if getattr(e, "code", 0) != -2:
+                    raise
+                onepass = False
+    if conv_db is None and not onepass:
         if ws is None:
             ws = torch.empty((gn_bwd_ws_numel(k, n, c, groups),), device=dev, dtype=torch.float32)
         _lib.call("osd_groupnorm_relu_bwd_levels_fused", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),

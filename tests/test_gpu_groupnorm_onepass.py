@@ -157,3 +157,24 @@ def test_onepass_groupnorm_is_deterministic_beside_a_busy_stream_and_on_two_stre
             assert all(torch.equal(p, q) for p, q in zip(y, y0)), rep
             assert all(torch.equal(p, q) for p, q in zip(du, du0)), rep
     assert ops.gn_onepass_errors() == 0
+
+
+def test_onepass_groupnorm_hands_maps_too_large_for_one_resident_job_to_the_two_launch_kernels():
+    """A (level, image) whose pixels need more workgroups than can be resident together (> 192 of 320 / 128 pixels) must not run
+    the hand-off at all — the spin would end in the error word: the C entry refuses it (OSD_ERR_UNSUPPORTED) and ops falls back to
+    the two-launch kernels, bit for bit."""
+    from oneshotdet_amd import _lib, ops
+    xs, dts, gamma, beta = _levels(1, 256, [(400, 512)], seed=9)       # 204,800 pixels: 640 forward / 1,600 backward workgroups
+    y1, ab1, du1, dg1, db1 = _run(ops, xs, dts, gamma, beta, 32, True)
+    y2, ab2, du2, dg2, db2 = _run(ops, xs, dts, gamma, beta, 32, False)
+    assert torch.equal(y1[0], y2[0]) and torch.equal(ab1, ab2) and torch.equal(du1[0], du2[0])
+    with pytest.raises(_lib.OsdError):
+        import ctypes as C
+        hws = (C.c_int32 * 1)(400 * 512)
+        sync = torch.zeros(4096, device="cuda", dtype=torch.int32)
+        ws = torch.empty(1 << 22, device="cuda")
+        y = torch.empty_like(xs[0])
+        ab = torch.empty((1, 4, 1, 256), device="cuda")
+        _lib.call("osd_groupnorm_relu_fwd_levels_onepass", 1, ops._ptr_array(xs), ops._ptr_array([y]), hws, ops._ptr(gamma), ops._ptr(beta),
+                  ops._ptr(ab), ops._ptr(ws), ops._ptr(sync), 1, 256, 32, 1e-5, ops._dt(xs[0]), ops._stream())
+    assert ops.gn_onepass_errors() == 0
