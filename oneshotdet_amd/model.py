@@ -24,6 +24,7 @@ def _bn(sd, p):
     return (sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"])
 
 
+FPN_OUT_GROUPED = os.environ.get("OSD_NO_FPN_GROUPED", "0") == "0"       # the FPN's P3 + P4 output convs as one launch
 FUSE_DOWNSAMPLE = os.environ.get("OSD_NO_FUSE_DS", "0") == "0"      # A/B switch: conv3 + downsample of a stage's first block as one GEMM
 
 
@@ -129,9 +130,12 @@ def run_backbone(wts, images, dtype, return_body=False):
     inner4 = ops.conv2d(c5, f["fpn_inner4"])
     p5 = ops.conv2d(inner4, f["fpn_layer4"], pad=1)
     inner3 = ops.conv2d(c4, f["fpn_inner3"], res=inner4, res_mode=RES_UP2X)
-    p4 = ops.conv2d(inner3, f["fpn_layer3"], pad=1)
     inner2 = ops.conv2d(c3, f["fpn_inner2"], res=inner3, res_mode=RES_UP2X)
-    p3 = ops.conv2d(inner2, f["fpn_layer2"], pad=1)
+    if FPN_OUT_GROUPED:      # the P3 and P4 output convs as one launch: 400 + 100 pixel tiles = 1.95 rounds of 256 CUs instead of 1.56 and 0.4
+        p3, p4 = ops.conv2d_multi([inner2, inner3], [f["fpn_layer2"], f["fpn_layer3"]], pad=1)
+    else:
+        p4 = ops.conv2d(inner3, f["fpn_layer3"], pad=1)
+        p3 = ops.conv2d(inner2, f["fpn_layer2"], pad=1)
     p6 = ops.conv2d(p5, f["top_blocks.p6"], stride=2, pad=1)
     p7 = ops.conv2d(p6, f["top_blocks.p7"], stride=2, pad=1, relu_in=True)
     out = [p3, p4, p5, p6, p7]
@@ -172,9 +176,13 @@ def run_backbones(wt, wq, images, queries, dtype):
     inner4 = ops.conv2d_multi(c5, f("fpn_inner4"))
     p5 = ops.conv2d_multi(inner4, f("fpn_layer4"), pad=1)
     inner3 = ops.conv2d_multi(c4, f("fpn_inner3"), residuals=inner4, res_mode=RES_UP2X)
-    p4 = ops.conv2d_multi(inner3, f("fpn_layer3"), pad=1)
     inner2 = ops.conv2d_multi(c3, f("fpn_inner2"), residuals=inner3, res_mode=RES_UP2X)
-    p3 = ops.conv2d_multi(inner2, f("fpn_layer2"), pad=1)
+    if FPN_OUT_GROUPED:
+        p34 = ops.conv2d_multi(inner2 + inner3, f("fpn_layer2") + f("fpn_layer3"), pad=1)
+        p3, p4 = p34[:2], p34[2:]
+    else:
+        p4 = ops.conv2d_multi(inner3, f("fpn_layer3"), pad=1)
+        p3 = ops.conv2d_multi(inner2, f("fpn_layer2"), pad=1)
     p6 = ops.conv2d_multi(p5, f("top_blocks.p6"), stride=2, pad=1)
     p7 = [ops.conv2d(p6[j], f("top_blocks.p7")[j], stride=2, pad=1, relu_in=True) for j in (0, 1)]   # relu prologue: tiny
     return [[p3[j], p4[j], p5[j], p6[j], p7[j]] for j in (0, 1)]

@@ -161,6 +161,8 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         # the forward statistics (sum, sum of squares of the tower conv's outputs) in the forward conv's epilogue: no extra operand
         # there, two atomics per wave and group — and still a loss: the conv over P3 + P4 of both towers 243 -> 275 us to save
         # 2 x 13 us of statistics pass, 11.85 vs 11.55 ms per step in same-box A/B.  OSD_GN_FWD_FUSION=1 turns it on
+        # the FPN's P3 and P4 output convs (and their data gradients) as one launch each (OSD_NO_FPN_GROUPED=1: one launch per level)
+        self.fpn_out_grouped = os.environ.get("OSD_NO_FPN_GROUPED", "0") == "0"
         # the tower convs' bias gradients from the GroupNorm backward's sums instead of the weight-gradient launch's column sums
         # (-11 % on that launch); not in ordered mode (its sum order over (level, image) is atomic) and bf16 / fp32 alike
         self.gn_conv_db = (not self.ordered_wgrad and os.environ.get("OSD_NO_GN_CONV_DB", "0") == "0")

@@ -260,8 +260,14 @@ class BackwardPass(object):
         W(f + "fpn_layer4", col("inner4"), d_p5, 1, 1)
         W(f + "fpn_layer3", col("inner3"), dp4, 1, 1)
         W(f + "fpn_layer2", col("inner2"), dp3, 1, 1)
-        d_inner2 = D(f + "fpn_layer2", dp3)
-        d_inner3 = D(f + "fpn_layer3", dp4)
+        if self.fpn_out_grouped:        # the data gradients of the P3 and P4 output convs as one launch (see the forward pass)
+            c_ = cv[bbs[0] + f + "fpn_layer2"]
+            d23 = ops.conv2d_multi(dp3 + dp4, [cv[bb + f + "fpn_layer2"].pd for bb in bbs] + [cv[bb + f + "fpn_layer3"].pd for bb in bbs],
+                                   pad=c_.r - 1 - (c_.r // 2))
+            d_inner2, d_inner3 = d23[:nb], d23[nb:]
+        else:
+            d_inner2 = D(f + "fpn_layer2", dp3)
+            d_inner3 = D(f + "fpn_layer3", dp4)
         d_inner3 = [ops.upsample2x_bwd(a, b) for a, b in zip(d_inner2, d_inner3)]
         d_inner4 = D(f + "fpn_layer4", d_p5)
         d_inner4 = [ops.upsample2x_bwd(a, b) for a, b in zip(d_inner3, d_inner4)]

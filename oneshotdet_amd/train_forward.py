@@ -74,9 +74,16 @@ class ForwardPass(object):
         inner4 = ops.conv2d_multi(c5, pcs(f + "fpn_inner4"))
         p5 = ops.conv2d_multi(inner4, pcs(f + "fpn_layer4"), pad=1)
         inner3 = ops.conv2d_multi(c4, pcs(f + "fpn_inner3"), residuals=inner4, res_mode=RES_UP2X)
-        p4 = ops.conv2d_multi(inner3, pcs(f + "fpn_layer3"), pad=1)
         inner2 = ops.conv2d_multi(c3, pcs(f + "fpn_inner2"), residuals=inner3, res_mode=RES_UP2X)
-        p3 = ops.conv2d_multi(inner2, pcs(f + "fpn_layer2"), pad=1)
+        if self.fpn_out_grouped:
+            # the P3 and P4 output convs (fpn.py:66-75: same 3x3 256 -> 256 geometry, their own weights) as ONE launch: alone, P3's
+            # 400 pixel tiles are 1.56 rounds of the 256 CUs and P4's 100 fill 40 % of one; together 500 tiles are 1.95 rounds —
+            # the tower launch's shape (the grouped-launch tuner may still cut it where that measures faster)
+            p34 = ops.conv2d_multi(inner2 + inner3, pcs(f + "fpn_layer2") + pcs(f + "fpn_layer3"), pad=1)
+            p3, p4 = p34[:len(inner2)], p34[len(inner2):]
+        else:
+            p4 = ops.conv2d_multi(inner3, pcs(f + "fpn_layer3"), pad=1)
+            p3 = ops.conv2d_multi(inner2, pcs(f + "fpn_layer2"), pad=1)
         p6 = ops.conv2d_multi(p5, pcs(f + "top_blocks.p6"), stride=2, pad=1)
         p6r = [ops.add_mask(t, None, t) for t in p6]        # relu(P6), materialised: the P7 weight gradient reads it
         p7 = ops.conv2d_multi(p6r, pcs(f + "top_blocks.p7"), stride=2, pad=1)
