@@ -94,7 +94,10 @@ class ConvTimer(object):
             rs_, ms_ = kw.get("residuals", a[3] if len(a) > 3 else None), kw.get("masks", a[5] if len(a) > 5 else None)
             by = sum(conv_bytes(xi, yi, pc, None if not rs_ else rs_[i], None if not ms_ else ms_[i]) for i, (xi, yi) in enumerate(zip(xs, ys)))
             by -= (len(xs) - 1) * pc.w.numel() * pc.w.element_size() if all(q is pc for q in pcs) else 0.0      # levels share one weight
-            timer.labels.append(("conv%dx%d_grouped" % (pc.r, pc.s), m, pc.cout, k_real, 2.0 * m * pc.cout * k_real, by))
+            # "_grouped": the FPN levels of ONE conv (an FCOS tower layer); "_levels": every segment its own conv (the FPN's P3 + P4
+            # output convs as one launch, round 5) — a backbone / FPN row for roofline.backbone_convs, which skips the tower rows
+            kind = "conv%dx%d_grouped" if len(set(id(q) for q in pcs)) < len(pcs) or len(pcs) == 1 else "conv%dx%d_levels"
+            timer.labels.append((kind % (pc.r, pc.s), m, pc.cout, k_real, 2.0 * m * pc.cout * k_real, by))
             timer.flops += 2.0 * m * pc.cout * k_real
             timer.launches += 1
             return ys
