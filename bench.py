@@ -705,6 +705,9 @@ def main_train(args, rank, world, backend="nccl"):
             torch.cuda.synchronize()
 
     elapsed = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, "cuda")
+    # outside the timed region: a one-pass GroupNorm launch whose hand-off timed out has written NaN and set its error word — such a
+    # run is not a measurement (raises OsdError -> non-zero exit, no JSON line)
+    ops.gn_onepass_check("bench.py, after the timed training steps")
     roofline = None
     if not args.no_conv_timing:
         timer = TrainTimer()
@@ -942,6 +945,7 @@ def main():
             return eng.detect(images, queries, second_stage=two)
 
     elapsed = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, "cuda")
+    ops.gn_onepass_check("bench.py, after the timed forward passes")      # see main_train
 
     # Roofline of the dominant kernel family (conv_igemm): HIP events around every conv launch, on the stream the
     # kernel is launched on, over `steps` further steps of the SAME workload in this process, run eagerly on one

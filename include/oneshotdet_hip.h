@@ -66,10 +66,10 @@ typedef struct osd_conv_desc {
   float act_scale;
   int32_t relu_in;        /* 1: apply ReLU to x while staging (P7 = conv(relu(P6)), fpn.py:98) */
   int32_t algo;           /* 0 = library heuristic; otherwise 1 + impl*32 + variant*8 + tile (see osd_conv_algo_count /
-                             DESIGN.md 4.1): lets the host autotune per layer shape by measurement.  41 (impl 1, variant 1,
-                             tile 0) = the persistent pointwise kernel: bf16, plain 1x1 / stride 1 conv of one dense NHWC
-                             tensor, cin in 64s, cout in 128s, residual OSD_RES_SAME or none, activation none / ReLU
-                             (osd_conv2d_fwd only) */
+                             DESIGN.md 4.1): lets the host autotune per layer shape by measurement.  Ids are only
+                             meaningful for ONE osd_abi_version(): 41 (the persistent pointwise kernel of ABI 3's first
+                             builds) is retired and returns OSD_ERR_UNSUPPORTED; tile 5 / tile 6 variant 0 name other kernels
+                             than they did before ABI 4 — a cached id must be stored with the ABI version it was tuned under */
   int32_t reserved0;      /* (keeps the pointer below 8-byte aligned; set to 0) */
   void* ordered_ws;       /* weight-gradient entries only (ABI 3): NULL = partial tiles are added with fp32 atomics; otherwise
                              a caller-owned scratch buffer of ordered_ws_bytes bytes — the launch STORES its partial tiles
@@ -438,7 +438,10 @@ int osd_groupnorm_relu_fwd_levels_fused(int n_levels, const void* const* xs, voi
  *   ws:   osd_groupnorm_onepass_workspace_bytes(n_levels, hws, n, c, groups, backward) bytes, no initialisation needed;
  *   sync: osd_groupnorm_onepass_sync_bytes(n_levels, n) bytes, ZERO before the first launch that uses it; every launch leaves it zero
  *         again (no memset per launch).  Launches that may overlap in time (different streams) need sync buffers of their own.
- *         sync[2] != 0 after a launch: a workgroup gave up waiting for its job (~1 s), the results are invalid.
+ *         sync[2] != 0 after a launch: a workgroup gave up waiting for its job (~1 s); since ABI 4 such a workgroup also writes NaN
+ *         into every output element it owns (and into the saved statistics), so the failure is visible in the data as well.
+ *   Residency: the forward-progress argument needs two whole jobs resident at once; the launcher checks the occupancy API's answer
+ *   for the device and returns OSD_ERR_UNSUPPORTED when it does not hold (the caller then uses the two-launch entries).
  * Replaces maskrcnn_benchmark/modeling/rpn/fcos/fcos.py:29-37 (GroupNorm + ReLU of a tower layer; torch.nn.GroupNorm forward and
  * autograd backward in the reference). */
 int64_t osd_groupnorm_onepass_workspace_bytes(int n_levels, const int32_t* hws, int n, int c, int groups, int backward);
@@ -449,6 +452,12 @@ int osd_groupnorm_relu_fwd_levels_onepass(int n_levels, const void* const* xs, v
 int osd_groupnorm_relu_bwd_levels_onepass(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
                                           const int32_t* hws, const float* ab, const float* gamma, const float* beta, float* ws,
                                           int32_t* sync, float* dgamma, float* dbeta, int n, int c, int groups, int dtype, void* stream);
+/* DIAGNOSTIC: osd_groupnorm_relu_fwd_levels_onepass with its last workgroup never started and `spin_limit` polls per wait, so that
+ * the timeout path runs (error word set, NaN outputs for the incomplete job).  Leaves `sync` dirty: give it a buffer of its own.
+ * No reference counterpart (torch.nn.GroupNorm, fcos.py:37, cannot fail this way); exists so that the failure path is tested. */
+int osd_groupnorm_onepass_selftest_timeout(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
+                                           const float* gamma, const float* beta, float* ab, float* ws, int32_t* sync, int n, int c,
+                                           int groups, float eps, int dtype, int spin_limit, void* stream);
 int osd_groupnorm_relu_bwd_levels(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
                                   const int32_t* hws, const float* ab, const float* gamma, const float* beta, float* ws,
                                   float* dgamma, float* dbeta, int n, int c, int groups, int dtype, void* stream);

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OSD_LIB_PATH") or os.path.join(_HERE, "lib", "liboneshotdet_hip.so")
 
 OSD_F32, OSD_BF16 = 0, 1
+ABI_VERSION = 4      # include/oneshotdet_hip.h: osd_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_EXP_SCALE = 0, 1, 2
 RES_NONE, RES_SAME, RES_UP2X = 0, 1, 2
 GN_SPLITS = 64
@@ -71,6 +72,7 @@ SIGNATURES = {
     "osd_groupnorm_onepass_sync_bytes": (_i64, [_i, _i]),
     "osd_groupnorm_relu_fwd_levels_onepass": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
     "osd_groupnorm_relu_bwd_levels_onepass": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "osd_groupnorm_onepass_selftest_timeout": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p]),
     "osd_sgd_momentum_multi": (_i, [_p, _p, _i, _p, _p, _p, _f, _f, _i, _p]),
     "osd_sgd_momentum_pack_multi": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _f, _i, _i, _p]),
     "osd_pack_multi": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _p]),
@@ -140,6 +142,9 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.osd_abi_version() != ABI_VERSION:
+        raise OsdError("%s reports ABI %d, this binding is written for ABI %d: rebuild it (`python -m oneshotdet_amd.build`)"
+                       % (LIB_PATH, lib.osd_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

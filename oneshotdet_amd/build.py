@@ -31,6 +31,12 @@ def build_library(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     # every header under csrc/ is a dependency of every object (a handful of small files: a finer map is not worth a stale build)
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(os.path.dirname(HERE), "include", "oneshotdet_hip.h")]
+    # objects of sources that are no longer built (retired kernels) do not stay behind: nothing links them, but they travel with
+    # the snapshot and read as live code
+    keep = set(src.replace(".hip", ".o") for src in SOURCES)
+    for f in os.listdir(objdir):
+        if f.endswith(".o") and f not in keep:
+            os.remove(os.path.join(objdir, f))
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -13,12 +13,19 @@
 // Forward progress: a workgroup takes a TICKET (atomic counter) when it starts and its job follows from the ticket, so the
 // workgroups that hold slots on the chip are always the ones with the lowest tickets; a job's workgroups have consecutive tickets
 // and a job is at most ~100 workgroups (512 resident slots), so the lowest incomplete job can always become fully resident —
-// whatever order the hardware starts blockIdx in, and beside other streams' kernels (they finish without us).  The spin is
-// bounded all the same: after ~1 s a workgroup sets the error word (sync[2]) and goes on with what it has.
+// whatever order the hardware starts blockIdx in, and beside other streams' kernels (they finish without us).  The launcher checks
+// the premise (gn1p_resident_slots: the occupancy API's workgroups per CU x CUs must hold two whole jobs, else UNSUPPORTED and the
+// caller runs the two-launch kernels), and the spin is bounded all the same: after ~1 s a workgroup sets the error word (sync[2])
+// AND POISONS what it writes — every output element, the saved statistics (forward) / every du (backward) become NaN, so a step
+// that ran on incomplete sums cannot pass for a valid one (round 6; until then it "went on with what it had").  Hosts read the
+// error word where they synchronise anyway (ops.gn_onepass_check: bench.py after the timed region, TrainEngine.state_dict).
+// Determinism: the group statistics and every output are bit-reproducible (fixed slot order, double sums); the backward's d gamma /
+// d beta are folded per job in part order but ADDED across jobs with float atomics, so their last bits depend on timing.
 // The sync words are zero before the first launch and every launch leaves them zero (the last workgroup to leave a job clears its
 // counters, the last one of the launch clears the ticket counter): no memset per launch.  One sync buffer per concurrent stream.
 #include "osd_common.h"
 #include <stdlib.h>
+#include <mutex>
 
 #define OSD_STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -36,6 +43,7 @@ struct Gn1pParams {
   void* y[kL];             // forward: t = relu(gn(u)); backward: du
   int hw[kL], parts[kL], ticket_begin[kL + 1], slot_begin[kL];
   int n_levels, n, c, groups, total;
+  int spin_limit;          // polls before a waiting workgroup gives up (kSpinLimit; the self-test passes a small one)
   float eps;
   const float* gamma;
   const float* beta;
@@ -91,21 +99,24 @@ __device__ __forceinline__ Gn1pJob gn1p_take(const Gn1pParams& P, int* sh) {
   return j;
 }
 
-// all partials of this workgroup are stored: signal, then wait for the job's other workgroups
-__device__ __forceinline__ void gn1p_arrive_and_wait(const Gn1pParams& P, const Gn1pJob& j) {
+// all partials of this workgroup are stored: signal, then wait for the job's other workgroups.  -> true when the wait timed out
+// (the job's sums are incomplete: the caller poisons everything it writes)
+__device__ __forceinline__ bool gn1p_arrive_and_wait(const Gn1pParams& P, const Gn1pJob& j, int* sh) {
   wait_vm0();
   __syncthreads();
   if (threadIdx.x == 0) {
     int* a = P.sync + kSyncStride * (1 + j.job);
-    int spins = 0;
+    int spins = 0, bad = 0;
     // the add's own return value is the first poll: the last workgroup to arrive (the one everybody waits for) goes straight on
     if (__hip_atomic_fetch_add(a, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 < j.parts)
     while (__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < j.parts) {
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > kSpinLimit) { __hip_atomic_store(P.sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (++spins > P.spin_limit) { __hip_atomic_store(P.sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad = 1; break; }
     }
+    sh[2] = bad;
   }
   __syncthreads();
+  return __builtin_amdgcn_readfirstlane(sh[2]) != 0;
 }
 
 // -> true for the LAST workgroup to leave the job (it has cleared the job's counters)
@@ -195,7 +206,7 @@ template <int U>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) gn1p_fwd_kernel(Gn1pParams P) {
   typedef __bf16 T;
   constexpr int E = 8;
-  __shared__ int sh[2];
+  __shared__ int sh[4];
   __shared__ float red[2][kThreads];
   __shared__ double scratch[kThreads];
   __shared__ double tot[128];
@@ -234,13 +245,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4
       for (int k = 0; k < cpgc; ++k) t += red[which][l * cch + g * cpgc + k];
     st_sc1(slots + (size_t)j.part * nv + threadIdx.x, t);
   }
-  gn1p_arrive_and_wait(P, j);
+  const bool timed_out = gn1p_arrive_and_wait(P, j, sh);
   gn1p_sum_slots(slots, j.parts, nv, scratch, tot);
   const int g = cc / cpgc;
   const double cnt = (double)hw * (c / groups);
   const double mean = tot[2 * g] / cnt;
   double var = tot[2 * g + 1] / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
+  // a timed-out wait: NaN in the saved planes and in every output element (`poison`, below)
   const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)P.eps));
   float av[E], bv[E];
 #pragma unroll
@@ -249,15 +261,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4
     av[e] = P.gamma[ch] * frstd;
     bv[e] = P.beta[ch] - fmean * av[e];
   }
+  const unsigned poison = (unsigned)__builtin_amdgcn_readfirstlane(timed_out ? -1 : 0);
   if (j.part == 0 && pl == 0) {
     const int n = P.n;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int ch = cc * E + e;
-      P.ab[(((size_t)j.lvl * 4 + 0) * n + j.img) * c + ch] = av[e];
-      P.ab[(((size_t)j.lvl * 4 + 1) * n + j.img) * c + ch] = bv[e];
-      P.ab[(((size_t)j.lvl * 4 + 2) * n + j.img) * c + ch] = frstd;
-      P.ab[(((size_t)j.lvl * 4 + 3) * n + j.img) * c + ch] = -fmean * frstd;
+      P.ab[(((size_t)j.lvl * 4 + 0) * n + j.img) * c + ch] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, av[e]) | poison);
+      P.ab[(((size_t)j.lvl * 4 + 1) * n + j.img) * c + ch] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, bv[e]) | poison);
+      P.ab[(((size_t)j.lvl * 4 + 2) * n + j.img) * c + ch] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, frstd) | poison);
+      P.ab[(((size_t)j.lvl * 4 + 3) * n + j.img) * c + ch] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, -fmean * frstd) | poison);
     }
   }
 #pragma unroll
@@ -267,7 +280,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4
       float o[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) o[e] = fmaxf(fmaf(bf_at(v[k], e), av[e], bv[e]), 0.f);
-      *reinterpret_cast<gn_u32x4*>(y + ((unsigned)(p0 + k * PL) * rowb + cofs)) = bf_pack(o);
+      gn_u32x4 po = bf_pack(o);
+      po |= poison;                                  // 0, or all ones (bf16 NaN pairs) after a timed-out wait: an SGPR operand, no register
+      *reinterpret_cast<gn_u32x4*>(y + ((unsigned)(p0 + k * PL) * rowb + cofs)) = po;
     }
   }
   gn1p_depart(P, j, sh);
@@ -280,7 +295,7 @@ template <int U>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) gn1p_bwd_kernel(Gn1pParams P) {
   typedef __bf16 T;
   constexpr int E = 8;
-  __shared__ int sh[2];
+  __shared__ int sh[4];
   __shared__ float red[2][kThreads];
   __shared__ double scratch[kThreads];
   __shared__ double tot[128];
@@ -365,11 +380,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4
     for (int l = 0; l < PL; ++l) t += redc[((size_t)which * PL + l) * c + ch];
     st_sc1(pws + (size_t)j.part * 2 * c + i, t);
   }
-  gn1p_arrive_and_wait(P, j);
+  const bool timed_out = gn1p_arrive_and_wait(P, j, sh);
   gn1p_sum_slots(slots, j.parts, nv, scratch, tot);
   const int g = cc / cpgc;
   const float inv_m = 1.f / ((float)hw * (c / groups));
-  const float c1 = (float)tot[2 * g] * inv_m, c2 = (float)tot[2 * g + 1] * inv_m;
+  // a timed-out wait: c1 = NaN makes every du of this workgroup NaN
+  const float c1 = timed_out ? __builtin_nanf("") : (float)tot[2 * g] * inv_m, c2 = (float)tot[2 * g + 1] * inv_m;
   unsigned chain = 0u;
 #pragma unroll
   for (int k = 0; k < U; ++k) {
@@ -447,6 +463,41 @@ int gn1p_fill(Gn1pParams& P, const char* who, int n_levels, const void* const* x
   }
   P.ticket_begin[kL] = (int)total;
   P.n_levels = n_levels; P.n = n; P.c = c; P.groups = groups; P.total = (int)total;
+  P.spin_limit = kSpinLimit;
+  return OSD_OK;
+}
+
+// Forward progress rests on residency: the workgroups of the lowest incomplete job of THIS launch and of one more one-pass launch
+// on another stream (the two towers) must fit the chip together.  The occupancy API's answer for the kernel about to be launched
+// (registers, LDS, 512 threads) x the device's CU count is checked against 2 x the largest job: a part with fewer CUs, a
+// partitioned device or a build whose register use halves the residency gets OSD_ERR_UNSUPPORTED here and the caller's two-launch
+// kernels — not a 1 s stall.  (What the API cannot see — a CU mask set from outside — is what the poisoned timeout is for.)
+int gn1p_check_residency(const Gn1pParams& P, const char* who, const void* kernel, size_t dyn_lds) {
+  struct Entry { const void* k; int dev; size_t lds; int slots; };
+  static std::mutex mu;
+  static Entry cache[16];
+  static int n_cache = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "%s: hipGetDevice failed", who);
+  int slots = -1;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < n_cache; ++i)
+      if (cache[i].k == kernel && cache[i].dev == dev && cache[i].lds == dyn_lds) slots = cache[i].slots;
+    if (slots < 0) {
+      int cus = 0, per_cu = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, dyn_lds) != hipSuccess)
+        return osd_fail(OSD_ERR_LAUNCH, "%s: occupancy query failed", who);
+      slots = cus * per_cu;
+      if (n_cache < 16) cache[n_cache++] = Entry{kernel, dev, dyn_lds, slots};
+    }
+  }
+  int maxparts = 0;
+  for (int l = 0; l < P.n_levels; ++l) maxparts = P.parts[l] > maxparts ? P.parts[l] : maxparts;
+  if (2 * maxparts > slots)
+    return osd_fail(OSD_ERR_UNSUPPORTED, "%s: a job of %d workgroups x 2 launches does not fit the %d workgroups this device holds at once: "
+                    "use the two-launch form", who, maxparts, slots);
   return OSD_OK;
 }
 
@@ -465,6 +516,22 @@ extern "C" int64_t osd_groupnorm_onepass_sync_bytes(int n_levels, int n) {
   return (int64_t)kSyncStride * (1 + (int64_t)n_levels * n) * 4;
 }
 
+// launch the forward kernel for U pixels per thread; `drop` workgroups (0, or 1 in the self-test) are not started
+static int gn1p_launch_fwd(const Gn1pParams& P, int U, int drop, void* stream) {
+  const void* kern = U == 8 ? reinterpret_cast<const void*>(gn1p_fwd_kernel<8>) : U == 18 ? reinterpret_cast<const void*>(gn1p_fwd_kernel<18>)
+                   : U == 20 ? reinterpret_cast<const void*>(gn1p_fwd_kernel<20>) : reinterpret_cast<const void*>(gn1p_fwd_kernel<16>);
+  const int rc = gn1p_check_residency(P, "groupnorm_fwd_onepass", kern, 0);
+  if (rc) return rc;
+  const dim3 grid((unsigned)(P.total - drop)), block(kThreads);
+  switch (U) {
+    case 8: hipLaunchKernelGGL(gn1p_fwd_kernel<8>, grid, block, 0, OSD_STREAM(stream), P); break;
+    case 18: hipLaunchKernelGGL(gn1p_fwd_kernel<18>, grid, block, 0, OSD_STREAM(stream), P); break;
+    case 20: hipLaunchKernelGGL(gn1p_fwd_kernel<20>, grid, block, 0, OSD_STREAM(stream), P); break;
+    default: hipLaunchKernelGGL(gn1p_fwd_kernel<16>, grid, block, 0, OSD_STREAM(stream), P); break;
+  }
+  return osd_check_launch("gn1p_fwd");
+}
+
 extern "C" int osd_groupnorm_relu_fwd_levels_onepass(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
                                                      const float* gamma, const float* beta, float* ab, float* ws, int32_t* sync,
                                                      int n, int c, int groups, float eps, int dtype, void* stream) {
@@ -476,14 +543,27 @@ extern "C" int osd_groupnorm_relu_fwd_levels_onepass(int n_levels, const void* c
   int rc = gn1p_fill(P, "groupnorm_fwd_onepass", n_levels, xs, nullptr, ys, hws, n, c, groups, dtype, U);
   if (rc) return rc;
   P.eps = eps; P.gamma = gamma; P.beta = beta; P.ab = ab; P.ws = ws; P.sync = sync; P.dgamma = nullptr; P.dbeta = nullptr;
-  const dim3 grid((unsigned)P.total), block(kThreads);
-  switch (U) {
-    case 8: hipLaunchKernelGGL(gn1p_fwd_kernel<8>, grid, block, 0, OSD_STREAM(stream), P); break;
-    case 18: hipLaunchKernelGGL(gn1p_fwd_kernel<18>, grid, block, 0, OSD_STREAM(stream), P); break;
-    case 20: hipLaunchKernelGGL(gn1p_fwd_kernel<20>, grid, block, 0, OSD_STREAM(stream), P); break;
-    default: hipLaunchKernelGGL(gn1p_fwd_kernel<16>, grid, block, 0, OSD_STREAM(stream), P); break;
-  }
-  return osd_check_launch("gn1p_fwd");
+  return gn1p_launch_fwd(P, U, 0, stream);
+}
+
+// DIAGNOSTIC (tests/test_gpu_groupnorm_onepass.py): the forward launch with its LAST workgroup never started and a short spin —
+// the job that workgroup belongs to can never complete, so its other workgroups must time out, set the error word of `sync` and
+// write NaN.  `sync` is left dirty (counters of the incomplete job): pass a buffer of its own and throw it away afterwards.
+extern "C" int osd_groupnorm_onepass_selftest_timeout(int n_levels, const void* const* xs, void* const* ys, const int32_t* hws,
+                                                      const float* gamma, const float* beta, float* ab, float* ws, int32_t* sync,
+                                                      int n, int c, int groups, float eps, int dtype, int spin_limit, void* stream) {
+  if (!gamma || !beta || !ab || !ws || !sync) return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_onepass_selftest: null argument");
+  Gn1pParams P;
+  if (n_levels < 1 || n_levels > kL || !hws || n < 1 || c < 8 || c % 8 != 0 || c > 512 || kThreads % (c / 8) != 0)
+    return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_onepass_selftest: bad arguments");
+  const int U = gn1p_u_fwd(n_levels, hws, n, c);
+  int rc = gn1p_fill(P, "groupnorm_onepass_selftest", n_levels, xs, nullptr, ys, hws, n, c, groups, dtype, U);
+  if (rc) return rc;
+  if (P.total < 2 || P.parts[n_levels - 1] < 2)
+    return osd_fail(OSD_ERR_INVALID_ARG, "groupnorm_onepass_selftest: the last level must be cut into >= 2 workgroups per image");
+  P.eps = eps; P.gamma = gamma; P.beta = beta; P.ab = ab; P.ws = ws; P.sync = sync; P.dgamma = nullptr; P.dbeta = nullptr;
+  P.spin_limit = spin_limit > 0 ? spin_limit : 1024;
+  return gn1p_launch_fwd(P, U, 1, stream);
 }
 
 extern "C" int osd_groupnorm_relu_bwd_levels_onepass(int n_levels, const void* const* us, const void* const* dts, void* const* dus,
@@ -497,6 +577,12 @@ extern "C" int osd_groupnorm_relu_bwd_levels_onepass(int n_levels, const void* c
   if (rc) return rc;
   P.eps = 0.f; P.gamma = gamma; P.beta = beta; P.ab = const_cast<float*>(ab); P.ws = ws; P.sync = sync; P.dgamma = dgamma; P.dbeta = dbeta;
   const size_t lds = (size_t)2 * (kThreads / (c / 8)) * c * sizeof(float);
+  {
+    const void* kern = U == 4 ? reinterpret_cast<const void*>(gn1p_bwd_kernel<4>) : U == 6 ? reinterpret_cast<const void*>(gn1p_bwd_kernel<6>)
+                     : U == 8 ? reinterpret_cast<const void*>(gn1p_bwd_kernel<8>) : reinterpret_cast<const void*>(gn1p_bwd_kernel<7>);
+    rc = gn1p_check_residency(P, "groupnorm_bwd_onepass", kern, lds);
+    if (rc) return rc;
+  }
   const dim3 grid((unsigned)P.total), block(kThreads);
   switch (U) {
     case 4: hipLaunchKernelGGL(gn1p_bwd_kernel<4>, grid, block, lds, OSD_STREAM(stream), P); break;

@@ -107,7 +107,10 @@ def save_tuner_choices(ops, path):
     from it (load_tuner_choices).  Plain data only — the caches map tuples of ints to ints, so nothing needs pickle (a pickle
     read back from a predictable path would run whatever a planted file holds)."""
     import json
+    from . import _lib
     data = {name: sorted([repr(_plain_key(k)), int(v)] for k, v in getattr(ops, name).items()) for name in TUNER_CACHES}
+    # algorithm ids are only meaningful for one library generation (ids were reused for other kernels in round 5: ADVICE r5)
+    data["abi"] = int(_lib.ABI_VERSION)
     tmp = "%s.tmp.%d" % (path, os.getpid())
     with open(tmp, "w") as f:
         json.dump(data, f)
@@ -122,12 +125,19 @@ def load_tuner_choices(ops, path):
         data = json.load(f)
     if not isinstance(data, dict):
         raise ValueError("%s: not a tuner cache file" % path)
+    from . import _lib
+    if data.get("abi") != _lib.ABI_VERSION:
+        # written by another library generation (or before the stamp existed): its ids may name other kernels now -> tune afresh
+        import warnings
+        warnings.warn("%s: tuner cache of ABI %r ignored (library ABI %d)" % (path, data.get("abi"), _lib.ABI_VERSION))
+        return False
     for name in TUNER_CACHES:
         for entry in data.get(name, []):
             if not (isinstance(entry, list) and len(entry) == 2 and isinstance(entry[0], str) and isinstance(entry[1], int)
                     and not isinstance(entry[1], bool)):
                 raise ValueError("%s: bad entry %r in %s" % (path, entry, name))
             getattr(ops, name)[_plain_key(ast.literal_eval(entry[0]))] = entry[1]
+    return True
 
 
 class GradExchange(object):

@@ -987,6 +987,8 @@ def gn_onepass_ok(x, groups):
 
 def _gn1p_sync(dev, k, n):
     need = int(_lib.load().osd_groupnorm_onepass_sync_bytes(k, n)) // 4
+    # keyed on the CURRENT stream, which is also the stream _stream() hands to the launch that follows (both read
+    # torch.cuda.current_stream() inside one `with torch.cuda.stream(...)` scope: no stream switch between the two calls)
     key = (dev.index, torch.cuda.current_stream().cuda_stream)
     buf = _GN1P_SYNC.get(key)
     if buf is None or buf.numel() < need:
@@ -997,6 +999,15 @@ def _gn1p_sync(dev, k, n):
 def gn_onepass_errors():
     """sum of the error words of every one-pass sync buffer (0 = no workgroup ever gave up waiting); synchronises"""
     return int(sum(int(b[2].item()) for b in _GN1P_SYNC.values()))
+
+
+def gn_onepass_check(where=""):
+    """raise when any one-pass GroupNorm launch timed out waiting for a workgroup of its job (such a launch has also written NaN
+    into its outputs: groupnorm_onepass.hip).  Synchronises: call it where the host synchronises anyway (bench.py after the timed
+    region, TrainEngine.state_dict, the end of an evaluation loop), never per step."""
+    if _GN1P_SYNC and gn_onepass_errors() != 0:
+        raise _lib.OsdError("one-pass GroupNorm%s: a workgroup timed out waiting for its (level, image)'s partial sums — the outputs "
+                            "of that launch are NaN; set OSD_GN_ONEPASS=0 for the two-launch kernels" % (" (%s)" % where if where else ""))
 
 
 def _gn1p_ws(dev, k, hws, n, c, groups, backward):

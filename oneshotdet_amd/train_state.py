@@ -89,6 +89,10 @@ class State(object):
         `DetectronCheckpointer.save` (utils/checkpoint.py:35-52) would write for the hot-path modules.  Frozen tensors
         (stem, layer1, every FrozenBN buffer) are returned unchanged."""
         self.join()
+        # a checkpoint is where a training loop synchronises anyway: weights updated from a one-pass GroupNorm launch whose hand-off
+        # timed out (NaN outputs + error word, groupnorm_onepass.hip) must not be written out as if they were valid
+        from . import ops
+        ops.gn_onepass_check("TrainEngine.state_dict")
         out = {k: v.clone() for k, v in self._frozen_sd.items()}
         out.update(self._export_flat(self.flat_w))
         return out

@@ -93,9 +93,20 @@ import tempfile
 path = os.path.join(tempfile.gettempdir(), "osd_tuner_%d_%d.json" % (os.getpid(), rank))
 dist_utils.save_tuner_choices(fake, path)
 fake2 = types.SimpleNamespace(ALGO_CACHE={}, SPLIT_CACHE={}, WGRAD_ALGO_CACHE={})
-dist_utils.load_tuner_choices(fake2, path)
-os.remove(path)
+ok3 = ok3 and dist_utils.load_tuner_choices(fake2, path) is True
 ok3 = ok3 and fake2.ALGO_CACHE == fake.ALGO_CACHE and fake2.WGRAD_ALGO_CACHE == fake.WGRAD_ALGO_CACHE
+# a file of another library generation (algorithm ids were reused for other kernels: ADVICE r5) is ignored, not replayed
+import json, warnings
+with open(path) as f:
+    stale = json.load(f)
+stale["abi"] = 3
+with open(path, "w") as f:
+    json.dump(stale, f)
+fake3 = types.SimpleNamespace(ALGO_CACHE={}, SPLIT_CACHE={}, WGRAD_ALGO_CACHE={})
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    ok3 = ok3 and dist_utils.load_tuner_choices(fake3, path) is False and not fake3.ALGO_CACHE and not fake3.WGRAD_ALGO_CACHE
+os.remove(path)
 print("RANK %d TUNER=%s" % (rank, ok3), flush=True)
 dist.destroy_process_group()
 sys.exit(0 if (ok and ok2 and ok3) else 1)

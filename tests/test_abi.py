@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol(lib_path):
     for name in declared_symbols():
         assert hasattr(lib, name), name
     lib.osd_abi_version.restype = ctypes.c_int
-    assert lib.osd_abi_version() == 3
+    from oneshotdet_amd import _lib
+    assert lib.osd_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_ops_fail_loudly_without_gpu():

@@ -178,3 +178,44 @@ def test_onepass_groupnorm_hands_maps_too_large_for_one_resident_job_to_the_two_
         _lib.call("osd_groupnorm_relu_fwd_levels_onepass", 1, ops._ptr_array(xs), ops._ptr_array([y]), hws, ops._ptr(gamma), ops._ptr(beta),
                   ops._ptr(ab), ops._ptr(ws), ops._ptr(sync), 1, 256, 32, 1e-5, ops._dt(xs[0]), ops._stream())
     assert ops.gn_onepass_errors() == 0
+
+
+def test_onepass_groupnorm_timeout_is_loud():
+    """VERDICT r5 item 4 / ADVICE r5: a workgroup that gives up waiting for its job must not "go on with what it has" silently.  The
+    diagnostic entry launches the forward kernel WITHOUT its last workgroup and with a short spin: the incomplete job's workgroups
+    time out, set the error word, and write NaN into every output element and into the saved statistics of that (level, image);
+    complete jobs are untouched; `ops.gn_onepass_check()` (what bench.py and TrainEngine.state_dict call) raises."""
+    import ctypes as C
+    from oneshotdet_amd import _lib, ops
+    n, c, groups = 2, 256, 32
+    sizes = [(50, 64), (25, 32)]                        # 3200 / 800 pixels per image: 10 / 3 workgroups of 320 pixels each
+    xs, _, gamma, beta = _levels(n, c, sizes, seed=11)
+    ys = [torch.zeros_like(x) for x in xs]
+    ab = torch.zeros((2, 4, n, c), device="cuda")
+    hws = (C.c_int32 * 2)(*[h * w for h, w in sizes])
+    sync = torch.zeros(32 * 64, device="cuda", dtype=torch.int32)          # a buffer of its own: left dirty by the self-test
+    ws = torch.empty(int(_lib.load().osd_groupnorm_onepass_workspace_bytes(2, hws, n, c, groups, 0)) // 4, device="cuda")
+    assert ops.gn_onepass_errors() == 0
+    _lib.call("osd_groupnorm_onepass_selftest_timeout", 2, ops._ptr_array(xs), ops._ptr_array(ys), hws, ops._ptr(gamma), ops._ptr(beta),
+              ops._ptr(ab), ops._ptr(ws), ops._ptr(sync), n, c, groups, 1e-5, ops._dt(xs[0]), 2000, ops._stream())
+    torch.cuda.synchronize()
+    assert int(sync[2].item()) == 1
+    # the dropped workgroup is the LAST ticket: level 1, image 1, last part.  Its job's other workgroups wrote NaN ...
+    last = ys[1][1].float().reshape(-1, c)
+    px = 320
+    assert torch.isnan(last[:2 * px]).all()
+    assert (last[2 * px:] == 0).all()                   # ... the dropped one wrote nothing
+    assert torch.isnan(ab[1, :, 1]).all()
+    # ... and every complete job is what the normal launch gives
+    y_ref, ab_ref = ops.groupnorm_relu_levels(xs, gamma, beta, groups=groups)
+    assert torch.equal(ys[0], y_ref[0]) and torch.equal(ys[1][0], y_ref[1][0])
+    assert torch.equal(ab[0], ab_ref[0]) and torch.equal(ab[1, :, 0], ab_ref[1, :, 0])
+    # the host-side check: the error word of a REGISTERED sync buffer raises where the host synchronises
+    key = ("selftest", 0)
+    ops._GN1P_SYNC[key] = sync
+    try:
+        with pytest.raises(_lib.OsdError):
+            ops.gn_onepass_check("test")
+    finally:
+        del ops._GN1P_SYNC[key]
+    assert ops.gn_onepass_errors() == 0
