@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3)
   // make hipcc copy the whole table to scratch
   struct {
     const void* x; const void* dy; float* dw; const float* scale; float* db;
-    int H, W, Cin, Ho, Wo, Cout, HoWo, R, S, sh, sw, ph, pw, dy_stride, M, tilesCo, tilesCi, rows_per_split, Ktot;
+    int H, W, Cin, Ho, Wo, Cout, HoWo, R, S, sh, sw, ph, pw, dy_stride, M, tilesCo, tilesCi, rows_per_split, Ktot, owner;
   } p;
   typedef const __attribute__((address_space(4))) char* kptr;
   typedef unsigned long long u64;
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3)
   p.Cin = OSD_WSEG(int, Cin); p.Cout = OSD_WSEG(int, Cout); p.R = OSD_WSEG(int, R); p.S = OSD_WSEG(int, S);
   p.sh = OSD_WSEG(int, sh); p.sw = OSD_WSEG(int, sw); p.ph = OSD_WSEG(int, ph); p.pw = OSD_WSEG(int, pw);
   p.dy_stride = OSD_WSEG(int, dy_stride); p.tilesCo = OSD_WSEG(int, tilesCo); p.tilesCi = OSD_WSEG(int, tilesCi);
-  p.Ktot = OSD_WSEG(int, Ktot);
+  p.Ktot = OSD_WSEG(int, Ktot); p.owner = OSD_WSEG(int, owner);
   const int slot_id = bid;            // logical id over the whole launch: the partial tile's slot in ordered mode
   bid -= OSD_WSEG(int, block_begin);
 #undef OSD_WSEG
@@ -341,6 +341,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && WCO + WCI == 3)
 #pragma unroll
       for (int e = 0; e < 4; ++e) scv[i][e] = p.scale ? p.scale[co_w + i * 16 + e] : 1.f;
     float* base = dw + (size_t)co_w * p.Ktot + tap * p.Cin + ci_w;
+    if (p.owner != 0) {                                   // the only writer of this tile in this launch: plain load + store
+      wg_owner_add<TA, TB>(base, p.Ktot, acc, scv);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < TA; ++i)
 #pragma unroll
@@ -933,6 +937,15 @@ static int wgrad_xr_launch(int n_seg, const WgradProblem* pr, hipStream_t s) {
     nblocks += (long long)g.tilesCo * g.tilesCi * 3 * splits;
     if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
   }
+  // owner mode needs the segment's dW (and db: its adds stay atomic) to be named by no other segment of the launch; never in
+  // ordered mode (the partial tiles go to the scratch slots) or team mode (several teams add into one dW).  OSD_WGRAD_NO_OWNER=1: A/B
+  static int no_owner = -1;
+  if (no_owner < 0) { const char* e = getenv("OSD_WGRAD_NO_OWNER"); no_owner = (e && atoi(e) != 0) ? 1 : 0; }
+  for (int i = 0; i < n_seg; ++i) {
+    if (no_owner || d0->ordered_ws != nullptr || p.sk_units > 0) p.seg[i].owner = 0;
+    for (int j = 0; j < n_seg && p.seg[i].owner; ++j)
+      if (j != i && p.seg[j].dw == p.seg[i].dw) p.seg[i].owner = 0;
+  }
   for (int i = n_seg; i < kMaxSeg; ++i) p.seg[i] = p.seg[0];
   p.n_blocks = (int)nblocks;
   p.partials = nullptr;         // the filter-row kernel has no ordered mode
@@ -1027,8 +1040,11 @@ static int wgrad_launch_v(int n_seg, const WgradProblem* pr, hipStream_t s, int 
     WgradSeg& g = p.seg[i];
     int sp = (int)((g.M + rows - 1) / rows);
     if (sp < 1) sp = 1;
+    // (round 6, measured and dropped: keeping a segment up to 25 % over the target at ONE split so that it owns its tiles — the
+    // layer3 stage launch then runs 108 workgroups instead of its best 216: 480 vs 405 us; the tuner's target codes decide alone)
     g.rows_per_split = cdiv(cdiv(g.M, sp), 32) * 32;
     const int splits = cdiv(g.M, g.rows_per_split);
+    g.owner = splits == 1 ? 1 : 0;
     g.block_begin = (int)nblocks;
     nblocks += (long long)g.tilesCo * g.tilesCi * g.R * g.S * splits;
     if (nblocks > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
@@ -1063,6 +1079,15 @@ static int wgrad_launch_v(int n_seg, const WgradProblem* pr, hipStream_t s, int 
     if (total > 0x7fffffffLL) return osd_fail(OSD_ERR_INVALID_ARG, "wgrad: bad grid");
     p.sk_units = units; p.sk_teams = (int)teams; p.sk_total = (int)total;
     nblocks = teams * units;
+  }
+  // owner mode needs the segment's dW (and db: its adds stay atomic) to be named by no other segment of the launch; never in
+  // ordered mode (the partial tiles go to the scratch slots) or team mode (several teams add into one dW).  OSD_WGRAD_NO_OWNER=1: A/B
+  static int no_owner = -1;
+  if (no_owner < 0) { const char* e = getenv("OSD_WGRAD_NO_OWNER"); no_owner = (e && atoi(e) != 0) ? 1 : 0; }
+  for (int i = 0; i < n_seg; ++i) {
+    if (no_owner || d0->ordered_ws != nullptr || p.sk_units > 0) p.seg[i].owner = 0;
+    for (int j = 0; j < n_seg && p.seg[i].owner; ++j)
+      if (j != i && p.seg[j].dw == p.seg[i].dw) p.seg[i].owner = 0;
   }
   for (int i = n_seg; i < kMaxSeg; ++i) p.seg[i] = p.seg[0];
   p.n_blocks = (int)nblocks;

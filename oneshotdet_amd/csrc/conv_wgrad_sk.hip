@@ -357,14 +357,18 @@ __global__ void __launch_bounds__(64 * NW, 1) conv_wgrad_sk_kernel(WgradParams g
 #pragma unroll
           for (int e = 0; e < 4; ++e) scv[i][e] = pscale ? pscale[co_w + i * 16 + e] : 1.f;
         float* base = pdw + (size_t)co_w * Ktot + tap * Cin + ci_w;
+        if (!team && OSD_KSEG(sidx, int, owner) != 0) {
+          wg_owner_add<TA, TB>(base, Ktot, acc, scv);       // the only writer of this tile: plain load + store
+        } else {
 #pragma unroll
-        for (int i = 0; i < TA; ++i)
+          for (int i = 0; i < TA; ++i)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float* row = base + (size_t)(i * 16 + e) * Ktot;
+            for (int e = 0; e < 4; ++e) {
+              float* row = base + (size_t)(i * 16 + e) * Ktot;
 #pragma unroll
-            for (int j = 0; j < TB; ++j) wg_atomic_add(row + j * 16, acc[i][j][e] * scv[i][e]);
-          }
+              for (int j = 0; j < TB; ++j) wg_atomic_add(row + j * 16, acc[i][j][e] * scv[i][e]);
+            }
+        }
       } else {
         // ragged tile (channel counts that are not multiples of the tile): per-element bounds checks
 #pragma unroll

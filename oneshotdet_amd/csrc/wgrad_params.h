@@ -19,6 +19,8 @@ struct WgradSeg {
   int Cin, Cout, R, S, sh, sw, ph, pw, dy_stride, tilesCo, tilesCi, Ktot;
   int block_begin;      // first (logical) workgroup of this segment; its workgroups: tilesCo x R*S*tilesCi x splits
   int stage_begin;      // team mode (conv_wgrad_sk.hip): first 64-pixel stage of this segment on the launch's concatenated pixel axis
+  int owner;            // round 6: 1 = every output tile of this segment belongs to ONE workgroup of the launch (one pixel split, no
+                        // other segment names its dW): the tile is added by plain load + store instead of memory-side atomics
 };
 
 // Every segment is a complete problem (its own tensors, geometry and outputs; segments that share a dW simply repeat the
@@ -40,6 +42,28 @@ struct WgradParams {
 typedef __attribute__((address_space(1))) float wg_gfloat;
 __device__ __forceinline__ void wg_atomic_add(float* ptr, float v) {
   (void)__hip_atomic_fetch_add((wg_gfloat*)ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Owner mode (WgradSeg.owner): dW[rows i*16 + e][cols j*16] += acc * scale by plain loads and stores — this workgroup is the only
+// writer of the tile in this launch.  Memory-side float atomics run at ~1.3 TB/s chip-wide (MI355X_MICROARCH.md): a 256 x 256
+// fp32 tile per workgroup on every CU at once is ~50 us of epilogue, plain traffic ~20; and the layer4 + FPN stage launch wrote
+// 329 MB of partial tiles for 60 MB of dW (profiles/r5_pmc_traffic_by_kernel.txt).  One row group (16 co rows) at a time: 4 x TB
+// loads in flight, then their stores; the sched_barrier keeps hipcc from hoisting the next group's loads (registers).
+template <int TA, int TB>
+__device__ __forceinline__ void wg_owner_add(float* base, int Ktot, const f32x4 (&acc)[TA][TB], const float (&scv)[TA][4]) {
+#pragma unroll
+  for (int i = 0; i < TA; ++i) {
+    float old[4][TB];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < TB; ++j) old[e][j] = ((const wg_gfloat*)(base + (size_t)(i * 16 + e) * Ktot))[j * 16];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < TB; ++j) ((wg_gfloat*)(base + (size_t)(i * 16 + e) * Ktot))[j * 16] = old[e][j] + acc[i][j][e] * scv[i][e];
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

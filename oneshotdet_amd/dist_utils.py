@@ -4,6 +4,8 @@ contiguous all-reduces — RCCL over xGMI with backend "nccl", gloo in the CPU t
 import os
 
 import torch
+
+from . import streams
 import torch.distributed as dist
 
 
@@ -209,7 +211,7 @@ class GradExchange(object):
             self.comm.wait_event(ev)
         if self._skip_collective:          # skip_collective_for_timing(): events and streams, no collective
             return
-        with torch.cuda.stream(self.comm):
+        with streams.on(self.comm):
             if self.wire_dtype is not None and lo % 8 == 0 and (hi - lo) % 8 == 0:
                 from . import _lib, ops
                 if self._wire is None:
@@ -232,9 +234,9 @@ class GradExchange(object):
         """Exchange whatever has not been announced yet, then order the current stream after the whole exchange."""
         if not self.active:
             return
-        cur = [torch.cuda.current_stream()] if self.cuda else ()
+        cur = [streams.current()] if self.cuda else ()
         for name in [n for n in self.ranges if n in self.pending]:
             self.ready(name, cur)
         if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.comm)
+            streams.current().wait_stream(self.comm)
         self.begin()

@@ -11,6 +11,8 @@ import os
 
 import torch
 
+from . import streams as _streams
+
 from . import ops, spec
 from .ops import ACT_EXP_SCALE, ACT_NONE, ACT_RELU, RES_SAME, RES_UP2X
 
@@ -252,9 +254,9 @@ def run_head(hw, feats, streams=None):
         return run_head_merged(hw, feats)
     if not streams:
         return list(zip(run_head_tower(hw, feats, "cls_tower"), run_head_tower(hw, feats, "bbox_tower")))
-    main = torch.cuda.current_stream()
+    main = _streams.current()
     streams[0].wait_stream(main)
-    with torch.cuda.stream(streams[0]):
+    with _streams.on(streams[0]):
         box_out = run_head_tower(hw, feats, "bbox_tower")
     cls_out = run_head_tower(hw, feats, "cls_tower")
     main.wait_stream(streams[0])
@@ -390,9 +392,9 @@ class HotPathEngine(object):
             feats, qfeats = run_backbones(self.backbone, self.supp_backbone, images, queries, self.dtype)
             pooled = run_query_pool(qfeats, q_sizes, batch)
         elif concurrent:
-            main, side = torch.cuda.current_stream(), self.side_streams()[0]
+            main, side = _streams.current(), self.side_streams()[0]
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with _streams.on(side):
                 qfeats = run_backbone(self.supp_backbone, queries, self.dtype)
                 pooled = run_query_pool(qfeats, q_sizes, batch)
             feats = run_backbone(self.backbone, images, self.dtype)
@@ -460,11 +462,11 @@ class GraphedDetect(object):
         self.queries = queries.clone()
         engine.tune(self.images, self.queries, second_stage=bool(kw.get("second_stage")))
         side = torch.cuda.Stream(device=engine.device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        side.wait_stream(_streams.current())
+        with _streams.on(side):
             for _ in range(warmup):
                 engine.detect(self.images, self.queries, **kw)
-        torch.cuda.current_stream().wait_stream(side)
+        _streams.current().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

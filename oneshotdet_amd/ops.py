@@ -12,8 +12,14 @@ from ._lib import (ACT_EXP_SCALE, ACT_NONE, ACT_RELU, GN_SPLITS, OSD_BF16, OSD_F
 __all__ = ["ACT_NONE", "ACT_RELU", "ACT_EXP_SCALE", "RES_NONE", "RES_SAME", "RES_UP2X"]
 
 
+from . import streams
+
+# the current stream's raw handle without torch.cuda.current_stream()'s ~8 us of Python per call (streams.py)
+_stream_handle = streams.raw_handle
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_stream_handle())
 
 
 from .trace import rec as _rec      # launch trace (tests only): oneshotdet_amd/trace.py
@@ -150,6 +156,44 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
     _chk_dev(x, res, out)
     if x2 is not None:
         return _conv2d_two_sources(x, x2, x2_stride, pc, act, out, algo, pc2, bias)
+    # The descriptor of a (layer geometry, input shape, epilogue) combination never changes: it is built once and reused — ~25 ctypes
+    # field stores and a 14-tuple cache key per call otherwise, 210 calls per training step on a host that is the bottleneck of the
+    # small multi-scale geometries.  The library reads *d during the call only (launch parameters are copied).
+    shape = x.shape
+    okey = None if out is None else out.shape[-1]
+    ckey = (shape, x.dtype, pc.cout_store, pc.w_rows, pc.cin_k, pc.r, pc.s, pc.stem, stride, pad, act, res_mode,
+            None if res is None else res.shape, bool(relu_in), float(act_scale), mask is not None, out_hw, okey)
+    ent = _CONV_DESCS.get(ckey)
+    if ent is None:
+        ent = _CONV_DESCS[ckey] = _build_conv_desc(x, pc, stride, pad, act, res, res_mode, relu_in, act_scale, out, out_hw, mask)
+    d, oshape, key = ent[0], ent[1], ent[2]
+    if out is None:
+        out = torch.empty(oshape, device=x.device, dtype=x.dtype)
+    if mask is not None:
+        assert mask.shape == out.shape and mask.dtype == out.dtype
+    args = (_p(x), _p(pc.w), _p(pc.bias), _p(res), _p(mask), _p(act_scale_dev), None, _p(out), _stream())
+    if algo is None:
+        algo = ALGO_CACHE.get(key)             # (looked up per call: tests and rank > 0 replace the cache's contents)
+        if algo is None:
+            algo = _tune(key, d, lambda: _lib.call("osd_conv2d_fwd", C.byref(d), *args)) if _TUNING[0] else 0
+    d.algo = algo
+    _lib.call("osd_conv2d_fwd", C.byref(d), *args)
+    _rec("conv", x=x, w=pc.w, bias=pc.bias, cout=pc.cout_store, r=pc.r, s=pc.s, stem=pc.stem, stride=stride, pad=pad, act=act,
+         res=res, res_mode=res_mode, relu_in=bool(relu_in), act_scale=float(act_scale), act_scale_dev=act_scale_dev, mask=mask,
+         out=out)
+    return out
+
+
+_CONV_DESCS = {}      # conv2d: (geometry, input shape, epilogue) -> (ConvDesc, output shape, tuner key)
+
+
+def _p(t):
+    """device address of a tensor the CALLER keeps alive across the launch (a named tensor, an attribute): a plain int.  `_ptr` is
+    for temporaries built inside an argument list."""
+    return None if t is None else t.data_ptr()
+
+
+def _build_conv_desc(x, pc, stride, pad, act, res, res_mode, relu_in, act_scale, out, out_hw, mask):
     n, h, w, c = x.shape
     d = ConvDesc()
     d.dtype = _dt(x)
@@ -170,32 +214,18 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
         d.stride_h = d.stride_w = stride
         d.pad_h = d.pad_w = pad
     d.ho, d.wo, d.cout, d.w_rows = ho, wo, pc.cout_store, pc.w_rows
-    if out is None:
-        out = torch.empty((n, ho, wo, pc.cout_store), device=x.device, dtype=x.dtype)
-    d.out_stride = out.shape[-1]
+    oshape = (n, ho, wo, pc.cout_store)
+    d.out_stride = pc.cout_store if out is None else out.shape[-1]
     d.res_mode = res_mode
     if res_mode != RES_NONE:
         d.res_h, d.res_w, d.res_stride = res.shape[1], res.shape[2], res.shape[3]
         if res_mode == RES_UP2X:
             assert res.shape[1] * 2 == ho and res.shape[2] * 2 == wo, "top-down map must be exactly half size"
     d.act, d.act_scale, d.relu_in = act, float(act_scale), int(relu_in)
-    if mask is not None:
-        assert mask.shape == out.shape and mask.dtype == out.dtype
-    args = (_ptr(x), _ptr(pc.w), _ptr(pc.bias), _ptr(res), _ptr(mask), _ptr(act_scale_dev), None, _ptr(out), _stream())
-    if algo is None:
-        # full geometry in the key: some algorithms only exist for some map widths (the row-reuse kernel: W in 64/128/256),
-        # and a transposed batch (1024x800 after 800x1024) has the same n*ho*wo
-        key = (d.dtype, n, ho, wo, d.cout, d.cin, d.r, d.s, d.stride_h, d.pad_h, res_mode, act, int(relu_in),
-               mask is not None)
-        algo = ALGO_CACHE.get(key)
-        if algo is None:
-            algo = _tune(key, d, lambda: _lib.call("osd_conv2d_fwd", C.byref(d), *args)) if _TUNING[0] else 0
-    d.algo = algo
-    _lib.call("osd_conv2d_fwd", C.byref(d), *args)
-    _rec("conv", x=x, w=pc.w, bias=pc.bias, cout=pc.cout_store, r=pc.r, s=pc.s, stem=pc.stem, stride=stride, pad=pad, act=act,
-         res=res, res_mode=res_mode, relu_in=bool(relu_in), act_scale=float(act_scale), act_scale_dev=act_scale_dev, mask=mask,
-         out=out)
-    return out
+    # full geometry in the tuner key: some algorithms only exist for some map widths (the row-reuse kernel: W in 64/128/256),
+    # and a transposed batch (1024x800 after 800x1024) has the same n*ho*wo
+    key = (d.dtype, n, ho, wo, d.cout, d.cin, d.r, d.s, d.stride_h, d.pad_h, res_mode, act, int(relu_in), mask is not None)
+    return (d, oshape, key)
 
 
 def _conv2d_two_sources(x, x2, x2_stride, pc, act, out, algo, pc2=None, bias=None):
@@ -629,7 +659,7 @@ def wgrad_set_workspace(stream=None, nbytes=1 << 30):
 
 def _wgrad_ws(d):
     """Fill the descriptor's ordered-mode fields from the current stream's registered scratch buffer (if any)."""
-    buf = _WGRAD_WS.get(torch.cuda.current_stream().cuda_stream)
+    buf = _WGRAD_WS.get(_stream_handle())
     if buf is not None:
         d.ordered_ws, d.ordered_ws_bytes = buf.data_ptr(), buf.numel() * 4
     return d
@@ -637,7 +667,7 @@ def _wgrad_ws(d):
 
 def _wgrad_mode():
     """Part of the weight-gradient tuner's cache key: the best variant differs between atomics and ordered mode."""
-    return torch.cuda.current_stream().cuda_stream in _WGRAD_WS
+    return _stream_handle() in _WGRAD_WS
 
 
 def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None, db=None, algo=None):
@@ -989,7 +1019,7 @@ def _gn1p_sync(dev, k, n):
     need = int(_lib.load().osd_groupnorm_onepass_sync_bytes(k, n)) // 4
     # keyed on the CURRENT stream, which is also the stream _stream() hands to the launch that follows (both read
     # torch.cuda.current_stream() inside one `with torch.cuda.stream(...)` scope: no stream switch between the two calls)
-    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    key = (dev.index, _stream_handle())
     buf = _GN1P_SYNC.get(key)
     if buf is None or buf.numel() < need:
         buf = _GN1P_SYNC[key] = torch.zeros((max(need, 32 * 513),), device=dev, dtype=torch.int32)

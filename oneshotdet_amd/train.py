@@ -17,6 +17,8 @@ import os
 
 import torch
 
+from . import streams
+
 from . import ops, spec
 
 from .train_backward import BackwardPass
@@ -172,7 +174,7 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         # this engine's weight-gradient streams explicitly either way (close() / __del__ release the scratch buffers)
         # (the second stage's weight gradients run on the proposal stream: box_head_forward_backward)
         cands = (self.wstream, self.wstream2) + ((self.pstream,) if self.second_stage else ())
-        self._wgrad_streams = list({id(x): x for x in cands if x is not None}.values()) or [torch.cuda.current_stream()]
+        self._wgrad_streams = list({id(x): x for x in cands if x is not None}.values()) or [streams.current()]
         if self.ordered_wgrad and self.second_stage:
             import warnings
             warnings.warn("ordered_wgrad makes every conv_wgrad launch bit-reproducible, the second stage's included; its "
@@ -313,7 +315,7 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         which have slack: +1.2 % .. +3.5 % images/s on three boxes (profiles/r4_stream_order_ab.txt).  OSD_WARM_ORDER=main,w,s1,w2,p,u
         restores the old pairing.  The engine calls this at construction; call it again before anything else in the process
         creates streams of its own only if the engine was built without it (torch.distributed / RCCL: see attach_exchange)."""
-        cur = torch.cuda.current_stream()
+        cur = streams.current()
         probe = torch.zeros(64, device=self.device, dtype=torch.float32)
         by_name = {"main": cur, "w": self.wstream, "s1": self.s1, "w2": self.wstream2, "p": self.pstream, "u": self.ustream}
         order = [n for n in os.environ.get("OSD_WARM_ORDER", "main,s1,u,w,w2,p").split(",") if n in by_name]
@@ -321,7 +323,7 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
             st = by_name[name]
             if st is None:
                 continue
-            with torch.cuda.stream(st):
+            with streams.on(st):
                 ops.add_mask(probe, None, None, out=probe)
         torch.cuda.synchronize()
 
@@ -383,7 +385,7 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
             queries, query_sizes = queries.tensors, queries.image_sizes
         elif isinstance(queries, ops.PackedImages):
             query_sizes = queries.image_sizes
-        main, s1 = torch.cuda.current_stream(), self.s1
+        main, s1 = streams.current(), self.s1
         # train_step(defer_join) left the previous step's tail (last weight gradients, exchange, update, repack, proposals)
         # running on the side streams: the frozen prefix of this forward goes first, then the main stream joins them
         deferred, self._deferred = self._deferred, None
@@ -427,7 +429,7 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
             if s1 is None and af is not None:       # single stream: the join cannot be deferred past the query backbone
                 af()
                 af = None
-            with torch.cuda.stream(side):
+            with streams.on(side):
                 (qfeats,), (qctx,) = self._backbones_forward(self.BBS[1:], (queries,))
                 pooled = pool(qfeats)
             (feats,), (tctx,) = self._backbones_forward(self.BBS[:1], (images,), af)
@@ -439,7 +441,7 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
             ps = self.pstream if self.pstream is not None else main                        # independent of loss/backward
             if ps is not main:
                 ps.wait_stream(main)
-            with torch.cuda.stream(ps):
+            with streams.on(ps):
                 pb, ps_, pc = model.run_proposals(head_out, images.shape[-2], images.shape[-1],
                                                   spec.PRE_NMS_TOP_N_TRAIN, spec.POST_NMS_TOP_N_TRAIN, spec.NMS_THRESH,
                                                   image_sizes=image_sizes,    # padded batch: clip to each image's size
@@ -469,7 +471,7 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
             if ps is not main:
                 main.wait_stream(ps)
             self.box_losses, gx, gqs = box_out
-        with torch.cuda.stream(side):      # the query branch's small pooling-backward chain beside d feat
+        with streams.on(side):      # the query branch's small pooling-backward chain beside d feat
             dQ = []
             for dql, qf, scale in zip(dq, qfeats, spec.POOLER_SCALES):
                 dv = ops.shot_mean_bwd(dql, shots)
@@ -521,7 +523,7 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         exchange, update, repack, proposals).  Call before reading weights, gradients or proposals on this stream."""
         d, self._deferred = self._deferred, None
         if d is not None:
-            cur = torch.cuda.current_stream()
+            cur = streams.current()
             for ev in d["events"]:
                 cur.wait_event(ev)
             self._joined_refs = d["refs"]          # dropped at the next step: the waits above are enqueued, not finished
@@ -565,11 +567,11 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         self.defer_join = False        # a captured graph must join every stream it forked
         self._prop_depth = None        # the lagged NMS-depth feedback queries events from the host: not capturable
         side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        side.wait_stream(streams.current())
+        with streams.on(side):
             for _ in range(warmup):
                 self.train_step(*self._static)
-        torch.cuda.current_stream().wait_stream(side)
+        streams.current().wait_stream(side)
         torch.cuda.synchronize()
         # the captured forward + backward owns its own zeroing of the gradient buffer: `_grads_clean` is a HOST flag, and a graph
         # captured while it was set would hold no memset — correct only while every replay follows a consuming update.  An eager

@@ -4,6 +4,8 @@ exchange as soon as their last writer is enqueued.  The reference gets all of th
 
 import torch
 
+from . import streams
+
 from . import ops, spec
 
 
@@ -21,7 +23,7 @@ class BackwardPass(object):
         ev = torch.cuda.Event()
         ev.record()
         ws.wait_event(ev)
-        with torch.cuda.stream(ws):
+        with streams.on(ws):
             fn()
         self._keep.append(tensors)        # keep the operands alive until the side stream has been joined
 
@@ -32,7 +34,7 @@ class BackwardPass(object):
         stream: the bucket's data-gradient convs (enqueued before this point) read the packed weights it rewrites."""
         if not self._overlap or name is None:
             return
-        cur = torch.cuda.current_stream()
+        cur = streams.current()
         ws = self._wstream_of(which)
         producers = [cur if ws is None else ws] + list(extra)
         if self._fuse_update and cur not in producers:
@@ -47,7 +49,7 @@ class BackwardPass(object):
                 ev = torch.cuda.Event()
                 ev.record(st)
                 ust.wait_event(ev)
-        with torch.cuda.stream(ust):
+        with streams.on(ust):
             self._update_bucket(name)
 
     def _flush_wgrads(self, j, which):
@@ -108,10 +110,10 @@ class BackwardPass(object):
         if self.towers_merged:
             d_t = self._towers_backward(ctxs, pred_grads, self.TOWERS, nl)
         else:
-            main = torch.cuda.current_stream()
+            main = streams.current()
             side = self.s1 if self.s1 is not None else main
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with streams.on(side):
                 d_t = self._towers_backward(ctxs, pred_grads, ("bbox_tower",), nl)
             if self.fuse_head_sum:
                 # d combined = d(cls tower input) + d(bbox tower input): the cls tower's LAST data-gradient conv takes the bbox
@@ -222,7 +224,7 @@ class BackwardPass(object):
         if self.tower_wgrad_at != point or not self._held_wgrads:
             return
         held, self._held_wgrads = self._held_wgrads, []
-        cur = torch.cuda.current_stream()
+        cur = streams.current()
         for job in held:
             self._on_wstream(*job)
         self._bucket_ready("head", 0, [st for st in (cur, self.wstream, self.wstream2) if st is not None])

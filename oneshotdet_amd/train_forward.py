@@ -4,6 +4,8 @@ prediction convs.  Reference: generalized_rcnn.py:226-312, fcos.py:83-99, fcos/l
 
 import torch
 
+from . import streams
+
 from . import ops, spec
 from .ops import ACT_EXP_SCALE, ACT_RELU, RES_UP2X
 
@@ -103,7 +105,7 @@ class ForwardPass(object):
             outs, ctx = self._towers_forward(feats, self.TOWERS)
             return list(zip(outs["cls_tower"], outs["bbox_tower"])), ctx
         # one stream per tower: the HBM-bound GroupNorm passes of one tower run beside the MFMA-bound convs of the other
-        main = torch.cuda.current_stream()
+        main = streams.current()
         side = self.s1 if self.s1 is not None else main
         if self.split_levels and len(feats) == 5 and None not in (self.s1, self.wstream, self.wstream2):
             # ... and one CHAIN per level group: the levels of a tower never meet before the loss, so P5-P7 (34 pixel tiles,
@@ -112,11 +114,11 @@ class ForwardPass(object):
             big, small = [0, 1], [2, 3, 4]
             for st in (self.s1, self.wstream, self.wstream2):
                 st.wait_stream(main)
-            with torch.cuda.stream(self.wstream):
+            with streams.on(self.wstream):
                 ocs, ccs = self._towers_forward(feats, ("cls_tower",), small)
-            with torch.cuda.stream(self.wstream2):
+            with streams.on(self.wstream2):
                 obs, cbs = self._towers_forward(feats, ("bbox_tower",), small)
-            with torch.cuda.stream(self.s1):
+            with streams.on(self.s1):
                 obb, cbb = self._towers_forward(feats, ("bbox_tower",), big)
             ocb, ccb = self._towers_forward(feats, ("cls_tower",), big)
             for st in (self.s1, self.wstream, self.wstream2):
@@ -129,7 +131,7 @@ class ForwardPass(object):
             ctx = {"cls_tower": merge(ccb, ccs, "cls_tower"), "bbox_tower": merge(cbb, cbs, "bbox_tower")}
             return list(zip(ocb["cls_tower"] + ocs["cls_tower"], obb["bbox_tower"] + obs["bbox_tower"])), ctx
         side.wait_stream(main)
-        with torch.cuda.stream(side):
+        with streams.on(side):
             ob, cb = self._towers_forward(feats, ("bbox_tower",))
         oc, cc = self._towers_forward(feats, ("cls_tower",))
         main.wait_stream(side)

@@ -5,6 +5,8 @@ import os
 
 import torch
 
+from . import streams
+
 from . import ops
 from .ops import PackedConv
 
@@ -165,7 +167,7 @@ class Update(object):
             self.repack()
             return
         if self._overlap:              # (never inside a captured graph: capture() turns the overlap off)
-            main = torch.cuda.current_stream()
+            main = streams.current()
             main.wait_stream(self.ustream)
             if self.exchange.comm is not None:
                 main.wait_stream(self.exchange.comm)

@@ -1069,6 +1069,31 @@ def test_conv_wgrad_mixed_geometries_in_one_launch(dt):
                 torch.testing.assert_close(it[4], rb, rtol=1e-3, atol=1e-3 * float(rb.abs().max()))
 
 
+def test_conv_wgrad_owner_mode_adds_into_a_nonzero_gradient_and_respects_shared_weights():
+    """Round 6: a segment whose pixels are ONE split owns its dW tiles and adds them with plain loads + stores instead of memory-side
+    atomics (wgrad_params.h: wg_owner_add) — the `+=` contract must hold on a gradient buffer that is NOT zero, and two segments
+    that name the SAME dW (FPN levels sharing a conv) must keep the atomics (each would overwrite the other's sum).  Every tile family: the 128 x 128 ring kernel, the 256 x 256 8-wave tiles, the
+    software-pipelined kernel with the launcher's splits; full and ragged channel tiles."""
+    from oneshotdet_amd import ops
+    for (n, cin, h, w, cout, k) in [(2, 256, 20, 20, 512, 3), (1, 320, 20, 26, 384, 1), (2, 512, 10, 16, 256, 1)]:
+        p = k // 2
+        x = rnd(n, cin, h, w, seed=41).bfloat16().float()
+        dy = rnd(n, cout, h, w, seed=42).bfloat16().float()
+        wt = (rnd(cout, cin, k, k, seed=43) / np.sqrt(cin * k * k)).requires_grad_(True)
+        (F.conv2d(x, wt, None, stride=1, padding=p) * dy).sum().backward()
+        ref = wt.grad.permute(0, 2, 3, 1)
+        xx, dd = to_nhwc(x, torch.bfloat16), to_nhwc(dy, torch.bfloat16)
+        init = rnd(cout, k, k, cin, seed=44).cuda() * float(ref.abs().max())
+        for algo in (1 + 0 + 16 * 3, 1 + 4 + 16 * 3, 1 + 5 + 16 * 3, 1 + 13 + 16 * 3, 1 + 13 + 16 * 2, 1 + 10 + 16 * 3, 1 + 11 + 16 * 3):
+            dw = init.clone()
+            ops.conv2d_wgrad(xx, dd, dw, k, k, 1, p, cout, algo=algo)             # target 64 / 128 workgroups: one split per tile
+            assert ((dw - init).cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item(), (n, cin, cout, k, algo)
+            # the same tensors as two "levels" of one conv: shared dW -> atomics, twice the gradient on top of the initial values
+            dw = init.clone()
+            ops.conv2d_wgrad_grouped([(xx, dd), (xx, dd)], dw, k, k, 1, p, cout, algo=algo)
+            assert ((dw - init).cpu() - 2 * ref).abs().max().item() <= 2e-2 * 2 * ref.abs().max().item(), (n, cin, cout, k, algo)
+
+
 def test_two_ranks_on_one_gpu_average_gradients():
     """World size 2 with BOTH ranks on this GPU (gloo moves the device tensors): the real TrainEngine with the
     overlapped, bucketed gradient exchange must produce the average of the two ranks' gradients, and train_step must
