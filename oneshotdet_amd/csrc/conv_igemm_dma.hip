@@ -11,6 +11,7 @@
 //   * the epilogue stages the fp32 accumulator tile through LDS and writes NHWC rows with 16-byte-per-lane, fully
 //     coalesced stores (and 16-byte residual loads): one output pixel's BN channels are one contiguous run.
 #include "osd_common.h"
+#include <stdlib.h>
 #include "conv_params.h"
 #include "conv_epilogue.h"
 #include <type_traits>
@@ -395,5 +396,15 @@ int osd_conv_dma_dispatch(int dtype, int tile, int variant, const ConvKParams& p
   if (variant == 3) return dispatch_tile_dma<__bf16, 64, 3>(tile, p, s);
   if (p.Cin % 64 != 0 || variant == 2) return dispatch_tile_dma<__bf16, 64, 4>(tile, p, s);
   if (variant == 1) return dispatch_tile_dma<__bf16, 128, 2>(tile, p, s);
+  if (tile == 2 && p.x2 == nullptr && !p.relu_in) {
+    // EXPERIMENT (tools/small_m_cold.py): OSD_DMA_DEEP=5 / 8 runs the 64 x 64 tile's deep-ring variant with 5 / 8 stages (80 / 128 KB:
+    // 64 / 112 KB of weights + pixels in flight per workgroup).  The latency-sized launches of the query backbone stream weights that
+    // are COLD inside the step (touched once per step, ~1 GB of parameter state between two uses): round 4's deep-ring verdict was
+    // taken on a warm benchmark loop
+    static int deep = -1;
+    if (deep < 0) { const char* e = getenv("OSD_DMA_DEEP"); deep = e ? atoi(e) : 0; }
+    if (deep == 8) return launch_dma<__bf16, 64, 64, 128, 2, 2, 8>(p, s);
+    if (deep == 5) return launch_dma<__bf16, 64, 64, 128, 2, 2, 5>(p, s);
+  }
   return dispatch_tile_dma<__bf16, 128, 3>(tile, p, s);
 }
