@@ -376,6 +376,12 @@ def timed_steps(step, steps, warmup, world, device_sync, reduce_device):
     for _ in range(warmup):
         step()
     sync()
+    # the host's cyclic garbage collector stays out of the timed region (a generation-2 pass over the engine's object graph is
+    # tens of milliseconds; the step allocates no cycles of its own)
+    import gc
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()
     use_ev = reduce_device != "cpu" and torch.cuda.is_available()
     evs = []
     t0 = time.perf_counter()
@@ -391,6 +397,8 @@ def timed_steps(step, steps, warmup, world, device_sync, reduce_device):
         evs.append(e)
     sync()
     elapsed = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
     STEP_STATS.clear()
     if use_ev and len(evs) > 1:
         ms = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
@@ -647,8 +655,37 @@ def main_train(args, rank, world, backend="nccl"):
     if cache_file and os.path.exists(cache_file):
         from oneshotdet_amd import dist_utils
         dist_utils.load_tuner_choices(ops, cache_file)
+    refined = None
     if rank == 0:
         tune_all()
+        if os.environ.get("OSD_REFINE"):      # opt-in: 77 swaps tried on the default workload, none kept — 90 s for nothing
+            # second tuning phase (tuner.refine_in_step): for the shapes that weigh most in the step, the runners-up of the isolated
+            # timing are tried INSIDE the step and kept where the step itself gets faster twice in a row.  Before the timed region,
+            # like all tuning; the other ranks replay the result
+            rs = [0]
+
+            def rstep():
+                bt = batches[rs[0] % len(batches)]
+                rs[0] += 1
+                eng.train_step(*bt)
+            # The refinement runs a few thousand steps: with the learning rate at 0 and the momentum buffer restored afterwards they leave
+            # the model exactly as it was.  (They must: the step time is DATA-dependent — trained for ~1,500 steps on one synthetic batch
+            # the model's scores sharpen and the training proposals' NMS has to look several times deeper, 10.3 -> 14.2 ms per step,
+            # tools/sustained.py / profiles/r6_sustained.txt — and a yardstick that drifts while it measures ranks nothing.)
+            dj, eng.defer_join = eng.defer_join, True
+            lr0, eng.lr = eng.lr, 0.0
+            buf0, steps0 = eng._sgd["buf"].clone(), eng._sgd["steps"]
+            try:
+                refined = ops.refine_in_step(rstep, torch.cuda.synchronize, n_steps=12, cycle=len(batches),
+                                             budget_s=float(os.environ.get("OSD_REFINE_BUDGET_S", "90")),
+                                             verbose=bool(os.environ.get("OSD_TUNE_VERBOSE")))
+            finally:
+                eng.join()
+                torch.cuda.synchronize()
+                eng.defer_join, eng.lr = dj, lr0
+                eng._sgd["buf"].copy_(buf0)
+                eng._sgd["steps"] = steps0
+            torch.cuda.synchronize()
         if cache_file and not os.path.exists(cache_file):
             from oneshotdet_amd import dist_utils
             dist_utils.save_tuner_choices(ops, cache_file)
@@ -833,6 +870,9 @@ def main_train(args, rank, world, backend="nccl"):
             line["metric"] = "images/sec/GPU fwd+bwd, multi-scale {640,800,1024} short-edge target + 5-shot 127x127 query stack, bs=4"
         # which part of the reference's training step (engine/trainer.py:79-93) the line covers: the north_star hot path is
         # the siamese-FCOS first stage; the reference's trainer also runs roi_heads on its proposals
+        line["config"]["tuner"] = ("per-shape kernel choice by isolated timing before the timed region (latency-sized convs timed with cold "
+                                   "weights)" + ("" if refined is None else "; second phase inside the step (tuner.refine_in_step): %d of the "
+                                   "heaviest shapes' choices replaced by a runner-up that made the step itself faster twice" % len(refined)))
         line["config"]["stages"] = ("first + second stage: the reference's complete training step" if two else
                                     "first stage (SURVEY.md 8a R0-R12 = BASELINE.json north_star); the reference's trainer also "
                                     "runs the second-stage roi_heads losses/backward: that step is `--second-stage`, do not "

@@ -396,15 +396,19 @@ int osd_conv_dma_dispatch(int dtype, int tile, int variant, const ConvKParams& p
   if (variant == 3) return dispatch_tile_dma<__bf16, 64, 3>(tile, p, s);
   if (p.Cin % 64 != 0 || variant == 2) return dispatch_tile_dma<__bf16, 64, 4>(tile, p, s);
   if (variant == 1) return dispatch_tile_dma<__bf16, 128, 2>(tile, p, s);
-  if (tile == 2 && p.x2 == nullptr && !p.relu_in) {
-    // EXPERIMENT (tools/small_m_cold.py): OSD_DMA_DEEP=5 / 8 runs the 64 x 64 tile's deep-ring variant with 5 / 8 stages (80 / 128 KB:
-    // 64 / 112 KB of weights + pixels in flight per workgroup).  The latency-sized launches of the query backbone stream weights that
-    // are COLD inside the step (touched once per step, ~1 GB of parameter state between two uses): round 4's deep-ring verdict was
-    // taken on a warm benchmark loop
-    static int deep = -1;
-    if (deep < 0) { const char* e = getenv("OSD_DMA_DEEP"); deep = e ? atoi(e) : 0; }
-    if (deep == 8) return launch_dma<__bf16, 64, 64, 128, 2, 2, 8>(p, s);
-    if (deep == 5) return launch_dma<__bf16, 64, 64, 128, 2, 2, 5>(p, s);
-  }
   return dispatch_tile_dma<__bf16, 128, 3>(tile, p, s);
+}
+
+// Round 6: the 64 x 64 tile with a DEEP ring (algos 58 / 59: five / eight 16 KB stages = 64 / 112 KB of operands in flight per
+// workgroup).  For the latency-sized launches of the query backbone (M = 128 .. 2,048 pixels at bs 8: 16 - 64 workgroups that each
+// stream a 64-row slice of a weight matrix which is COLD inside the step — ~1 GB of parameter state passes between two uses of a
+// weight).  Round 4 dropped this form on a warm benchmark loop (14.5 vs 15.0 us); with cold weights the two-stage ring the warm
+// timing prefers is the SLOWEST candidate (31 us against 20 - 23 for the deep rings, tools/small_m_cold.py), so the tuner now times
+// these shapes cold (tuner._time_launches_cold).
+int osd_conv_dma_deep(int dtype, int nst, const ConvKParams& p, hipStream_t s) {
+  if (dtype != OSD_BF16 || p.Cin % 64 != 0 || p.x2 != nullptr || p.relu_in)
+    return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the deep-ring 64 x 64 tile is bf16, cin in 64s, one source, no relu_in");
+  if (nst == 8) return launch_dma<__bf16, 64, 64, 128, 2, 2, 8>(p, s);
+  if (nst == 5) return launch_dma<__bf16, 64, 64, 128, 2, 2, 5>(p, s);
+  return osd_fail(OSD_ERR_INVALID_ARG, "conv: deep ring of %d stages not built", nst);
 }

@@ -64,6 +64,8 @@ struct ConvKParams {
 
 // conv_igemm_dma.hip
 int osd_conv_dma_dispatch(int dtype, int tile, int variant, const ConvKParams& p, hipStream_t s);
+// conv_igemm_dma.hip: the 64 x 64 tile with a ring of 5 / 8 stages (algos 58 / 59: cold weight streams of the latency-sized launches)
+int osd_conv_dma_deep(int dtype, int nst, const ConvKParams& p, hipStream_t s);
 // conv_igemm_sp.hip: bf16, 3x3 / stride 1 / pad 1, pixel rows fetched once per filter row, software-pipelined operand
 // fragments and a mid-stage barrier (tile id 6, variant 1:
 // any map width — the padded-image form where every width is 64 / 128 / 256, else the consecutive-rows form; variant 2 =

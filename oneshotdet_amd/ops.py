@@ -136,7 +136,7 @@ def stem_input(images, dtype):
     return pack_image(images, dtype, hp, wp), (ho, wo)
 
 
-from .tuner import (ALGO_CACHE, CONV_ALGO_PX, CONV_ALGO_PX_WIDE, SPLIT_CACHE, WGRAD_ALGO_CACHE, _TUNING, _candidate_runs, _photo_finish, _time_launches, _tune, _tune_wgrad,      # noqa: E402,F401
+from .tuner import (TUNE_LOG, refine_in_step, wgrad_timer, ALGO_CACHE, CONV_ALGO_PX, CONV_ALGO_PX_WIDE, SPLIT_CACHE, WGRAD_ALGO_CACHE, _TUNING, _candidate_runs, _photo_finish, _time_launches, _tune, _tune_wgrad,      # noqa: E402,F401
                     conv_algo_candidates, replaying, tuning, wgrad_algo_candidates, wgrad_xr_candidates)
 
 
@@ -175,7 +175,8 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
     if algo is None:
         algo = ALGO_CACHE.get(key)             # (looked up per call: tests and rank > 0 replace the cache's contents)
         if algo is None:
-            algo = _tune(key, d, lambda: _lib.call("osd_conv2d_fwd", C.byref(d), *args)) if _TUNING[0] else 0
+            # (latency-sized shapes are timed with cold weights and the input re-touched: tuner._time_launches_cold)
+            algo = _tune(key, d, lambda: _lib.call("osd_conv2d_fwd", C.byref(d), *args), prewarm=lambda: x.float().sum()) if _TUNING[0] else 0
     d.algo = algo
     _lib.call("osd_conv2d_fwd", C.byref(d), *args)
     _rec("conv", x=x, w=pc.w, bias=pc.bias, cout=pc.cout_store, r=pc.r, s=pc.s, stem=pc.stem, stride=stride, pad=pad, act=act,
@@ -349,6 +350,7 @@ def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mod
                 run(c)                                  # tunes the algorithms of the parts
                 timed.append((_time_launches(lambda: run(c)), c))
             SPLIT_CACHE[skey] = cut = _photo_finish(timed, lambda c: _time_launches(lambda: run(c)))
+            TUNE_LOG["SPLIT_CACHE"][skey] = sorted(timed)
         if cut is not None:       # (cut 0 = one launch over all segments: also through run(), so that the launch is a `_whole` call)
             return run(cut)
     c = xs[0].shape[-1]
@@ -861,16 +863,18 @@ def conv2d_wgrad_mixed(items, algo=None):
             sdw = [scratch.setdefault(id(t), torch.empty_like(t)) for t in real_dws]
             sdb = [None if t is None else scratch.setdefault(id(t), torch.empty_like(t)) for t in real_dbs]
             timed = []
+            timer = wgrad_timer()
             for cand in wgrad_algo_candidates(descs[0].dtype, max(d.cout for d in descs), max(d.cin for d in descs)):
                 descs[0].algo = cand
                 if not _candidate_runs(lambda: launch(sdw, sdb)):
                     continue
-                timed.append((_time_launches(lambda: launch(sdw, sdb)), cand))
+                timed.append((timer(lambda: launch(sdw, sdb)), cand))
 
             def retime(cand):
                 descs[0].algo = cand
-                return _time_launches(lambda: launch(sdw, sdb))
+                return timer(lambda: launch(sdw, sdb))
             WGRAD_ALGO_CACHE[key] = algo = _photo_finish(timed, retime)
+            TUNE_LOG["WGRAD_ALGO_CACHE"][key] = sorted(timed)
         else:
             algo = 0
     descs[0].algo = algo
