@@ -375,9 +375,9 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
       if (d->dtype != OSD_BF16 || src2 != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the pixel-stationary 1x1 kernel is bf16 only, one source");
       return osd_conv_px_launch(p, s, tile == 1);
     }
-    if (impl == 1 && variant == 3 && (tile == 1 || tile == 2)) {      // algos 58 / 59 (round 6): the 64 x 64 LDS-DMA tile, ring of 5 / 8 stages
-      if (src2 != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the deep-ring tile takes one source");
-      return osd_conv_dma_deep(d->dtype, tile == 1 ? 5 : 8, p, s);
+    if (impl == 1 && variant == 3 && tile <= 3) {      // algos 57 - 60 (round 6): small LDS-DMA tiles with deep rings (conv_igemm_dma.hip)
+      if (src2 != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the deep-ring tiles take one source");
+      return osd_conv_dma_deep(d->dtype, tile == 0 ? 832 : tile == 1 ? 5 : tile == 2 ? 8 : 816, p, s);      // 64x32x8, 64x64x5, 64x64x8, 32x64x8
     }
     if (impl == 1 && variant == 1 && tile == 0)        // algo 41 was the persistent pointwise kernel of round 4 (conv_pw.hip: retired in
       return osd_fail(OSD_ERR_UNSUPPORTED, "conv: algo 41 (conv_pw) was retired in round 5");      // round 5, never the tuner's pick inside the step; git history)

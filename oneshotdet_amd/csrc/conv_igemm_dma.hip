@@ -410,5 +410,10 @@ int osd_conv_dma_deep(int dtype, int nst, const ConvKParams& p, hipStream_t s) {
     return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the deep-ring 64 x 64 tile is bf16, cin in 64s, one source, no relu_in");
   if (nst == 8) return launch_dma<__bf16, 64, 64, 128, 2, 2, 8>(p, s);
   if (nst == 5) return launch_dma<__bf16, 64, 64, 128, 2, 2, 5>(p, s);
+  // algos 57 / 60: 64 x 32 (pixels x channels; 4 x 1 waves) and 32 x 64 (2 x 2 waves) tiles, eight stages — twice the workgroups of the
+  // 64 x 64 tile; the 64 x 32 one streams HALF the (cold) weight rows per workgroup: the per-CU intake from HBM (~23 GB/s) is what
+  // bounds these launches, so more CUs pulling is what helps
+  if (nst == 832) return launch_dma<__bf16, 64, 32, 128, 4, 1, 8>(p, s);
+  if (nst == 816) return launch_dma<__bf16, 32, 64, 128, 2, 2, 8>(p, s);
   return osd_fail(OSD_ERR_INVALID_ARG, "conv: deep ring of %d stages not built", nst);
 }

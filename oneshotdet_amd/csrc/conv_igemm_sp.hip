@@ -351,6 +351,9 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
 #ifdef OSD_SP_STAMPS
   const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();
 #endif
+  // (round 6, measured and removed — tools/sp_lib_bench.py, tower P3 + P4 launch, two interleaved rounds: default 125 - 127 us; `s_setprio 1`
+  // for waves 4 - 7 (MI355X_MICROARCH.md, two waves per SIMD, item 4) 131 - 133; for waves 0 - 3 129 - 132; SIMD partners issuing their weight DMA
+  // in opposite halves of the half stage through a wave-uniform run-time branch 216 - 218: the branch un-pins the schedule)
   // Group loop.  Weight stage index w = 3 g + s alternates buffers, and with 3 stages per group a group flips the parity:
   // (ab, bb) are the image / weight buffers of the group's tap 0.
   int ab = 0, bb = 0;

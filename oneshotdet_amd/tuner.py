@@ -67,7 +67,7 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False, pixels=None):
     if cout_store > 16 and not relu_in and pixels is not None and pixels <= DEEP_MAX_PIXELS and not os.environ.get("OSD_NO_DEEP_RING"):
         # latency-sized launches (the query backbone at bs 8): 16 - 64 workgroups each streaming a slice of a weight matrix that is
         # cold inside the step — deep rings keep 64 / 112 KB in flight per workgroup (bf16, cin in 64s; refused elsewhere)
-        cands += [CONV_ALGO_DEEP5, CONV_ALGO_DEEP8]
+        cands += [CONV_ALGO_DEEP5, CONV_ALGO_DEEP8, CONV_ALGO_DEEP8 - 2, CONV_ALGO_DEEP8 + 1]      # + 64 x 32 and 32 x 64 tiles, eight stages (57, 60)
     if cout_store >= 64 and not relu_in and os.environ.get("OSD_PX"):
         # pixel-stationary pointwise kernel (round 5; bf16 1x1 / stride 1 convs with cin 64 / 128 / 256: refused elsewhere).  Opt-in,
         # like round 4's persistent conv_pw (retired): timed alone it wins layer2's expanding convs by 8 - 10 % and the tuner picks it there, but inside the step

@@ -12,7 +12,7 @@ shapes = [(8, 8, 8, 256, 256, 3, 1), (8, 4, 4, 512, 512, 3, 1), (8, 8, 8, 1024, 
           (8, 4, 4, 512, 2048, 1, 0), (8, 8, 8, 256, 1024, 1, 0)]
 flush = torch.zeros(150 * 1024 * 1024, device="cuda")
 REPS = 12
-algos = [1 + v * 8 + 2 for v in (0, 1, 2, 3)] + [1 + v * 8 + 1 for v in (0, 1)] + [1 + 32 + 2]
+algos = [1 + v * 8 + 2 for v in (0, 1, 2)] + [57, 58, 59, 60]
 for (n, h, w, cin, cout, k, p) in shapes:
     x = torch.randn(n, h, w, cin, device="cuda").to(dt)
     wt = torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5
@@ -40,6 +40,6 @@ for (n, h, w, cin, cout, k, p) in shapes:
         b.record()
         torch.cuda.synchronize()
         a0 = algo - 1
-        res.append((cold / REPS * 1e3, a.elapsed_time(b) / REPS * 1e3, "%s v%d t%d" % ("dma" if a0 < 32 else "reg", (a0 >> 3) & 3, a0 & 7)))
+        res.append((cold / REPS * 1e3, a.elapsed_time(b) / REPS * 1e3, ("%s v%d t%d" % ("dma", (a0 >> 3) & 3, a0 & 7)) if a0 < 32 else {56: "64x32x8", 57: "64x64x5", 58: "64x64x8", 59: "32x64x8"}[a0]))
     res.sort()
     print("M=%4d N=%4d K=%4d  cold / warm us: " % (n * h * w, cout, cin * k * k) + "  ".join("%s %.1f/%.1f" % (nm, c, wm) for c, wm, nm in res))
