@@ -844,6 +844,38 @@ extern "C" int osd_proposals_sort_nms_hint(const float* keys, const float* boxes
   int limit = cdiv(max_keep * 5 / 4 + 64, 64) * 64;
   if (head_hint > limit) limit = cdiv(head_hint, 64) * 64;
   if (limit > max_count) limit = max_count;
+  int* need_full = reinterpret_cast<int*>(mask_ws);
+  unsigned long long* mk = reinterpret_cast<unsigned long long*>(mask_ws) + cdiv(n, 2) + 8;
+  if (2 * limit > max_count) {
+    // Round 6, the DEEP regime: the feedback says the greedy scan reads most of the order (a model whose scores have sharpened: a few
+    // hundred near-1 candidates per object, every one of them suppressed by the first — NMS cannot fill max_keep from a short head).
+    // The head machinery (histogram select + rank_head, built for heads of ~5,000) then costs MORE than ranking everything at once:
+    // 6.2 ms per call at 8 x 17,064 candidates against 0.37 ms (rank_sort_gather) + 3.2 ms (mask + scan) — tools/proposals_probe.py.
+    // So: every candidate ranked exactly in one pass, then the same two-phase NMS over the first `limit` rows / the whole order;
+    // depth_out keeps reporting, so the hint shrinks again when the data change.  Same results (same order, same greedy rule).
+    hipLaunchKernelGGL(rank_sort_gather_kernel<false>, dim3(cdiv(total, 256), n), dim3(256), 0, st, keys, boxes, total, max_count, topn, lt,
+                       boxes_sorted, scores_sorted, idx_sorted, counts, (const int*)nullptr);      // counts: zeroed by the memset above
+    int rc = osd_check_launch("rank_sort_gather(deep)");
+    if (rc) return rc;
+    const int lb = cdiv(limit, 64);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_grid(lb), n), dim3(256), 0, st, boxes_sorted, counts, max_count,
+                       col_blocks, thresh, cuda_semantics, mk, limit, (const int*)nullptr);
+    rc = osd_check_launch("nms_mask(deep)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8 + max_keep * 4, st, boxes_sorted, scores_sorted, counts, max_count,
+                       col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, limit, need_full, 1, (const int*)counts,
+                       depth_out);
+    rc = osd_check_launch("nms_scan(deep)");
+    if (rc || limit >= max_count) return rc;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_grid(col_blocks, 96), n), dim3(256), 0, st, boxes_sorted, counts, max_count,
+                       col_blocks, thresh, cuda_semantics, mk, max_count, (const int*)need_full);
+    rc = osd_check_launch("nms_mask(deep, full)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), col_blocks * 8 + max_keep * 4, st, boxes_sorted, scores_sorted, counts, max_count,
+                       col_blocks, max_keep, mk, out_boxes, out_scores, out_pos, out_count, max_count, need_full, 2,
+                       (const int*)nullptr, depth_out);
+    return osd_check_launch("nms_scan(deep, full)");
+  }
   const int want = limit + 256;
   hipLaunchKernelGGL(select_head_kernel, dim3(n), dim3(1024), 0, st, keys, total, max_count, topn, lt, want, keys_sel, idx_sel, meta);
   int rc = osd_check_launch("select_head");
@@ -853,8 +885,6 @@ extern "C" int osd_proposals_sort_nms_hint(const float* keys, const float* boxes
   rc = osd_check_launch("rank_head");
   if (rc) return rc;
   hipLaunchKernelGGL(meta_counts_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, meta, counts, n);
-  int* need_full = reinterpret_cast<int*>(mask_ws);
-  unsigned long long* mk = reinterpret_cast<unsigned long long*>(mask_ws) + cdiv(n, 2) + 8;
   const int lim_blocks = cdiv(limit, 64);
   // phase 1: the exactly sorted head (valid[img] candidates), at most `limit` of them
   hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_grid(lim_blocks), n), dim3(256), 0, st, boxes_sorted, valid, max_count,

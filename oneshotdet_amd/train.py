@@ -187,6 +187,10 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
             self.warm_streams()
         self.defer_join = False       # opt-in: train_step leaves its tail on the side streams (see train_step / join)
         self._deferred, self._defer_now, self._joined_refs = None, False, None
+        # (Round 6, measured and removed: leaving the proposal stream out of the events the next step waits for — its NMS is data-dependent
+        # and reads every candidate once a model's scores have sharpened.  11.62 vs 11.67 ms per step in that regime
+        # (profiles/r6_sustained.txt): the main chain does not WAIT for the proposals, it shares the chip with them; what helped is the
+        # deep-regime path of osd_proposals_sort_nms_hint, 14.2 -> 11.6 ms.)
         self.repack()
         self.zero_bias = torch.zeros(4096, device=self.device, dtype=torch.float32)
         # SGD with the reference's parameter groups (solver/build.py:8-26): a parameter whose reference KEY contains "bias"

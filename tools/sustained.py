@@ -130,3 +130,5 @@ for blk in range(N // 100):
     if blk % 5 == 4:
         print("   ", alloc_info, flush=True)
 ops.gn_onepass_check("sustained run")
+if os.environ.get("OSD_SAVE_HEAD"):      # the head outputs of the last step: what the proposal pipeline sees after N steps of training
+    torch.save([(a.float().cpu(), b.float().cpu()) for a, b in eng.last_head_out], os.environ["OSD_SAVE_HEAD"])
