@@ -90,12 +90,12 @@ def pack_conv(weight, bias=None, bn=None, dtype=torch.float32, stem=False):
     if stem:
         assert (cin, r, s) == (3, 7, 7)
         wp = torch.empty((w_rows, 7, 32), device=weight.device, dtype=dtype)
-        _lib.call("osd_pack_stem_weight", _ptr(weight), _ptr(scale), _ptr(wp), cout, w_rows, _dt(wp), _stream())
+        _lib.call("osd_pack_stem_weight", _p(weight), _p(scale), _p(wp), cout, w_rows, _dt(wp), _stream())
         return PackedConv(wp, bias_p, cout, cout_store, w_rows, 32, 7, 1, stem=True, cin_real=3)
     mult = 64 if dtype == torch.bfloat16 else 16
     cin_pad = _round_up(cin, mult)
     wp = torch.empty((w_rows, r, s, cin_pad), device=weight.device, dtype=dtype)
-    _lib.call("osd_pack_conv_weight", _ptr(weight), _ptr(scale), _ptr(wp), cout, cin, r, s, w_rows, cin_pad, _dt(wp),
+    _lib.call("osd_pack_conv_weight", _p(weight), _p(scale), _p(wp), cout, cin, r, s, w_rows, cin_pad, _dt(wp),
               _stream())
     return PackedConv(wp, bias_p, cout, cout_store, w_rows, cin_pad, r, s, cin_real=cin)
 
@@ -106,7 +106,7 @@ def pack_image(images, dtype, hp, wp, pad_t=3, pad_l=3):
     n, c, h, w = images.shape
     assert c == 3 and images.dtype == torch.float32
     out = torch.empty((n, hp, wp, 4), device=images.device, dtype=dtype)
-    _lib.call("osd_pack_image", _ptr(images.contiguous()), _ptr(out), n, h, w, hp, wp, pad_t, pad_l, _dt(out), _stream())
+    _lib.call("osd_pack_image", _ptr(images.contiguous()), _p(out), n, h, w, hp, wp, pad_t, pad_l, _dt(out), _stream())
     _rec("pack_image", x=images, out=out, pad_t=pad_t, pad_l=pad_l)
     return out
 
@@ -255,7 +255,7 @@ def _conv2d_two_sources(x, x2, x2_stride, pc, act, out, algo, pc2=None, bias=Non
     d.act, d.act_scale, d.relu_in = act, 1.0, 0
     src2 = ConvSrc2(x2.contiguous().data_ptr(), pc2.w.data_ptr() if pc2 is not None else None, c2, x2.shape[1], x2.shape[2],
                     int(x2_stride))
-    args = (_ptr(x), _ptr(pc.w), _ptr(bias), None, None, None, C.byref(src2), _ptr(out), _stream())
+    args = (_p(x), _p(pc.w), _p(bias), None, None, None, C.byref(src2), _p(out), _stream())
     if algo is None:
         key = ("src2", d.dtype, n, h, w, d.cout, c, c2, int(x2_stride), act, pc2 is not None)
         algo = ALGO_CACHE.get(key)
@@ -307,9 +307,15 @@ def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mod
     GroupNorm + ReLU backward): dict(us, abs, gammas, wss, pws: one entry per segment, None where not wanted; n, groups); forward
     ones (the conv whose outputs a GroupNorm normalises): dict(wss; n, groups).  The leading run of segments with an entry goes
     out as its own launch of the software-pipelined kernel, the rest as usual."""
-    _chk_dev(*xs)
     k = len(xs)
     pc = pcs[0]
+    if k == 1 and algo is None and not _whole and gnb is None:      # one pair (every backbone conv of a non-lockstep engine comes through
+        # here): straight to the plain launch — all algorithms, its own tuning entry — ahead of the list checks (host time, DESIGN.md 6f)
+        return [conv2d(xs[0], pc, stride=stride, pad=pad, act=act, res=None if residuals is None else residuals[0],
+                       res_mode=(RES_NONE if residuals is None else RES_SAME) if res_mode is None else res_mode, act_scale=act_scale,
+                       mask=None if masks is None else masks[0],
+                       act_scale_dev=None if act_scale_devs is None else act_scale_devs[0])]
+    _chk_dev(*xs)
     if gnb is not None and not _whole:
         on = [w is not None for w in gnb["wss"]]
         c = 0
@@ -418,7 +424,7 @@ def maxpool3x3s2(x):
     n, h, w, c = x.shape
     ho, wo = conv_out(h, 3, 2, 1), conv_out(w, 3, 2, 1)
     y = torch.empty((n, ho, wo, c), device=x.device, dtype=x.dtype)
-    _lib.call("osd_maxpool3x3s2_fwd", _ptr(x), _ptr(y), n, h, w, c, ho, wo, _dt(x), _stream())
+    _lib.call("osd_maxpool3x3s2_fwd", _p(x), _p(y), n, h, w, c, ho, wo, _dt(x), _stream())
     _rec("maxpool", x=x, out=y)
     return y
 
@@ -430,12 +436,12 @@ def groupnorm_relu(x, gamma, beta, groups=32, eps=1e-5, out=None):
     ws = torch.empty((n, GN_SPLITS, groups, 2), device=x.device, dtype=torch.float32)
     ab = torch.empty((2, n, c), device=x.device, dtype=torch.float32)
     st = _stream()
-    _lib.call("osd_groupnorm_stats", _ptr(x), _ptr(ws), n, h * w, c, groups, _dt(x), st)
-    _lib.call("osd_groupnorm_finalize", _ptr(ws), _ptr(gamma), _ptr(beta), _ptr(ab[0]), _ptr(ab[1]), n, h * w, c, groups,
+    _lib.call("osd_groupnorm_stats", _p(x), _p(ws), n, h * w, c, groups, _dt(x), st)
+    _lib.call("osd_groupnorm_finalize", _p(ws), _p(gamma), _p(beta), _p(ab[0]), _p(ab[1]), n, h * w, c, groups,
               float(eps), st)
     if out is None:
         out = torch.empty_like(x)
-    _lib.call("osd_groupnorm_relu_apply", _ptr(x), _ptr(ab[0]), _ptr(ab[1]), _ptr(out), n, h * w, c, _dt(x), st)
+    _lib.call("osd_groupnorm_relu_apply", _p(x), _p(ab[0]), _p(ab[1]), _p(out), n, h * w, c, _dt(x), st)
     return out
 
 
@@ -445,7 +451,7 @@ def roi_align(x, rois, spatial_scale, ph, pw, sampling_ratio):
     n, h, w, c = x.shape
     r = rois.shape[0]
     y = torch.empty((r, ph, pw, c), device=x.device, dtype=torch.float32)
-    _lib.call("osd_roialign_fwd", _ptr(x), _ptr(rois.contiguous().float()), _ptr(y), n, h, w, c, r, float(spatial_scale),
+    _lib.call("osd_roialign_fwd", _p(x), _ptr(rois.contiguous().float()), _p(y), n, h, w, c, r, float(spatial_scale),
               ph, pw, sampling_ratio, _dt(x), _stream())
     _rec("roi_align", x=x, rois=rois, scale=float(spatial_scale), ph=ph, pw=pw, sampling_ratio=sampling_ratio, out=y)
     return y
@@ -457,7 +463,7 @@ def shot_mean(x, batch):
     d, c = x.shape
     assert d % batch == 0
     y = torch.empty((batch, c), device=x.device, dtype=torch.float32)
-    _lib.call("osd_shot_mean", _ptr(x.contiguous()), _ptr(y), batch, d // batch, c, _stream())
+    _lib.call("osd_shot_mean", _ptr(x.contiguous()), _p(y), batch, d // batch, c, _stream())
     _rec("shot_mean", x=x, batch=batch, out=y)
     return y
 
@@ -469,7 +475,7 @@ def correlate(x, q, out=None):
     assert q.shape == (n, c) and q.dtype == torch.float32
     if out is None:
         out = torch.empty_like(x)
-    _lib.call("osd_correlate_fwd", _ptr(x), _ptr(q.contiguous()), _ptr(out), n, h * w, c, _dt(x), _stream())
+    _lib.call("osd_correlate_fwd", _p(x), _ptr(q.contiguous()), _p(out), n, h * w, c, _dt(x), _stream())
     _rec("correlate", x=x, q=q, out=out)
     return out
 
@@ -508,7 +514,7 @@ def nhwc_to_nchw_f32(x, c0=0, c=None):
     n, h, w, stride = x.shape
     c = stride - c0 if c is None else c
     y = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
-    _lib.call("osd_nhwc_to_nchw_f32", _ptr(x), _ptr(y), n, h, w, c, stride, c0, _dt(x), _stream())
+    _lib.call("osd_nhwc_to_nchw_f32", _p(x), _p(y), n, h, w, c, stride, c0, _dt(x), _stream())
     return y
 
 
@@ -516,7 +522,7 @@ def nchw_f32_to_nhwc(x, dtype):
     _chk_dev(x)
     n, c, h, w = x.shape
     y = torch.empty((n, h, w, c), device=x.device, dtype=dtype)
-    _lib.call("osd_nchw_f32_to_nhwc", _ptr(x.contiguous().float()), _ptr(y), n, c, h, w, _dt(y), _stream())
+    _lib.call("osd_nchw_f32_to_nhwc", _ptr(x.contiguous().float()), _p(y), n, c, h, w, _dt(y), _stream())
     return y
 
 
@@ -524,14 +530,14 @@ def fcos_score_decode(cls_ctr, reg, scores, boxes, stride, loc_offset, img_h, im
     """img_hw: optional [N,2] fp32 device tensor of true (height, width) per image (padded batches)."""
     _chk_dev(cls_ctr, reg, scores, boxes, img_hw)
     n, h, w, ccs = cls_ctr.shape
-    _lib.call("osd_fcos_score_decode_sizes", _ptr(cls_ctr), _ptr(reg), _ptr(scores), _ptr(boxes), n, h, w, ccs,
-              reg.shape[-1], stride, loc_offset, scores.shape[1], float(img_h), float(img_w), _ptr(img_hw), _dt(cls_ctr),
+    _lib.call("osd_fcos_score_decode_sizes", _p(cls_ctr), _p(reg), _p(scores), _p(boxes), n, h, w, ccs,
+              reg.shape[-1], stride, loc_offset, scores.shape[1], float(img_h), float(img_w), _p(img_hw), _dt(cls_ctr),
               _stream())
 
 
 def level_topk(keys, lo, cnt, topn):
     n, total = keys.shape
-    _lib.call("osd_level_topk", _ptr(keys), _ptr(keys), n, total, lo, cnt, topn, _stream())
+    _lib.call("osd_level_topk", _p(keys), _p(keys), n, total, lo, cnt, topn, _stream())
 
 
 def rank_sort_gather(keys, boxes, max_count, levels=None, topn=0):
@@ -550,8 +556,8 @@ def rank_sort_gather(keys, boxes, max_count, levels=None, topn=0):
         nl = len(levels)
     else:
         lo, lc, nl = None, None, 0
-    _lib.call("osd_rank_sort_gather", _ptr(keys), _ptr(boxes), n, total, max_count, lo, lc, nl, int(topn), _ptr(bs),
-              _ptr(ss), _ptr(idx), _ptr(cnt), _stream())
+    _lib.call("osd_rank_sort_gather", _p(keys), _p(boxes), n, total, max_count, lo, lc, nl, int(topn), _p(bs),
+              _p(ss), _p(idx), _p(cnt), _stream())
     return bs, ss, idx, cnt
 
 
@@ -566,8 +572,8 @@ def nms_sorted(boxes_sorted, scores_sorted, counts, thresh, max_keep, cuda_seman
     os_ = torch.zeros((n, max_keep), device=dev, dtype=torch.float32)
     op = torch.zeros((n, max_keep), device=dev, dtype=torch.int32)
     oc = torch.empty((n,), device=dev, dtype=torch.int32)
-    _lib.call("osd_nms_sorted", _ptr(boxes_sorted), _ptr(scores_sorted), _ptr(counts), n, max_count, float(thresh),
-              int(cuda_semantics), max_keep, _ptr(workspace), _ptr(ob), _ptr(os_), _ptr(op), _ptr(oc), _stream())
+    _lib.call("osd_nms_sorted", _p(boxes_sorted), _p(scores_sorted), _p(counts), n, max_count, float(thresh),
+              int(cuda_semantics), max_keep, _p(workspace), _p(ob), _p(os_), _p(op), _p(oc), _stream())
     return ob, os_, op, oc
 
 
@@ -581,7 +587,7 @@ def nms(dets, scores, thresh, cuda_semantics=True):
     count = torch.empty((1,), device=dev, dtype=torch.int32)
     need = int(_lib.load().osd_nms_single_workspace_bytes(n))
     ws = torch.empty((need // 8 + 1,), device=dev, dtype=torch.int64)
-    _lib.call("osd_nms", _ptr(dets), _ptr(scores), n, float(thresh), int(cuda_semantics), _ptr(ws), _ptr(keep), _ptr(count),
+    _lib.call("osd_nms", _p(dets), _p(scores), n, float(thresh), int(cuda_semantics), _p(ws), _p(keep), _p(count),
               _stream())
     return keep, count
 
@@ -590,7 +596,7 @@ def sigmoid_focal_loss_fwd(logits, targets, gamma, alpha):
     _chk_dev(logits, targets)
     m, classes = logits.shape
     losses = torch.empty_like(logits)
-    _lib.call("osd_sigmoid_focal_fwd", _ptr(logits.contiguous()), _ptr(targets.contiguous()), _ptr(losses), m, classes,
+    _lib.call("osd_sigmoid_focal_fwd", _ptr(logits.contiguous()), _ptr(targets.contiguous()), _p(losses), m, classes,
               float(gamma), float(alpha), _stream())
     return losses
 
@@ -599,7 +605,7 @@ def sigmoid_focal_loss_bwd(logits, targets, d_losses, gamma, alpha):
     m, classes = logits.shape
     d_logits = torch.empty_like(logits)
     _lib.call("osd_sigmoid_focal_bwd", _ptr(logits.contiguous()), _ptr(targets.contiguous()),
-              _ptr(d_losses.contiguous()), _ptr(d_logits), m, classes, float(gamma), float(alpha), _stream())
+              _ptr(d_losses.contiguous()), _p(d_logits), m, classes, float(gamma), float(alpha), _stream())
     return d_logits
 
 
@@ -625,7 +631,7 @@ def pack_conv_master(w_orsi, scale, dtype, w_rows=None):
     mult = 64 if dtype == torch.bfloat16 else 16
     cin_pad = _round_up(cin, mult)
     wp = torch.empty((w_rows, r, s, cin_pad), device=w_orsi.device, dtype=dtype)
-    _lib.call("osd_pack_conv_weight_ex", _ptr(w_orsi), _ptr(scale), _ptr(wp), cout, cin, r, s, w_rows, cin_pad, 1, _dt(wp),
+    _lib.call("osd_pack_conv_weight_ex", _p(w_orsi), _p(scale), _p(wp), cout, cin, r, s, w_rows, cin_pad, 1, _dt(wp),
               _stream())
     return wp
 
@@ -637,7 +643,7 @@ def pack_conv_master_dgrad(w_orsi, scale, dtype):
     mult = 64 if dtype == torch.bfloat16 else 16
     cout_pad = _round_up(cout, mult)
     wp = torch.empty((rows, r, s, cout_pad), device=w_orsi.device, dtype=dtype)
-    _lib.call("osd_pack_conv_weight_dgrad", _ptr(w_orsi), _ptr(scale), _ptr(wp), cout, cin, r, s, rows, cout_pad, 1,
+    _lib.call("osd_pack_conv_weight_dgrad", _p(w_orsi), _p(scale), _p(wp), cout, cin, r, s, rows, cout_pad, 1,
               _dt(wp), _stream())
     return wp
 
@@ -680,7 +686,7 @@ def conv2d_wgrad(x, dy, dw_packed, r, s, stride, pad, cout, scale=None, db=None,
     st = _stream()
 
     def launch(dw, dbias):
-        _lib.call("osd_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(scale), _ptr(dw), _ptr(dbias), st)
+        _lib.call("osd_conv2d_wgrad", C.byref(d), _p(x), _p(dy), _p(scale), _p(dw), _p(dbias), st)
     key = (d.dtype, tuple(x.shape), cout, r, s, stride, pad, dy.shape[-1], db is not None, _wgrad_mode())
     if algo is None:
         algo = WGRAD_ALGO_CACHE.get(key)
@@ -711,7 +717,7 @@ def pred_dy_gather(dys, cout, cin):
     ns = (C.c_int32 * k)(*[t.shape[0] for t in dys])
     hs = (C.c_int32 * k)(*[t.shape[1] for t in dys])
     ws = (C.c_int32 * k)(*[t.shape[2] for t in dys])
-    _lib.call("osd_pred_dy_gather", C.byref(d), k, ptrs, ns, hs, ws, _ptr(g), _stream())
+    _lib.call("osd_pred_dy_gather", C.byref(d), k, ptrs, ns, hs, ws, _p(g), _stream())
     _rec("pred_gather", dys=list(dys), cout=cout, out=g)
     return g
 
@@ -720,7 +726,7 @@ def pred_dgrad_pack(w_master, cout, cin, dtype, out=None):
     """The prediction conv's fp32 master [cout][3][3][cin] as the packed weights of the 1x1 data-gradient conv over G: a PackedConv
     with cin rows of 64 columns (column tap * 4 + co)."""
     wd = torch.empty((cin, 1, 1, PRED_G), device=w_master.device, dtype=dtype) if out is None else out
-    _lib.call("osd_pred_dgrad_pack", _dt(wd), _ptr(w_master), cout, cin, _ptr(wd), _stream())
+    _lib.call("osd_pred_dgrad_pack", _dt(wd), _p(w_master), cout, cin, _p(wd), _stream())
     _rec("pred_dgrad_pack", w=w_master, cout=cout, cin=cin, out=wd)
     return wd
 
@@ -742,17 +748,17 @@ def conv2d_wgrad_grouped(pairs, dw_packed, r, s, stride, pad, cout, scale=None, 
         # prediction convs (2 / 4 output channels): the read-once kernel, not a 128-channel MFMA tile
         if g is not None and not os.environ.get("OSD_PRED_WGRAD_READONCE"):
             wsp = torch.empty((64 + PRED_G * x0.shape[-1] + 64,), device=x0.device, dtype=torch.float32)
-            _lib.call("osd_conv2d_wgrad_pred_gathered", C.byref(d), k, xs, _ptr(g), ns, hs, ws, _ptr(dw_packed), _ptr(db), _ptr(wsp), st)
+            _lib.call("osd_conv2d_wgrad_pred_gathered", C.byref(d), k, xs, _p(g), ns, hs, ws, _p(dw_packed), _p(db), _p(wsp), st)
         else:
             need = int(_lib.load().osd_conv2d_wgrad_pred_workspace_bytes(k, ns, hs, ws, x0.shape[-1]))
             wsp = torch.empty((need // 4 + 1,), device=x0.device, dtype=torch.float32)
-            _lib.call("osd_conv2d_wgrad_pred", C.byref(d), k, xs, dys, ns, hs, ws, _ptr(dw_packed), _ptr(db), _ptr(wsp), st)
+            _lib.call("osd_conv2d_wgrad_pred", C.byref(d), k, xs, dys, ns, hs, ws, _p(dw_packed), _p(db), _p(wsp), st)
         _rec("wgrad", items=[dict(x=x, dy=dy, dw=dw_packed, scale=None, db=db, r=r, s=s, stride=stride, pad=pad, cout=cout)
                              for x, dy in pairs])
         return
 
     def launch(dw, dbias):
-        _lib.call("osd_conv2d_wgrad_grouped", C.byref(d), k, xs, dys, ns, hs, ws, _ptr(scale), _ptr(dw), _ptr(dbias), st)
+        _lib.call("osd_conv2d_wgrad_grouped", C.byref(d), k, xs, dys, ns, hs, ws, _p(scale), _p(dw), _p(dbias), st)
     key = (d.dtype, tuple(tuple(x.shape) for x, _ in pairs), cout, r, s, stride, pad, dy0.shape[-1], db is not None, _wgrad_mode())
     if algo is None:
         algo = WGRAD_ALGO_CACHE.get(key)
@@ -885,13 +891,13 @@ def conv2d_wgrad_mixed(items, algo=None):
 
 def bias_grad(dy, db, c):
     n, h, w, stride = dy.shape
-    _lib.call("osd_bias_grad", _ptr(dy), _ptr(db), n * h * w, c, stride, _dt(dy), _stream())
+    _lib.call("osd_bias_grad", _p(dy), _p(db), n * h * w, c, stride, _dt(dy), _stream())
 
 
 def conv2d_dgrad_naive(dy, w_fwd_packed, x_shape, r, s, stride, pad, cout, mask=None, addend=None):
     d = _conv_desc(x_shape, _dt(dy), cout, r, s, stride, pad, dy.shape[-1])
     dx = torch.empty(x_shape, device=dy.device, dtype=dy.dtype)
-    _lib.call("osd_conv2d_dgrad_naive", C.byref(d), _ptr(dy), _ptr(w_fwd_packed), _ptr(mask), _ptr(addend), _ptr(dx),
+    _lib.call("osd_conv2d_dgrad_naive", C.byref(d), _p(dy), _p(w_fwd_packed), _p(mask), _p(addend), _p(dx),
               _stream())
     return dx
 
@@ -900,14 +906,14 @@ def scatter2x(src, out_hw, mask=None, addend=None):
     n, ho, wo, c = src.shape
     h, w = out_hw
     dst = torch.empty((n, h, w, c), device=src.device, dtype=src.dtype)
-    _lib.call("osd_scatter2x", _ptr(src), _ptr(mask), _ptr(addend), _ptr(dst), n, h, w, ho, wo, c, _dt(src), _stream())
+    _lib.call("osd_scatter2x", _p(src), _p(mask), _p(addend), _p(dst), n, h, w, ho, wo, c, _dt(src), _stream())
     _rec("scatter2x", x=src, mask=mask, addend=addend, out=dst)
     return dst
 
 
 def add_mask(a, b=None, mask=None, out=None):
     out = torch.empty_like(a) if out is None else out
-    _lib.call("osd_add_mask", _ptr(a), _ptr(b), _ptr(mask), _ptr(out), a.numel(), _dt(a), _stream())
+    _lib.call("osd_add_mask", _p(a), _p(b), _p(mask), _p(out), a.numel(), _dt(a), _stream())
     _rec("add_mask", a=a, b=b, mask=mask, out=out)
     return out
 
@@ -915,7 +921,7 @@ def add_mask(a, b=None, mask=None, out=None):
 def upsample2x_bwd(inner, prev=None):
     n, h2, w2, c = inner.shape
     top = torch.empty((n, h2 // 2, w2 // 2, c), device=inner.device, dtype=inner.dtype)
-    _lib.call("osd_upsample2x_bwd", _ptr(inner), _ptr(prev), _ptr(top), n, h2 // 2, w2 // 2, c, _dt(inner), _stream())
+    _lib.call("osd_upsample2x_bwd", _p(inner), _p(prev), _p(top), n, h2 // 2, w2 // 2, c, _dt(inner), _stream())
     _rec("upsample2x_bwd", inner=inner, prev=prev, out=top)
     return top
 
@@ -923,7 +929,7 @@ def upsample2x_bwd(inner, prev=None):
 def correlate_bwd_query(g, feat):
     n, h, w, c = g.shape
     dq = torch.empty((n, c), device=g.device, dtype=torch.float32)
-    _lib.call("osd_correlate_bwd_query", _ptr(g), _ptr(feat), _ptr(dq), n, h * w, c, _dt(g), _stream())
+    _lib.call("osd_correlate_bwd_query", _p(g), _p(feat), _p(dq), n, h * w, c, _dt(g), _stream())
     _rec("correlate_bwd_query", g=g, feat=feat, out=dq)
     return dq
 
@@ -931,7 +937,7 @@ def correlate_bwd_query(g, feat):
 def roi_align_bwd(gy, rois, x_shape, spatial_scale, ph, pw, sampling_ratio):
     b, h, w, c = x_shape
     gx = torch.empty(x_shape, device=gy.device, dtype=torch.float32)
-    _lib.call("osd_roialign_bwd", _ptr(gy.contiguous()), _ptr(rois), _ptr(gx), b, h, w, c, rois.shape[0],
+    _lib.call("osd_roialign_bwd", _ptr(gy.contiguous()), _p(rois), _p(gx), b, h, w, c, rois.shape[0],
               float(spatial_scale), ph, pw, sampling_ratio, _stream())
     _rec("roi_align_bwd", gy=gy, rois=rois, scale=float(spatial_scale), ph=ph, pw=pw, sampling_ratio=sampling_ratio, out=gx)
     return gx
@@ -940,14 +946,14 @@ def roi_align_bwd(gy, rois, x_shape, spatial_scale, ph, pw, sampling_ratio):
 def shot_mean_bwd(gy, shots):
     b, c = gy.shape
     gx = torch.empty((b * shots, c), device=gy.device, dtype=torch.float32)
-    _lib.call("osd_shot_mean_bwd", _ptr(gy.contiguous()), _ptr(gx), b, shots, c, _stream())
+    _lib.call("osd_shot_mean_bwd", _ptr(gy.contiguous()), _p(gx), b, shots, c, _stream())
     _rec("shot_mean_bwd", gy=gy, shots=shots, out=gx)
     return gx
 
 
 def cast_f32(x, dtype):
     y = torch.empty(x.shape, device=x.device, dtype=dtype)
-    _lib.call("osd_cast_f32", _ptr(x.contiguous()), _ptr(y), x.numel(), _dt(y), _stream())
+    _lib.call("osd_cast_f32", _ptr(x.contiguous()), _p(y), x.numel(), _dt(y), _stream())
     _rec("cast", x=x, out=y)
     return y
 
@@ -966,9 +972,9 @@ def fcos_loss_level(phase, cls_ctr, reg, gt_boxes, gt_count, stride, size_lo, si
                     sums, d_cls_ctr=None, d_reg=None, d_scale_raw=None):
     n, h, w, _ = cls_ctr.shape
     gs = d_cls_ctr.shape[-1] if d_cls_ctr is not None else 4
-    _lib.call("osd_fcos_loss_level", phase, _ptr(cls_ctr), _ptr(reg), _ptr(gt_boxes), _ptr(gt_count), gt_boxes.shape[1], n,
-              h, w, stride, float(size_lo), float(size_hi), float(radius), float(gamma), float(alpha), _ptr(scale_dev),
-              _ptr(sums), _ptr(d_cls_ctr), _ptr(d_reg), gs, _ptr(d_scale_raw), _dt(cls_ctr), _stream())
+    _lib.call("osd_fcos_loss_level", phase, _p(cls_ctr), _p(reg), _p(gt_boxes), _p(gt_count), gt_boxes.shape[1], n,
+              h, w, stride, float(size_lo), float(size_hi), float(radius), float(gamma), float(alpha), _p(scale_dev),
+              _p(sums), _p(d_cls_ctr), _p(d_reg), gs, _p(d_scale_raw), _dt(cls_ctr), _stream())
 
 
 def _ptr_array(tensors):
@@ -988,8 +994,8 @@ def fcos_loss_levels(phase, head_out, gt_boxes, gt_count, strides, size_ranges, 
     hi = (C.c_float * k)(*[float(b) for _, b in size_ranges])
     none = C.c_void_p(0)
     _lib.call("osd_fcos_loss_levels", phase, k, _ptr_array([c for c, _ in head_out]), _ptr_array([r for _, r in head_out]),
-              _ptr(gt_boxes), _ptr(gt_count), gt_boxes.shape[1], n, hs, ws, st, lo, hi, float(radius), float(gamma), float(alpha),
-              _ptr_array(scale_devs) if scale_devs is not None else none, _ptr(sums),
+              _p(gt_boxes), _p(gt_count), gt_boxes.shape[1], n, hs, ws, st, lo, hi, float(radius), float(gamma), float(alpha),
+              _ptr_array(scale_devs) if scale_devs is not None else none, _p(sums),
               _ptr_array(d_cls_ctrs) if d_cls_ctrs is not None else none, _ptr_array(d_regs) if d_regs is not None else none,
               gs, _ptr_array(d_scale_raws) if d_scale_raws is not None else none, _dt(head_out[0][0]), _stream())
     _rec("fcos_loss", phase=phase, head_out=list(head_out), gt_boxes=gt_boxes, gt_count=gt_count, gamma=float(gamma), alpha=float(alpha),
@@ -1066,8 +1072,8 @@ def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5, ws=None, fused_m
         sync = _gn1p_sync(dev, k, n)
         ws1 = _gn1p_ws(dev, k, hws, n, c, groups, False)       # a NAMED tensor: a temporary would be freed (and handed out again) before the launch
         try:
-            _lib.call("osd_groupnorm_relu_fwd_levels_onepass", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),
-                      _ptr(ws1), _ptr(sync), n, c, groups, float(eps), _dt(xs[0]), _stream())
+            _lib.call("osd_groupnorm_relu_fwd_levels_onepass", k, _ptr_array(xs), _ptr_array(ys), hws, _p(gamma), _p(beta), _p(ab),
+                      _p(ws1), _p(sync), n, c, groups, float(eps), _dt(xs[0]), _stream())
         except _lib.OsdError as e:
             if getattr(e, "code", 0) != -2:       # OSD_ERR_UNSUPPORTED: a map too large for one resident job — the two launches below
                 raise
@@ -1075,8 +1081,8 @@ def groupnorm_relu_levels(xs, gamma, beta, groups=32, eps=1e-5, ws=None, fused_m
     if not onepass:
         if ws is None:
             ws = torch.empty((k * n * GN_SPLITS * groups * 2,), device=dev, dtype=torch.float32)
-        _lib.call("osd_groupnorm_relu_fwd_levels_fused", k, _ptr_array(xs), _ptr_array(ys), hws, _ptr(gamma), _ptr(beta), _ptr(ab),
-                  _ptr(ws), n, c, groups, float(eps), _dt(xs[0]), int(fused_mask), _stream())
+        _lib.call("osd_groupnorm_relu_fwd_levels_fused", k, _ptr_array(xs), _ptr_array(ys), hws, _p(gamma), _p(beta), _p(ab),
+                  _p(ws), n, c, groups, float(eps), _dt(xs[0]), int(fused_mask), _stream())
     for x, y in zip(xs, ys):
         _rec("gn_relu", x=x, gamma=gamma, beta=beta, groups=groups, eps=float(eps), out=y)
     return ys, ab
@@ -1108,16 +1114,16 @@ def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32
     if conv_db is not None:
         assert fused_mask == 0 and ws is None
         ws = torch.empty((k * n * GN_SPLITS * (groups * 2 + 3 * c),), device=dev, dtype=torch.float32)
-        _lib.call("osd_groupnorm_relu_bwd_levels_convbias", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab),
-                  _ptr(gamma), _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), _ptr(conv_db), n, c, groups, _dt(us[0]), _stream())
+        _lib.call("osd_groupnorm_relu_bwd_levels_convbias", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _p(ab),
+                  _p(gamma), _p(beta), _p(ws), _p(dgamma), _p(dbeta), _p(conv_db), n, c, groups, _dt(us[0]), _stream())
     else:
         onepass = fused_mask == 0 and GN_ONEPASS_BWD and gn_onepass_ok(us[0], groups)
         if onepass:
             sync = _gn1p_sync(dev, k, n)
             ws1 = _gn1p_ws(dev, k, hws, n, c, groups, True)
             try:
-                _lib.call("osd_groupnorm_relu_bwd_levels_onepass", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab),
-                          _ptr(gamma), _ptr(beta), _ptr(ws1), _ptr(sync), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), _stream())
+                _lib.call("osd_groupnorm_relu_bwd_levels_onepass", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _p(ab),
+                          _p(gamma), _p(beta), _p(ws1), _p(sync), _p(dgamma), _p(dbeta), n, c, groups, _dt(us[0]), _stream())
             except _lib.OsdError as e:
                 if getattr(e, "code", 0) != -2:
                     raise
@@ -1125,8 +1131,8 @@ def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32
     if conv_db is None and not onepass:
         if ws is None:
             ws = torch.empty((gn_bwd_ws_numel(k, n, c, groups),), device=dev, dtype=torch.float32)
-        _lib.call("osd_groupnorm_relu_bwd_levels_fused", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _ptr(ab), _ptr(gamma),
-                  _ptr(beta), _ptr(ws), _ptr(dgamma), _ptr(dbeta), n, c, groups, _dt(us[0]), int(fused_mask), _stream())
+        _lib.call("osd_groupnorm_relu_bwd_levels_fused", k, _ptr_array(us), _ptr_array(dts), _ptr_array(dus), hws, _p(ab), _p(gamma),
+                  _p(beta), _p(ws), _p(dgamma), _p(dbeta), n, c, groups, _dt(us[0]), int(fused_mask), _stream())
     _rec("gn_relu_bwd", us=list(us), dts=list(dts), gamma=gamma, beta=beta, groups=groups, dgamma=dgamma, dbeta=dbeta, outs=dus,
          conv_db=conv_db)
     return dus
@@ -1148,8 +1154,8 @@ def roi_pool_levels(feats, scales, boxes, counts, pool, sampling_ratio, out=None
     ws = (C.c_int32 * k)(*[f.shape[2] for f in feats])
     sc = (C.c_float * k)(*[float(s) for s in scales])
     assert all(f.shape[0] == n and f.shape[-1] == c and f.is_contiguous() for f in feats)
-    _lib.call("osd_roi_pool_levels", k, xs, hs, ws, sc, _ptr(boxes.contiguous()), _ptr(counts), _ptr(out), n, c, r, pool,
-              sampling_ratio, out.shape[-1], _ptr(lv), _dt(out), _stream())
+    _lib.call("osd_roi_pool_levels", k, xs, hs, ws, sc, _ptr(boxes.contiguous()), _p(counts), _p(out), n, c, r, pool,
+              sampling_ratio, out.shape[-1], _p(lv), _dt(out), _stream())
     return (out, lv) if want_levels else out
 
 
@@ -1162,7 +1168,7 @@ def groupnorm_act_rois(x, gamma, beta, groups=32, eps=1e-5, slope=0.2, addend=No
         out = torch.empty_like(x)
     if addend is not None:
         assert addend.dtype == x.dtype and addend.shape[1:] == x.shape[1:] and addend.is_contiguous()
-    _lib.call("osd_groupnorm_act_rois", _ptr(x), _ptr(addend), _ptr(gamma), _ptr(beta), _ptr(out), r, h * w, c, groups,
+    _lib.call("osd_groupnorm_act_rois", _p(x), _p(addend), _p(gamma), _p(beta), _p(out), r, h * w, c, groups,
               float(eps), float(slope), rois_per_add, add_stride, add_offset, _dt(x), _stream())
     return out
 
@@ -1180,8 +1186,8 @@ def box_decode(pred, rois, counts, reg_weights, img_h, img_w, score_thresh, want
     lo = torch.empty((m, 2), device=dev, dtype=torch.float32) if want_raw else None
     ro = torch.empty((m, 8), device=dev, dtype=torch.float32) if want_raw else None
     rw = (C.c_float * 4)(*[float(v) for v in reg_weights])
-    _lib.call("osd_box_decode", _ptr(pred), _ptr(rois.contiguous()), _ptr(counts), _ptr(scores), _ptr(boxes), _ptr(lo),
-              _ptr(ro), n, r, s, p, rw, float(img_h), float(img_w), _ptr(img_hw), float(score_thresh), _dt(pred), _stream())
+    _lib.call("osd_box_decode", _p(pred), _ptr(rois.contiguous()), _p(counts), _p(scores), _p(boxes), _p(lo),
+              _p(ro), n, r, s, p, rw, float(img_h), float(img_w), _p(img_hw), float(score_thresh), _dt(pred), _stream())
     return (scores, boxes, lo, ro) if want_raw else (scores, boxes)
 
 
@@ -1203,9 +1209,9 @@ def box_match_sample(boxes, counts, gt_boxes, gt_count, keys, batch_per_image, p
     am = torch.empty((n, p), device=dev, dtype=torch.int32) if want_all else None
     rw = (C.c_float * 4)(*[float(v) for v in reg_weights])
     assert keys.shape == (n, p) and keys.dtype == torch.float32
-    _lib.call("osd_box_match_sample", _ptr(boxes.contiguous()), _ptr(counts), _ptr(gt_boxes.contiguous().float()), _ptr(gt_count),
-              _ptr(gt_labels), _ptr(keys.contiguous()), n, p, gt_boxes.shape[1], s, float(positive_fraction), float(iou_thresh),
-              rw, _ptr(sb), _ptr(sl), _ptr(st), _ptr(si), _ptr(sc), _ptr(al), _ptr(am), _stream())
+    _lib.call("osd_box_match_sample", _ptr(boxes.contiguous()), _p(counts), _ptr(gt_boxes.contiguous().float()), _p(gt_count),
+              _p(gt_labels), _ptr(keys.contiguous()), n, p, gt_boxes.shape[1], s, float(positive_fraction), float(iou_thresh),
+              rw, _p(sb), _p(sl), _p(st), _p(si), _p(sc), _p(al), _p(am), _stream())
     return (sb, sl, st, si, sc, al, am) if want_all else (sb, sl, st, si, sc)
 
 
@@ -1216,8 +1222,8 @@ def box_loss(pred, labels, targets, s_count, n, rois_per_image, w_cls, w_box, gr
     pred2 = pred.reshape(m, -1)
     losses = torch.empty((3,), device=pred.device, dtype=torch.float32)
     d = torch.empty((m, grad_stride), device=pred.device, dtype=pred.dtype) if grad_stride else None
-    _lib.call("osd_box_loss", _ptr(pred2), _ptr(labels), _ptr(targets), _ptr(s_count), n, rois_per_image, pred2.shape[1],
-              float(w_cls), float(w_box), _ptr(losses), _ptr(d), int(grad_stride), _dt(pred), _stream())
+    _lib.call("osd_box_loss", _p(pred2), _p(labels), _p(targets), _p(s_count), n, rois_per_image, pred2.shape[1],
+              float(w_cls), float(w_box), _p(losses), _p(d), int(grad_stride), _dt(pred), _stream())
     return losses, d
 
 
@@ -1227,8 +1233,8 @@ def groupnorm_act_rois_bwd(x, gamma, beta, dy, dgamma, dbeta, groups=32, eps=1e-
     r, h, w, c = x.shape
     dx = torch.empty_like(x)
     ws = torch.empty((r * 2 * c,), device=x.device, dtype=torch.float32)
-    _lib.call("osd_groupnorm_act_rois_bwd", _ptr(x), _ptr(addend), _ptr(gamma), _ptr(beta), _ptr(dy.contiguous()), _ptr(dx), _ptr(ws),
-              _ptr(dgamma), _ptr(dbeta), r, h * w, c, groups, float(eps), float(slope), rois_per_add, add_stride, add_offset,
+    _lib.call("osd_groupnorm_act_rois_bwd", _p(x), _p(addend), _p(gamma), _p(beta), _ptr(dy.contiguous()), _p(dx), _p(ws),
+              _p(dgamma), _p(dbeta), r, h * w, c, groups, float(eps), float(slope), rois_per_add, add_stride, add_offset,
               _dt(x), _stream())
     return dx
 
@@ -1237,7 +1243,7 @@ def rois_sum(x, n, rois_per_image):
     """[n * rois_per_image, ...] -> [n, ...]: the sum over each image's ROIs."""
     elems = x[0].numel()
     out = torch.empty((n,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
-    _lib.call("osd_rois_sum", _ptr(x), _ptr(out), n, rois_per_image, elems, _dt(x), _stream())
+    _lib.call("osd_rois_sum", _p(x), _p(out), n, rois_per_image, elems, _dt(x), _stream())
     return out
 
 
@@ -1250,7 +1256,7 @@ def roi_pool_levels_bwd(shapes, scales, boxes, counts, dy, pool, sampling_ratio)
     hs = (C.c_int32 * k)(*[h for h, _ in shapes])
     ws = (C.c_int32 * k)(*[w for _, w in shapes])
     sc = (C.c_float * k)(*[float(v) for v in scales])
-    _lib.call("osd_roi_pool_levels_bwd", k, _ptr_array(gxs), hs, ws, sc, _ptr(boxes.contiguous()), _ptr(counts), _ptr(dy.contiguous()),
+    _lib.call("osd_roi_pool_levels_bwd", k, _ptr_array(gxs), hs, ws, sc, _ptr(boxes.contiguous()), _p(counts), _ptr(dy.contiguous()),
               n, c, r, pool, sampling_ratio, dy.shape[-1], _dt(dy), _stream())
     return gxs
 
@@ -1265,8 +1271,8 @@ def append_gt_boxes(boxes, scores, counts, gt_boxes, gt_count):
     ob = torch.empty((n, cap + g, 4), device=dev, dtype=torch.float32)
     os_ = torch.empty((n, cap + g), device=dev, dtype=torch.float32)
     oc = torch.empty((n,), device=dev, dtype=torch.int32)
-    _lib.call("osd_append_gt_boxes", _ptr(boxes.contiguous()), _ptr(scores.contiguous()), _ptr(counts),
-              _ptr(gt_boxes.contiguous().float()), _ptr(gt_count), _ptr(ob), _ptr(os_), _ptr(oc), n, cap, g, _stream())
+    _lib.call("osd_append_gt_boxes", _ptr(boxes.contiguous()), _ptr(scores.contiguous()), _p(counts),
+              _ptr(gt_boxes.contiguous().float()), _p(gt_count), _p(ob), _p(os_), _p(oc), n, cap, g, _stream())
     return ob, os_, oc
 
 
@@ -1289,7 +1295,7 @@ def proposals_sort_nms(keys, boxes, max_count, levels, topn, thresh, max_keep, c
         nl = len(levels)
     else:
         lo, lc, nl = None, None, 0
-    _lib.call("osd_proposals_sort_nms_hint", _ptr(keys), _ptr(boxes), n, total, max_count, lo, lc, nl, int(topn), float(thresh),
-              int(cuda_semantics), max_keep, int(head_hint), _ptr(workspace), _ptr(ob), _ptr(os_), _ptr(oc), _ptr(depth_out),
+    _lib.call("osd_proposals_sort_nms_hint", _p(keys), _p(boxes), n, total, max_count, lo, lc, nl, int(topn), float(thresh),
+              int(cuda_semantics), max_keep, int(head_hint), _p(workspace), _p(ob), _p(os_), _p(oc), _p(depth_out),
               _stream())
     return ob, os_, oc
