@@ -1104,7 +1104,9 @@ def groupnorm_relu_bwd_levels(us, dts, ab, gamma, beta, dgamma, dbeta, groups=32
     """ws / fused_mask: the levels whose bit is set had their sums accumulated into (the zeroed) ws by the conv that wrote dts
     (conv2d_multi(gnb=...)); their statistics pass is skipped.
     conv_db [c] fp32 (optional; not with fused_mask): += the bias gradient of the conv that produced us (sum of du over levels,
-    images, pixels), from sums the two passes gather anyway (osd_groupnorm_relu_bwd_levels_convbias)."""
+    images, pixels), from sums the two passes gather anyway (osd_groupnorm_relu_bwd_levels_convbias).  Precedence: a non-None
+    conv_db always selects the two-launch conv-bias kernels (the one-pass backward kernel does not emit that sum); TrainEngine
+    therefore leaves conv_db off when OSD_GN_ONEPASS asks for the one-pass backward."""
     n, _, _, c = us[0].shape
     k = len(us)
     dev = us[0].device

@@ -167,7 +167,9 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         self.fpn_out_grouped = os.environ.get("OSD_NO_FPN_GROUPED", "0") == "0"
         # the tower convs' bias gradients from the GroupNorm backward's sums instead of the weight-gradient launch's column sums
         # (-11 % on that launch); not in ordered mode (its sum order over (level, image) is atomic) and bf16 / fp32 alike
-        self.gn_conv_db = (not self.ordered_wgrad and os.environ.get("OSD_NO_GN_CONV_DB", "0") == "0")
+        # (a conv-bias GroupNorm backward always takes the two-launch kernels, so asking for the one-pass BACKWARD —
+        # OSD_GN_ONEPASS=b / 1, an A/B configuration — turns the conv-bias form off; otherwise that switch could not reach its kernel)
+        self.gn_conv_db = (not self.ordered_wgrad and os.environ.get("OSD_NO_GN_CONV_DB", "0") == "0" and not ops.GN_ONEPASS_BWD)
         self.fuse_gn_fwd = (not self.ordered_wgrad and self.dtype == torch.bfloat16 and os.environ.get("OSD_GN_FWD_FUSION", "0") != "0")
         self._gnf_ws = {}
         # torch hands out stream handles from a pool, so a handle may carry an earlier engine's registration: set the mode of
