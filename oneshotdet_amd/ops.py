@@ -178,7 +178,16 @@ def conv2d(x, pc, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, re
             # (latency-sized shapes are timed with cold weights and the input re-touched: tuner._time_launches_cold)
             algo = _tune(key, d, lambda: _lib.call("osd_conv2d_fwd", C.byref(d), *args), prewarm=lambda: x.float().sum()) if _TUNING[0] else 0
     d.algo = algo
-    _lib.call("osd_conv2d_fwd", C.byref(d), *args)
+    try:
+        _lib.call("osd_conv2d_fwd", C.byref(d), *args)
+    except _lib.OsdError as e:
+        # a cached id this library does not build for this shape (a cache that slipped past the ABI stamp, a hand-edited file):
+        # drop the entry and run the library's own choice instead of failing every step
+        if getattr(e, "code", 0) != -2 or algo == 0 or ALGO_CACHE.get(key) != algo:
+            raise
+        del ALGO_CACHE[key]
+        d.algo = 0
+        _lib.call("osd_conv2d_fwd", C.byref(d), *args)
     _rec("conv", x=x, w=pc.w, bias=pc.bias, cout=pc.cout_store, r=pc.r, s=pc.s, stem=pc.stem, stride=stride, pad=pad, act=act,
          res=res, res_mode=res_mode, relu_in=bool(relu_in), act_scale=float(act_scale), act_scale_dev=act_scale_dev, mask=mask,
          out=out)

@@ -665,3 +665,21 @@ def test_correlate_levels_forward_and_query_gradient(dt):
         dref = (g.float() * x.float()).sum(dim=(1, 2))
         torch.testing.assert_close(dq, dref, rtol=1e-4, atol=1e-3)
         torch.testing.assert_close(dq, o.correlate_bwd_query(g, x), rtol=1e-5, atol=1e-4)
+
+
+def test_conv2d_drops_a_cached_algorithm_the_library_refuses():
+    """a tuner cache entry that names a kernel this library does not build for the shape (ids were reused across library
+    generations; a file can be hand-edited) must not fail every step: the entry is dropped and the library's own choice runs."""
+    o = ops()
+    x = to_nhwc(rnd(1, 64, 9, 11, seed=5), torch.bfloat16)
+    wt = rnd(64, 64, 1, 1, seed=6) / 8
+    pc = o.pack_conv(wt.cuda(), bias=torch.zeros(64).cuda(), dtype=torch.bfloat16)
+    ref = o.conv2d(x, pc, algo=0)
+    key = (o.OSD_BF16, 1, 9, 11, 64, 64, 1, 1, 1, 0, o.RES_NONE, o.ACT_NONE, 0, False)
+    o.ALGO_CACHE[key] = 41                       # the retired persistent pointwise kernel: OSD_ERR_UNSUPPORTED
+    try:
+        y = o.conv2d(x, pc)
+        assert key not in o.ALGO_CACHE
+        assert torch.equal(y, ref)
+    finally:
+        o.ALGO_CACHE.pop(key, None)
