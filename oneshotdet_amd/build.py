@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, "lib")
 # object dir) for A/B timing through OSD_LIB_PATH; the default build is untouched
 TAG = os.environ.get("OSD_BUILD_TAG", "")
 LIB = os.path.join(LIBDIR, "liboneshotdet_hip%s.so" % ("_" + TAG if TAG else ""))
-SOURCES = ["osd_error.hip", "conv_igemm.hip", "conv_igemm_dma.hip", "conv_igemm_sp.hip", "conv_px.hip", "conv_wgrad.hip", "conv_wgrad_sk.hip", "backward.hip", "groupnorm_onepass.hip", "loss.hip", "elementwise.hip", "proposals.hip", "box_head.hip", "transforms.hip", "box_train.hip", "evaluation.hip"]
+SOURCES = ["osd_error.hip", "conv_igemm.hip", "conv_igemm_dma.hip", "conv_igemm_sp.hip", "conv_pred.hip", "conv_px.hip", "conv_wgrad.hip", "conv_wgrad_sk.hip", "backward.hip", "groupnorm_onepass.hip", "loss.hip", "elementwise.hip", "proposals.hip", "box_head.hip", "transforms.hip", "box_train.hip", "evaluation.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"] + os.environ.get("OSD_BUILD_FLAGS", "").split()
 

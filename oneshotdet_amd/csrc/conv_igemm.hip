@@ -375,6 +375,10 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
       if (d->dtype != OSD_BF16 || src2 != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the pixel-stationary 1x1 kernel is bf16 only, one source");
       return osd_conv_px_launch(p, s, tile == 1);
     }
+    if (impl == 1 && variant == 2 && tile == 2) {      // algo 51 (round 6): the prediction convs' patch kernel (conv_pred.hip)
+      if (d->dtype != OSD_BF16 || src2 != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the prediction-conv kernel is bf16 only, one source");
+      return osd_conv_pred_launch(p, s);
+    }
     if (impl == 1 && variant == 3 && tile <= 3) {      // algos 57 - 60 (round 6): small LDS-DMA tiles with deep rings (conv_igemm_dma.hip)
       if (src2 != nullptr) return osd_fail(OSD_ERR_UNSUPPORTED, "conv: the deep-ring tiles take one source");
       return osd_conv_dma_deep(d->dtype, tile == 0 ? 832 : tile == 1 ? 5 : tile == 2 ? 8 : 816, p, s);      // 64x32x8, 64x64x5, 64x64x8, 32x64x8
@@ -479,6 +483,10 @@ static int conv_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* 
   p.H = p.seg[0].H; p.W = p.seg[0].W; p.Ho = p.seg[0].Ho; p.Wo = p.seg[0].Wo; p.HoWo = p.Ho * p.Wo;
   p.sN = p.seg[0].sN; p.sH = p.seg[0].sH; p.M = (int)mtot;
   int tile = choose_tile((int)mtot, p.Cout), variant = 0;
+  if (d->algo == 51) {      // the prediction convs' patch kernel (conv_pred.hip): all levels of a tower output in one launch
+    if (d->dtype != OSD_BF16 || gn) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: the prediction-conv kernel is bf16 only, no statistics");
+    return osd_conv_pred_launch(p, reinterpret_cast<hipStream_t>(stream));
+  }
   if (d->algo > 0) {
     const int a = d->algo - 1;
     if (a >= 32) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: algo %d is not an LDS-DMA algorithm", d->algo);

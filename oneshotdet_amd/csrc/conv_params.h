@@ -75,3 +75,6 @@ int osd_conv_sp_launch(const ConvKParams& p, hipStream_t s, bool general_width =
 // the workgroups stream only weight chunks (algo ids 49 / 50: eight waves of 16 pixels / four of 32; the expanding bottleneck convs
 // and conv1's data gradient)
 int osd_conv_px_launch(const ConvKParams& p, hipStream_t s, bool wide_waves);
+// conv_pred.hip (round 6, algo 51): bf16 3x3 / stride 1 / pad 1 convs with <= 4 output channels (the FCOS prediction convs' forward): an
+// 8 x 32 output patch per workgroup, the 10 x 34 input patch staged once per 64-channel slab and read by all nine taps
+int osd_conv_pred_launch(const ConvKParams& p, hipStream_t s);

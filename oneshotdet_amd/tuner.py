@@ -40,6 +40,7 @@ CONV_ALGO_DEEP5 = 1 + 1 * 32 + 3 * 8 + 1   # the 64 x 64 LDS-DMA tile with a rin
 CONV_ALGO_DEEP8 = 1 + 1 * 32 + 3 * 8 + 2   # ... eight stages: 112 KB of operands in flight per workgroup
 COLD_MAX_PIXELS = int(os.environ.get("OSD_TUNE_COLD_PIXELS", "32768"))      # convs with at most this many output pixels are timed with cold weights (below)
 DEEP_MAX_PIXELS = 4096                      # ... and get the deep-ring 64 x 64 tiles as candidates
+CONV_ALGO_PRED = 1 + 1 * 32 + 2 * 8 + 2    # conv_pred.hip (round 6): 3x3 convs with <= 4 output channels on an 8 x 32 output patch per workgroup
 CONV_ALGO_PX = 1 + 1 * 32 + 2 * 8 + 0      # conv_px.hip, eight waves of 16 pixels
 CONV_ALGO_PX_WIDE = CONV_ALGO_PX + 1       # ... four waves of 32 pixels
 
@@ -49,6 +50,8 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False, pixels=None):
     if cout_store <= 16:
         tiles = [3, 2]
     cands = [1 + 0 * 32 + v * 8 + t for v in (0, 1, 2, 3) for t in tiles]      # v 3: three short stages (many workgroups per CU)
+    if cout_store <= 4 and not relu_in and not has_mask and not os.environ.get("OSD_NO_PRED_KERNEL"):
+        cands.append(CONV_ALGO_PRED)                  # the FCOS prediction convs' forward (bf16, 3x3 / 1 / 1; refused elsewhere)
     if cout_store >= 256 and not relu_in:
         cands.append(1 + 0 * 32 + 1 * 8 + 4)          # 256x256 tile, shallow ring
         cands.append(1 + 0 * 32 + 2 * 8 + 4)          # 256x256 tile, short stages x 4

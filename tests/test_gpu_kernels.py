@@ -683,3 +683,46 @@ def test_conv2d_drops_a_cached_algorithm_the_library_refuses():
         assert torch.equal(y, ref)
     finally:
         o.ALGO_CACHE.pop(key, None)
+
+
+def test_prediction_conv_patch_kernel_matches_the_tile_kernels():
+    """conv_pred.hip (algo 51, round 6): the FCOS prediction convs' forward (fcos.py:50-61, 91-97: 3x3 256 -> 2 / 4 channels, bbox with
+    exp(scale_l x)) on an 8 x 32 output patch per workgroup with the input patch staged once per 64-channel slab.  Against the
+    256 x 16 LDS-DMA tile (another fp32 summation order: within one bf16 rounding step, few elements differing) and the fp32
+    reference; single maps and all five levels in one grouped launch (P3 .. P7 sizes, ragged maps smaller than a patch, several
+    images), the learnable per-level Scale read on the device; what it does not cover is refused."""
+    from oneshotdet_amd import _lib
+    o = ops()
+    PRED, DMA = 51, 1 + 0 * 8 + 3
+    assert PRED in o.conv_algo_candidates(4, False) and PRED not in o.conv_algo_candidates(4, False, has_mask=True)
+    for cout in (2, 4):
+        wt = rnd(cout, 256, 3, 3, seed=2) / 48
+        pc = o.pack_conv(wt.cuda(), bias=rnd(cout, seed=3).cuda() * 0.1, dtype=torch.bfloat16)
+        sizes = [(2, 100, 128), (2, 50, 64), (2, 25, 32), (2, 13, 16), (2, 7, 8), (3, 9, 33), (1, 1, 1), (1, 8, 32), (1, 17, 65)]
+        xs = [torch.relu(to_nhwc(rnd(n, 256, h, w, seed=10 + i), torch.bfloat16)) for i, (n, h, w) in enumerate(sizes)]
+        for x in xs:
+            ref = o.conv2d(x, pc, pad=1, algo=DMA)
+            y = o.conv2d(x, pc, pad=1, algo=PRED)
+            d = (y.float() - ref.float()).abs()
+            assert bool((d <= 2.0 ** -7 * ref.float().abs().clamp(min=1.0)).all()), (cout, tuple(x.shape), d.max().item())
+            assert (d > 0).float().mean().item() < 0.05
+            for rep in range(3):
+                assert torch.equal(o.conv2d(x, pc, pad=1, algo=PRED), y)
+        # all levels in one launch, exp(scale_l * x) with the scales on the device
+        scales = [torch.tensor([0.5 + 0.25 * i], device="cuda") for i in range(5)]
+        ys = o.conv2d_grouped(xs[:5], pc, pad=1, act=o.ACT_EXP_SCALE, act_scale_devs=scales, algo=PRED, _whole=True)
+        rs = o.conv2d_grouped(xs[:5], pc, pad=1, act=o.ACT_EXP_SCALE, act_scale_devs=scales, algo=DMA, _whole=True)
+        for ya, ra in zip(ys, rs):
+            d = (ya.float() - ra.float()).abs()
+            assert bool((d <= 2.0 ** -6 * ra.float().abs().clamp(min=1e-3)).all()), (cout, tuple(ya.shape), d.max().item())
+        # the fp32 reference
+        xf = rnd(2, 256, 23, 40, seed=31)
+        y = o.conv2d(to_nhwc(xf, torch.bfloat16), pc, pad=1, algo=PRED)
+        ref = F.conv2d(xf.bfloat16().float(), wt.bfloat16().float(), pc.bias[:cout].cpu(), padding=1)
+        np.testing.assert_allclose(y.float().cpu()[..., :cout].permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+    # refused: wide convs, strides, 1x1
+    wide = o.pack_conv((rnd(64, 256, 3, 3, seed=4) / 48).cuda(), bias=torch.zeros(64).cuda(), dtype=torch.bfloat16)
+    with pytest.raises(_lib.OsdError):
+        o.conv2d(xs[2], wide, pad=1, algo=PRED)
+    with pytest.raises(_lib.OsdError):
+        o.conv2d(xs[2], pc, pad=1, stride=2, algo=PRED)
