@@ -69,7 +69,10 @@ typedef struct osd_conv_desc {
                              DESIGN.md 4.1): lets the host autotune per layer shape by measurement.  Ids are only
                              meaningful for ONE osd_abi_version(): 41 (the persistent pointwise kernel of ABI 3's first
                              builds) is retired and returns OSD_ERR_UNSUPPORTED; tile 5 / tile 6 variant 0 name other kernels
-                             than they did before ABI 4 — a cached id must be stored with the ABI version it was tuned under */
+                             than they did before ABI 4 — a cached id must be stored with the ABI version it was tuned under.
+                             New in ABI 4: 57 - 60 = deep-ring small tiles (64 x 32 x 8 stages, 64 x 64 x 5, 64 x 64 x 8, 32 x 64 x 8;
+                             bf16, cin in 64s: the latency-sized launches), 51 = the prediction convs' patch kernel (bf16, 3x3 / 1 / 1,
+                             cout <= 4, no residual / mask) */
   int32_t reserved0;      /* (keeps the pointer below 8-byte aligned; set to 0) */
   void* ordered_ws;       /* weight-gradient entries only (ABI 3): NULL = partial tiles are added with fp32 atomics; otherwise
                              a caller-owned scratch buffer of ordered_ws_bytes bytes — the launch STORES its partial tiles
@@ -105,7 +108,7 @@ int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void* w, const f
 /* The same convolution applied to n_seg <= OSD_CONV_MAX_SEG dense NHWC tensors of different batch / spatial size in ONE
  * launch: the FPN levels that share an FCOS tower or prediction conv (fcos.py:83-99 loops `for l, feature in enumerate(x)`
  * over the same modules).  d gives dtype, cin, cout, r, s, strides, pads, w_rows, out_stride, res_mode (NONE, SAME, or UP2X
- * with an addend of exactly half the output size), res_stride, act, act_scale, algo (LDS-DMA algorithms 1..32 only);
+ * with an addend of exactly half the output size), res_stride, act, act_scale, algo (LDS-DMA algorithms 1..32, and 51);
  * xs / ys / residuals / masks / act_scale_devs are HOST arrays of n_seg device pointers (the last three nullable as a
  * whole; act_scale_devs[l] = the level's Scale), ns / hs / ws HOST arrays with each tensor's batch, height and width. */
 #define OSD_CONV_MAX_SEG 12

@@ -39,3 +39,14 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("20 steps back to back: host returns after %.2f ms/step, device done after %.2f ms/step" % ((t1 - t0) / 20 * 1e3, (t2 - t0) / 20 * 1e3))
+if os.environ.get("OSD_CPROFILE"):      # where the host time goes: the top functions by own time over 9 steps
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    torch.cuda.synchronize()
+    pr.enable()
+    for _ in range(9):
+        eng.train_step(images, queries, gt_boxes, gt_count)
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(int(os.environ.get("OSD_CPROFILE")) if os.environ["OSD_CPROFILE"].isdigit() and int(os.environ["OSD_CPROFILE"]) > 1 else 40)
