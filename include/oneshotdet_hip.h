@@ -41,6 +41,9 @@ extern "C" {
 #define OSD_RES_NONE 0
 #define OSD_RES_SAME 1   /* y += res[n,ho,wo,c]            Bottleneck `out += identity`, modeling/backbone/resnet.py:312 */
 #define OSD_RES_UP2X 2   /* y += res[n,ho/2,wo/2,c]        FPN top-down nearest 2x + add, modeling/backbone/fpn.py:59-64 */
+#define OSD_RES_DOWN2X 3 /* y += res[n,2ho,2wo,c]          the identity of a bottleneck computed on every other pixel only: layer1's last block,
+                            whose output nothing but layer2.0's stride-2 1x1 convs reads (resnet.py:295-315, 138-145); res_h >= 2 ho - 1, res_w >= 2 wo - 1
+                            (osd_conv2d_fwd_grouped: exactly twice the output size) */
 
 const char* osd_last_error_string(void);
 int osd_abi_version(void);
@@ -107,7 +110,7 @@ int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void* w, const f
 
 /* The same convolution applied to n_seg <= OSD_CONV_MAX_SEG dense NHWC tensors of different batch / spatial size in ONE
  * launch: the FPN levels that share an FCOS tower or prediction conv (fcos.py:83-99 loops `for l, feature in enumerate(x)`
- * over the same modules).  d gives dtype, cin, cout, r, s, strides, pads, w_rows, out_stride, res_mode (NONE, SAME, or UP2X
+ * over the same modules).  d gives dtype, cin, cout, r, s, strides, pads, w_rows, out_stride, res_mode (NONE, SAME, DOWN2X from a map of exactly twice the size, or UP2X
  * with an addend of exactly half the output size), res_stride, act, act_scale, algo (LDS-DMA algorithms 1..32, and 51);
  * xs / ys / residuals / masks / act_scale_devs are HOST arrays of n_seg device pointers (the last three nullable as a
  * whole; act_scale_devs[l] = the level's Scale), ns / hs / ws HOST arrays with each tensor's batch, height and width. */

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("OSD_LIB_PATH") or os.path.join(_HERE, "lib", "libones
 OSD_F32, OSD_BF16 = 0, 1
 ABI_VERSION = 4      # include/oneshotdet_hip.h: osd_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_EXP_SCALE = 0, 1, 2
-RES_NONE, RES_SAME, RES_UP2X = 0, 1, 2
+RES_NONE, RES_SAME, RES_UP2X, RES_DOWN2X = 0, 1, 2, 3
 GN_SPLITS = 64
 
 

@@ -50,7 +50,9 @@ __device__ __forceinline__ ConvView conv_select_view(const ConvKParams& p, int& 
     }
     tile_m -= OSD_KSEG(int, tile_begin);
 #undef OSD_KSEG
-    q.res_h = q.Ho >> 1; q.res_w = q.Wo >> 1;     // nearest-2x top-down add: the addend is exactly half size (checked by the host)
+    // nearest-2x top-down add: the addend is exactly half size; every-other-pixel identity: exactly double size (checked by the host)
+    if (p.res_mode == OSD_RES_DOWN2X) { q.res_h = q.Ho << 1; q.res_w = q.Wo << 1; }
+    else { q.res_h = q.Ho >> 1; q.res_w = q.Wo >> 1; }
   }
   q.HoWo = q.Ho * q.Wo;
   return q;
@@ -195,7 +197,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
         }
       };
       const bool hr = p.res_mode == OSD_RES_SAME, hm = q_mask != nullptr;
-      if (p.res_mode != OSD_RES_UP2X && (hr || hm)) {
+      if ((p.res_mode == OSD_RES_NONE || p.res_mode == OSD_RES_SAME) && (hr || hm)) {
         if (hr && hm) piped(std::true_type(), std::true_type());
         else if (hr) piped(std::true_type(), std::false_type());
         else piped(std::false_type(), std::true_type());
@@ -256,14 +258,16 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
 #pragma unroll
         for (int it = 0; it < ITER; ++it)
           rr[it] = *(const OSD_G Vec*)(rg + (size_t)(mrow + it * (64 / CPR)) * p.res_stride + c);
-      } else if (p.res_mode == OSD_RES_UP2X) {
+      } else if (p.res_mode != OSD_RES_NONE) {      // UP2X: (ho / 2, wo / 2) of a half-size map; DOWN2X: (2 ho, 2 wo) of a double-size one
+        const bool down = p.res_mode == OSD_RES_DOWN2X;
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-          const int m = mrow + it * (64 / CPR);
+          const int m = min(mrow + it * (64 / CPR), q_M - 1);      // (rows past M are computed and dropped: keep their addend address inside the map)
           const int n_img = m / q_HoWo;
           const int rem = m - n_img * q_HoWo;
           const int ho = rem / q_Wo, wo = rem - (rem / q_Wo) * q_Wo;
-          rr[it] = *(const OSD_G Vec*)(rg + ((size_t)(n_img * q.res_h + (ho >> 1)) * q.res_w + (wo >> 1)) * p.res_stride + c);
+          const int hr = down ? (ho << 1) : (ho >> 1), wr = down ? (wo << 1) : (wo >> 1);
+          rr[it] = *(const OSD_G Vec*)(rg + ((size_t)(n_img * q.res_h + hr) * q.res_w + wr) * p.res_stride + c);
         }
       }
       if (q_mask) {
@@ -435,7 +439,8 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[TN][TM], const ConvKP
           const int n_img = m / q_HoWo;
           const int rem = m - n_img * q_HoWo;
           const int ho = rem / q_Wo, wo = rem - (rem / q_Wo) * q_Wo;
-          res_off = ((size_t)(n_img * q.res_h + (ho >> 1)) * q.res_w + (wo >> 1)) * p.res_stride + c;
+          const bool down = p.res_mode == OSD_RES_DOWN2X;
+          res_off = ((size_t)(n_img * q.res_h + (down ? (ho << 1) : (ho >> 1))) * q.res_w + (down ? (wo << 1) : (wo >> 1))) * p.res_stride + c;
         }
         if constexpr (sizeof(T) == 2) {
           if (vec_ok && nval[it] == EPC) {

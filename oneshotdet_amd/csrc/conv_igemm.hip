@@ -218,11 +218,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvKParams p) {
     size_t res_off = 0;
     if (p.res_mode == OSD_RES_SAME) {
       res_off = (size_t)m * p.res_stride;
-    } else if (p.res_mode == OSD_RES_UP2X) {
+    } else if (p.res_mode != OSD_RES_NONE) {
       const int n_img = m / p.HoWo;
       const int rem = m - n_img * p.HoWo;
       const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
-      res_off = ((size_t)(n_img * p.res_h + (ho >> 1)) * p.res_w + (wo >> 1)) * p.res_stride;
+      const bool down = p.res_mode == OSD_RES_DOWN2X;
+      res_off = ((size_t)(n_img * p.res_h + (down ? (ho << 1) : (ho >> 1))) * p.res_w + (down ? (wo << 1) : (wo >> 1))) * p.res_stride;
     }
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
@@ -321,6 +322,11 @@ extern "C" int osd_conv2d_fwd(const osd_conv_desc* d, const void* x, const void*
                     d->out_stride);
   if (d->res_mode != OSD_RES_NONE && (!res || d->res_stride % 4 != 0))
     return osd_fail(OSD_ERR_INVALID_ARG, "conv: residual requested without a valid residual tensor");
+  if (d->res_mode < OSD_RES_NONE || d->res_mode > OSD_RES_DOWN2X) return osd_fail(OSD_ERR_INVALID_ARG, "conv: bad res_mode %d", d->res_mode);
+  if (d->res_mode == OSD_RES_UP2X && (d->res_h * 2 < d->ho || d->res_w * 2 < d->wo))
+    return osd_fail(OSD_ERR_INVALID_ARG, "conv: the nearest-2x addend (%d x %d) is smaller than half the output (%d x %d)", d->res_h, d->res_w, d->ho, d->wo);
+  if (d->res_mode == OSD_RES_DOWN2X && (d->res_h < 2 * d->ho - 1 || d->res_w < 2 * d->wo - 1))
+    return osd_fail(OSD_ERR_INVALID_ARG, "conv: the every-other-pixel addend (%d x %d) does not cover the output (%d x %d)", d->res_h, d->res_w, d->ho, d->wo);
   if (d->w_rows < d->cout) return osd_fail(OSD_ERR_INVALID_ARG, "conv: w_rows < cout");
   const int epc = d->dtype == OSD_BF16 ? 8 : 4;
   // every staged 16-byte chunk must be 16-byte aligned: dense NHWC (pixel stride multiple of a chunk) or the stem's
@@ -427,7 +433,7 @@ static int conv_fwd_multi(const osd_conv_desc* d, int n_seg, const void* const* 
   if (d->relu_in) return osd_fail(OSD_ERR_UNSUPPORTED, "conv_grouped: the relu_in prologue is not supported");
   if (d->cout % 4 != 0 || d->out_stride % 4 != 0)
     return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: cout/out_stride must be multiples of 4");
-  if (d->res_mode != OSD_RES_NONE && d->res_mode != OSD_RES_SAME && d->res_mode != OSD_RES_UP2X)
+  if (d->res_mode != OSD_RES_NONE && d->res_mode != OSD_RES_SAME && d->res_mode != OSD_RES_UP2X && d->res_mode != OSD_RES_DOWN2X)
     return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: bad res_mode %d", d->res_mode);
   if (d->res_mode != OSD_RES_NONE && (!residuals || d->res_stride % 4 != 0))
     return osd_fail(OSD_ERR_INVALID_ARG, "conv_grouped: residual requested without residual tensors");

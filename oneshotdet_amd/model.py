@@ -14,7 +14,7 @@ import torch
 from . import streams as _streams
 
 from . import ops, spec
-from .ops import ACT_EXP_SCALE, ACT_NONE, ACT_RELU, RES_SAME, RES_UP2X
+from .ops import ACT_EXP_SCALE, ACT_NONE, ACT_RELU, RES_DOWN2X, RES_SAME, RES_UP2X
 
 
 LOCKSTEP = os.environ.get("OSD_LOCKSTEP", "0") != "0"            # inference engine: both backbones per launch (A/B)
@@ -26,6 +26,7 @@ def _bn(sd, p):
     return (sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"])
 
 
+RES_DOWN2X_OK = os.environ.get("OSD_NO_RES_DOWN2X", "0") == "0"      # A/B switch: copy the identity's even pixels instead (the form until round 6)
 FPN_OUT_GROUPED = os.environ.get("OSD_NO_FPN_GROUPED", "0") == "0"       # the FPN's P3 + P4 output convs as one launch
 FUSE_DOWNSAMPLE = os.environ.get("OSD_NO_FUSE_DS", "0") == "0"      # A/B switch: conv3 + downsample of a stage's first block as one GEMM
 
@@ -118,13 +119,17 @@ def run_backbone(wts, images, dtype, return_body=False):
             continue
         identity = x if blk["ds"] is None else ops.conv2d(x, blk["ds"], stride=s)
         out = ops.conv2d(x, blk["c1"], stride=s, act=ACT_RELU)
+        rmode = RES_SAME
         if quarter:
             out = ops.conv2d(out, blk["c2"], stride=2, pad=1, act=ACT_RELU)
-            identity = identity[:, ::2, ::2].contiguous()
+            if RES_DOWN2X_OK:        # the 1x1's epilogue reads the identity at (2 ho, 2 wo) itself (round 6: no strided copy of a 210 MB map)
+                rmode = RES_DOWN2X
+            else:
+                identity = identity[:, ::2, ::2].contiguous()
             halved = True
         else:
             out = ops.conv2d(out, blk["c2"], pad=1, act=ACT_RELU)
-        x = ops.conv2d(out, blk["c3"], act=ACT_RELU, res=identity, res_mode=RES_SAME)
+        x = ops.conv2d(out, blk["c3"], act=ACT_RELU, res=identity, res_mode=rmode)
         if blk["last_of_stage"]:
             feats.append(x)
     c3, c4, c5 = feats[1], feats[2], feats[3]
@@ -162,13 +167,17 @@ def run_backbones(wt, wq, images, queries, dtype):
         quarter = SKIP_UNUSED_C2 and bi == spec.STAGE_BLOCKS[0] - 1         # see run_backbone
         identity = xs if bt["ds"] is None else ops.conv2d_multi(xs, [bt["ds"], bq["ds"]], stride=s)
         out = ops.conv2d_multi(xs, [bt["c1"], bq["c1"]], stride=s, act=ACT_RELU)
+        rmode = RES_SAME
         if quarter:
             out = ops.conv2d_multi(out, [bt["c2"], bq["c2"]], stride=2, pad=1, act=ACT_RELU)
-            identity = [t[:, ::2, ::2].contiguous() for t in identity]
+            if RES_DOWN2X_OK and all(t.shape[1] % 2 == 0 and t.shape[2] % 2 == 0 for t in identity):
+                rmode = RES_DOWN2X
+            else:
+                identity = [t[:, ::2, ::2].contiguous() for t in identity]
             halved = True
         else:
             out = ops.conv2d_multi(out, [bt["c2"], bq["c2"]], pad=1, act=ACT_RELU)
-        xs = ops.conv2d_multi(out, [bt["c3"], bq["c3"]], act=ACT_RELU, residuals=identity)
+        xs = ops.conv2d_multi(out, [bt["c3"], bq["c3"]], act=ACT_RELU, residuals=identity, res_mode=rmode)
         if bt["last_of_stage"]:
             feats.append(xs)
     c3, c4, c5 = feats[1], feats[2], feats[3]

@@ -6,10 +6,10 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (ACT_EXP_SCALE, ACT_NONE, ACT_RELU, GN_SPLITS, OSD_BF16, OSD_F32, RES_NONE, RES_SAME, RES_UP2X,
+from ._lib import (ACT_EXP_SCALE, ACT_NONE, ACT_RELU, GN_SPLITS, OSD_BF16, OSD_F32, RES_DOWN2X, RES_NONE, RES_SAME, RES_UP2X,
                    ConvDesc)
 
-__all__ = ["ACT_NONE", "ACT_RELU", "ACT_EXP_SCALE", "RES_NONE", "RES_SAME", "RES_UP2X"]
+__all__ = ["ACT_NONE", "ACT_RELU", "ACT_EXP_SCALE", "RES_NONE", "RES_SAME", "RES_UP2X", "RES_DOWN2X"]
 
 
 from . import streams
@@ -231,6 +231,8 @@ def _build_conv_desc(x, pc, stride, pad, act, res, res_mode, relu_in, act_scale,
         d.res_h, d.res_w, d.res_stride = res.shape[1], res.shape[2], res.shape[3]
         if res_mode == RES_UP2X:
             assert res.shape[1] * 2 == ho and res.shape[2] * 2 == wo, "top-down map must be exactly half size"
+        if res_mode == RES_DOWN2X:
+            assert res.shape[1] >= 2 * ho - 1 and res.shape[2] >= 2 * wo - 1, "the every-other-pixel addend must cover the output"
     d.act, d.act_scale, d.relu_in = act, float(act_scale), int(relu_in)
     # full geometry in the tuner key: some algorithms only exist for some map widths (the row-reuse kernel: W in 64/128/256),
     # and a transposed batch (1024x800 after 800x1024) has the same n*ho*wo
@@ -384,6 +386,9 @@ def conv2d_multi(xs, pcs, stride=1, pad=0, act=ACT_NONE, residuals=None, res_mod
         d.res_stride = residuals[0].shape[-1]
         if res_mode == RES_SAME:
             assert all(r.shape == o.shape for r, o in zip(residuals, outs))
+        elif res_mode == RES_DOWN2X:
+            assert all(r.shape[1] == 2 * o.shape[1] and r.shape[2] == 2 * o.shape[2] and r.shape[3] == o.shape[3]
+                       for r, o in zip(residuals, outs)), "the every-other-pixel addend of a grouped launch must be exactly twice the size"
         else:
             assert all(r.shape[1] * 2 == o.shape[1] and r.shape[2] * 2 == o.shape[2] and r.shape[3] == o.shape[3]
                        for r, o in zip(residuals, outs)), "top-down map must be exactly half size"

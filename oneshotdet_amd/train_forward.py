@@ -6,8 +6,9 @@ import torch
 
 from . import streams
 
+from . import model as _model
 from . import ops, spec
-from .ops import ACT_EXP_SCALE, ACT_RELU, RES_UP2X
+from .ops import ACT_EXP_SCALE, ACT_RELU, RES_DOWN2X, RES_SAME, RES_UP2X
 
 SIZE_RANGES = ((-1.0, 64.0), (64.0, 128.0), (128.0, 256.0), (256.0, 512.0), (512.0, float(spec.INF)))
 
@@ -55,13 +56,17 @@ class ForwardPass(object):
                     continue
                 identity = ops.conv2d_multi(xs, pcs(p + "downsample.0"), stride=s) if has_ds else xs
                 o1 = ops.conv2d_multi(xs, pcs(p + "conv1"), stride=s, act=ACT_RELU)
+                rmode = RES_SAME
                 if quarter:
                     o2 = ops.conv2d_multi(o1, pcs(p + "conv2"), stride=2, pad=1, act=ACT_RELU)
-                    identity = [t[:, ::2, ::2].contiguous() for t in identity]
+                    if _model.RES_DOWN2X_OK and all(t.shape[1] % 2 == 0 and t.shape[2] % 2 == 0 for t in identity):
+                        rmode = RES_DOWN2X       # conv3's epilogue reads the identity at (2 ho, 2 wo): no strided copy of the 210 MB map
+                    else:
+                        identity = [t[:, ::2, ::2].contiguous() for t in identity]
                     halved = True
                 else:
                     o2 = ops.conv2d_multi(o1, pcs(p + "conv2"), pad=1, act=ACT_RELU)
-                y = ops.conv2d_multi(o2, pcs(p + "conv3"), act=ACT_RELU, residuals=identity)
+                y = ops.conv2d_multi(o2, pcs(p + "conv3"), act=ACT_RELU, residuals=identity, res_mode=rmode)
                 if si >= 1:
                     for j in nb:
                         blocks[j].append(dict(p=p, s=s, ds=has_ds, x=xs[j], o1=o1[j], o2=o2[j], y=y[j],

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from . import hotpath_ref as orc
 
 ACT_NONE, ACT_RELU, ACT_EXP_SCALE = 0, 1, 2
-RES_NONE, RES_SAME, RES_UP2X = 0, 1, 2
+RES_NONE, RES_SAME, RES_UP2X, RES_DOWN2X = 0, 1, 2, 3
 
 
 def nchw(t):
@@ -79,6 +79,8 @@ def conv_launch(x, w, bias, cout, r, s, stem=False, stride=1, pad=0, act=ACT_NON
         y = y + nchw(res)[:, :cout]
     elif res_mode == RES_UP2X:
         y = y + F.interpolate(nchw(res)[:, :cout], scale_factor=2, mode="nearest")
+    elif res_mode == RES_DOWN2X:
+        y = y + nchw(res)[:, :cout, ::2, ::2]
     if mask is not None:
         y = torch.where(nchw(mask)[:, :cout] > 0, y, torch.zeros_like(y))
     if act == ACT_RELU:

@@ -135,6 +135,45 @@ def test_conv2d_fpn_lateral_upsample_add(dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv2d_identity_on_every_other_pixel(dt):
+    """out = relu(conv1x1(mid) + identity[:, :, ::2, ::2]): conv3 of layer1's last block computed on the even pixels only (its
+    output is read by layer2.0's stride-2 1x1 convs and by nothing else: resnet.py:295-315, 138-145), the epilogue reading the
+    identity at (2 ho, 2 wo) — OSD_RES_DOWN2X — on every algorithm, on odd and even identity maps, with a ragged pixel tail; the
+    grouped launch gives the same bits as the single ones."""
+    from oneshotdet_amd import _lib
+    o = ops()
+    T = DT[dt]
+    for (n, cin, cout, hh, ww) in ((2, 64, 256, 21, 27), (1, 64, 256, 40, 64), (3, 128, 128, 9, 10)):
+        ho, wo = (hh + 1) // 2, (ww + 1) // 2
+        x, wt, b, idn = rnd(n, cin, ho, wo, seed=1), rnd(cout, cin, 1, 1, seed=2) / 8, rnd(cout, seed=3), rnd(n, cout, hh, ww, seed=4)
+        if dt == "bf16":
+            x, wt, idn = x.bfloat16().float(), wt.bfloat16().float(), idn.bfloat16().float()
+        ref = F.relu(F.conv2d(x, wt, b) + idn[:, :, ::2, ::2])
+        pc = o.pack_conv(wt.cuda(), bias=b.cuda(), dtype=T)
+        xx, rr = to_nhwc(x, T), to_nhwc(idn, T)
+        ran = 0
+        for algo in [None] + o.conv_algo_candidates(cout, False):
+            try:
+                y = o.conv2d(xx, pc, act=o.ACT_RELU, res=rr, res_mode=o.RES_DOWN2X, algo=algo)
+            except _lib.OsdError:
+                continue
+            ran += 1
+            torch.testing.assert_close(from_nhwc(y), ref, **TOL[dt])
+        assert ran >= 4
+    with pytest.raises(Exception):       # an identity map that does not cover the output
+        o.conv2d(xx, pc, act=o.ACT_RELU, res=to_nhwc(rnd(3, 128, 4, 4, seed=5), T), res_mode=o.RES_DOWN2X)
+    # grouped: identity maps of exactly twice the size
+    sizes = [(2, 10, 12), (1, 3, 8)]
+    pcs = [o.pack_conv((rnd(128, 64, 1, 1, seed=10 + i) / 8).cuda(), bias=rnd(128, seed=20 + i).cuda(), dtype=T) for i in range(2)]
+    xs = [to_nhwc(rnd(n, 64, h, w, seed=30 + i), T) for i, (n, h, w) in enumerate(sizes)]
+    res = [to_nhwc(rnd(n, 128, 2 * h, 2 * w, seed=40 + i), T) for i, (n, h, w) in enumerate(sizes)]
+    ys = o.conv2d_multi(xs, pcs, act=o.ACT_RELU, residuals=res, res_mode=o.RES_DOWN2X, _whole=True)
+    for x1, pc1, r1, y1 in zip(xs, pcs, res, ys):
+        assert torch.equal(y1, o.conv2d(x1, pc1, act=o.ACT_RELU, res=r1, res_mode=o.RES_DOWN2X))
+        assert torch.equal(y1, o.conv2d(x1, pc1, act=o.ACT_RELU, res=r1[:, ::2, ::2].contiguous(), res_mode=o.RES_SAME))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv2d_relu_in_and_exp_scale(dt):
     n, cin, h, w = 1, 256, 9, 7
     x, wt, b = rnd(n, cin, h, w, seed=1), rnd(4, cin, 3, 3, seed=2) / 48, rnd(4, seed=3) * 0.1
