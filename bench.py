@@ -769,7 +769,7 @@ def main_train(args, rank, world, backend="nccl"):
         roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
                     "peak_measured": measured_peaks(args.dtype), "traffic_source": traffic_src,
-                    "kernel": "conv_sp_kernel / conv_dma_kernel / conv_igemm_kernel (forward + data gradient) and conv_wgrad_sk_kernel / conv_wgrad_kernel",
+                    "kernel": "conv_sp_kernel / conv_dma_kernel / conv_pred_kernel / conv_igemm_kernel (forward + data gradient) and conv_wgrad_sk_kernel / conv_wgrad_kernel",
                     "avg_launch_us": round(conv_ms * 1e3 / max(timer.launches, 1), 2),
                     "launches_per_step": timer.launches // nst,
                     "gflop_per_step": round(timer.flops / nst / 1e9, 1),

@@ -28,7 +28,7 @@ def main():
             # (round 5: conv_sp_kernel — the dominant launch — conv_pw / conv_px and conv_wgrad_sk_kernel were missing from these lists
             # since round 3: the rounds' "conv family" traffic figures counted the LDS-DMA tile kernels only, which is also why the
             # launch count never matched the run's)
-            k = "conv_fwd_dgrad" if any(t in n for t in ("conv_dma", "conv_igemm", "conv_sp_kernel", "conv_pw_kernel", "conv_px_kernel")) else (
+            k = "conv_fwd_dgrad" if any(t in n for t in ("conv_dma", "conv_igemm", "conv_sp_kernel", "conv_pred_kernel", "conv_pw_kernel", "conv_px_kernel")) else (
                 "conv_wgrad" if ("conv_wgrad_kernel" in n or "conv_wgrad_sk_kernel" in n or "conv_wgrad_xr_kernel" in n) else (
                     "correlate" if ("correlate_kernel" in n or "correlate_levels_kernel" in n) else None))
             if k is None:

@@ -47,7 +47,7 @@ def summarize_train(d, out, line, stats, trace):
     r = line["roofline"]
     ph, nst = phases_of(trace, line)
     dur = lambda x: (int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3      # noqa: E731
-    is_conv = lambda n: any(t in n for t in ("conv_igemm", "conv_dma", "conv_sp_kernel", "conv_pw_kernel", "conv_px_kernel", "conv_wgrad_kernel",   # noqa: E731
+    is_conv = lambda n: any(t in n for t in ("conv_igemm", "conv_dma", "conv_sp_kernel", "conv_pred_kernel", "conv_pw_kernel", "conv_px_kernel", "conv_wgrad_kernel",   # noqa: E731
                                              "conv_wgrad_sk_kernel", "conv_wgrad_xr_kernel"))
     is_corr = lambda n: "correlate_levels_kernel" in n or ("correlate_kernel" in n)      # noqa: E731
     per = {}
@@ -100,7 +100,7 @@ def main():
     stats = list(csv.DictReader(open(os.path.join(d, "run_kernel_stats.csv"))))
     trace = [r for r in csv.DictReader(open(os.path.join(d, "run_kernel_trace.csv")))]
     is_train = "configs[2]" in line["config"]["workload"]
-    convs = [r for r in trace if any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_dma", "conv_sp_kernel", "conv_pw_kernel", "conv_px_kernel")) or
+    convs = [r for r in trace if any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_dma", "conv_sp_kernel", "conv_pred_kernel", "conv_pw_kernel", "conv_px_kernel")) or
              (is_train and any(t in r["Kernel_Name"] for t in ("conv_wgrad_kernel", "conv_wgrad_sk_kernel", "conv_wgrad_xr_kernel")))]
     launches = workload.conv_launches(8, 800, 1024, 8, 127, 127)
     per = (line.get("roofline") or {}).get("launches_per_step") or len(launches)   # the tuner may split grouped launches
