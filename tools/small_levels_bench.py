@@ -51,6 +51,6 @@ for label, masks in (("forward", None), ("data gradient (mask)", ms)):
             cold += a.elapsed_time(b) * 1e3 / 8
         res.append((cold, warm, name(algo), algo))
     res.sort()
-    print("%s, M = %d grouped over 3 levels (OSD_CONV_PREFETCH=%s):" % (label, M, os.environ.get("OSD_CONV_PREFETCH", "")))
+    print("%s, M = %d grouped over 3 levels:" % (label, M))
     for c, t, nm, algo in res[:12]:
         print("   %-16s (algo %2d) cold %6.1f us  warm %6.1f us  %5.0f TFLOP/s" % (nm, algo, c, t, fl / t / 1e6))
