@@ -47,6 +47,8 @@ SIGNATURES = {
     "osd_groupnorm_relu_apply": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "osd_roialign_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _p]),
     "osd_shot_mean": (_i, [_p, _p, _i, _i, _i, _p]),
+    "osd_query_pool_levels": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
+    "osd_query_pool_levels_bwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p]),
     "osd_correlate_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "osd_correlate_levels": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "osd_correlate_bwd_query_levels": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p]),

@@ -536,6 +536,71 @@ __global__ void __launch_bounds__(64) roialign_bwd_kernel(const float* __restric
   }
 }
 
+// ---- backward of the all-levels query pooling (elementwise.hip: query_pool_levels_kernel; round 6): per ROI the gradient of its target
+// image's pooled vector / shots (shot_mean_bwd_kernel's value) scattered by roialign_bwd_kernel's rule into a zeroed fp32 map, all FPN
+// levels in one launch; then one cast launch writes the maps in the engine's dtype.  Same expressions as the 4 x levels launches it
+// replaces (and every ROI adds into its own image, sample after sample: the same bits).
+constexpr int kQPoolLevels = 8;
+struct QPoolBwdLevels {
+  const float* dq[kQPoolLevels];      // [batch][c]
+  float* gx[kQPoolLevels];            // [batch * shots][h][w][c] fp32, zeroed
+  void* out[kQPoolLevels];            // the same maps in the engine's dtype
+  long long begin[kQPoolLevels + 1];  // first element of each level in the concatenation of the maps (cast kernel)
+  int h[kQPoolLevels], w[kQPoolLevels];
+  float scale[kQPoolLevels];
+  int n_levels;
+};
+
+__global__ void __launch_bounds__(64) query_pool_levels_bwd_kernel(QPoolBwdLevels L, const float* __restrict__ rois, int c, int shots, int sampling) {
+  const int lvl = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+  const int h = L.h[lvl], w = L.w[lvl];
+  const float scale = L.scale[lvl];
+  const float* roi = rois + (size_t)r * 5;
+  const int b = (int)roi[0];
+  const float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
+  const float roi_w = fmaxf(rew - rsw, 1.f), roi_h = fmaxf(reh - rsh, 1.f);
+  const float bin_h = roi_h / 1.f, bin_w = roi_w / 1.f;
+  const int gh = sampling > 0 ? sampling : (int)ceilf(roi_h / 1);
+  const int gw = sampling > 0 ? sampling : (int)ceilf(roi_w / 1);
+  const float inv = (float)(gh * gw);
+  float* img = L.gx[lvl] + (size_t)b * h * w * c;
+  const float* grow = L.dq[lvl] + (size_t)(r / shots) * c;
+  for (int iy = 0; iy < gh; ++iy) {
+    const float yy = rsh + 0 * bin_h + (iy + .5f) * bin_h / (float)gh;
+    for (int ix = 0; ix < gw; ++ix) {
+      const float xx = rsw + 0 * bin_w + (ix + .5f) * bin_w / (float)gw;
+      float yv = yy, xv = xx;
+      if (yv < -1.0f || yv > (float)h || xv < -1.0f || xv > (float)w) continue;      // wave-uniform
+      if (yv <= 0.f) yv = 0.f;
+      if (xv <= 0.f) xv = 0.f;
+      int yl = (int)yv, xl = (int)xv, yh, xh;
+      if (yl >= h - 1) { yh = yl = h - 1; yv = (float)yl; } else { yh = yl + 1; }
+      if (xl >= w - 1) { xh = xl = w - 1; xv = (float)xl; } else { xh = xl + 1; }
+      const float ly = yv - yl, lx = xv - xl, hy = 1.f - ly, hx = 1.f - lx;
+      float* t1 = img + ((size_t)yl * w + xl) * c, *t2 = img + ((size_t)yl * w + xh) * c;
+      float* t3 = img + ((size_t)yh * w + xl) * c, *t4 = img + ((size_t)yh * w + xh) * c;
+      for (int ch = lane; ch < c; ch += 64) {
+        const float g = (grow[ch] / (float)shots) / inv;
+        atomicAdd(t1 + ch, g * hy * hx);
+        atomicAdd(t2 + ch, g * hy * lx);
+        atomicAdd(t3 + ch, g * ly * hx);
+        atomicAdd(t4 + ch, g * ly * lx);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) query_pool_levels_cast_kernel(QPoolBwdLevels L) {
+  const long long total = L.begin[L.n_levels];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int l = 0;
+    while (l + 1 < L.n_levels && i >= L.begin[l + 1]) ++l;
+    const long long j = i - L.begin[l];
+    reinterpret_cast<T*>(L.out[l])[j] = from_f32<T>(L.gx[l][j]);
+  }
+}
+
 __global__ void shot_mean_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int b, int shots, int c) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b * shots * c) return;
@@ -811,6 +876,36 @@ extern "C" int osd_roialign_bwd(const float* gy, const float* rois, float* gx, i
   hipLaunchKernelGGL(roialign_bwd_kernel, dim3((unsigned)cells), dim3(64), 0, OSD_STREAM(stream),
                      gy, rois, gx, h, w, c, num_rois, spatial_scale, ph, pw, sampling_ratio);
   return osd_check_launch("roialign_bwd");
+}
+
+extern "C" int osd_query_pool_levels_bwd(int n_levels, const float* const* dqs, const int32_t* hs, const int32_t* ws, const float* scales,
+                                         const float* rois, int batch, int shots, int c, int sampling_ratio, float* gx32,
+                                         void* const* outs, int dtype, void* stream) {
+  if (n_levels < 1 || n_levels > kQPoolLevels || !dqs || !hs || !ws || !scales || !rois || !gx32 || !outs || shots < 1 || c < 1)
+    return osd_fail(OSD_ERR_INVALID_ARG, "query_pool_levels_bwd: bad arguments");
+  if (batch == 0) return OSD_OK;
+  QPoolBwdLevels L;
+  L.n_levels = n_levels;
+  long long off = 0;
+  for (int l = 0; l < kQPoolLevels; ++l) {
+    const int j = l < n_levels ? l : 0;
+    if (!dqs[j] || !outs[j] || hs[j] < 1 || ws[j] < 1) return osd_fail(OSD_ERR_INVALID_ARG, "query_pool_levels_bwd: bad level %d", j);
+    L.dq[l] = dqs[j]; L.out[l] = outs[j]; L.h[l] = hs[j]; L.w[l] = ws[j]; L.scale[l] = scales[j];
+    L.begin[l] = off;
+    L.gx[l] = gx32 + (l < n_levels ? off : 0);
+    if (l < n_levels) off += (long long)batch * shots * hs[j] * ws[j] * c;
+  }
+  for (int l = n_levels; l <= kQPoolLevels; ++l) L.begin[l] = off;
+  hipError_t er = hipMemsetAsync(gx32, 0, sizeof(float) * (size_t)off, OSD_STREAM(stream));
+  if (er != hipSuccess) return osd_fail(OSD_ERR_LAUNCH, "query_pool_levels_bwd: memset failed");
+  hipLaunchKernelGGL(query_pool_levels_bwd_kernel, dim3(batch * shots, n_levels), dim3(64), 0, OSD_STREAM(stream), L, rois, c, shots, sampling_ratio);
+  int rc = osd_check_launch("query_pool_levels_bwd");
+  if (rc) return rc;
+  const int g = grid_for(off, 256);
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(query_pool_levels_cast_kernel<float>, dim3(g), dim3(256), 0, OSD_STREAM(stream), L),
+      hipLaunchKernelGGL(query_pool_levels_cast_kernel<__bf16>, dim3(g), dim3(256), 0, OSD_STREAM(stream), L));
+  return osd_check_launch("query_pool_levels_cast");
 }
 
 extern "C" int osd_shot_mean_bwd(const float* gy, float* gx, int b, int shots, int c, void* stream) {

@@ -250,6 +250,52 @@ __global__ void groupnorm_relu_apply_kernel(const T* __restrict__ x, const float
 // channel run of each tap: lane l owns channels 4 l .. 4 l + 3 of every 256-channel slab (8 / 16 bytes per lane and tap: one
 // contiguous 512 / 1,024-byte run per wave-instruction).  The per-channel arithmetic is the reference's expression in its order
 // (out += w1 v1 + w2 v2 + w3 v3 + w4 v4 per sample, / count at the end).
+// the samples of ONE output cell for the lane's four channels of one 256-channel slab (shared by the per-level kernel and the
+// all-levels query pooling below: the same expressions in the same order, so the two give the same bits)
+template <typename T>
+__device__ __forceinline__ void roialign_cell_slab(const T* __restrict__ img, int h, int w, int c, int ch, bool vec, float rsw, float rsh,
+                                                   float bin_w, float bin_h, int gh, int gw, int px, int py, float (&acc)[4]) {
+  for (int iy = 0; iy < gh; ++iy) {
+    const float yy = rsh + py * bin_h + (iy + .5f) * bin_h / (float)gh;
+    for (int ix = 0; ix < gw; ++ix) {
+      const float xx = rsw + px * bin_w + (ix + .5f) * bin_w / (float)gw;
+      float yv = yy, xv = xx;
+      if (yv < -1.0f || yv > (float)h || xv < -1.0f || xv > (float)w) continue;      // wave-uniform
+      if (yv <= 0.f) yv = 0.f;
+      if (xv <= 0.f) xv = 0.f;
+      int yl = (int)yv, xl = (int)xv, yh, xh;
+      if (yl >= h - 1) { yh = yl = h - 1; yv = (float)yl; } else { yh = yl + 1; }
+      if (xl >= w - 1) { xh = xl = w - 1; xv = (float)xl; } else { xh = xl + 1; }
+      const float ly = yv - yl, lx = xv - xl, hy = 1.f - ly, hx = 1.f - lx;
+      const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+      const T* t1 = img + ((size_t)yl * w + xl) * c, *t2 = img + ((size_t)yl * w + xh) * c;
+      const T* t3 = img + ((size_t)yh * w + xl) * c, *t4 = img + ((size_t)yh * w + xh) * c;
+      if (vec) {
+        if (ch < c) {
+          float v1[4], v2[4], v3[4], v4[4];
+          if constexpr (sizeof(T) == 2) {
+            const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(t1 + ch), a2 = *reinterpret_cast<const bf16x4*>(t2 + ch);
+            const bf16x4 a3 = *reinterpret_cast<const bf16x4*>(t3 + ch), a4 = *reinterpret_cast<const bf16x4*>(t4 + ch);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v1[e] = (float)a1[e]; v2[e] = (float)a2[e]; v3[e] = (float)a3[e]; v4[e] = (float)a4[e]; }
+          } else {
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(t1 + ch), a2 = *reinterpret_cast<const f32x4*>(t2 + ch);
+            const f32x4 a3 = *reinterpret_cast<const f32x4*>(t3 + ch), a4 = *reinterpret_cast<const f32x4*>(t4 + ch);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v1[e] = a1[e]; v2[e] = a2[e]; v3[e] = a3[e]; v4[e] = a4[e]; }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+        }
+      } else {                                          // channel counts that are not multiples of 4: one value at a time
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (ch + e < c) acc[e] += w1 * to_f32(t1[ch + e]) + w2 * to_f32(t2[ch + e]) + w3 * to_f32(t3[ch + e]) + w4 * to_f32(t4[ch + e]);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(64) roialign_fwd_kernel(const T* __restrict__ x, const float* __restrict__ rois, float* __restrict__ y, int h,
                                                           int w, int c, int num_rois, float scale, int ph, int pw, int sampling) {
@@ -270,51 +316,60 @@ __global__ void __launch_bounds__(64) roialign_fwd_kernel(const T* __restrict__ 
   for (int c0 = 0; c0 < c; c0 += 256) {                   // 256-channel slabs (the FPN maps have exactly one)
     const int ch = c0 + lane * 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int iy = 0; iy < gh; ++iy) {
-      const float yy = rsh + py * bin_h + (iy + .5f) * bin_h / (float)gh;
-      for (int ix = 0; ix < gw; ++ix) {
-        const float xx = rsw + px * bin_w + (ix + .5f) * bin_w / (float)gw;
-        float yv = yy, xv = xx;
-        if (yv < -1.0f || yv > (float)h || xv < -1.0f || xv > (float)w) continue;      // wave-uniform
-        if (yv <= 0.f) yv = 0.f;
-        if (xv <= 0.f) xv = 0.f;
-        int yl = (int)yv, xl = (int)xv, yh, xh;
-        if (yl >= h - 1) { yh = yl = h - 1; yv = (float)yl; } else { yh = yl + 1; }
-        if (xl >= w - 1) { xh = xl = w - 1; xv = (float)xl; } else { xh = xl + 1; }
-        const float ly = yv - yl, lx = xv - xl, hy = 1.f - ly, hx = 1.f - lx;
-        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-        const T* t1 = img + ((size_t)yl * w + xl) * c, *t2 = img + ((size_t)yl * w + xh) * c;
-        const T* t3 = img + ((size_t)yh * w + xl) * c, *t4 = img + ((size_t)yh * w + xh) * c;
-        if (vec) {
-          if (ch < c) {
-            float v1[4], v2[4], v3[4], v4[4];
-            if constexpr (sizeof(T) == 2) {
-              const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(t1 + ch), a2 = *reinterpret_cast<const bf16x4*>(t2 + ch);
-              const bf16x4 a3 = *reinterpret_cast<const bf16x4*>(t3 + ch), a4 = *reinterpret_cast<const bf16x4*>(t4 + ch);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v1[e] = (float)a1[e]; v2[e] = (float)a2[e]; v3[e] = (float)a3[e]; v4[e] = (float)a4[e]; }
-            } else {
-              const f32x4 a1 = *reinterpret_cast<const f32x4*>(t1 + ch), a2 = *reinterpret_cast<const f32x4*>(t2 + ch);
-              const f32x4 a3 = *reinterpret_cast<const f32x4*>(t3 + ch), a4 = *reinterpret_cast<const f32x4*>(t4 + ch);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v1[e] = a1[e]; v2[e] = a2[e]; v3[e] = a3[e]; v4[e] = a4[e]; }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
-          }
-        } else {                                          // channel counts that are not multiples of 4: one value at a time
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (ch + e < c) acc[e] += w1 * to_f32(t1[ch + e]) + w2 * to_f32(t2[ch + e]) + w3 * to_f32(t3[ch + e]) + w4 * to_f32(t4[ch + e]);
-        }
-      }
-    }
+    roialign_cell_slab<T>(img, h, w, c, ch, vec, rsw, rsh, bin_w, bin_h, gh, gw, px, py, acc);
     if (vec) {
       if (ch < c) *reinterpret_cast<f32x4*>(out_row + ch) = f32x4{acc[0] / count, acc[1] / count, acc[2] / count, acc[3] / count};
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (ch + e < c) out_row[ch + e] = acc[e] / count;
+    }
+  }
+}
+
+// ---- query pooling of ALL FPN levels in one launch (round 6): SuppAlignLayer's 1 x 1 ROIAlign of every query's whole-image box
+// (generalized_rcnn.py:20-52) + batch_pooling's mean over the shots of a target image (:100-104).  One wavefront per (target image,
+// level); per shot the cell value is roialign_fwd_kernel's (acc / count), the mean shot_mean_kernel's (sum in shot order, / shots):
+// the same bits as the 2 x levels launches it replaces (tests/test_gpu_kernels.py).
+constexpr int kQPoolLevels = 8;
+struct QPoolLevels {
+  const void* x[kQPoolLevels];
+  float* y[kQPoolLevels];
+  int h[kQPoolLevels], w[kQPoolLevels];
+  float scale[kQPoolLevels];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(64) query_pool_levels_kernel(QPoolLevels L, const float* __restrict__ rois, int c, int shots, int sampling) {
+  const int lvl = blockIdx.y, bimg = blockIdx.x, lane = threadIdx.x;
+  const int h = L.h[lvl], w = L.w[lvl];
+  const float scale = L.scale[lvl];
+  const T* x = reinterpret_cast<const T*>(L.x[lvl]);
+  float* out_row = L.y[lvl] + (size_t)bimg * c;
+  const bool vec = (c & 3) == 0;
+  for (int c0 = 0; c0 < c; c0 += 256) {
+    const int ch = c0 + lane * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < shots; ++k) {
+      const float* roi = rois + (size_t)(bimg * shots + k) * 5;
+      const int b = (int)roi[0];
+      const float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
+      const float roi_w = fmaxf(rew - rsw, 1.f), roi_h = fmaxf(reh - rsh, 1.f);
+      const float bin_h = roi_h / 1.f, bin_w = roi_w / 1.f;
+      const int gh = sampling > 0 ? sampling : (int)ceilf(roi_h / 1);
+      const int gw = sampling > 0 ? sampling : (int)ceilf(roi_w / 1);
+      const float count = (float)(gh * gw);
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      roialign_cell_slab<T>(x + (size_t)b * h * w * c, h, w, c, ch, vec, rsw, rsh, bin_w, bin_h, gh, gw, 0, 0, acc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += acc[e] / count;
+    }
+    if (vec) {
+      if (ch < c) *reinterpret_cast<f32x4*>(out_row + ch) = f32x4{s[0] / (float)shots, s[1] / (float)shots, s[2] / (float)shots, s[3] / (float)shots};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (ch + e < c) out_row[ch + e] = s[e] / (float)shots;
     }
   }
 }
@@ -592,6 +647,24 @@ extern "C" int osd_shot_mean(const float* x, float* y, int b, int shots, int c, 
   if (!x || !y || shots < 1) return osd_fail(OSD_ERR_INVALID_ARG, "shot_mean: bad args");
   hipLaunchKernelGGL(shot_mean_kernel, dim3(cdiv(b * c, 256)), dim3(256), 0, OSD_STREAM(stream), x, y, b, shots, c);
   return osd_check_launch("shot_mean");
+}
+
+extern "C" int osd_query_pool_levels(int n_levels, const void* const* xs, const int32_t* hs, const int32_t* ws, const float* scales,
+                                     const float* rois, int batch, int shots, int c, int sampling_ratio, float* const* ys, int dtype,
+                                     void* stream) {
+  if (n_levels < 1 || n_levels > kQPoolLevels || !xs || !hs || !ws || !scales || !rois || !ys || shots < 1 || c < 1)
+    return osd_fail(OSD_ERR_INVALID_ARG, "query_pool_levels: bad arguments");
+  if (batch == 0) return OSD_OK;
+  QPoolLevels L;
+  for (int l = 0; l < kQPoolLevels; ++l) {
+    const int j = l < n_levels ? l : 0;
+    if (!xs[j] || !ys[j] || hs[j] < 1 || ws[j] < 1) return osd_fail(OSD_ERR_INVALID_ARG, "query_pool_levels: bad level %d", j);
+    L.x[l] = xs[j]; L.y[l] = ys[j]; L.h[l] = hs[j]; L.w[l] = ws[j]; L.scale[l] = scales[j];
+  }
+  OSD_DISPATCH_DTYPE(dtype,
+      hipLaunchKernelGGL(query_pool_levels_kernel<float>, dim3(batch, n_levels), dim3(64), 0, OSD_STREAM(stream), L, rois, c, shots, sampling_ratio),
+      hipLaunchKernelGGL(query_pool_levels_kernel<__bf16>, dim3(batch, n_levels), dim3(64), 0, OSD_STREAM(stream), L, rois, c, shots, sampling_ratio));
+  return osd_check_launch("query_pool_levels");
 }
 
 extern "C" int osd_correlate_fwd(const void* x, const float* q, void* y, int n, int hw, int c, int dtype, void* stream) {

@@ -227,6 +227,8 @@ def image_sizes_dev(image_sizes, device):
 def run_query_pool(qfeats, q_sizes, batch):
     """SuppAlignLayer (generalized_rcnn.py:20-52) + batch_pooling (:100-104) -> 5 x [B, C] fp32."""
     rois = whole_image_rois(q_sizes, qfeats[0].device)
+    if ops.QUERY_POOL_LEVELS and len(qfeats) <= 8:
+        return ops.query_pool_levels(qfeats, rois, spec.POOLER_SCALES, batch, spec.POOLER_SAMPLING_RATIO)
     pooled = []
     for feat, scale in zip(qfeats, spec.POOLER_SCALES):
         v = ops.roi_align(feat, rois, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)

@@ -482,6 +482,49 @@ def shot_mean(x, batch):
     return y
 
 
+QUERY_POOL_LEVELS = os.environ.get("OSD_NO_QUERY_POOL_LEVELS", "0") == "0"     # A/B switch: the per-level launches (until round 6)
+
+
+def query_pool_levels(feats, rois, scales, batch, sampling_ratio):
+    """SuppAlignLayer's 1 x 1 ROIAlign of every query's whole-image box + the mean over the shots of a target image
+    (generalized_rcnn.py:20-52, 100-104) for ALL FPN levels in one launch: feats[l] NHWC [batch * shots, h, w, C] -> [B, C] fp32 per
+    level (views of one buffer).  The same bits as roi_align(..., 1, 1, ...) + shot_mean per level."""
+    _chk_dev(rois, *feats)
+    k = len(feats)
+    r, c = feats[0].shape[0], feats[0].shape[-1]
+    assert r % batch == 0 and rois.shape[0] == r and all(f.shape[0] == r and f.shape[-1] == c for f in feats)
+    flat = torch.empty((k, batch, c), device=feats[0].device, dtype=torch.float32)
+    ys = [flat[l] for l in range(k)]
+    _lib.call("osd_query_pool_levels", k, _ptr_array(feats), (C.c_int32 * k)(*[f.shape[1] for f in feats]),
+              (C.c_int32 * k)(*[f.shape[2] for f in feats]), (C.c_float * k)(*[float(v) for v in scales]), _p(rois), batch, r // batch, c,
+              int(sampling_ratio), _ptr_array(ys), _dt(feats[0]), _stream())
+    _rec("query_pool", xs=list(feats), rois=rois, scales=[float(v) for v in scales], batch=batch, sampling_ratio=sampling_ratio, outs=ys)
+    return ys
+
+
+def query_pool_levels_bwd(dqs, rois, shapes, scales, shots, sampling_ratio, dtype):
+    """Backward of query_pool_levels: dqs[l] [B, C] fp32 -> the gradient of the query feature maps, [B * shots, h, w, C] `dtype` per
+    level (views of one buffer): shot_mean_bwd + roi_align_bwd + cast_f32 per level, as three launches for all levels."""
+    _chk_dev(rois, *dqs)
+    k = len(dqs)
+    b, c = dqs[0].shape
+    r = b * shots
+    dqs = [d.contiguous() for d in dqs]
+    sizes = [r * h * w * c for (_, h, w, _) in shapes]
+    assert all(tuple(sh) == (r, sh[1], sh[2], c) for sh in shapes) and rois.shape[0] == r
+    gx32 = torch.empty((sum(sizes),), device=dqs[0].device, dtype=torch.float32)
+    flat = torch.empty((sum(sizes),), device=dqs[0].device, dtype=dtype)
+    outs, off = [], 0
+    for sh, n in zip(shapes, sizes):
+        outs.append(flat[off:off + n].view(tuple(sh)))
+        off += n
+    _lib.call("osd_query_pool_levels_bwd", k, _ptr_array(dqs), (C.c_int32 * k)(*[sh[1] for sh in shapes]),
+              (C.c_int32 * k)(*[sh[2] for sh in shapes]), (C.c_float * k)(*[float(v) for v in scales]), _p(rois), b, shots, c,
+              int(sampling_ratio), _p(gx32), _ptr_array(outs), _dt(flat), _stream())
+    _rec("query_pool_bwd", dqs=dqs, rois=rois, scales=[float(v) for v in scales], shots=shots, sampling_ratio=sampling_ratio, outs=outs)
+    return outs
+
+
 def correlate(x, q, out=None):
     """x NHWC [N,H,W,C] * q [N,C] fp32 (broadcast over H, W)."""
     _chk_dev(x, q)

@@ -419,6 +419,8 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
         af = join_previous if deferred is not None else None
 
         def pool(qf):
+            if ops.QUERY_POOL_LEVELS and len(qf) <= 8:      # all levels in one launch (round 6: 10 launches -> 1)
+                return ops.query_pool_levels(qf, rois, spec.POOLER_SCALES, batch, spec.POOLER_SAMPLING_RATIO)
             out = []
             for feat, scale in zip(qf, spec.POOLER_SCALES):
                 v = ops.roi_align(feat, rois, scale, 1, 1, spec.POOLER_SAMPLING_RATIO)
@@ -479,11 +481,15 @@ class TrainEngine(ForwardPass, BackwardPass, SecondStage, Update, State):
             self.box_losses, gx, gqs = box_out
         with streams.on(side):      # the query branch's small pooling-backward chain beside d feat
             dQ = []
-            for dql, qf, scale in zip(dq, qfeats, spec.POOLER_SCALES):
-                dv = ops.shot_mean_bwd(dql, shots)
-                gxq = ops.roi_align_bwd(dv.view(-1, 1, 1, dv.shape[-1]), rois, qf.shape, scale, 1, 1,
-                                        spec.POOLER_SAMPLING_RATIO)
-                dQ.append(ops.cast_f32(gxq, self.dtype))
+            if ops.QUERY_POOL_LEVELS and len(dq) <= 8:      # all levels in three launches (round 6: 20 launches + 5 memsets before)
+                dQ = ops.query_pool_levels_bwd(dq, rois, [tuple(qf.shape) for qf in qfeats], spec.POOLER_SCALES, shots,
+                                               spec.POOLER_SAMPLING_RATIO, self.dtype)
+            else:
+                for dql, qf, scale in zip(dq, qfeats, spec.POOLER_SCALES):
+                    dv = ops.shot_mean_bwd(dql, shots)
+                    gxq = ops.roi_align_bwd(dv.view(-1, 1, 1, dv.shape[-1]), rois, qf.shape, scale, 1, 1,
+                                            spec.POOLER_SAMPLING_RATIO)
+                    dQ.append(ops.cast_f32(gxq, self.dtype))
             if second:                  # the second stage's gradient w.r.t. the query features joins the first stage's
                 for lvl, gq in gqs:
                     if shots > 1:       # only the first query of every image reached the second stage's loss

@@ -131,6 +131,19 @@ def shot_mean_bwd_launch(gy, shots):
     return (gy.float() / shots)[:, None, :].expand(b, shots, c).reshape(b * shots, c).contiguous()
 
 
+def query_pool_launch(xs, rois, scales, batch, sampling_ratio):
+    """the 1 x 1 ROIAlign of every query's whole-image box + the mean over the shots, per level (generalized_rcnn.py:20-52, 100-104)"""
+    return [shot_mean_launch(roi_align_launch(x, rois, sc, 1, 1, sampling_ratio).reshape(x.shape[0], -1), batch) for x, sc in zip(xs, scales)]
+
+
+def query_pool_bwd_launch(dqs, rois, shapes, scales, shots, sampling_ratio):
+    out = []
+    for dq, sh, sc in zip(dqs, shapes, scales):
+        dv = shot_mean_bwd_launch(dq, shots)
+        out.append(roi_align_bwd_launch(dv.view(-1, 1, 1, dv.shape[-1]), rois, tuple(sh), sc, 1, 1, sampling_ratio))
+    return out
+
+
 def correlate_launch(x, q):
     """generalized_rcnn.py:307-311: features * pooled.expand(...)."""
     return x.float() * q.float()[:, None, None, :]

@@ -258,6 +258,36 @@ def test_shot_mean():
     torch.testing.assert_close(y.cpu(), x.view(2, 5, 256).mean(1), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("shots", [1, 5])
+def test_query_pool_levels_equals_the_per_level_launches(dt, shots):
+    """osd_query_pool_levels / _bwd (all FPN levels of the query branch in one / three launches) against osd_roialign_fwd (1 x 1) +
+    osd_shot_mean and osd_shot_mean_bwd + osd_roialign_bwd + osd_cast_f32 per level: the same bits, for one and five shots, query
+    boxes of different sizes (generalized_rcnn.py:20-52, 100-104, 257), and against the oracle's ROIAlign."""
+    o = ops()
+    T = DT[dt]
+    batch, c = 3, 256
+    r = batch * shots
+    sizes = [(16, 16), (8, 8), (4, 5), (2, 3), (1, 1)]
+    scales = [1 / 8, 1 / 16, 1 / 32, 1 / 64, 1 / 128]
+    feats = [to_nhwc(rnd(r, c, h, w, seed=10 + i), T) for i, (h, w) in enumerate(sizes)]
+    g = torch.Generator().manual_seed(5)
+    hw = torch.rand(r, 2, generator=g) * 60 + 67            # whole-image boxes of queries between 67 and 127 pixels, as (0, 0, h, w)
+    rois = torch.cat([torch.arange(r).float()[:, None], torch.zeros(r, 2), hw], 1).cuda()
+    pooled = o.query_pool_levels(feats, rois, scales, batch, 2)
+    for f, sc, p in zip(feats, scales, pooled):
+        v = o.roi_align(f, rois, sc, 1, 1, 2)
+        assert torch.equal(p, o.shot_mean(v.view(r, -1), batch))
+    ref0 = orc.roi_align(from_nhwc(feats[0]).to(T).float(), rois.cpu(), scales[0], 1, 1, 2).view(batch, shots, c).mean(1)
+    torch.testing.assert_close(pooled[0].cpu(), ref0, rtol=1e-5, atol=1e-5)
+    dqs = [rnd(batch, c, seed=30 + i).cuda() for i in range(len(sizes))]
+    outs = o.query_pool_levels_bwd(dqs, rois, [tuple(f.shape) for f in feats], scales, shots, 2, T)
+    for dq, f, sc, out in zip(dqs, feats, scales, outs):
+        dv = o.shot_mean_bwd(dq, shots)
+        gx = o.roi_align_bwd(dv.view(-1, 1, 1, c), rois, f.shape, sc, 1, 1, 2)
+        assert out.dtype == T and torch.equal(out, o.cast_f32(gx, T))
+
+
 def test_empty_inputs_are_noops():
     o = ops()
     y = o.correlate(torch.zeros(0, 4, 4, 256, device="cuda"), torch.zeros(0, 256, device="cuda"))

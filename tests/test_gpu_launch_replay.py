@@ -84,6 +84,17 @@ class Replayer(object):
         self._check("roi_align_bwd", r["out"], lr.roi_align_bwd_launch(cpu(r["gy"]), cpu(r["rois"]), tuple(r["out"].shape), r["scale"],
                                                                       r["ph"], r["pw"], r["sampling_ratio"]))
 
+    def do_query_pool(self, r):
+        refs = lr.query_pool_launch([cpu(x) for x in r["xs"]], cpu(r["rois"]), r["scales"], r["batch"], r["sampling_ratio"])
+        for out, ref in zip(r["outs"], refs):
+            self._check("query_pool", out, ref)
+
+    def do_query_pool_bwd(self, r):
+        refs = lr.query_pool_bwd_launch([cpu(d) for d in r["dqs"]], cpu(r["rois"]), [tuple(o.shape) for o in r["outs"]], r["scales"],
+                                        r["shots"], r["sampling_ratio"])
+        for out, ref in zip(r["outs"], refs):
+            self._check("query_pool_bwd", out, ref)
+
     def do_shot_mean(self, r):
         self._check("shot_mean", r["out"], lr.shot_mean_launch(cpu(r["x"]), r["batch"]))
 
@@ -204,8 +215,8 @@ def test_every_launch_of_a_training_step_matches_its_cpu_restatement(name, dt):
              len(rp.acc)))
     assert not rp.failures, rp.failures[:6]
     # coverage: the step's launch kinds are all there ...
-    for kind in ("pack_image", "conv1x1", "conv3x3", "conv7x1", "maxpool", "roi_align", "shot_mean", "correlate", "gn_relu",
-                 "fcos_loss_grad", "gn_relu_bwd", "correlate_bwd_query", "roi_align_bwd", "shot_mean_bwd", "wgrad", "add_mask",
+    for kind in ("pack_image", "conv1x1", "conv3x3", "conv7x1", "maxpool", "query_pool", "correlate", "gn_relu",
+                 "fcos_loss_grad", "gn_relu_bwd", "correlate_bwd_query", "query_pool_bwd", "wgrad", "add_mask",
                  "scatter2x", "upsample2x_bwd", "pred_gather", "pred_dgrad_pack"):
         assert rp.counts.get(kind, 0) > 0, "no %s launch in the trace" % kind
     # ... and every trainable conv weight / bias / GroupNorm affine gradient was produced by replayed launches
