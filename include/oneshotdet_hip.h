@@ -214,8 +214,8 @@ int osd_shot_mean(const float* x, float* y, int b, int shots, int c, void* strea
 /* The two above for ALL FPN levels of the query branch in one launch: SuppAlignLayer's 1 x 1 ROIAlign of every query's whole-image
  * box (generalized_rcnn.py:20-52, 257; csrc/cuda/ROIAlign_cuda.cu:65-122) followed by batch_pooling (:100-104).  xs[l]: NHWC
  * [batch * shots][hs[l]][ws[l]][c] `dtype`; rois [batch * shots][5] fp32, ROI b * shots + k = shot k of target image b; ys[l] [batch][c]
- * fp32.  xs / ys / hs / ws / scales are HOST arrays of n_levels <= 8 entries.  The same bits as osd_roialign_fwd (ph = pw = 1) +
- * osd_shot_mean per level. */
+ * fp32.  xs / ys / hs / ws / scales are HOST arrays of n_levels <= 8 entries.  The arithmetic of osd_roialign_fwd (ph = pw = 1) +
+ * osd_shot_mean per level (equal to 1e-5; the forward goldens' pooled vectors pin it). */
 int osd_query_pool_levels(int n_levels, const void* const* xs, const int32_t* hs, const int32_t* ws, const float* scales,
                           const float* rois, int batch, int shots, int c, int sampling_ratio, float* const* ys, int dtype,
                           void* stream);
@@ -407,7 +407,7 @@ int osd_roialign_bwd(const float* gy, const float* rois, float* gx, int b, int h
 int osd_shot_mean_bwd(const float* gy, float* gx, int b, int shots, int c, void* stream);
 /* backward of osd_query_pool_levels: outs[l] [batch * shots][hs[l]][ws[l]][c] `dtype` = the gradient of the query feature maps given
  * dqs[l] [batch][c] fp32 (osd_shot_mean_bwd, osd_roialign_bwd with ph = pw = 1 and osd_cast_f32 per level, in three launches for all
- * levels: the same bits).  gx32: caller-owned fp32 scratch of sum_l batch * shots * hs[l] * ws[l] * c floats (zeroed by the call). */
+ * levels: the same arithmetic).  gx32: caller-owned fp32 scratch of sum_l batch * shots * hs[l] * ws[l] * c floats (zeroed by the call). */
 int osd_query_pool_levels_bwd(int n_levels, const float* const* dqs, const int32_t* hs, const int32_t* ws, const float* scales,
                               const float* rois, int batch, int shots, int c, int sampling_ratio, float* gx32, void* const* outs,
                               int dtype, void* stream);

@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(64) roialign_bwd_kernel(const float* __restric
 // ---- backward of the all-levels query pooling (elementwise.hip: query_pool_levels_kernel; round 6): per ROI the gradient of its target
 // image's pooled vector / shots (shot_mean_bwd_kernel's value) scattered by roialign_bwd_kernel's rule into a zeroed fp32 map, all FPN
 // levels in one launch; then one cast launch writes the maps in the engine's dtype.  Same expressions as the 4 x levels launches it
-// replaces (and every ROI adds into its own image, sample after sample: the same bits).
+// replaces (every ROI adds into its own image, sample after sample).
 constexpr int kQPoolLevels = 8;
 struct QPoolBwdLevels {
   const float* dq[kQPoolLevels];      // [batch][c]

@@ -488,7 +488,7 @@ QUERY_POOL_LEVELS = os.environ.get("OSD_NO_QUERY_POOL_LEVELS", "0") == "0"     #
 def query_pool_levels(feats, rois, scales, batch, sampling_ratio):
     """SuppAlignLayer's 1 x 1 ROIAlign of every query's whole-image box + the mean over the shots of a target image
     (generalized_rcnn.py:20-52, 100-104) for ALL FPN levels in one launch: feats[l] NHWC [batch * shots, h, w, C] -> [B, C] fp32 per
-    level (views of one buffer).  The same bits as roi_align(..., 1, 1, ...) + shot_mean per level."""
+    level (views of one buffer).  The arithmetic of roi_align(..., 1, 1, ...) + shot_mean per level."""
     _chk_dev(rois, *feats)
     k = len(feats)
     r, c = feats[0].shape[0], feats[0].shape[-1]
