@@ -75,6 +75,19 @@ constexpr int SP_AROWS = 336;
 constexpr int SP_ABYTES = SP_AROWS * SP_KB;
 constexpr int SP_BBYTES = SP_BN * SP_KB;
 constexpr int SP_LDS = 2 * SP_ABYTES + 2 * SP_BBYTES;
+// per tile (round 6): the pixel images and weight stages of a BM x BN tile, or its epilogue's staging (8 waves x 2 regions x rows x
+// (64 channels x 4 B + 16)) — whichever is larger.  The 128 x 128 tile needs 76 KB, so TWO of its workgroups share a CU (117 VGPRs): its
+// launches are the latency-sized ones (a tower layer over P5 - P7: 134 workgroups waiting for cold weights), and one's waits now sit
+// under the other's MFMAs where the step leaves them fewer CUs than workgroups
+constexpr int sp_arows(int bm) { return bm + 16 + 16 * (bm / 64); }
+constexpr int sp_lds_bytes(int tm, int wn) {
+  const int bm = (8 / wn) * tm * 16, bn = wn * SP_TN * 16;
+  const int ring = 2 * sp_arows(bm) * SP_KB + 2 * bn * SP_KB;
+  const int npass = tm >= 8 ? tm / 2 : (tm >= 2 ? 2 : 1);
+  const int epi = 8 * 2 * ((tm / npass) * 16) * (SP_TN * 16 * 4 + 16);
+  return ring > epi ? ring : epi;
+}
+static_assert(sp_arows(SP_BM) == SP_AROWS && sp_lds_bytes(8, 4) == SP_LDS, "the 256 x 256 tile's LDS plan");
 constexpr unsigned SP_OOB = 0x80000000u;            // beyond any buffer of < 2 GiB: the DMA writes zeros
 
 // GNB: the epilogue also gathers GroupNorm statistics (1: backward or forward per segment, 2: forward only; conv_epilogue.h); GENW: any
@@ -90,6 +103,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   constexpr int BN = WN * TN * 16;                      // channels per tile
   constexpr int NBW = BN / 64;                          // weight DMA instructions (8 rows each) per wave and stage
   constexpr int BBYTES = BN * KB;                       // one weight stage
+  constexpr int ABYTES = sp_arows(BM) * KB;             // one pixel image (SP_ABYTES for the 256-pixel tiles)
   static_assert(BM <= SP_BM && BN <= SP_BN && BM % 64 == 0, "tile geometry");
   constexpr int PA = BM / 64;                           // pixel DMA instructions (8 rows each) per wave and image
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,7 +134,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   // is rewritten by each image's DMA) ----
   if constexpr (!GENW) {
     uint4 z = {0u, 0u, 0u, 0u};
-    for (int i = tid; i < 2 * SP_ABYTES / 16; i += 512) *reinterpret_cast<uint4*>(smem + i * 16) = z;
+    for (int i = tid; i < 2 * ABYTES / 16; i += 512) *reinterpret_cast<uint4*>(smem + i * 16) = z;
   }
 
   // ---- per-lane DMA sources (byte offsets).  One wave-instruction = 8 rows x 128 B; wave w owns pixel instructions
@@ -183,8 +197,8 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   }
   const int line_bytes = q_W * Cin * 2;
 
-  const unsigned a_lds[2] = {lds0, lds0 + (unsigned)SP_ABYTES};
-  const unsigned b_lds[2] = {lds0 + 2u * SP_ABYTES, lds0 + 2u * SP_ABYTES + (unsigned)BBYTES};
+  const unsigned a_lds[2] = {lds0, lds0 + (unsigned)ABYTES};
+  const unsigned b_lds[2] = {lds0 + 2u * ABYTES, lds0 + 2u * ABYTES + (unsigned)BBYTES};
 
   // pixel instruction i of group (kr, kc) into pixel image `buf`
   auto issue_a = [&](int buf, int i, int kr, int kc) {
@@ -252,8 +266,8 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
     constexpr bool dma_early = true;
     constexpr int s_n = decltype(sn_tag)::value, kb_n = decltype(kbn_tag)::value;
     constexpr bool NEXT = decltype(has_next)::value, FB = decltype(fb_tag)::value, FA = decltype(fa_tag)::value;
-    const char* xs = smem + ab_n * SP_ABYTES;
-    const char* ws = smem + 2 * SP_ABYTES + bb_n * BBYTES;
+    const char* xs = smem + ab_n * ABYTES;
+    const char* ws = smem + 2 * ABYTES + bb_n * BBYTES;
 #ifndef OSD_SP_BAR_AT
 #define OSD_SP_BAR_AT 1
 #endif
@@ -341,7 +355,7 @@ __global__ void __launch_bounds__(512) conv_sp_kernel(ConvKParams p) {
   __builtin_amdgcn_s_barrier();                         // ... and everyone's
   {
     const char* xs = smem;
-    const char* ws = smem + 2 * SP_ABYTES;
+    const char* ws = smem + 2 * ABYTES;
 #pragma unroll
     for (int i = 0; i < TN; ++i) wf0[i] = *reinterpret_cast<const uint4*>(ws + w_off0 + i * 16 * KB);
 #pragma unroll
@@ -485,16 +499,16 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
   p.KT = p.Ktot / SP_BKE;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<1, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<2, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes(8, 4));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<1, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes(8, 4));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<2, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes(8, 4));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes(8, 4));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes(4, 4));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes(4, 4));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes(4, 2));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes(4, 2));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, false, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes(2, 2));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp_kernel<0, true, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_lds_bytes(2, 2));
     attr_done = true;
   }
   const long long nblocks = (long long)p.tilesM * p.tilesN;
@@ -513,21 +527,21 @@ int osd_conv_sp_launch(const ConvKParams& pin, hipStream_t stream, bool general_
     }
     bool backward = false;
     for (int i = 0; i < p.n_seg; ++i) backward = backward || p.seg[i].gn.u != nullptr;
-    if (backward) hipLaunchKernelGGL((conv_sp_kernel<1, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
-    else hipLaunchKernelGGL((conv_sp_kernel<2, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    if (backward) hipLaunchKernelGGL((conv_sp_kernel<1, false, 8>), dim3((unsigned)nblocks), dim3(512), sp_lds_bytes(8, 4), stream, p);
+    else hipLaunchKernelGGL((conv_sp_kernel<2, false, 8>), dim3((unsigned)nblocks), dim3(512), sp_lds_bytes(8, 4), stream, p);
   } else if (small_tile) {
-    if (genw) hipLaunchKernelGGL((conv_sp_kernel<0, true, 2, 2>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
-    else hipLaunchKernelGGL((conv_sp_kernel<0, false, 2, 2>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    if (genw) hipLaunchKernelGGL((conv_sp_kernel<0, true, 2, 2>), dim3((unsigned)nblocks), dim3(512), sp_lds_bytes(2, 2), stream, p);
+    else hipLaunchKernelGGL((conv_sp_kernel<0, false, 2, 2>), dim3((unsigned)nblocks), dim3(512), sp_lds_bytes(2, 2), stream, p);
   } else if (narrow) {
-    if (genw) hipLaunchKernelGGL((conv_sp_kernel<0, true, 4, 2>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
-    else hipLaunchKernelGGL((conv_sp_kernel<0, false, 4, 2>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    if (genw) hipLaunchKernelGGL((conv_sp_kernel<0, true, 4, 2>), dim3((unsigned)nblocks), dim3(512), sp_lds_bytes(4, 2), stream, p);
+    else hipLaunchKernelGGL((conv_sp_kernel<0, false, 4, 2>), dim3((unsigned)nblocks), dim3(512), sp_lds_bytes(4, 2), stream, p);
   } else if (half_tile) {
-    if (genw) hipLaunchKernelGGL((conv_sp_kernel<0, true, 4>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
-    else hipLaunchKernelGGL((conv_sp_kernel<0, false, 4>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    if (genw) hipLaunchKernelGGL((conv_sp_kernel<0, true, 4>), dim3((unsigned)nblocks), dim3(512), sp_lds_bytes(4, 4), stream, p);
+    else hipLaunchKernelGGL((conv_sp_kernel<0, false, 4>), dim3((unsigned)nblocks), dim3(512), sp_lds_bytes(4, 4), stream, p);
   } else if (genw) {
-    hipLaunchKernelGGL((conv_sp_kernel<0, true, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    hipLaunchKernelGGL((conv_sp_kernel<0, true, 8>), dim3((unsigned)nblocks), dim3(512), sp_lds_bytes(8, 4), stream, p);
   } else {
-    hipLaunchKernelGGL((conv_sp_kernel<0, false, 8>), dim3((unsigned)nblocks), dim3(512), SP_LDS, stream, p);
+    hipLaunchKernelGGL((conv_sp_kernel<0, false, 8>), dim3((unsigned)nblocks), dim3(512), sp_lds_bytes(8, 4), stream, p);
   }
   return osd_check_launch("conv_igemm_sp");
 }
