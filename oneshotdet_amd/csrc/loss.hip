@@ -178,13 +178,13 @@ __device__ __forceinline__ void fcos_loss_body(const T* __restrict__ cls_ctr, co
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    if (PHASE == 0) {
-#pragma unroll
-      for (int k = 0; k < 5; ++k) atomicAdd(sums + k, red[k][0]);
-    } else {
-      atomicAdd(d_scale_raw, red[5][0]);
-    }
+  // the five sums of a workgroup go out as ONE atomic wave-instruction (lanes 0..4 on five consecutive words of one line): as five
+  // instructions of thread 0 the ~550 workgroups of a launch queued 2,700 same-line operations at the memory-side atomic unit, and the
+  // statistics phase took 45 us against 14 - 24 for the gradient phase that does more arithmetic (profiles/r6_bench_train_bf16_kernel_stats.csv)
+  if (PHASE == 0) {
+    if (threadIdx.x < 5) atomicAdd(sums + threadIdx.x, red[threadIdx.x][0]);
+  } else if (threadIdx.x == 0) {
+    atomicAdd(d_scale_raw, red[5][0]);
   }
 }
 
