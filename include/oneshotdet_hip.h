@@ -517,6 +517,10 @@ int osd_fcos_loss_levels(int phase, int n_levels, const void* const* cls_ctrs, c
                          void* const* d_regs, int grad_stride, float* const* d_scale_raws, int dtype, void* stream);
 /* losses[4] = {loss_cls, loss_reg, loss_centerness, num_pos} */
 int osd_fcos_loss_finalize(const float* sums, float* losses, int n, void* stream);
+/* ... and, in the same launch, the gradient of the learnable per-level Scale (fcos.py:81, 95-97): d_scales[l] += d_scale_raw[l] /
+ * scales[l] for l < n_levels (d_scale_raw: what osd_fcos_loss_levels(phase 1) accumulated, sum ds * log(reg)). */
+int osd_fcos_loss_finalize_scales(const float* sums, float* losses, int n, const float* d_scale_raw, const float* scales,
+                                  float* d_scales, int n_levels, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Second-stage few-shot ROI box head (modeling/roi_heads/box_head/box_head.py:81-259).  Its

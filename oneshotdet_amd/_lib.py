@@ -101,6 +101,7 @@ SIGNATURES = {
     "osd_fcos_loss_level": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _p, _p, _p, _p, _i, _p, _i, _p]),
     "osd_fcos_loss_levels": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p, _i, _p, _i, _p]),
     "osd_fcos_loss_finalize": (_i, [_p, _p, _i, _p]),
+    "osd_fcos_loss_finalize_scales": (_i, [_p, _p, _i, _p, _p, _p, _i, _p]),
     "osd_roi_pool_levels": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "osd_groupnorm_act_rois": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i, _p]),
     "osd_box_decode": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _f, _f, _p, _f, _i, _p]),

@@ -225,7 +225,14 @@ __global__ void __launch_bounds__(256) fcos_loss_levels_kernel(LossLevels L, con
   fcos_loss_body<T, PHASE>(cc, rg, gt, gt_count, max_gt, lv, n_images, gamma, alpha, sd, sums, dcc, drg, gstride, dsr, blockIdx.x, nbx);
 }
 
-__global__ void fcos_loss_finalize_kernel(const float* __restrict__ sums, float* __restrict__ losses, int n_images) {
+// (raw, scales, gscales: optional — the gradient of the learnable per-level Scale, fcos.py:81: gscales[l] += raw[l] / scales[l], which was
+// a torch division and a torch add on the main chain between the loss and the backward pass: two launches and their gaps in the one
+// window of the step where nothing else runs.  Round 6.)
+__global__ void fcos_loss_finalize_kernel(const float* __restrict__ sums, float* __restrict__ losses, int n_images,
+                                          const float* __restrict__ raw, const float* __restrict__ scales, float* __restrict__ gscales,
+                                          int n_levels) {
+  if (raw != nullptr && (int)threadIdx.x < n_levels) gscales[threadIdx.x] += raw[threadIdx.x] / scales[threadIdx.x];
+  if (threadIdx.x != 0) return;
   const float npos = sums[0], sw = sums[1];
   losses[0] = sums[2] / (npos + (float)n_images);
   losses[1] = npos > 0.f ? (sw > 0.f ? sums[3] / sw : sums[3] / npos) : 0.f;
@@ -266,7 +273,17 @@ extern "C" int osd_fcos_loss_level(int phase, const void* cls_ctr, const void* r
 // losses[4] = {loss_cls, loss_reg, loss_centerness, num_pos} from the accumulated sums
 extern "C" int osd_fcos_loss_finalize(const float* sums, float* losses, int n, void* stream) {
   if (!sums || !losses) return osd_fail(OSD_ERR_INVALID_ARG, "fcos_loss_finalize: null argument");
-  hipLaunchKernelGGL(fcos_loss_finalize_kernel, dim3(1), dim3(1), 0, OSD_STREAM(stream), sums, losses, n);
+  hipLaunchKernelGGL(fcos_loss_finalize_kernel, dim3(1), dim3(1), 0, OSD_STREAM(stream), sums, losses, n, (const float*)nullptr,
+                     (const float*)nullptr, (float*)nullptr, 0);
+  return osd_check_launch("fcos_loss_finalize");
+}
+
+extern "C" int osd_fcos_loss_finalize_scales(const float* sums, float* losses, int n, const float* d_scale_raw, const float* scales,
+                                             float* d_scales, int n_levels, void* stream) {
+  if (!sums || !losses || !d_scale_raw || !scales || !d_scales || n_levels < 1 || n_levels > 64)
+    return osd_fail(OSD_ERR_INVALID_ARG, "fcos_loss_finalize_scales: bad arguments");
+  hipLaunchKernelGGL(fcos_loss_finalize_kernel, dim3(1), dim3(64), 0, OSD_STREAM(stream), sums, losses, n, d_scale_raw, scales, d_scales,
+                     n_levels);
   return osd_check_launch("fcos_loss_finalize");
 }
 

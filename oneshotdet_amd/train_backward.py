@@ -83,13 +83,7 @@ class BackwardPass(object):
         nl = len(dpred)
         g = ops.pred_dy_gather(dpred, c.cout, c.cin)
         self._wgrad_grouped(c, [(t_last[l], dpred[l]) for l in range(nl)], which, g=g)
-        key = ("pred_dgrad", c.name)
-        ent = self._pred_dgrad.get(key)
-        if ent is None:
-            wd = torch.empty((c.cin, 1, 1, ops.PRED_G), device=self.device, dtype=self.dtype)
-            ent = self._pred_dgrad[key] = ops.PackedConv(wd, torch.zeros(ops._round_up(c.cin, 16), device=self.device, dtype=torch.float32),
-                                                         c.cin, c.cin, c.cin, ops.PRED_G, 1, 1, cin_real=9 * c.cout)
-        ops.pred_dgrad_pack(c.w, c.cout, c.cin, self.dtype, out=ent.w)      # (the master changes every step: 256 x 64 values)
+        ent = self.pred_dgrad_weights(c, fresh_ok=True)
         dx = ops.conv2d(g.view(1, 1, g.shape[0], ops.PRED_G), ent)
         out, q0 = [], 0
         for t in dpred:
@@ -97,6 +91,28 @@ class BackwardPass(object):
             out.append(dx.view(-1, c.cin)[q0:q0 + n * hh * ww].view(n, hh, ww, c.cin))
             q0 += n * hh * ww
         return out
+
+    def pred_dgrad_weights(self, c, fresh_ok=False):
+        """The prediction conv's weights in the gathered data-gradient form (osd_pred_dgrad_pack: 256 x 64 values, from the master that
+        changes every step).  The FORWARD pass calls this right behind the prediction conv, on that conv's stream (round 6): between the
+        loss and the backward pass the chain is a string of small launches with nothing running beside them, and this one needs nothing
+        from the loss.  fresh_ok: the backward pass's call — packs only if this step's forward did not."""
+        key = ("pred_dgrad", c.name)
+        ent = self._pred_dgrad.get(key)
+        if ent is None:
+            wd = torch.empty((c.cin, 1, 1, ops.PRED_G), device=self.device, dtype=self.dtype)
+            ent = self._pred_dgrad[key] = ops.PackedConv(wd, torch.zeros(ops._round_up(c.cin, 16), device=self.device, dtype=torch.float32),
+                                                         c.cin, c.cin, c.cin, ops.PRED_G, 1, 1, cin_real=9 * c.cout)
+        fresh = getattr(self, "_pred_dgrad_fresh", None)
+        if fresh is None:
+            fresh = self._pred_dgrad_fresh = set()
+        if fresh_ok and c.name in fresh:
+            fresh.discard(c.name)
+            return ent
+        ops.pred_dgrad_pack(c.w, c.cout, c.cin, self.dtype, out=ent.w)
+        if not fresh_ok:
+            fresh.add(c.name)
+        return ent
 
     def _dgrad_levels(self, c, dys):
         """Data gradient of a conv shared by the FPN levels: one grouped launch (forward kernel, flipped weights)."""

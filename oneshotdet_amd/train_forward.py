@@ -185,11 +185,16 @@ class ForwardPass(object):
                 layers[tw].append((t[tw], u, ab))
                 t[tw] = t2
         outs = {}
+        prepack = not self.split_levels and hasattr(self, "pred_dgrad_weights")
         if "cls_tower" in towers:
             outs["cls_tower"] = ops.conv2d_grouped(t["cls_tower"], cv[h + "cls_ctr"].pc, pad=1)
+            if prepack:
+                self.pred_dgrad_weights(cv[h + "cls_ctr"])
         if "bbox_tower" in towers:
             outs["bbox_tower"] = ops.conv2d_grouped(t["bbox_tower"], cv[h + "bbox_pred"].pc, pad=1, act=ACT_EXP_SCALE,
                                                     act_scale_devs=[scales[l:l + 1] for l in lv])
+            if prepack:
+                self.pred_dgrad_weights(cv[h + "bbox_pred"])
         return outs, {tw: (layers[tw], t[tw]) for tw in towers}
 
     def loss_and_grads(self, head_out, gt_boxes, gt_count):
@@ -197,13 +202,15 @@ class ForwardPass(object):
         h = "rpn.head."
         scales, gscales = self.extra[h + "scales"]
         n = head_out[0][0].shape[0]
-        sums = torch.zeros(8, device=self.device, dtype=torch.float32)
+        # one zeroed buffer for the loss sums and the Scale gradients' raw sums (one fill launch on the chain instead of two)
+        zbuf = torch.zeros(16, device=self.device, dtype=torch.float32)
+        sums = zbuf[:8]
         nl = len(head_out)
         ops.fcos_loss_levels(0, head_out, gt_boxes, gt_count, spec.FPN_STRIDES[:nl], SIZE_RANGES[:nl], spec.POS_RADIUS,
                              spec.LOSS_GAMMA, spec.LOSS_ALPHA, None, sums)
         gstride = self.convs[h + "bbox_pred"].pd.cin_k
         grads = []
-        raw = torch.zeros(5, device=self.device, dtype=torch.float32)
+        raw = zbuf[8:8 + max(nl, 5)]
         for lvl, (cc, rg) in enumerate(head_out):
             shape = cc.shape[:3] + (gstride,)
             # persistent gradient buffers: the kernel rewrites the real channels of EVERY location each step, the padding
@@ -216,9 +223,10 @@ class ForwardPass(object):
         ops.fcos_loss_levels(1, head_out, gt_boxes, gt_count, spec.FPN_STRIDES[:nl], SIZE_RANGES[:nl], spec.POS_RADIUS,
                              spec.LOSS_GAMMA, spec.LOSS_ALPHA, [scales[l:l + 1] for l in range(nl)], sums,
                              [g[0] for g in grads], [g[1] for g in grads], [raw[l:l + 1] for l in range(nl)])
-        gscales.add_(raw / scales)      # d loss / d scale_l = sum ds * x, x = log(reg) / scale_l
         losses = torch.empty(4, device=self.device, dtype=torch.float32)
-        ops._lib.call("osd_fcos_loss_finalize", ops._ptr(sums), ops._ptr(losses), n, ops._stream())
+        # the losses, and d loss / d scale_l = sum ds * x, x = log(reg) / scale_l: gscales += raw / scales in the same launch
+        ops._lib.call("osd_fcos_loss_finalize_scales", ops._p(sums), ops._p(losses), n, ops._p(raw), ops._p(scales), ops._p(gscales), nl,
+                      ops._stream())
         # {num_pos, sum_w, sum_focal, sum_w*(1-giou), sum_bce}: the un-normalised sums are additive over images (tests)
         self.last_loss_sums = sums
         return losses, grads
