@@ -61,6 +61,8 @@ def conv_algo_candidates(cout_store, relu_in, has_mask=False, pixels=None):
             cands.append(1 + 0 * 32 + 0 * 8 + 6)      # ... on 128 x 128 tiles: half the weight stream per workgroup (layer4's 3x3: K = 4,608 on 6,400 pixels)
     if 64 < cout_store <= 128 and not relu_in and not os.environ.get("OSD_NO_SP") and not os.environ.get("OSD_NO_SP_NARROW"):
         cands.append(1 + 0 * 32 + 1 * 8 + 6)          # the same kernel on a 256-pixel x 128-channel tile (4 x 2 waves): layer2's 3x3 convs
+        if not os.environ.get("OSD_NO_SP_SMALL128"):
+            cands.append(1 + 0 * 32 + 0 * 8 + 6)      # ... and on the 128 x 128 tile: 76 KB of LDS, two workgroups per CU (round 6)
     if cout_store >= 128 and not relu_in:
         cands += [1 + 0 * 32 + v * 8 + 7 for v in (0, 1, 2, 3)]      # 256x128 tile on 8 waves: deep / shallow ring / short stages
     if cout_store >= 256 and not relu_in:
