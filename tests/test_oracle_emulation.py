@@ -138,6 +138,32 @@ def test_conv_launches_chain_into_the_reference_bottleneck_and_fpn_lateral():
     torch.testing.assert_close(y2, y, rtol=1e-5, atol=1e-5)
     y3 = lr.conv_launch(o2, w3, b3 + bd, 64, 1, 1, act=lr.ACT_RELU, x2=xh, x2_stride=2, w2=wd)
     torch.testing.assert_close(y3, y, rtol=1e-5, atol=1e-5)
+    # the bottleneck computed on every other pixel only (layer1's last block: its output is read by layer2.0's stride-2 1x1 convs and by
+    # nothing else): the 3x3 at stride 2, conv3 + the identity at (2 ho, 2 wo) = the even pixels of the full block
+    xs1 = torch.randn(2, 12, 12, 64)
+    w1s, w2s, w3s = torch.randn(16, 64, 1, 1) * 0.1, torch.randn(16, 16, 3, 3) * 0.1, torch.randn(64, 16, 1, 1) * 0.1
+    z16, z64 = torch.zeros(16), torch.zeros(64)
+    f1 = lr.conv_launch(xs1, _pack(w1s), z16, 16, 1, 1, act=lr.ACT_RELU)
+    full = lr.conv_launch(lr.conv_launch(f1, _pack(w2s), z16, 16, 3, 3, pad=1, act=lr.ACT_RELU), _pack(w3s), z64, 64, 1, 1, act=lr.ACT_RELU,
+                          res=xs1, res_mode=lr.RES_SAME)
+    half = lr.conv_launch(lr.conv_launch(f1, _pack(w2s), z16, 16, 3, 3, stride=2, pad=1, act=lr.ACT_RELU), _pack(w3s), z64, 64, 1, 1,
+                          act=lr.ACT_RELU, res=xs1, res_mode=lr.RES_DOWN2X)
+    torch.testing.assert_close(half, full[:, ::2, ::2], rtol=1e-5, atol=1e-5)
+    # the query branch's pooling of all levels = ROIAlign (1 x 1, whole-image boxes) + the mean over the shots per level, and its backward
+    # = autograd of that (generalized_rcnn.py:20-52, 100-104)
+    feats = [torch.randn(4, 8, 8, 8), torch.randn(4, 4, 4, 8)]
+    rois = torch.tensor([[i, 0.0, 0.0, 50.0 + 3 * i, 60.0 - 2 * i] for i in range(4)])
+    pooled = lr.query_pool_launch(feats, rois, [1 / 8, 1 / 16], 2, 2)
+    assert [tuple(t.shape) for t in pooled] == [(2, 8), (2, 8)]
+    fa = [f.clone().requires_grad_(True) for f in feats]
+    want_p = [orc.roi_align(f.permute(0, 3, 1, 2), rois, sc, 1, 1, 2).view(2, 2, 8).mean(1) for f, sc in zip(fa, [1 / 8, 1 / 16])]
+    for a, b in zip(pooled, want_p):
+        torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
+    dqs = [torch.randn(2, 8), torch.randn(2, 8)]
+    sum((w * d).sum() for w, d in zip(want_p, dqs)).backward()
+    got_g = lr.query_pool_bwd_launch(dqs, rois, [tuple(f.shape) for f in feats], [1 / 8, 1 / 16], 2, 2)
+    for g, f in zip(got_g, fa):
+        torch.testing.assert_close(g, f.grad, rtol=1e-5, atol=1e-6)
     # FPN lateral + top-down (fpn.py:57-60) and P7 = conv(relu(P6)) (fpn.py:98)
     wl, bl = torch.randn(8, 64, 1, 1) * 0.1, torch.randn(8)
     top = torch.randn(2, 3, 3, 8)
