@@ -290,6 +290,30 @@ def test_query_pool_levels_equals_the_per_level_launches(dt, shots):
         torch.testing.assert_close(out.float(), o.cast_f32(gx, T).float(), rtol=1e-5 if dt == "f32" else 1e-2, atol=1e-6 if dt == "f32" else 1e-4)
 
 
+def test_small_tile_convs_sharing_cus_on_two_streams_match_their_serial_results():
+    """conv_sp's 128 x 128 tile asks for 76 KB of LDS, so two of its workgroups share a CU (round 6) — also workgroups of two
+    different launches.  Two tower-sized 3x3 convs (each 134 workgroups) and a layer3-sized one (400) launched back and forth on two
+    streams, 20 rounds: every result bit-equal to the same launch alone on the default stream."""
+    o = ops()
+    T = torch.bfloat16
+    shapes = [(4, 40, 40, 256, 256), (4, 20, 20, 256, 256), (8, 50, 64, 256, 256)]
+    xs = [to_nhwc(rnd(n, c, h, w, seed=60 + i), T) for i, (n, h, w, c, _) in enumerate(shapes)]
+    pcs = [o.pack_conv((rnd(co, c, 3, 3, seed=70 + i) / 48).cuda(), bias=rnd(co, seed=80 + i).cuda(), dtype=T)
+           for i, (_, _, _, c, co) in enumerate(shapes)]
+    algo = 1 + 0 * 32 + 0 * 8 + 6
+    want = [o.conv2d(x, pc, pad=1, act=o.ACT_RELU, algo=algo) for x, pc in zip(xs, pcs)]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(20):
+        for j, (x, pc) in enumerate(zip(xs, pcs)):
+            with torch.cuda.stream(s1 if (j + rep) % 2 == 0 else s2):
+                outs.append((j, o.conv2d(x, pc, pad=1, act=o.ACT_RELU, algo=algo)))
+    torch.cuda.synchronize()
+    for j, y in outs:
+        assert torch.equal(y, want[j])
+
+
 def test_empty_inputs_are_noops():
     o = ops()
     y = o.correlate(torch.zeros(0, 4, 4, 256, device="cuda"), torch.zeros(0, 256, device="cuda"))
